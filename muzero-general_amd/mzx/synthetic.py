@@ -1,0 +1,119 @@
+"""
+Synthetic, fixed-shape inputs for benchmarking and parity tests.
+
+Nothing here mirrors a reference file: the reference ships no benchmark.  These
+helpers produce (a) deterministic non-trivial weights for any reference-format
+``state_dict`` layout, and (b) the synthetic observation batches the metric is
+quoted on.  Deterministic given the seed and independent of torch's RNG so the
+same tensors can be rebuilt on the GPU box, in the build container and inside
+``oracle/make_golden.py``.
+"""
+import collections
+
+import numpy
+import torch
+
+
+def fill_state_dict(template, seed):
+    """
+    Return an OrderedDict with the same keys / shapes / dtypes as ``template``
+    (a reference-format state_dict or a {name: tensor} spec) filled from
+    ``numpy.random.RandomState(seed)`` in key order:
+      * ``*.running_var``  U(0.5, 1.5)      * ``*.running_mean``  0.1 N(0,1)
+      * BatchNorm weight   U(0.5, 1.5)      * biases              0.1 N(0,1)
+      * conv / linear weights  N(0,1) / sqrt(fan_in)
+      * integer tensors (``num_batches_tracked``) are zero.
+    """
+    rs = numpy.random.RandomState(seed)
+    out = collections.OrderedDict()
+    for name, ref in template.items():
+        shape = tuple(ref.shape)
+        if not ref.dtype.is_floating_point:
+            out[name] = torch.zeros(shape, dtype=ref.dtype)
+            continue
+        n = int(numpy.prod(shape)) if shape else 1
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "running_var":
+            v = rs.uniform(0.5, 1.5, n)
+        elif leaf == "running_mean":
+            v = 0.1 * rs.standard_normal(n)
+        elif leaf == "bias":
+            v = 0.1 * rs.standard_normal(n)
+        elif len(shape) == 1:  # BatchNorm gamma
+            v = rs.uniform(0.5, 1.5, n)
+        else:
+            fan_in = int(numpy.prod(shape[1:]))
+            v = rs.standard_normal(n) / numpy.sqrt(fan_in)
+        out[name] = torch.from_numpy(v.astype(numpy.float32).reshape(shape))
+    return out
+
+
+def observations(batch, observation_shape, seed=123):
+    """RandomState(seed).rand(B, *observation_shape) as float32."""
+    return numpy.random.RandomState(seed).rand(batch, *observation_shape).astype(numpy.float32)
+
+
+def _hash_u32(x):
+    """32-bit integer mix (Wang/Jenkins style) on numpy uint64 lanes, result < 2**32."""
+    x = numpy.asarray(x, dtype=numpy.uint64) & numpy.uint64(0xFFFFFFFF)
+    x = ((x ^ numpy.uint64(61)) ^ (x >> numpy.uint64(16))) & numpy.uint64(0xFFFFFFFF)
+    x = (x * numpy.uint64(9)) & numpy.uint64(0xFFFFFFFF)
+    x = x ^ (x >> numpy.uint64(4))
+    x = (x * numpy.uint64(0x27D4EB2D)) & numpy.uint64(0xFFFFFFFF)
+    x = x ^ (x >> numpy.uint64(15))
+    return x
+
+
+def make_synthetic_game(observation_shape, num_actions, num_players=1):
+    """
+    Build a ``Game`` class with the reference plugin surface
+    (games/abstract_game.py:9-105) for a fixed-shape synthetic environment:
+    the next observation is a counter hash of (seed, step, action), the reward
+    is one hash bit in {0, 1}, every action is always legal and the episode
+    never terminates on its own (``config.max_moves`` ends it), so all games of
+    a shard stay in lock-step.
+    """
+    shape = tuple(observation_shape)
+    size = int(numpy.prod(shape))
+    lane = numpy.arange(size, dtype=numpy.uint64)
+
+    class SyntheticGame:
+        def __init__(self, seed=None):
+            self.seed = 0 if seed is None else int(seed)
+            self.t = 0
+            self.player = 0
+            self.key = self.seed & 0xFFFFFFFF
+
+        def _observation(self):
+            h = _hash_u32(lane * numpy.uint64(2654435761) + numpy.uint64(self.key))
+            return (h.astype(numpy.float64) / 4294967296.0).astype(numpy.float32).reshape(shape)
+
+        def reset(self):
+            self.t = 0
+            self.player = 0
+            self.key = int(_hash_u32(self.seed * 7919 + 17))
+            return self._observation()
+
+        def step(self, action):
+            self.t += 1
+            self.key = int(_hash_u32(self.key * 31 + int(action) * 131 + self.t))
+            self.player = (self.player + 1) % num_players
+            reward = int(self.key & 1)
+            return self._observation(), reward, False
+
+        def to_play(self):
+            return self.player
+
+        def legal_actions(self):
+            return list(range(num_actions))
+
+        def render(self):
+            print(f"SyntheticGame t={self.t} key={self.key:08x}")
+
+        def close(self):
+            pass
+
+        def action_to_string(self, action_number):
+            return str(action_number)
+
+    return SyntheticGame

@@ -1,0 +1,287 @@
+"""
+TEST INFRASTRUCTURE ONLY -- generates tests/golden/* by EXECUTING the unmodified
+reference (/root/reference) in the build container.  Run from the repo root:
+
+    python oracle/make_golden.py
+
+Nothing here edits reference code: instrumentation is done by wrapping
+``Node.expand`` / ``MinMaxStats.__init__`` / the model's inference methods from
+the outside.  The emitted fixtures are what pins the oracle (oracle/*.py) and,
+through it, the HIP path:
+
+  tree_<game>.npz   lock-step traces of MCTS.run: recorded network outputs per
+                    expansion + the final tree in canonical node order
+                    (SURVEY.md section 8c') + min-max bounds + per-simulation trace.
+  net_<name>.npz    initial_inference / recurrent_inference outputs of models.py
+                    on seeded inputs and seeded weights (mzx.synthetic.fill_state_dict).
+  game_<game>.npz   whole GameHistory of SelfPlay.play_game.
+"""
+import json
+import os
+import sys
+
+import numpy
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "muzero-general_amd"))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim  # noqa: E402
+from mzx import synthetic  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _config(game, **overrides):
+    cfg = ref_shim.game_module(game).MuZeroConfig()
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _reference_model(models, cfg, weight_seed):
+    torch.manual_seed(0)
+    net = models.MuZeroNetwork(cfg)
+    if weight_seed is not None:
+        net.set_weights(synthetic.fill_state_dict(net.state_dict(), weight_seed))
+    net.eval()
+    return net
+
+
+class _Recorder:
+    """Wraps a reference model; logs every inference output (no behaviour change)."""
+
+    def __init__(self, net):
+        self.net = net
+        self.log = []
+
+    def parameters(self):
+        return self.net.parameters()
+
+    def initial_inference(self, obs):
+        out = self.net.initial_inference(obs)
+        self.log.append(out)
+        return out
+
+    def recurrent_inference(self, hidden, action):
+        out = self.net.recurrent_inference(hidden, action)
+        self.log.append(out)
+        return out
+
+
+def trace_search(models, self_play, cfg, net, observation, legal, to_play, rng_seed):
+    """Run the reference MCTS once and dump everything in canonical order."""
+    order = []
+    minmax = []
+    orig_expand = self_play.Node.expand
+    orig_mm_init = self_play.MinMaxStats.__init__
+
+    def expand(node, actions, tp, reward, logits, hidden):
+        node._idx = len(order)
+        order.append(node)
+        orig_expand(node, actions, tp, reward, logits, hidden)
+        node._priors0 = [c.prior for c in node.children.values()]
+
+    def mm_init(self):
+        orig_mm_init(self)
+        minmax.append(self)
+
+    self_play.Node.expand = expand
+    self_play.MinMaxStats.__init__ = mm_init
+    rec = _Recorder(net)
+    try:
+        numpy.random.seed(rng_seed)
+        with torch.no_grad():
+            root, info = self_play.MCTS(cfg).run(rec, observation, legal, to_play, True)
+    finally:
+        self_play.Node.expand = orig_expand
+        self_play.MinMaxStats.__init__ = orig_mm_init
+
+    n = len(order)
+    A = len(cfg.action_space)
+    F = 2 * cfg.support_size + 1
+    out = dict(
+        visit=numpy.zeros(n, numpy.int32), value_sum=numpy.zeros(n, numpy.float64),
+        reward=numpy.zeros(n, numpy.float64), to_play=numpy.zeros(n, numpy.int32),
+        parent=numpy.full(n, -1, numpy.int32), parent_action=numpy.full(n, -1, numpy.int32),
+        depth=numpy.zeros(n, numpy.int32),
+        prior=numpy.zeros((n, A), numpy.float64), child=numpy.full((n, A), -1, numpy.int32),
+        n_children=numpy.zeros(n, numpy.int32), child_action=numpy.full((n, A), -1, numpy.int32),
+        net_value=numpy.zeros(n, numpy.float64), net_reward=numpy.zeros(n, numpy.float64),
+        net_priors=numpy.zeros((n, A), numpy.float64),
+        value_logits=numpy.zeros((n, F), numpy.float32), reward_logits=numpy.zeros((n, F), numpy.float32),
+        policy_logits=numpy.zeros((n, A), numpy.float32),
+    )
+    hidden = []
+    for i, node in enumerate(order):
+        out["visit"][i] = node.visit_count
+        out["value_sum"][i] = node.value_sum
+        out["reward"][i] = node.reward
+        out["to_play"][i] = node.to_play
+        out["n_children"][i] = len(node.children)
+        for s, (a, c) in enumerate(node.children.items()):
+            out["child_action"][i, s] = a
+            out["prior"][i, s] = c.prior
+            if hasattr(c, "_idx"):
+                out["child"][i, s] = c._idx
+                out["parent"][c._idx] = i
+                out["parent_action"][c._idx] = a
+        out["net_priors"][i, : len(node._priors0)] = node._priors0
+        v, r, p, h = rec.log[i]
+        out["net_value"][i] = models.support_to_scalar(v, cfg.support_size).item()
+        out["net_reward"][i] = models.support_to_scalar(r, cfg.support_size).item()
+        out["value_logits"][i] = v[0].numpy()
+        out["reward_logits"][i] = r[0].numpy()
+        out["policy_logits"][i] = p[0].numpy()
+        hidden.append(h[0].numpy().reshape(-1))
+    for i in range(1, n):
+        out["depth"][i] = out["depth"][out["parent"][i]] + 1
+    if hidden[0].size <= 256:  # keep fixtures small: connect4's 2688-float states are not stored
+        out["hidden"] = numpy.stack(hidden).astype(numpy.float32)
+    out["minmax"] = numpy.array([minmax[0].minimum, minmax[0].maximum], numpy.float64)
+    out["max_tree_depth"] = numpy.int32(info["max_tree_depth"])
+    out["root_predicted_value"] = numpy.float64(info["root_predicted_value"])
+    for i, node in enumerate(order):
+        if hasattr(node, "_idx"):
+            del node._idx
+    return out
+
+
+def make_tree_fixture(name, game, n_cases, weight_seed, legal_fn, overrides=None, players_fn=None,
+                      zero_keys=()):
+    models, self_play = ref_shim.load()
+    cfg = _config(game, **(overrides or {}))
+    net = _reference_model(models, cfg, weight_seed)
+    if zero_keys:  # e.g. zero policy head -> equal priors -> repeated argmax ties
+        sd = net.state_dict()
+        for k in zero_keys:
+            sd[k] = torch.zeros_like(sd[k])
+        net.set_weights(sd)
+    cases = {}
+    obs_all = synthetic.observations(n_cases, cfg.observation_shape, seed=123)
+    meta = dict(game=game, weight_seed=weight_seed, n_cases=n_cases,
+                num_simulations=cfg.num_simulations, overrides=overrides or {},
+                zero_keys=list(zero_keys), cases=[])
+    for c in range(n_cases):
+        legal = legal_fn(c, cfg)
+        to_play = 0 if players_fn is None else players_fn(c, cfg)
+        rng_seed = 1000 + c
+        tr = trace_search(models, self_play, cfg, net, obs_all[c], legal, to_play, rng_seed)
+        for k, v in tr.items():
+            cases[f"c{c}_{k}"] = v
+        cases[f"c{c}_obs"] = obs_all[c]
+        meta["cases"].append(dict(legal=list(legal), to_play=int(to_play), rng_seed=rng_seed))
+    cases["meta"] = numpy.array(json.dumps(meta))
+    numpy.savez_compressed(os.path.join(OUT, f"tree_{name}.npz"), **cases)
+    print("tree", name, "cases", n_cases, "nodes", tr["visit"].shape[0])
+
+
+def make_net_fixture(name, game, weight_seed, batch, overrides=None, state_dict=None):
+    models, _ = ref_shim.load()
+    cfg = _config(game, **(overrides or {}))
+    net = _reference_model(models, cfg, weight_seed)
+    if state_dict is not None:
+        net.set_weights(state_dict)
+    A = len(cfg.action_space)
+    c_in = cfg.observation_shape[0] * (cfg.stacked_observations + 1) + cfg.stacked_observations
+    obs = synthetic.observations(batch, (c_in,) + tuple(cfg.observation_shape[1:]), seed=321)
+    rs = numpy.random.RandomState(7)
+    act1 = rs.randint(0, A, size=(batch, 1))
+    act2 = rs.randint(0, A, size=(batch, 1))
+    data = dict(obs=obs, act1=act1.astype(numpy.int32), act2=act2.astype(numpy.int32))
+    with torch.no_grad():
+        o = net.initial_inference(torch.tensor(obs))
+        r1 = net.recurrent_inference(o[3], torch.tensor(act1))
+        r2 = net.recurrent_inference(r1[3], torch.tensor(act2))
+        # the same sample evaluated alone (the shape MCTS uses)
+        o_b1 = net.initial_inference(torch.tensor(obs[:1]))
+    for tag, res in (("init", o), ("rec1", r1), ("rec2", r2), ("init_b1", o_b1)):
+        for key, t in zip(("value", "reward", "policy", "hidden"), res):
+            data[f"{tag}_{key}"] = t.numpy()
+        data[f"{tag}_value_scalar"] = models.support_to_scalar(res[0], cfg.support_size).numpy()
+        data[f"{tag}_reward_scalar"] = models.support_to_scalar(res[1], cfg.support_size).numpy()
+    sd = net.state_dict()
+    meta = dict(game=game, weight_seed=weight_seed, overrides=overrides or {}, batch=batch,
+                keys=[[k, list(v.shape), str(v.dtype)] for k, v in sd.items()],
+                n_float_params=int(sum(v.numel() for v in sd.values() if v.dtype.is_floating_point)))
+    data["meta"] = numpy.array(json.dumps(meta))
+    if state_dict is not None:  # trained weights: ship them (small)
+        data["flat_weights"] = numpy.concatenate(
+            [v.numpy().reshape(-1) for v in sd.values() if v.dtype.is_floating_point]
+        ).astype(numpy.float32)
+    numpy.savez_compressed(os.path.join(OUT, f"net_{name}.npz"), **data)
+    print("net", name, "params", meta["n_float_params"])
+
+
+def make_game_fixture(name, game, weight_seed, seed, overrides=None, synthetic_game=False,
+                      temperature=1.0):
+    models, self_play = ref_shim.load()
+    cfg = _config(game, **(overrides or {}))
+    if synthetic_game:
+        Game = synthetic.make_synthetic_game(cfg.observation_shape, len(cfg.action_space), len(cfg.players))
+    else:
+        Game = ref_shim.game_module(game).Game
+    torch.manual_seed(0)
+    template = models.MuZeroNetwork(cfg).state_dict()
+    weights = synthetic.fill_state_dict(template, weight_seed)
+    sp = self_play.SelfPlay({"weights": weights}, Game, cfg, seed)
+    gh = sp.play_game(temperature, cfg.temperature_threshold, False, "self", 0)
+    A = len(cfg.action_space)
+    data = dict(
+        action_history=numpy.array([int(a) for a in gh.action_history], numpy.int32),
+        reward_history=numpy.array([float(r) for r in gh.reward_history], numpy.float64),
+        to_play_history=numpy.array([int(p) for p in gh.to_play_history], numpy.int32),
+        child_visits=numpy.array(gh.child_visits, numpy.float64).reshape(-1, A),
+        root_values=numpy.array([float(v) for v in gh.root_values], numpy.float64),
+        observation_history=numpy.array([numpy.array(o, dtype=numpy.float64) for o in gh.observation_history]),
+    )
+    meta = dict(game=game, weight_seed=weight_seed, seed=seed, overrides=overrides or {},
+                synthetic_game=synthetic_game, temperature=temperature)
+    data["meta"] = numpy.array(json.dumps(meta))
+    numpy.savez_compressed(os.path.join(OUT, f"game_{name}.npz"), **data)
+    print("game", name, "moves", len(gh.action_history) - 1)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    full = lambda c, cfg: list(cfg.action_space)
+
+    def subset(c, cfg):  # ragged legal sets incl. a single legal action
+        rs = numpy.random.RandomState(50 + c)
+        k = 1 if c == 0 else rs.randint(2, len(cfg.action_space) + 1)
+        return sorted(rs.choice(cfg.action_space, size=k, replace=False).tolist())
+
+    # ---- lock-step tree traces -------------------------------------------------
+    make_tree_fixture("cartpole", "cartpole", 8, 11, full)
+    make_tree_fixture("tictactoe", "tictactoe", 8, 12, subset, players_fn=lambda c, cfg: c % 2)
+    make_tree_fixture("connect4", "connect4", 3, 13, subset,
+                      overrides=dict(num_simulations=60), players_fn=lambda c, cfg: c % 2)
+    # equal priors / zero logits force repeated argmax ties (stresses the tie tape)
+    make_tree_fixture("cartpole_ties", "cartpole", 4, 14, full,
+                      overrides=dict(root_exploration_fraction=0.0, num_simulations=20),
+                      zero_keys=("prediction_policy_network.module.2.weight",
+                                 "prediction_policy_network.module.2.bias"))
+
+    # ---- network outputs -------------------------------------------------------
+    make_net_fixture("fc_cartpole", "cartpole", 21, 8)
+    ckpt = torch.load(os.path.join(ref_shim.REFERENCE_ROOT, "results", "cartpole", "model.checkpoint"),
+                      weights_only=False, map_location="cpu")
+    make_net_fixture("fc_cartpole_pretrained", "cartpole", None, 8, state_dict=ckpt["weights"])
+    make_net_fixture("fc_cartpole_stacked", "cartpole", 22, 4,
+                     overrides=dict(stacked_observations=3, fc_representation_layers=[12],
+                                    fc_dynamics_layers=[16, 12], encoding_size=10))
+    make_net_fixture("resnet_tictactoe", "tictactoe", 23, 8)
+    make_net_fixture("resnet_connect4", "connect4", 24, 4)
+    make_net_fixture("resnet_breakout", "breakout", 25, 2)
+
+    # ---- whole games -----------------------------------------------------------
+    make_game_fixture("tictactoe", "tictactoe", 31, 5)
+    make_game_fixture("connect4", "connect4", 32, 6, overrides=dict(num_simulations=40))
+    make_game_fixture("cartpole_synth", "cartpole", 33, 7, overrides=dict(max_moves=12),
+                      synthetic_game=True)
+
+
+if __name__ == "__main__":
+    main()
