@@ -1,0 +1,199 @@
+/*
+ * mzx.h -- C ABI of the MI355X-native MuZero self-play hot path (libmzx.so).
+ *
+ * The reference (werner-duvaud/muzero-general) has no FFI: its boundary for this
+ * path is the duck-typed Python surface of models.py / self_play.py.  Every
+ * entry point below names the reference interface it stands behind
+ * (file:line relative to /root/reference); the Python host package
+ * (muzero-general_amd/mzx) binds them with ctypes and re-exposes the reference's
+ * own names (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain C types only; every `d_*` pointer is a DEVICE pointer (e.g.
+ *     torch.Tensor.data_ptr()); `h_*` pointers are host pointers read during
+ *     the call.  The library never allocates or frees device memory: the
+ *     caller owns every buffer (sizes via the *_bytes / *_floats queries).
+ *   - `stream` is a hipStream_t (0 = default stream).  Calls only ENQUEUE work
+ *     on it; they never synchronise.
+ *   - return value: MZX_OK or a negative MZX_ERR_* code; mzx_last_error() gives
+ *     the message of the calling thread's last failure.
+ *   - handles are host-side descriptors; one handle may be used by one thread
+ *     at a time (the reference runs one actor per process, self_play.py:11-29).
+ */
+#ifndef MZX_H
+#define MZX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZX_ABI_VERSION 1
+
+#define MZX_OK 0
+#define MZX_ERR_INVALID (-1)      /* bad argument / unsupported configuration */
+#define MZX_ERR_RUNTIME (-2)      /* HIP runtime error */
+#define MZX_ERR_WORKSPACE (-3)    /* caller-provided buffer too small */
+
+#define MZX_MAX_LAYERS 8          /* hidden layers per MLP */
+
+int mzx_abi_version(void);
+const char* mzx_last_error(void);
+/* 1 if the library was built for the GPU (always, for libmzx.so). */
+int mzx_is_device_build(void);
+
+/* ------------------------------------------------------------------------- *
+ * Network: replaces models.MuZeroNetwork(config) -- models.py:7-41 (factory),
+ * :80-195 (MuZeroFullyConnectedNetwork), :436-623 (MuZeroResidualNetwork).
+ * Field names are the MuZeroConfig attributes the factory reads.
+ * ------------------------------------------------------------------------- */
+typedef struct mzx_net_config {
+  int32_t network;               /* 0 = "fullyconnected", 1 = "resnet" */
+  int32_t observation_shape[3];  /* (channels, height, width) */
+  int32_t stacked_observations;
+  int32_t action_space_size;     /* len(config.action_space) */
+  int32_t support_size;
+  /* fullyconnected (models.py:80-126) */
+  int32_t encoding_size;
+  int32_t n_fc_representation_layers, fc_representation_layers[MZX_MAX_LAYERS];
+  int32_t n_fc_dynamics_layers, fc_dynamics_layers[MZX_MAX_LAYERS];
+  int32_t n_fc_reward_layers, fc_reward_layers[MZX_MAX_LAYERS];
+  int32_t n_fc_value_layers, fc_value_layers[MZX_MAX_LAYERS];
+  int32_t n_fc_policy_layers, fc_policy_layers[MZX_MAX_LAYERS];
+  /* resnet (models.py:436-520) */
+  int32_t downsample;            /* 0 = False, 1 = "resnet" ("CNN" is not on the BASELINE path) */
+  int32_t blocks, channels;
+  int32_t reduced_channels_reward, reduced_channels_value, reduced_channels_policy;
+  int32_t n_resnet_fc_reward_layers, resnet_fc_reward_layers[MZX_MAX_LAYERS];
+  int32_t n_resnet_fc_value_layers, resnet_fc_value_layers[MZX_MAX_LAYERS];
+  int32_t n_resnet_fc_policy_layers, resnet_fc_policy_layers[MZX_MAX_LAYERS];
+} mzx_net_config;
+
+typedef struct mzx_net mzx_net;
+
+/* models.MuZeroNetwork.__new__ (models.py:7-41): validates, builds the operator program. */
+int mzx_net_create(const mzx_net_config* cfg, mzx_net** out);
+void mzx_net_destroy(mzx_net* net);
+
+/* The flat weight buffer = every floating-point tensor of the reference
+ * state_dict (AbstractNetwork.get_weights, models.py:69-70) concatenated in
+ * state_dict order (BatchNorm running stats included, num_batches_tracked
+ * skipped).  This one buffer is what RCCL broadcasts. */
+int32_t mzx_net_num_tensors(const mzx_net* net);
+int64_t mzx_net_num_params(const mzx_net* net);
+/* i-th tensor: reference state_dict key (with the ".module." infix), offset/numel
+ * in floats, up to 4 dims (unused dims = 0). */
+int mzx_net_tensor_info(const mzx_net* net, int32_t i, char* name, int32_t name_cap,
+                        int64_t* offset, int64_t* numel, int32_t dims[4]);
+int64_t mzx_net_hidden_size(const mzx_net* net);     /* floats per encoded state */
+int64_t mzx_net_input_size(const mzx_net* net);      /* floats per stacked observation */
+int64_t mzx_net_derived_floats(const mzx_net* net);  /* folded-BatchNorm buffer size */
+int64_t mzx_net_workspace_floats(const mzx_net* net, int32_t max_batch);
+
+/* AbstractNetwork.set_weights (models.py:72-73): bind the flat device buffer
+ * (kept alive by the caller) and derive folded BatchNorm terms into d_derived. */
+int mzx_net_set_weights(mzx_net* net, const float* d_flat, int64_t n_floats,
+                        float* d_derived, int64_t derived_floats, void* stream);
+
+/* initial_inference(observation) (models.py:172-190 / :601-618).
+ * d_observation [batch][input_size]; outputs value_logits [batch][2s+1],
+ * policy_logits [batch][A], hidden [batch][hidden_size].  The reward of the
+ * root is log(one-hot at the support centre), i.e. scalar 0 -- d_reward_logits
+ * (nullable) is filled with -inf / 0 accordingly. */
+int mzx_net_initial_inference(mzx_net* net, const float* d_observation, int32_t batch,
+                              float* d_value_logits, float* d_reward_logits,
+                              float* d_policy_logits, float* d_hidden,
+                              float* d_workspace, int64_t workspace_floats, void* stream);
+
+/* recurrent_inference(encoded_state, action) (models.py:192-195 / :620-623). */
+int mzx_net_recurrent_inference(mzx_net* net, const float* d_hidden, const int32_t* d_action,
+                                int32_t batch, float* d_value_logits, float* d_reward_logits,
+                                float* d_policy_logits, float* d_next_hidden,
+                                float* d_workspace, int64_t workspace_floats, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Batched search: replaces MCTS(config).run(...) -- self_play.py:249-430 -- for
+ * num_trees independent roots at once (the reference runs one).
+ * ------------------------------------------------------------------------- */
+typedef struct mzx_search_config {
+  int32_t num_trees;           /* B parallel roots (one per game of the shard) */
+  int32_t num_simulations;     /* config.num_simulations */
+  int32_t action_space_size;   /* len(config.action_space) */
+  int32_t num_players;         /* len(config.players): 1 or 2 */
+  int32_t support_size;        /* config.support_size */
+  int32_t tape_words;          /* raw MT19937 words per tree for argmax tie draws */
+  double discount;             /* config.discount */
+  double root_exploration_fraction;
+  /* host tables, entries 0..num_simulations (index = parent visit count), built
+   * by the caller with the language's own math library so that they are the
+   * reference's values bit for bit (self_play.py:384-391):
+   *   h_pb_c_table[n] = log((n + pb_c_base + 1) / pb_c_base) + pb_c_init
+   *   h_sqrt_table[n] = sqrt(n) */
+  const double* h_pb_c_table;
+  const double* h_sqrt_table;
+} mzx_search_config;
+
+typedef struct mzx_search mzx_search;
+
+int mzx_search_create(const mzx_search_config* cfg, mzx_net* net /* nullable: lock-step only */,
+                      mzx_search** out);
+void mzx_search_destroy(mzx_search* s);
+/* Device memory the caller must provide as `d_arena` (trees + per-node hidden
+ * states + per-simulation scratch + network workspace). */
+int64_t mzx_search_arena_bytes(const mzx_search* s);
+
+/* Per-move inputs / outputs (all device pointers, all [num_trees] leading). */
+typedef struct mzx_search_io {
+  const float* d_observation;    /* [B][input_size] stacked observations (self_play.py:138-140) */
+  const int32_t* d_legal_actions;/* [B][A] game.legal_actions() in the game's order, padded with -1 */
+  const int32_t* d_to_play;      /* [B] game.to_play() */
+  const double* d_noise;         /* [B][A] Dirichlet sample per root child slot; NULL = no exploration noise */
+  const uint32_t* d_tape;        /* [B][tape_words] raw MT19937 words following the Dirichlet draw */
+  int32_t* d_visit_counts;       /* out [B][A] root child visit counts by action (0 if not a child) */
+  double* d_root_value;          /* out [B] root.value() */
+  double* d_root_predicted_value;/* out [B] support_to_scalar(initial value head) */
+  int32_t* d_info;               /* out [B][4]: max_tree_depth, flags (1 tape overflow, 2 node overflow),
+                                    tape words consumed, sum of leaf depths */
+} mzx_search_io;
+
+/* MCTS.run for B roots: initial_inference, root expansion (+noise), then
+ * num_simulations x {select, recurrent_inference, expand, backpropagate}. */
+int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_t arena_bytes, void* stream);
+
+/* Which implementation mzx_search_run uses: 0 = generic operator-per-kernel path
+ * (any configuration), 1 = fused LDS-resident persistent kernel (fully connected
+ * networks that fit; mzx_search_fused_supported tells).  Default: 1 when supported. */
+int mzx_search_fused_supported(const mzx_search* s);
+int mzx_search_set_mode(mzx_search* s, int32_t mode);
+
+/* Lock-step interface (parity harness, SURVEY.md section 8c'): the tree arithmetic
+ * alone, with the network outputs supplied by the caller in binary64.
+ *   begin : root expansion from d_root_priors [B][A] (slot order) and d_root_reward (+ io->d_noise)
+ *   select: one selection walk per tree -> d_parent/d_action/d_leaf [B]
+ *   apply : expand the selected leaf with (value, reward, priors [B][A]) and back-propagate
+ *   finish: write io outputs */
+int mzx_search_lockstep_begin(mzx_search* s, const mzx_search_io* io, const double* d_root_priors,
+                              const double* d_root_reward /* [B], NULL = decoded zero-reward head */,
+                              void* d_arena, int64_t arena_bytes, void* stream);
+int mzx_search_lockstep_select(mzx_search* s, const mzx_search_io* io, int32_t* d_parent, int32_t* d_action,
+                               int32_t* d_leaf, void* d_arena, void* stream);
+int mzx_search_lockstep_apply(mzx_search* s, const double* d_value, const double* d_reward,
+                              const double* d_priors, void* d_arena, void* stream);
+int mzx_search_finish(mzx_search* s, const mzx_search_io* io, void* d_arena, void* stream);
+
+/* Canonical-order dump of the trees (parity tests / diagnose tooling):
+ * copies node statistics of every tree into caller arrays sized for
+ * num_simulations+1 nodes: visit [B][N] i32, value_sum [B][N] f64, reward [B][N] f64,
+ * to_play [B][N] i32, parent [B][N] i32, child [B][N][A] i32, prior [B][N][A] f64,
+ * minmax [B][2] f64, n_nodes [B] i32.  Any pointer may be NULL. */
+typedef struct mzx_tree_dump {
+  int32_t* d_visit; double* d_value_sum; double* d_reward; int32_t* d_to_play; int32_t* d_parent;
+  int32_t* d_child; double* d_prior; double* d_minmax; int32_t* d_n_nodes;
+} mzx_tree_dump;
+int mzx_search_dump(mzx_search* s, const mzx_tree_dump* dump, void* d_arena, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MZX_H */

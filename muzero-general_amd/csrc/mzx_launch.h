@@ -1,0 +1,57 @@
+// mzx_launch.h -- how an element functor (mzx_ops.h) is executed.
+//
+// Product: one HIP kernel template, one thread per element; 256-thread blocks
+// for dense operators, 64-thread (one wavefront) blocks for per-tree operators
+// so that B trees spread over B/64 compute units instead of B/256.
+// tests/hostcheck: a serial loop (test infrastructure only).
+#pragma once
+#include "mzx_platform.h"
+
+namespace mzx {
+
+#ifdef MZX_HOSTCHECK
+
+typedef void* stream_t;
+
+template <int BLOCK, class Op>
+inline int launch(const Op& op, stream_t) {
+  const size_t n = op.size();
+  for (size_t i = 0; i < n; ++i) op(i);
+  return 0;
+}
+
+inline int copy_h2d(void* dst, const void* src, size_t bytes, stream_t) {
+  memcpy(dst, src, bytes);
+  return 0;
+}
+
+inline const char* runtime_error_string(int) { return "hostcheck"; }
+
+#else
+
+typedef hipStream_t stream_t;
+
+template <int BLOCK, class Op>
+__global__ void __launch_bounds__(BLOCK) op_kernel(const Op op, const size_t n) {
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n) op(i);
+}
+
+template <int BLOCK, class Op>
+inline int launch(const Op& op, stream_t stream) {
+  const size_t n = op.size();
+  if (n == 0) return 0;
+  const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+  hipLaunchKernelGGL((op_kernel<BLOCK, Op>), dim3(grid), dim3(BLOCK), 0, stream, op, n);
+  return (int)hipGetLastError();
+}
+
+inline int copy_h2d(void* dst, const void* src, size_t bytes, stream_t stream) {
+  return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+}
+
+inline const char* runtime_error_string(int e) { return hipGetErrorString((hipError_t)e); }
+
+#endif
+
+}  // namespace mzx

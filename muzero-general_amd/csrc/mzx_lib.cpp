@@ -1,0 +1,286 @@
+// mzx_lib.cpp -- the C ABI (include/mzx.h).  Compiled as HIP for gfx950 into
+// libmzx.so (product) and, with -DMZX_HOSTCHECK, as plain C++ into the test-only
+// libmzx_hostcheck.so.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+
+#include "mzx_search.h"
+#ifndef MZX_HOSTCHECK
+#include "mzx_fused_fc.h"
+#endif
+
+namespace mzx {
+
+static thread_local std::string g_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+}
+
+}  // namespace mzx
+
+using namespace mzx;
+
+extern "C" {
+
+int mzx_abi_version(void) { return MZX_ABI_VERSION; }
+
+const char* mzx_last_error(void) { return g_error.c_str(); }
+
+int mzx_is_device_build(void) {
+#ifdef MZX_HOSTCHECK
+  return 0;
+#else
+  return 1;
+#endif
+}
+
+// ---------------------------------------------------------------- network
+
+int mzx_net_create(const mzx_net_config* cfg, mzx_net** out) {
+  if (!cfg || !out) { set_error("mzx_net_create: null argument"); return MZX_ERR_INVALID; }
+  const int32_t counts[] = {cfg->n_fc_representation_layers, cfg->n_fc_dynamics_layers, cfg->n_fc_reward_layers,
+                            cfg->n_fc_value_layers, cfg->n_fc_policy_layers, cfg->n_resnet_fc_reward_layers,
+                            cfg->n_resnet_fc_value_layers, cfg->n_resnet_fc_policy_layers};
+  for (int32_t n : counts)
+    if (n < 0 || n > MZX_MAX_LAYERS) { set_error("more than %d hidden layers in an MLP", MZX_MAX_LAYERS); return MZX_ERR_INVALID; }
+  mzx_net* net = new (std::nothrow) mzx_net();
+  if (!net) { set_error("out of host memory"); return MZX_ERR_RUNTIME; }
+  net->cfg = *cfg;
+  NetBuilder b(net);
+  if (!b.build()) { delete net; return MZX_ERR_INVALID; }
+  *out = net;
+  return MZX_OK;
+}
+
+void mzx_net_destroy(mzx_net* net) { delete net; }
+
+int32_t mzx_net_num_tensors(const mzx_net* net) { return net ? (int32_t)net->tensors.size() : 0; }
+int64_t mzx_net_num_params(const mzx_net* net) { return net ? net->num_params : 0; }
+int64_t mzx_net_hidden_size(const mzx_net* net) { return net ? net->hidden_size : 0; }
+int64_t mzx_net_input_size(const mzx_net* net) { return net ? net->input_size : 0; }
+int64_t mzx_net_derived_floats(const mzx_net* net) { return net ? (net->derived_floats > 0 ? net->derived_floats : 1) : 0; }
+int64_t mzx_net_workspace_floats(const mzx_net* net, int32_t max_batch) {
+  if (!net || max_batch < 1) return 0;
+  return net->act_floats * net->n_temp * (int64_t)max_batch;
+}
+
+int mzx_net_tensor_info(const mzx_net* net, int32_t i, char* name, int32_t name_cap, int64_t* offset,
+                        int64_t* numel, int32_t dims[4]) {
+  if (!net || i < 0 || i >= (int32_t)net->tensors.size()) { set_error("tensor index out of range"); return MZX_ERR_INVALID; }
+  const TensorInfo& t = net->tensors[i];
+  if (name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (offset) *offset = t.offset;
+  if (numel) *numel = t.numel;
+  if (dims) for (int k = 0; k < 4; ++k) dims[k] = t.dims[k];
+  return MZX_OK;
+}
+
+int mzx_net_set_weights(mzx_net* net, const float* d_flat, int64_t n_floats, float* d_derived,
+                        int64_t derived_floats, void* stream) {
+  if (!net || !d_flat || !d_derived) { set_error("mzx_net_set_weights: null argument"); return MZX_ERR_INVALID; }
+  if (n_floats != net->num_params) {
+    set_error("flat weight buffer has %lld floats, network expects %lld", (long long)n_floats, (long long)net->num_params);
+    return MZX_ERR_INVALID;
+  }
+  if (derived_floats < net->derived_floats) { set_error("derived buffer too small"); return MZX_ERR_WORKSPACE; }
+  net->d_flat = d_flat;
+  net->d_derived = d_derived;
+  for (const BnRef& r : net->bns) {
+    BnFoldOp op;
+    op.weight = d_flat + r.weight; op.bias = d_flat + r.bias; op.mean = d_flat + r.mean; op.var = d_flat + r.var;
+    op.alpha = d_derived + r.alpha; op.beta = d_derived + r.beta; op.channels = r.channels;
+    MZX_TRY_LAUNCH(launch<256>(op, (stream_t)stream));
+  }
+  return MZX_OK;
+}
+
+static int check_net_call(const mzx_net* net, int32_t batch, int64_t workspace_floats) {
+  if (!net) { set_error("null network handle"); return MZX_ERR_INVALID; }
+  if (!net->d_flat) { set_error("network has no weights bound (call mzx_net_set_weights)"); return MZX_ERR_INVALID; }
+  if (batch < 1) { set_error("batch must be >= 1"); return MZX_ERR_INVALID; }
+  if (workspace_floats < net->act_floats * net->n_temp * (int64_t)batch) {
+    set_error("workspace too small: %lld floats given, %lld needed", (long long)workspace_floats,
+              (long long)(net->act_floats * net->n_temp * (int64_t)batch));
+    return MZX_ERR_WORKSPACE;
+  }
+  return MZX_OK;
+}
+
+int mzx_net_initial_inference(mzx_net* net, const float* d_observation, int32_t batch, float* d_value_logits,
+                              float* d_reward_logits, float* d_policy_logits, float* d_hidden, float* d_workspace,
+                              int64_t workspace_floats, void* stream) {
+  int rc = check_net_call(net, batch, workspace_floats);
+  if (rc) return rc;
+  if (!d_observation || !d_value_logits || !d_policy_logits || !d_hidden) { set_error("null buffer"); return MZX_ERR_INVALID; }
+  NetBuffers nb;
+  nb.in = d_observation; nb.action = nullptr; nb.hidden = d_hidden; nb.value = d_value_logits;
+  nb.reward = nullptr; nb.policy = d_policy_logits; nb.workspace = d_workspace;
+  rc = run_program(net, net->prog_initial, nb, batch, (stream_t)stream);
+  if (rc) return rc;
+  if (d_reward_logits) {
+    RewardFillOp f;
+    f.y = d_reward_logits; f.batch = batch; f.full_support = net->full_support;
+    MZX_TRY_LAUNCH(launch<256>(f, (stream_t)stream));
+  }
+  return MZX_OK;
+}
+
+int mzx_net_recurrent_inference(mzx_net* net, const float* d_hidden, const int32_t* d_action, int32_t batch,
+                                float* d_value_logits, float* d_reward_logits, float* d_policy_logits,
+                                float* d_next_hidden, float* d_workspace, int64_t workspace_floats, void* stream) {
+  int rc = check_net_call(net, batch, workspace_floats);
+  if (rc) return rc;
+  if (!d_hidden || !d_action || !d_value_logits || !d_reward_logits || !d_policy_logits || !d_next_hidden) {
+    set_error("null buffer");
+    return MZX_ERR_INVALID;
+  }
+  NetBuffers nb;
+  nb.in = d_hidden; nb.action = d_action; nb.hidden = d_next_hidden; nb.value = d_value_logits;
+  nb.reward = d_reward_logits; nb.policy = d_policy_logits; nb.workspace = d_workspace;
+  return run_program(net, net->prog_recurrent, nb, batch, (stream_t)stream);
+}
+
+// ----------------------------------------------------------------- search
+
+int mzx_search_create(const mzx_search_config* cfg, mzx_net* net, mzx_search** out) {
+  if (!cfg || !out) { set_error("mzx_search_create: null argument"); return MZX_ERR_INVALID; }
+  if (cfg->num_trees < 1 || cfg->num_simulations < 0 || cfg->action_space_size < 1) {
+    set_error("num_trees/num_simulations/action_space_size out of range");
+    return MZX_ERR_INVALID;
+  }
+  if (cfg->num_players != 1 && cfg->num_players != 2) {
+    // self_play.py:429-430
+    set_error("More than two player mode not implemented.");
+    return MZX_ERR_INVALID;
+  }
+  if (!cfg->h_pb_c_table || !cfg->h_sqrt_table) { set_error("pb_c / sqrt tables are required"); return MZX_ERR_INVALID; }
+  if (net && net->cfg.action_space_size != cfg->action_space_size) { set_error("network/search action space mismatch"); return MZX_ERR_INVALID; }
+  if (net && net->cfg.support_size != cfg->support_size) { set_error("network/search support size mismatch"); return MZX_ERR_INVALID; }
+  mzx_search* s = new (std::nothrow) mzx_search();
+  if (!s) { set_error("out of host memory"); return MZX_ERR_RUNTIME; }
+  s->cfg = *cfg;
+  s->net = net;
+  const int n = cfg->num_simulations + 2;
+  s->h_pbc.assign(cfg->h_pb_c_table, cfg->h_pb_c_table + (n - 1));
+  s->h_sqrt.assign(cfg->h_sqrt_table, cfg->h_sqrt_table + (n - 1));
+  s->h_pbc.push_back(0.0);
+  s->h_sqrt.push_back(0.0);
+  s->cfg.h_pb_c_table = nullptr;
+  s->cfg.h_sqrt_table = nullptr;
+  search_plan(s);
+#ifndef MZX_HOSTCHECK
+  s->fused_ok = fused_fc_supported(s);
+#endif
+  s->mode = s->fused_ok ? 1 : 0;
+  *out = s;
+  return MZX_OK;
+}
+
+void mzx_search_destroy(mzx_search* s) { delete s; }
+
+int64_t mzx_search_arena_bytes(const mzx_search* s) { return s ? s->arena_bytes : 0; }
+
+int mzx_search_fused_supported(const mzx_search* s) { return s ? s->fused_ok : 0; }
+
+int mzx_search_set_mode(mzx_search* s, int32_t mode) {
+  if (!s) { set_error("null search handle"); return MZX_ERR_INVALID; }
+  if (mode == 1 && !s->fused_ok) { set_error("fused search kernel does not support this configuration"); return MZX_ERR_INVALID; }
+  if (mode != 0 && mode != 1) { set_error("mode must be 0 or 1"); return MZX_ERR_INVALID; }
+  s->mode = mode;
+  return MZX_OK;
+}
+
+static int check_search_call(const mzx_search* s, const void* d_arena, int64_t arena_bytes, bool need_net) {
+  if (!s || !d_arena) { set_error("null search handle / arena"); return MZX_ERR_INVALID; }
+  if (arena_bytes >= 0 && arena_bytes < s->arena_bytes) {
+    set_error("arena too small: %lld bytes given, %lld needed", (long long)arena_bytes, (long long)s->arena_bytes);
+    return MZX_ERR_WORKSPACE;
+  }
+  if (need_net && (!s->net || !s->net->d_flat)) { set_error("search needs a network with bound weights"); return MZX_ERR_INVALID; }
+  return MZX_OK;
+}
+
+int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_t arena_bytes, void* stream) {
+  int rc = check_search_call(s, d_arena, arena_bytes, true);
+  if (rc) return rc;
+  if (!io || !io->d_observation || !io->d_legal_actions || !io->d_to_play || !io->d_tape || !io->d_visit_counts ||
+      !io->d_root_value || !io->d_info) {
+    set_error("mzx_search_run: missing io buffer");
+    return MZX_ERR_INVALID;
+  }
+#ifndef MZX_HOSTCHECK
+  if (s->mode == 1) return fused_fc_run(s, io, d_arena, (stream_t)stream);
+#endif
+  return search_run_generic(s, io, d_arena, (stream_t)stream);
+}
+
+int mzx_search_lockstep_begin(mzx_search* s, const mzx_search_io* io, const double* d_root_priors,
+                              const double* d_root_reward, void* d_arena, int64_t arena_bytes, void* stream) {
+  int rc = check_search_call(s, d_arena, arena_bytes, false);
+  if (rc) return rc;
+  if (!io || !io->d_legal_actions || !io->d_to_play || !d_root_priors) { set_error("lockstep_begin: missing buffer"); return MZX_ERR_INVALID; }
+  rc = ensure_tables(s, d_arena, (stream_t)stream);
+  if (rc) return rc;
+  const ArenaView v = arena_view(s, d_arena);
+  RootInitOp ri;
+  ri.arena = v.arena; ri.p = v.p; ri.value_logits = nullptr; ri.policy_logits = nullptr; ri.ext_priors = d_root_priors; ri.ext_root_reward = d_root_reward;
+  ri.legal = io->d_legal_actions; ri.to_play = io->d_to_play; ri.noise = io->d_noise; ri.root_predicted_value = nullptr;
+  MZX_TRY_LAUNCH(launch<64>(ri, (stream_t)stream));
+  return MZX_OK;
+}
+
+int mzx_search_lockstep_select(mzx_search* s, const mzx_search_io* io, int32_t* d_parent, int32_t* d_action,
+                               int32_t* d_leaf, void* d_arena, void* stream) {
+  int rc = check_search_call(s, d_arena, -1, false);
+  if (rc) return rc;
+  if (!io || !io->d_tape || !d_parent || !d_action || !d_leaf) { set_error("lockstep_select: missing buffer"); return MZX_ERR_INVALID; }
+  const ArenaView v = arena_view(s, d_arena);
+  SelectOp sel;
+  sel.arena = v.arena; sel.p = v.p; sel.tape = io->d_tape;
+  sel.sel_parent = d_parent; sel.sel_action = d_action; sel.sel_leaf = d_leaf;
+  MZX_TRY_LAUNCH(launch<64>(sel, (stream_t)stream));
+  return MZX_OK;
+}
+
+int mzx_search_lockstep_apply(mzx_search* s, const double* d_value, const double* d_reward, const double* d_priors,
+                              void* d_arena, void* stream) {
+  int rc = check_search_call(s, d_arena, -1, false);
+  if (rc) return rc;
+  if (!d_value || !d_reward || !d_priors) { set_error("lockstep_apply: missing buffer"); return MZX_ERR_INVALID; }
+  const ArenaView v = arena_view(s, d_arena);
+  ExpandBackpropOp eb;
+  eb.arena = v.arena; eb.p = v.p; eb.value_logits = nullptr; eb.reward_logits = nullptr; eb.policy_logits = nullptr;
+  eb.ext_value = d_value; eb.ext_reward = d_reward; eb.ext_priors = d_priors;
+  MZX_TRY_LAUNCH(launch<64>(eb, (stream_t)stream));
+  return MZX_OK;
+}
+
+int mzx_search_finish(mzx_search* s, const mzx_search_io* io, void* d_arena, void* stream) {
+  int rc = check_search_call(s, d_arena, -1, false);
+  if (rc) return rc;
+  if (!io || !io->d_visit_counts || !io->d_root_value || !io->d_info) { set_error("finish: missing buffer"); return MZX_ERR_INVALID; }
+  return search_finish(s, io, d_arena, (stream_t)stream);
+}
+
+int mzx_search_dump(mzx_search* s, const mzx_tree_dump* dump, void* d_arena, void* stream) {
+  int rc = check_search_call(s, d_arena, -1, false);
+  if (rc) return rc;
+  if (!dump) { set_error("dump: null"); return MZX_ERR_INVALID; }
+  const ArenaView v = arena_view(s, d_arena);
+  DumpOp op;
+  op.arena = v.arena; op.p = v.p; op.d = *dump;
+  MZX_TRY_LAUNCH(launch<64>(op, (stream_t)stream));
+  return MZX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// mzx_platform.h -- compile-target glue.
+//
+// Product build: hipcc --offload-arch=gfx950 (MZX_HOSTCHECK undefined).  The
+// element functors of mzx_ops.h run as HIP kernels; there is no CPU execution
+// path in the product library.
+//
+// tests/hostcheck build (g++ -DMZX_HOSTCHECK): the SAME functors are executed by
+// plain serial loops so the CPU test-suite can check the kernel logic against
+// the oracle without a GPU.  Test infrastructure only -- the mzx package never
+// loads that library.
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef MZX_HOSTCHECK
+#define MZX_HD
+#define MZX_DEVICE_ONLY 0
+#else
+#include <hip/hip_runtime.h>
+#define MZX_HD __host__ __device__
+#define MZX_DEVICE_ONLY 1
+#endif
+
+#define MZX_INF (__builtin_inf())
+
+namespace mzx {
+
+MZX_HD inline float mzx_expf(float x) { return expf(x); }
+MZX_HD inline float mzx_expm1f(float x) { return expm1f(x); }
+// torch.nn.ELU(alpha=1): x > 0 ? x : exp(x) - 1   (models.py:635)
+MZX_HD inline float mzx_elu(float x) { return x > 0.f ? x : mzx_expm1f(x); }
+
+}  // namespace mzx

@@ -1,0 +1,185 @@
+// mzx_search.h -- host-side driver of the batched search (generic path):
+// carves the caller's arena, sequences the per-simulation operators and exposes
+// the lock-step interface used by the parity harness.
+//
+// Reference: MCTS.run, /root/reference/self_play.py:260-361 -- the body of one
+// simulation (:319-355) becomes select -> gather hidden -> recurrent_inference
+// -> expand+backpropagate -> scatter hidden, each over all B trees at once.
+#pragma once
+#include <vector>
+
+#include "mzx_net.h"
+
+struct mzx_search {
+  mzx_search_config cfg;
+  mzx_net* net = nullptr;
+  mzx::SearchParams p;
+  mzx::TreeLayout L;
+  std::vector<double> h_pbc, h_sqrt;
+  // arena carve (byte offsets)
+  int64_t off_tables = 0, off_trees = 0, off_hidden = 0, off_dense_in = 0, off_dense_out = 0;
+  int64_t off_value = 0, off_reward = 0, off_policy = 0, off_sel = 0, off_ws = 0, arena_bytes = 0;
+  int64_t ws_floats = 0;
+  void* tables_arena = nullptr;  // arena whose table region is already filled
+  int32_t mode = 0;
+  int32_t fused_ok = 0;
+};
+
+namespace mzx {
+
+inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
+
+inline void search_plan(mzx_search* s) {
+  const mzx_search_config& c = s->cfg;
+  const int B = c.num_trees, N = c.num_simulations + 1, A = c.action_space_size;
+  const int F = 2 * c.support_size + 1;
+  const int64_t Hf = s->net ? s->net->hidden_size : 0;
+  s->L = TreeLayout::make(N, A);
+  SearchParams& p = s->p;
+  p.num_trees = B; p.num_sims = c.num_simulations; p.num_actions = A; p.num_nodes = N;
+  p.num_players = c.num_players; p.hidden_size = (int32_t)Hf; p.support_size = c.support_size;
+  p.tape_words = c.tape_words; p.discount = c.discount; p.exploration_fraction = c.root_exploration_fraction;
+  p.pbc_table = nullptr; p.sqrt_table = nullptr;
+  int64_t o = 0;
+  s->off_tables = o;    o += align256(int64_t(16) * (N + 1));
+  s->off_trees = o;     o += align256(s->L.tree_bytes * B);
+  s->off_hidden = o;    o += align256(int64_t(4) * B * N * Hf);
+  s->off_dense_in = o;  o += align256(int64_t(4) * B * Hf);
+  s->off_dense_out = o; o += align256(int64_t(4) * B * Hf);
+  s->off_value = o;     o += align256(int64_t(4) * B * F);
+  s->off_reward = o;    o += align256(int64_t(4) * B * F);
+  s->off_policy = o;    o += align256(int64_t(4) * B * A);
+  s->off_sel = o;       o += align256(int64_t(4) * B * 3);
+  s->ws_floats = s->net ? s->net->act_floats * s->net->n_temp * (int64_t)B : 0;
+  s->off_ws = o;        o += align256(int64_t(4) * s->ws_floats);
+  s->arena_bytes = o;
+}
+
+struct ArenaView {
+  TreeArena arena;
+  SearchParams p;
+  float *dense_in, *dense_out, *value, *reward, *policy, *ws;
+  int32_t *sel_parent, *sel_action, *sel_leaf;
+};
+
+inline ArenaView arena_view(const mzx_search* s, void* d_arena) {
+  char* base = (char*)d_arena;
+  ArenaView v;
+  v.arena.trees = base + s->off_trees;
+  v.arena.hidden = (float*)(base + s->off_hidden);
+  v.arena.L = s->L;
+  v.p = s->p;
+  v.p.pbc_table = (const double*)(base + s->off_tables);
+  v.p.sqrt_table = v.p.pbc_table + (s->p.num_nodes + 1);
+  v.dense_in = (float*)(base + s->off_dense_in);
+  v.dense_out = (float*)(base + s->off_dense_out);
+  v.value = (float*)(base + s->off_value);
+  v.reward = (float*)(base + s->off_reward);
+  v.policy = (float*)(base + s->off_policy);
+  v.sel_parent = (int32_t*)(base + s->off_sel);
+  v.sel_action = v.sel_parent + s->p.num_trees;
+  v.sel_leaf = v.sel_action + s->p.num_trees;
+  v.ws = (float*)(base + s->off_ws);
+  return v;
+}
+
+#define MZX_TRY_LAUNCH(expr)                                                        \
+  do {                                                                              \
+    int _rc = (expr);                                                               \
+    if (_rc) { set_error("launch failed: %s", runtime_error_string(_rc)); return MZX_ERR_RUNTIME; } \
+  } while (0)
+
+inline int ensure_tables(mzx_search* s, void* d_arena, stream_t stream) {
+  if (s->tables_arena == d_arena) return MZX_OK;
+  const int n = s->p.num_nodes + 1;
+  char* base = (char*)d_arena + s->off_tables;
+  MZX_TRY_LAUNCH(copy_h2d(base, s->h_pbc.data(), sizeof(double) * n, stream));
+  MZX_TRY_LAUNCH(copy_h2d(base + sizeof(double) * n, s->h_sqrt.data(), sizeof(double) * n, stream));
+  s->tables_arena = d_arena;
+  return MZX_OK;
+}
+
+inline int search_finish(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream) {
+  const ArenaView v = arena_view(s, d_arena);
+  FinalizeOp f;
+  f.arena = v.arena; f.p = v.p;
+  f.visit_counts = io->d_visit_counts; f.root_value = io->d_root_value; f.info = io->d_info;
+  MZX_TRY_LAUNCH(launch<64>(f, stream));
+  return MZX_OK;
+}
+
+// Generic path: one kernel per operator (any network configuration).
+inline int search_run_generic(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream) {
+  const ArenaView v = arena_view(s, d_arena);
+  mzx_net* net = s->net;
+  const int B = s->p.num_trees;
+  int rc = ensure_tables(s, d_arena, stream);
+  if (rc) return rc;
+
+  NetBuffers nb;
+  nb.in = io->d_observation; nb.action = nullptr; nb.hidden = v.dense_out;
+  nb.value = v.value; nb.reward = v.reward; nb.policy = v.policy; nb.workspace = v.ws;
+  rc = run_program(net, net->prog_initial, nb, B, stream);
+  if (rc) return rc;
+
+  RootInitOp ri;
+  ri.arena = v.arena; ri.p = v.p; ri.value_logits = v.value; ri.policy_logits = v.policy; ri.ext_priors = nullptr; ri.ext_root_reward = nullptr;
+  ri.legal = io->d_legal_actions; ri.to_play = io->d_to_play; ri.noise = io->d_noise;
+  ri.root_predicted_value = io->d_root_predicted_value;
+  MZX_TRY_LAUNCH(launch<64>(ri, stream));
+
+  HiddenMoveOp mv;
+  mv.arena = v.arena; mv.num_trees = B; mv.num_nodes = s->p.num_nodes; mv.hidden_size = s->p.hidden_size;
+  mv.dense = v.dense_out; mv.node = nullptr; mv.to_arena = 1;
+  MZX_TRY_LAUNCH(launch<256>(mv, stream));
+
+  SelectOp sel;
+  sel.arena = v.arena; sel.p = v.p; sel.tape = io->d_tape;
+  sel.sel_parent = v.sel_parent; sel.sel_action = v.sel_action; sel.sel_leaf = v.sel_leaf;
+  ExpandBackpropOp eb;
+  eb.arena = v.arena; eb.p = v.p; eb.value_logits = v.value; eb.reward_logits = v.reward; eb.policy_logits = v.policy;
+  eb.ext_value = nullptr; eb.ext_reward = nullptr; eb.ext_priors = nullptr;
+  nb.in = v.dense_in; nb.action = v.sel_action;
+
+  for (int k = 0; k < s->p.num_sims; ++k) {
+    MZX_TRY_LAUNCH(launch<64>(sel, stream));
+    mv.dense = v.dense_in; mv.node = v.sel_parent; mv.to_arena = 0;
+    MZX_TRY_LAUNCH(launch<256>(mv, stream));
+    rc = run_program(net, net->prog_recurrent, nb, B, stream);
+    if (rc) return rc;
+    MZX_TRY_LAUNCH(launch<64>(eb, stream));
+    mv.dense = v.dense_out; mv.node = v.sel_leaf; mv.to_arena = 1;
+    MZX_TRY_LAUNCH(launch<256>(mv, stream));
+  }
+  return search_finish(s, io, d_arena, stream);
+}
+
+// Copies the trees out in canonical node order (parity tests, diagnose tooling).
+struct DumpOp {
+  TreeArena arena;
+  SearchParams p;
+  mzx_tree_dump d;
+  MZX_HD size_t size() const { return (size_t)p.num_trees; }
+  MZX_HD void operator()(size_t i) const {
+    const int b = (int)i, N = p.num_nodes, A = p.num_actions;
+    const TreeRef t = arena.tree(b);
+    const int nn = t.meta(TM_N_NODES);
+    if (d.d_n_nodes) d.d_n_nodes[b] = nn;
+    if (d.d_minmax) { d.d_minmax[b * 2] = t.mm_min(); d.d_minmax[b * 2 + 1] = t.mm_max(); }
+    for (int n = 0; n < N; ++n) {
+      const bool live = n < nn;
+      const int64_t o = (int64_t)b * N + n;
+      if (d.d_visit) d.d_visit[o] = live ? t.visit(n) : 0;
+      if (d.d_value_sum) d.d_value_sum[o] = live ? t.value_sum(n) : 0.0;
+      if (d.d_reward) d.d_reward[o] = live ? t.reward(n) : 0.0;
+      if (d.d_to_play) d.d_to_play[o] = live ? t.to_play(n) : -1;
+      if (d.d_parent) d.d_parent[o] = live ? t.parent(n) : -1;
+      for (int a = 0; a < A; ++a) {
+        if (d.d_child) d.d_child[o * A + a] = live ? t.child(n, a) : -1;
+        if (d.d_prior) d.d_prior[o * A + a] = live ? t.prior(n, a) : 0.0;
+      }
+    }
+  }
+};
+
+}  // namespace mzx

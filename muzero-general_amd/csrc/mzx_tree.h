@@ -1,0 +1,337 @@
+// mzx_tree.h -- per-tree MCTS arithmetic (select / expand / backpropagate) as
+// host+device inline functions over a struct-of-arrays tree.
+//
+// Replaces the per-node Python object graph of the reference:
+//   MCTS.run            /root/reference/self_play.py:260-361
+//   MCTS.select_child   self_play.py:363-378     MCTS.ucb_score   self_play.py:380-404
+//   MCTS.backpropagate  self_play.py:406-430     Node             self_play.py:433-476
+//   MinMaxStats         self_play.py:553-570
+//
+// Bit-exactness contract (DESIGN.md "Tree arithmetic"): every statistic is IEEE
+// binary64, evaluated in the reference's operation order with contraction OFF
+// (-ffp-contract=off); log/sqrt terms come from host-built tables so the device
+// only executes +,-,*,/ which are correctly rounded on both sides.
+//
+// A node is addressed by its CANONICAL INDEX: root = 0, the leaf expanded by
+// simulation k is k+1.  A child slot is (node, position in the node's action
+// list).  Statistics of a child live in the child NODE (reachable through
+// child[node][slot]); a slot with child < 0 has visit_count 0.
+//
+// The same functions are compiled (a) for gfx950 by hipcc and (b) for the host
+// by g++ in tests/hostcheck (test-only build used by the CPU test-suite; the
+// product never loads it).
+#pragma once
+#include <stdint.h>
+
+#include "mzx_platform.h"
+
+namespace mzx {
+
+enum TreeMeta {
+  TM_N_NODES = 0,
+  TM_MAX_DEPTH = 1,
+  TM_TAPE_POS = 2,
+  TM_FLAGS = 3,
+  TM_ROOT_N = 4,
+  TM_CUR_PARENT = 5,
+  TM_CUR_SLOT = 6,
+  TM_CUR_DEPTH = 7,
+  TM_CUR_TO_PLAY = 8,
+  TM_TIE_DRAWS = 9,
+  TM_SUM_DEPTH = 10,
+  TM_CUR_LEAF = 11,
+  TM_WORDS = 16
+};
+
+enum TreeFlags { TF_TAPE_OVERFLOW = 1, TF_NODE_OVERFLOW = 2 };
+
+// Search-wide constants (one copy, passed by value to kernels).
+struct SearchParams {
+  int32_t num_trees;    // B
+  int32_t num_sims;     // S
+  int32_t num_actions;  // A = len(config.action_space)
+  int32_t num_nodes;    // N = S + 1 node slots per tree
+  int32_t num_players;  // len(config.players), 1 or 2
+  int32_t hidden_size;  // Hf floats per node
+  int32_t support_size;
+  int32_t tape_words;   // raw MT19937 words available per tree for tie draws
+  double discount;
+  double exploration_fraction;
+  const double* pbc_table;   // [N+1]: log((n + pb_c_base + 1) / pb_c_base) + pb_c_init, n = parent visits
+  const double* sqrt_table;  // [N+1]: sqrt(n)
+};
+
+// Byte layout of one tree inside the arena (all offsets multiples of 8).
+struct TreeLayout {
+  int32_t N, A;
+  int64_t off_value_sum, off_q, off_reward, off_prior, off_mm;
+  int64_t off_visit, off_to_play, off_parent, off_parent_slot, off_child, off_root_actions, off_meta;
+  int64_t tree_bytes;
+
+  MZX_HD static inline int64_t align8(int64_t x) { return (x + 7) & ~int64_t(7); }
+
+  MZX_HD static inline TreeLayout make(int32_t N, int32_t A) {
+    TreeLayout L;
+    L.N = N;
+    L.A = A;
+    int64_t o = 0;
+    L.off_value_sum = o; o += int64_t(8) * N;
+    L.off_q = o;         o += int64_t(8) * N;
+    L.off_reward = o;    o += int64_t(8) * N;
+    L.off_prior = o;     o += int64_t(8) * N * A;
+    L.off_mm = o;        o += 16;
+    L.off_visit = o;     o += align8(int64_t(4) * N);
+    L.off_to_play = o;   o += align8(int64_t(4) * N);
+    L.off_parent = o;    o += align8(int64_t(4) * N);
+    L.off_parent_slot = o; o += align8(int64_t(4) * N);
+    L.off_child = o;     o += align8(int64_t(4) * N * A);
+    L.off_root_actions = o; o += align8(int64_t(4) * A);
+    L.off_meta = o;      o += int64_t(4) * TM_WORDS;
+    L.tree_bytes = align8(o);
+    return L;
+  }
+};
+
+// View of ONE tree in generic (global or host) memory.
+struct TreeRef {
+  char* base;
+  TreeLayout L;
+
+  MZX_HD inline double& value_sum(int n) const { return ((double*)(base + L.off_value_sum))[n]; }
+  MZX_HD inline double& q(int n) const { return ((double*)(base + L.off_q))[n]; }
+  MZX_HD inline double& reward(int n) const { return ((double*)(base + L.off_reward))[n]; }
+  MZX_HD inline double& prior(int n, int s) const { return ((double*)(base + L.off_prior))[n * L.A + s]; }
+  MZX_HD inline double& mm_min() const { return ((double*)(base + L.off_mm))[0]; }
+  MZX_HD inline double& mm_max() const { return ((double*)(base + L.off_mm))[1]; }
+  MZX_HD inline int32_t& visit(int n) const { return ((int32_t*)(base + L.off_visit))[n]; }
+  MZX_HD inline int32_t& to_play(int n) const { return ((int32_t*)(base + L.off_to_play))[n]; }
+  MZX_HD inline int32_t& parent(int n) const { return ((int32_t*)(base + L.off_parent))[n]; }
+  MZX_HD inline int32_t& parent_slot(int n) const { return ((int32_t*)(base + L.off_parent_slot))[n]; }
+  MZX_HD inline int32_t& child(int n, int s) const { return ((int32_t*)(base + L.off_child))[n * L.A + s]; }
+  MZX_HD inline int32_t& root_action(int s) const { return ((int32_t*)(base + L.off_root_actions))[s]; }
+  MZX_HD inline int32_t& meta(int k) const { return ((int32_t*)(base + L.off_meta))[k]; }
+};
+
+// ---------------------------------------------------------------------------
+// UCB score of one child slot -- self_play.py:380-404, same operation order.
+// `pbc` = log((N+base+1)/base)+init and `sq` = sqrt(N) for the PARENT's visit
+// count N come from the host tables.  The value term uses q(child) =
+// reward + discount * (+-value()), cached by backpropagate (same expression,
+// same operands => same bits as recomputing it here).
+template <class T>
+MZX_HD inline double ucb_score(const T& t, int node, int slot, double pbc, double sq, double mn, double mx) {
+  const int c = t.child(node, slot);
+  const int n = (c >= 0) ? t.visit(c) : 0;
+  double pb_c = pbc * (sq / (double)(n + 1));   // pb_c *= sqrt(N) / (n + 1)
+  double score = pb_c * t.prior(node, slot);     // prior_score
+  if (n > 0) {
+    double v = t.q(c);
+    if (mx > mn) v = (v - mn) / (mx - mn);        // MinMaxStats.normalize, :566-570
+    score = score + v;
+  }
+  return score;
+}
+
+// Masked-rejection draw in [0, n) from a tape of raw MT19937 words: exactly
+// numpy's legacy randint(0, n) / choice(list of n) (n >= 2; tests pin it).
+MZX_HD inline int tape_draw(const uint32_t* tape, int tape_words, int32_t& pos, int32_t& flags, int n) {
+  uint32_t rng = (uint32_t)(n - 1), mask = rng;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  for (;;) {
+    if (pos >= tape_words) { flags |= TF_TAPE_OVERFLOW; return 0; }
+    uint32_t w = tape[pos++] & mask;
+    if (w <= rng) return (int)w;
+  }
+}
+
+// One selection walk (the `while node.expanded()` loop, self_play.py:325-334):
+// descends from the root to the first unexpanded child slot, allocates the new
+// leaf's canonical index and records (parent, slot, depth, virtual_to_play).
+// Returns the parent node.
+template <class T>
+MZX_HD inline int tree_select(const T& t, const SearchParams& p, const uint32_t* tape) {
+  int node = 0, depth = 0, slot = 0;
+  int vtp = t.to_play(0);
+  const double mn = t.mm_min(), mx = t.mm_max();
+  int32_t tape_pos = t.meta(TM_TAPE_POS), flags = t.meta(TM_FLAGS), ties = t.meta(TM_TIE_DRAWS);
+  for (;;) {
+    ++depth;
+    const int nc = (node == 0) ? t.meta(TM_ROOT_N) : p.num_actions;
+    const int N = t.visit(node);
+    const double pbc = p.pbc_table[N], sq = p.sqrt_table[N];
+    double best = 0.0;
+    int nbest = 0, first = 0;
+    for (int s = 0; s < nc; ++s) {
+      const double sc = ucb_score(t, node, s, pbc, sq, mn, mx);
+      if (s == 0 || sc > best) { best = sc; nbest = 1; first = s; }
+      else if (sc == best) { ++nbest; }
+    }
+    slot = first;
+    if (nbest > 1) {  // numpy.random.choice(ties): k-th maximiser in slot order
+      ++ties;
+      int k = tape_draw(tape, p.tape_words, tape_pos, flags, nbest);
+      for (int s = first; s < nc; ++s) {
+        if (ucb_score(t, node, s, pbc, sq, mn, mx) == best) {
+          if (k == 0) { slot = s; break; }
+          --k;
+        }
+      }
+    }
+    vtp = (vtp + 1 < p.num_players) ? vtp + 1 : 0;  // players turn by turn, :331-334
+    const int nxt = t.child(node, slot);
+    if (nxt < 0) break;
+    node = nxt;
+  }
+  int leaf = t.meta(TM_N_NODES);
+  if (leaf >= p.num_nodes) { flags |= TF_NODE_OVERFLOW; leaf = p.num_nodes - 1; }
+  t.meta(TM_TAPE_POS) = tape_pos;
+  t.meta(TM_FLAGS) = flags;
+  t.meta(TM_TIE_DRAWS) = ties;
+  t.meta(TM_CUR_PARENT) = node;
+  t.meta(TM_CUR_SLOT) = slot;
+  t.meta(TM_CUR_DEPTH) = depth;
+  t.meta(TM_CUR_TO_PLAY) = vtp;
+  t.meta(TM_CUR_LEAF) = leaf;
+  return node;
+}
+
+// Node.expand (self_play.py:451-465) for the leaf chosen by tree_select, then
+// MCTS.backpropagate (self_play.py:406-430) walking parent links leaf -> root.
+// `priors` are the fp32 softmax probabilities widened to binary64.
+template <class T, class PriorFn>
+MZX_HD inline void tree_expand_backprop(const T& t, const SearchParams& p, double value, double reward,
+                                        PriorFn prior_of_slot) {
+  const int parent = t.meta(TM_CUR_PARENT), slot = t.meta(TM_CUR_SLOT);
+  const int leaf = t.meta(TM_CUR_LEAF), to_play = t.meta(TM_CUR_TO_PLAY), depth = t.meta(TM_CUR_DEPTH);
+  t.child(parent, slot) = leaf;
+  t.parent(leaf) = parent;
+  t.parent_slot(leaf) = slot;
+  t.to_play(leaf) = to_play;
+  t.reward(leaf) = reward;
+  t.visit(leaf) = 0;
+  t.value_sum(leaf) = 0.0;
+  t.q(leaf) = 0.0;
+  for (int s = 0; s < p.num_actions; ++s) {
+    t.prior(leaf, s) = prior_of_slot(s);
+    t.child(leaf, s) = -1;
+  }
+  t.meta(TM_N_NODES) = leaf + 1;
+  if (depth > t.meta(TM_MAX_DEPTH)) t.meta(TM_MAX_DEPTH) = depth;
+  t.meta(TM_SUM_DEPTH) += depth;
+
+  double mn = t.mm_min(), mx = t.mm_max();
+  const double disc = p.discount;
+  if (p.num_players == 1) {
+    for (int n = leaf; n >= 0; n = t.parent(n)) {
+      const double vs = t.value_sum(n) + value;
+      const int vc = t.visit(n) + 1;
+      t.value_sum(n) = vs;
+      t.visit(n) = vc;
+      const double r = t.reward(n);
+      const double qv = r + disc * (vs / (double)vc);
+      t.q(n) = qv;
+      if (qv > mx) mx = qv;
+      if (qv < mn) mn = qv;
+      value = r + disc * value;
+    }
+  } else {
+    for (int n = leaf; n >= 0; n = t.parent(n)) {
+      const bool same = (t.to_play(n) == to_play);
+      const double vs = t.value_sum(n) + (same ? value : -value);
+      const int vc = t.visit(n) + 1;
+      t.value_sum(n) = vs;
+      t.visit(n) = vc;
+      const double r = t.reward(n);
+      const double qv = r + disc * (-(vs / (double)vc));
+      t.q(n) = qv;
+      if (qv > mx) mx = qv;
+      if (qv < mn) mn = qv;
+      value = (same ? -r : r) + disc * value;
+    }
+  }
+  t.mm_min() = mn;
+  t.mm_max() = mx;
+}
+
+// Root creation: Node(0) + root.expand(legal_actions, ...) + add_exploration_noise
+// (self_play.py:276-314, :467-476).  `legal` is the game's legal_actions() list
+// in ITS order (slot i = legal[i]; the reference's children dict keeps that
+// order), padded with -1 up to num_actions.  `noise` (slot order) may be null.
+template <class T, class PriorFn>
+MZX_HD inline void tree_init_root(const T& t, const SearchParams& p, const int32_t* legal, int to_play,
+                                  double root_reward, PriorFn prior_of_slot, const double* noise) {
+  for (int k = 0; k < TM_WORDS; ++k) t.meta(k) = 0;
+  t.mm_min() = MZX_INF;
+  t.mm_max() = -MZX_INF;
+  int nroot = 0;
+  while (nroot < p.num_actions && legal[nroot] >= 0) { t.root_action(nroot) = legal[nroot]; ++nroot; }
+  for (int s = nroot; s < p.num_actions; ++s) t.root_action(s) = -1;
+  t.meta(TM_ROOT_N) = nroot;
+  t.meta(TM_N_NODES) = 1;
+  t.visit(0) = 0;
+  t.value_sum(0) = 0.0;
+  t.q(0) = 0.0;
+  t.reward(0) = root_reward;
+  t.to_play(0) = to_play;
+  t.parent(0) = -1;
+  t.parent_slot(0) = -1;
+  const double frac = p.exploration_fraction;
+  for (int s = 0; s < p.num_actions; ++s) {
+    double pr = 0.0;
+    if (s < nroot) {
+      pr = prior_of_slot(s);
+      if (noise) pr = pr * (1.0 - frac) + noise[s] * frac;  // :476
+    }
+    t.prior(0, s) = pr;
+    t.child(0, s) = -1;
+  }
+}
+
+// fp32 helpers shared by the kernels that turn network heads into tree inputs.
+
+// Inverse of the value scaling h(x) (models.py:660-665), fp32, same op order as the
+// reference's tensor expression.  NOTE x = 0 gives sign(0) * (tiny negative) = -0.0f:
+// the reference's root reward is NEGATIVE zero (log one-hot head, models.py:176-183),
+// and the root is initialised with exactly this value to keep zero signs identical.
+MZX_HD inline float support_inverse_transform(float x) {
+  float t = fabsf(x) + 1.0f;
+  t = t + 0.001f;
+  t = 0.004f * t;
+  t = 1.0f + t;
+  t = sqrtf(t);
+  t = (t - 1.0f) / 0.002f;
+  t = t * t - 1.0f;
+  const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+  return sgn * t;
+}
+
+// models.support_to_scalar (models.py:645-666) for one row of 2*support+1 logits.
+MZX_HD inline float support_to_scalar(const float* logits, int support_size) {
+  const int F = 2 * support_size + 1;
+  float m = logits[0];
+  for (int i = 1; i < F; ++i) m = fmaxf(m, logits[i]);
+  float den = 0.f, num = 0.f;
+  for (int i = 0; i < F; ++i) {
+    const float e = mzx_expf(logits[i] - m);
+    den += e;
+  }
+  for (int i = 0; i < F; ++i) {
+    const float pr = mzx_expf(logits[i] - m) / den;
+    num += (float)(i - support_size) * pr;
+  }
+  return support_inverse_transform(num);
+}
+
+// fp32 softmax statistics over a subset of logits (Node.expand, self_play.py:460-462).
+struct SoftmaxStats { float m, den; };
+template <class LogitFn>
+MZX_HD inline SoftmaxStats softmax_stats(int n, LogitFn logit) {
+  SoftmaxStats s;
+  s.m = logit(0);
+  for (int i = 1; i < n; ++i) s.m = fmaxf(s.m, logit(i));
+  s.den = 0.f;
+  for (int i = 0; i < n; ++i) s.den += mzx_expf(logit(i) - s.m);
+  return s;
+}
+
+}  // namespace mzx

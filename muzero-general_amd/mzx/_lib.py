@@ -1,0 +1,162 @@
+"""
+ctypes binding of the C ABI declared in ``include/mzx.h`` (libmzx.so).
+
+This is the only place the package touches native code.  The product backend
+is the gfx950 HIP library next to this file; it is the ONLY backend the package
+ever constructs: if ``libmzx.so`` is missing, or no GPU is visible when a compute
+entry point is reached, an exception is raised -- there is no CPU fallback.
+(The CPU test-suite builds a serial test double of the same ABI under
+``tests/hostcheck`` and injects it explicitly; nothing in here knows about it.)
+"""
+import ctypes
+import os
+
+import torch
+
+MZX_MAX_LAYERS = 8
+ABI_VERSION = 1
+
+c_i32, c_i64, c_f64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+
+
+class NetConfig(ctypes.Structure):
+    _L = c_i32 * MZX_MAX_LAYERS
+    _fields_ = [
+        ("network", c_i32), ("observation_shape", c_i32 * 3), ("stacked_observations", c_i32),
+        ("action_space_size", c_i32), ("support_size", c_i32), ("encoding_size", c_i32),
+        ("n_fc_representation_layers", c_i32), ("fc_representation_layers", _L),
+        ("n_fc_dynamics_layers", c_i32), ("fc_dynamics_layers", _L),
+        ("n_fc_reward_layers", c_i32), ("fc_reward_layers", _L),
+        ("n_fc_value_layers", c_i32), ("fc_value_layers", _L),
+        ("n_fc_policy_layers", c_i32), ("fc_policy_layers", _L),
+        ("downsample", c_i32), ("blocks", c_i32), ("channels", c_i32),
+        ("reduced_channels_reward", c_i32), ("reduced_channels_value", c_i32), ("reduced_channels_policy", c_i32),
+        ("n_resnet_fc_reward_layers", c_i32), ("resnet_fc_reward_layers", _L),
+        ("n_resnet_fc_value_layers", c_i32), ("resnet_fc_value_layers", _L),
+        ("n_resnet_fc_policy_layers", c_i32), ("resnet_fc_policy_layers", _L),
+    ]
+
+
+class SearchConfig(ctypes.Structure):
+    _fields_ = [
+        ("num_trees", c_i32), ("num_simulations", c_i32), ("action_space_size", c_i32), ("num_players", c_i32),
+        ("support_size", c_i32), ("tape_words", c_i32), ("discount", c_f64), ("root_exploration_fraction", c_f64),
+        ("h_pb_c_table", ctypes.POINTER(c_f64)), ("h_sqrt_table", ctypes.POINTER(c_f64)),
+    ]
+
+
+class SearchIO(ctypes.Structure):
+    _fields_ = [
+        ("d_observation", c_vp), ("d_legal_actions", c_vp), ("d_to_play", c_vp), ("d_noise", c_vp), ("d_tape", c_vp),
+        ("d_visit_counts", c_vp), ("d_root_value", c_vp), ("d_root_predicted_value", c_vp), ("d_info", c_vp),
+    ]
+
+
+class TreeDump(ctypes.Structure):
+    _fields_ = [
+        ("d_visit", c_vp), ("d_value_sum", c_vp), ("d_reward", c_vp), ("d_to_play", c_vp), ("d_parent", c_vp),
+        ("d_child", c_vp), ("d_prior", c_vp), ("d_minmax", c_vp), ("d_n_nodes", c_vp),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/mzx.h declares
+PROTOTYPES = {
+    "mzx_abi_version": (ctypes.c_int, []),
+    "mzx_last_error": (ctypes.c_char_p, []),
+    "mzx_is_device_build": (ctypes.c_int, []),
+    "mzx_net_create": (ctypes.c_int, [ctypes.POINTER(NetConfig), ctypes.POINTER(c_vp)]),
+    "mzx_net_destroy": (None, [c_vp]),
+    "mzx_net_num_tensors": (c_i32, [c_vp]),
+    "mzx_net_num_params": (c_i64, [c_vp]),
+    "mzx_net_tensor_info": (ctypes.c_int, [c_vp, c_i32, ctypes.c_char_p, c_i32, ctypes.POINTER(c_i64),
+                                           ctypes.POINTER(c_i64), ctypes.POINTER(c_i32 * 4)]),
+    "mzx_net_hidden_size": (c_i64, [c_vp]),
+    "mzx_net_input_size": (c_i64, [c_vp]),
+    "mzx_net_derived_floats": (c_i64, [c_vp]),
+    "mzx_net_workspace_floats": (c_i64, [c_vp, c_i32]),
+    "mzx_net_set_weights": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "mzx_net_initial_inference": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "mzx_net_recurrent_inference": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "mzx_search_create": (ctypes.c_int, [ctypes.POINTER(SearchConfig), c_vp, ctypes.POINTER(c_vp)]),
+    "mzx_search_destroy": (None, [c_vp]),
+    "mzx_search_arena_bytes": (c_i64, [c_vp]),
+    "mzx_search_run": (ctypes.c_int, [c_vp, ctypes.POINTER(SearchIO), c_vp, c_i64, c_vp]),
+    "mzx_search_fused_supported": (ctypes.c_int, [c_vp]),
+    "mzx_search_set_mode": (ctypes.c_int, [c_vp, c_i32]),
+    "mzx_search_lockstep_begin": (ctypes.c_int, [c_vp, ctypes.POINTER(SearchIO), c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "mzx_search_lockstep_select": (ctypes.c_int, [c_vp, ctypes.POINTER(SearchIO), c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mzx_search_lockstep_apply": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mzx_search_finish": (ctypes.c_int, [c_vp, ctypes.POINTER(SearchIO), c_vp, c_vp]),
+    "mzx_search_dump": (ctypes.c_int, [c_vp, ctypes.POINTER(TreeDump), c_vp, c_vp]),
+}
+
+
+class MzxError(RuntimeError):
+    pass
+
+
+class Library:
+    """A loaded shared object exporting the mzx C ABI."""
+
+    def __init__(self, path):
+        if not os.path.isfile(path):
+            raise MzxError(
+                f"native library not found: {path}. Build it with `python __graft_entry__.py` "
+                "(hipcc --offload-arch=gfx950); the engine has no non-native path."
+            )
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
+        for name, (restype, argtypes) in PROTOTYPES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+            setattr(self, name, fn)
+        if self.mzx_abi_version() != ABI_VERSION:
+            raise MzxError(f"{path}: ABI version {self.mzx_abi_version()} != {ABI_VERSION}")
+
+    def check(self, rc):
+        if rc != 0:
+            raise MzxError(f"mzx error {rc}: {self.mzx_last_error().decode()}")
+
+
+class Backend:
+    """Library + the torch device its buffers live on + the stream calls are enqueued on."""
+
+    def __init__(self, lib, device):
+        self.lib = lib
+        self.device = torch.device(device)
+
+    def stream(self):
+        if self.device.type == "cuda":
+            return c_vp(torch.cuda.current_stream(self.device).cuda_stream)
+        return c_vp(0)
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    @staticmethod
+    def ptr(t):
+        return c_vp(0) if t is None else c_vp(t.data_ptr())
+
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmzx.so")
+_default = None
+
+
+def default_backend():
+    """The product backend: libmzx.so on the current CUDA(HIP) device.  Raises without a GPU."""
+    global _default
+    if _default is None:
+        lib = Library(LIB_PATH)
+        if not lib.mzx_is_device_build():
+            raise MzxError(f"{LIB_PATH} is not a device build")
+        if not torch.cuda.is_available():
+            raise MzxError(
+                "mzx needs an AMD GPU (torch.cuda.is_available() is False): the self-play engine "
+                "has no CPU execution path."
+            )
+        _default = Backend(lib, torch.device("cuda", torch.cuda.current_device()))
+    return _default

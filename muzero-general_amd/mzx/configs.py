@@ -47,8 +47,18 @@ class HotPathConfig:
         self.ratio = None
         self.__dict__.update(kw)
 
+    temperature_schedule = "fractions"
+
     def visit_softmax_temperature_fn(self, trained_steps):
-        # games/cartpole.py:115-128 (same schedule in tictactoe/connect4/breakout)
+        if self.temperature_schedule == "constant":  # games/tictactoe.py:112-122, games/connect4.py:112-122
+            return 1
+        if self.temperature_schedule == "breakout":  # games/breakout.py:117-133
+            if trained_steps < 500e3:
+                return 1.0
+            elif trained_steps < 750e3:
+                return 0.5
+            return 0.25
+        # games/cartpole.py:115-128
         if trained_steps < 0.5 * self.training_steps:
             return 1.0
         elif trained_steps < 0.75 * self.training_steps:
@@ -78,6 +88,7 @@ def tictactoe(**kw):
         reduced_channels_reward=16, reduced_channels_value=16, reduced_channels_policy=16,
         resnet_fc_reward_layers=[8], resnet_fc_value_layers=[8], resnet_fc_policy_layers=[8],
         encoding_size=32, fc_value_layers=[], fc_policy_layers=[], training_steps=1000000,
+        temperature_schedule="constant",
     )
     base.update(kw)
     return HotPathConfig(**base)
@@ -93,6 +104,7 @@ def connect4(**kw):
         resnet_fc_reward_layers=[64], resnet_fc_value_layers=[64], resnet_fc_policy_layers=[64],
         encoding_size=32, fc_dynamics_layers=[64], fc_reward_layers=[64],
         fc_value_layers=[], fc_policy_layers=[], training_steps=100000,
+        temperature_schedule="constant",
     )
     base.update(kw)
     return HotPathConfig(**base)
@@ -107,6 +119,7 @@ def breakout(**kw):
         reduced_channels_reward=4, reduced_channels_value=4, reduced_channels_policy=4,
         resnet_fc_reward_layers=[16], resnet_fc_value_layers=[16], resnet_fc_policy_layers=[16],
         encoding_size=10, fc_value_layers=[], fc_policy_layers=[], training_steps=int(1000e3),
+        temperature_schedule="breakout",
     )
     base.update(kw)
     return HotPathConfig(**base)

@@ -1,0 +1,272 @@
+"""
+Host-side mirror of the reference's network surface for the self-play path.
+
+Same names, arguments and return conventions as /root/reference/models.py:
+  MuZeroNetwork(config)                factory, models.py:7-41
+  net.initial_inference(observation)   models.py:172-190 / :601-618
+  net.recurrent_inference(state, act)  models.py:192-195 / :620-623
+  net.get_weights() / set_weights()    models.py:69-73 (reference state_dict keys,
+                                       including DataParallel's ".module." infix)
+  dict_to_cpu, support_to_scalar       models.py:44-53, :645-666
+All arithmetic runs in the gfx950 kernels behind include/mzx.h; this module only
+owns device buffers (torch tensors) and the flat weight buffer that RCCL
+broadcasts.  Training-only pieces (scalar_to_support, autograd) are out of scope.
+"""
+import collections
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+
+def dict_to_cpu(dictionary):
+    """models.py:44-53"""
+    cpu_dict = {}
+    for key, value in dictionary.items():
+        if isinstance(value, torch.Tensor):
+            cpu_dict[key] = value.cpu()
+        elif isinstance(value, dict):
+            cpu_dict[key] = dict_to_cpu(value)
+        else:
+            cpu_dict[key] = value
+    return cpu_dict
+
+
+def support_to_scalar(logits, support_size):
+    """models.py:645-666 (host/diagnostic use; the search decodes on the device)."""
+    probabilities = torch.softmax(logits, dim=1)
+    support = torch.arange(-support_size, support_size + 1, device=logits.device).float().expand(probabilities.shape)
+    x = torch.sum(support * probabilities, dim=1, keepdim=True)
+    return torch.sign(x) * (((torch.sqrt(1 + 4 * 0.001 * (torch.abs(x) + 1 + 0.001)) - 1) / (2 * 0.001)) ** 2 - 1)
+
+
+def _layers(values):
+    values = list(values)
+    if len(values) > _lib.MZX_MAX_LAYERS:
+        raise NotImplementedError(f"at most {_lib.MZX_MAX_LAYERS} hidden layers per MLP are supported")
+    arr = (ctypes.c_int32 * _lib.MZX_MAX_LAYERS)(*values)
+    return len(values), arr
+
+
+def net_config_from(config):
+    """MuZeroConfig attributes read by the factory (models.py:7-41) -> mzx_net_config."""
+    c = _lib.NetConfig()
+    if config.network == "fullyconnected":
+        c.network = 0
+    elif config.network == "resnet":
+        c.network = 1
+    else:
+        raise NotImplementedError('The network parameter should be "fullyconnected" or "resnet".')
+    c.observation_shape = (ctypes.c_int32 * 3)(*[int(v) for v in config.observation_shape])
+    c.stacked_observations = int(config.stacked_observations)
+    c.action_space_size = len(config.action_space)
+    c.support_size = int(config.support_size)
+    c.encoding_size = int(config.encoding_size)
+    for name in ("fc_representation_layers", "fc_dynamics_layers", "fc_reward_layers", "fc_value_layers",
+                 "fc_policy_layers", "resnet_fc_reward_layers", "resnet_fc_value_layers", "resnet_fc_policy_layers"):
+        n, arr = _layers(getattr(config, name))
+        setattr(c, "n_" + name, n)
+        setattr(c, name, arr)
+    if config.downsample in (False, None, 0):
+        c.downsample = 0
+    elif config.downsample == "resnet":
+        c.downsample = 1
+    elif config.downsample == "CNN":
+        raise NotImplementedError('downsample="CNN" is outside the accelerated path (DESIGN.md, out of scope)')
+    else:
+        raise NotImplementedError('downsample should be "resnet" or "CNN".')  # models.py:327
+    c.blocks = int(config.blocks)
+    c.channels = int(config.channels)
+    c.reduced_channels_reward = int(config.reduced_channels_reward)
+    c.reduced_channels_value = int(config.reduced_channels_value)
+    c.reduced_channels_policy = int(config.reduced_channels_policy)
+    return c
+
+
+class MuZeroNetwork:
+    """models.py:7-41: ``MuZeroNetwork(config)`` returns the network object."""
+
+    def __new__(cls, config, _backend=None):
+        return HipNetwork(config, _backend)
+
+
+class HipNetwork:
+    """The reference's AbstractNetwork surface (models.py:56-73) over the HIP kernels."""
+
+    def __init__(self, config, backend=None):
+        self.backend = backend if backend is not None else _lib.default_backend()
+        lib = self.backend.lib
+        self.action_space_size = len(config.action_space)
+        self.full_support_size = 2 * config.support_size + 1
+        self.support_size = config.support_size
+        self._cfg = net_config_from(config)
+        handle = ctypes.c_void_p()
+        lib.check(lib.mzx_net_create(ctypes.byref(self._cfg), ctypes.byref(handle)))
+        self.handle = handle
+        self.hidden_size = lib.mzx_net_hidden_size(handle)
+        self.input_size = lib.mzx_net_input_size(handle)
+        self.num_params = lib.mzx_net_num_params(handle)
+        self._tensors = []  # (key, offset, numel, shape)
+        name = ctypes.create_string_buffer(256)
+        off, numel, dims = ctypes.c_int64(), ctypes.c_int64(), (ctypes.c_int32 * 4)()
+        for i in range(lib.mzx_net_num_tensors(handle)):
+            lib.check(lib.mzx_net_tensor_info(handle, i, name, 256, ctypes.byref(off), ctypes.byref(numel),
+                                              ctypes.byref(dims)))
+            shape = tuple(d for d in dims if d > 0)
+            self._tensors.append((name.value.decode(), off.value, numel.value, shape))
+        if config.network == "resnet":
+            c_in = self._cfg.observation_shape[0] * (config.stacked_observations + 1) + config.stacked_observations
+            self.input_shape = (c_in, self._cfg.observation_shape[1], self._cfg.observation_shape[2])
+            hw = self.hidden_size // config.channels
+            h = (math.ceil(config.observation_shape[1] / 16) if config.downsample else config.observation_shape[1])
+            self.hidden_shape = (config.channels, h, hw // h)
+        else:
+            self.input_shape = (self.input_size,)
+            self.hidden_shape = (self.hidden_size,)
+        self._flat = self.backend.zeros((self.num_params,), torch.float32)
+        self._derived = self.backend.zeros((lib.mzx_net_derived_floats(handle),), torch.float32)
+        self._workspace = None
+        self._ws_batch = 0
+        self._num_batches_tracked = {}
+        self.set_weights(self._initial_weights())
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.backend.lib.mzx_net_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- torch.nn.Module-flavoured plumbing the reference callers use ----
+    def to(self, device):
+        """self_play.py:28 -- the engine only runs on the GPU it was created on."""
+        device = torch.device(device)
+        if device.type != self.backend.device.type:
+            raise _lib.MzxError(
+                f"mzx networks live on {self.backend.device}; .to({device}) is not supported "
+                "(set config.selfplay_on_gpu = True)"
+            )
+        return self
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        yield self._flat  # self_play.py:284 only reads next(model.parameters()).device
+
+    def state_dict(self):
+        out = collections.OrderedDict()
+        flat = self._flat
+        for key, off, numel, shape in self._tensors:
+            out[key] = flat[off:off + numel].view(shape)
+            if key.endswith(".running_var"):
+                nbt = key[: -len("running_var")] + "num_batches_tracked"
+                out[nbt] = self._num_batches_tracked.get(nbt, torch.zeros((), dtype=torch.int64))
+        return out
+
+    def get_weights(self):
+        """models.py:69-70"""
+        return dict_to_cpu(self.state_dict())
+
+    def flat_weights(self):
+        """The contiguous fp32 buffer holding every float tensor of the state_dict (RCCL payload)."""
+        return self._flat
+
+    def set_weights(self, weights):
+        """models.py:72-73 -- strict load of a reference-format state_dict."""
+        expected = [k for k, *_ in self._tensors]
+        missing = [k for k in expected if k not in weights]
+        extra = [k for k in weights if k not in set(expected) and not k.endswith("num_batches_tracked")]
+        if missing or extra:
+            raise RuntimeError(f"Error(s) in loading state_dict: missing keys {missing[:4]}..., unexpected keys {extra[:4]}...")
+        host = torch.empty(self.num_params, dtype=torch.float32)
+        for key, off, numel, shape in self._tensors:
+            t = weights[key]
+            if tuple(t.shape) != shape:
+                raise RuntimeError(f"size mismatch for {key}: {tuple(t.shape)} vs {shape}")
+            host[off:off + numel] = t.detach().to("cpu", torch.float32).reshape(-1)
+        for k, v in weights.items():
+            if k.endswith("num_batches_tracked"):
+                self._num_batches_tracked[k] = torch.as_tensor(v).clone().cpu()
+        self._flat.copy_(host)
+        self.refresh_derived()
+
+    def refresh_derived(self):
+        """Re-derive folded BatchNorm terms after the flat buffer changed in place (e.g. RCCL broadcast)."""
+        lib = self.backend.lib
+        lib.check(lib.mzx_net_set_weights(self.handle, self.backend.ptr(self._flat), self.num_params,
+                                          self.backend.ptr(self._derived), self._derived.numel(),
+                                          self.backend.stream()))
+
+    def _initial_weights(self):
+        """torch.nn default initialisation of the same layers (Linear/Conv2d kaiming-uniform, BatchNorm identity)."""
+        sd = collections.OrderedDict()
+        bounds = {}
+        for key, off, numel, shape in self._tensors:
+            leaf = key.rsplit(".", 1)[-1]
+            if leaf == "weight" and len(shape) >= 2:
+                fan_in = int(math.prod(shape[1:]))
+                bound = 1.0 / math.sqrt(fan_in)
+                bounds[key[: -len("weight")]] = bound
+                sd[key] = torch.empty(shape).uniform_(-bound, bound)
+            elif leaf == "weight":
+                sd[key] = torch.ones(shape)
+            elif leaf == "bias":
+                prefix = key[: -len("bias")]
+                if prefix in bounds:
+                    sd[key] = torch.empty(shape).uniform_(-bounds[prefix], bounds[prefix])
+                else:
+                    sd[key] = torch.zeros(shape)
+            elif leaf == "running_mean":
+                sd[key] = torch.zeros(shape)
+            elif leaf == "running_var":
+                sd[key] = torch.ones(shape)
+            else:
+                raise AssertionError(key)
+        return sd
+
+    # ---- inference ----
+    def _ws(self, batch):
+        if self._workspace is None or self._ws_batch < batch:
+            n = self.backend.lib.mzx_net_workspace_floats(self.handle, batch)
+            self._workspace = self.backend.empty((max(n, 1),), torch.float32)
+            self._ws_batch = batch
+        return self._workspace
+
+    def _prepare(self, x, per_sample):
+        x = x.to(self.backend.device, torch.float32)
+        if x.dim() < 2 or x[0].numel() != per_sample:
+            raise ValueError(f"expected [batch, ...] with {per_sample} values per sample, got {tuple(x.shape)}")
+        return x.contiguous()
+
+    def initial_inference(self, observation):
+        b, lib = self.backend, self.backend.lib
+        obs = self._prepare(observation, self.input_size)
+        n = obs.shape[0]
+        value = b.empty((n, self.full_support_size), torch.float32)
+        reward = b.empty((n, self.full_support_size), torch.float32)
+        policy = b.empty((n, self.action_space_size), torch.float32)
+        hidden = b.empty((n,) + self.hidden_shape, torch.float32)
+        ws = self._ws(n)
+        lib.check(lib.mzx_net_initial_inference(self.handle, b.ptr(obs), n, b.ptr(value), b.ptr(reward), b.ptr(policy),
+                                                b.ptr(hidden), b.ptr(ws), ws.numel(), b.stream()))
+        return value, reward, policy, hidden
+
+    def recurrent_inference(self, encoded_state, action):
+        b, lib = self.backend, self.backend.lib
+        state = self._prepare(encoded_state, self.hidden_size)
+        n = state.shape[0]
+        act = action.to(b.device).reshape(-1).to(torch.int32).contiguous()
+        if act.numel() != n:
+            raise ValueError("action must hold one action per sample")
+        value = b.empty((n, self.full_support_size), torch.float32)
+        reward = b.empty((n, self.full_support_size), torch.float32)
+        policy = b.empty((n, self.action_space_size), torch.float32)
+        hidden = b.empty((n,) + self.hidden_shape, torch.float32)
+        ws = self._ws(n)
+        lib.check(lib.mzx_net_recurrent_inference(self.handle, b.ptr(state), b.ptr(act), n, b.ptr(value), b.ptr(reward),
+                                                  b.ptr(policy), b.ptr(hidden), b.ptr(ws), ws.numel(), b.stream()))
+        return value, reward, policy, hidden

@@ -1,0 +1,508 @@
+"""
+Host-side mirror of the reference's self-play surface, driving the batched HIP search.
+
+Same names / arguments / error behaviour as /root/reference/self_play.py:
+  SelfPlay(initial_checkpoint, Game, config, seed)      :11-29
+  SelfPlay.continuous_self_play(shared_storage, replay_buffer, test_mode)  :31-108
+  SelfPlay.play_game(temperature, temperature_threshold, render, opponent, muzero_player)  :110-183
+  SelfPlay.select_action(node, temperature)              :222-245
+  MCTS(config).run(model, observation, legal_actions, to_play, add_exploration_noise)  :260-361
+  Node / GameHistory / MinMaxStats                        :433-570
+plus the batched forms the reference lacks ("Batch MCTS" is an open TODO in its
+README): ``BatchedMCTS`` searches B roots per call and ``SelfPlay(..., num_games=B)``
+plays B games in lock-step on one GPU (the game shard of this process).
+
+Division of labour: Python owns the plugin ``Game`` objects, the per-game numpy
+``RandomState`` streams and the ``GameHistory`` records; everything between "stacked
+observation" and "root visit counts" runs on the device behind include/mzx.h.
+
+Random streams.  The reference draws from the process-global numpy stream in
+this order per move: Dirichlet noise (:473), one ``choice`` per tied argmax
+(:371), the action sample (:229-243).  A batched engine needs one stream per
+game: game i of a shard uses ``RandomState(seed + i)`` -- the stream the
+reference's i-th actor has (muzero.py:185) -- and with ``num_games == 1`` the
+process-global stream itself, so a single game reproduces the reference draw for
+draw.  Tie draws happen on the device from a tape of the stream's next raw
+words (numpy's masked rejection, exactly); the host then advances the stream by
+the number of words the device consumed.
+"""
+import ctypes
+import math
+import time
+
+import numpy
+import torch
+
+from . import _lib, models
+
+TAPE_WORDS = 64
+
+
+class Node:
+    """self_play.py:433-476 -- read-only view of a searched node (built from the device tree)."""
+
+    def __init__(self, prior):
+        self.visit_count = 0
+        self.to_play = -1
+        self.prior = prior
+        self.value_sum = 0
+        self.children = {}
+        self.hidden_state = None
+        self.reward = 0
+
+    def expanded(self):
+        return len(self.children) > 0
+
+    def value(self):
+        if self.visit_count == 0:
+            return 0
+        return self.value_sum / self.visit_count
+
+
+class MinMaxStats:
+    """self_play.py:553-570 (the device keeps one per tree; this mirrors the class for tooling)."""
+
+    def __init__(self):
+        self.maximum = -float("inf")
+        self.minimum = float("inf")
+
+    def update(self, value):
+        self.maximum = max(self.maximum, value)
+        self.minimum = min(self.minimum, value)
+
+    def normalize(self, value):
+        if self.maximum > self.minimum:
+            return (value - self.minimum) / (self.maximum - self.minimum)
+        return value
+
+
+class GameHistory:
+    """self_play.py:479-550 -- field-identical record consumed by replay_buffer.py:33-65."""
+
+    def __init__(self):
+        self.observation_history = []
+        self.action_history = []
+        self.reward_history = []
+        self.to_play_history = []
+        self.child_visits = []
+        self.root_values = []
+        self.reanalysed_predicted_root_values = None
+        # For PER
+        self.priorities = None
+        self.game_priority = None
+
+    def store_search_statistics(self, root, action_space):
+        # self_play.py:496-511
+        if root is not None:
+            total = sum(child.visit_count for child in root.children.values())
+            self.child_visits.append(
+                [root.children[a].visit_count / total if a in root.children else 0 for a in action_space]
+            )
+            self.root_values.append(root.value())
+        else:
+            self.root_values.append(None)
+
+    def get_stacked_observations(self, index, num_stacked_observations, action_space_size):
+        # self_play.py:513-550
+        index = index % len(self.observation_history)
+        current = self.observation_history[index]
+        pieces = [current.copy() if hasattr(current, "copy") else numpy.array(current)]
+        first_plane = pieces[0][0]
+        for past in range(index - 1, index - 1 - num_stacked_observations, -1):
+            if past >= 0:
+                pieces.append(self.observation_history[past])
+                pieces.append([numpy.ones_like(first_plane) * self.action_history[past + 1] / action_space_size])
+            else:
+                pieces.append(numpy.zeros_like(current))
+                pieces.append([numpy.zeros_like(first_plane)])
+        if len(pieces) == 1:
+            return pieces[0]
+        return numpy.concatenate(pieces)
+
+
+class SearchResult:
+    """Per-root outputs of one batched search (host numpy arrays)."""
+
+    def __init__(self, visit_counts, root_values, root_predicted_values, info, legal_actions):
+        self.visit_counts = visit_counts                  # [B][A] int32, by action
+        self.root_values = root_values                    # [B] float64, root.value()
+        self.root_predicted_values = root_predicted_values  # [B] float64
+        self.max_tree_depth = info[:, 0]
+        self.flags = info[:, 1]
+        self.tape_used = info[:, 2]
+        self.sum_depth = info[:, 3]
+        self.legal_actions = legal_actions
+
+    def root(self, i):
+        """A ``Node`` whose children carry the visit counts of root i (self_play.py:222-245, :496-511)."""
+        node = Node(0)
+        total = int(self.visit_counts[i].sum())
+        node.visit_count = total
+        node.value_sum = float(self.root_values[i]) * total
+        for a in self.legal_actions[i]:
+            child = Node(0)
+            child.visit_count = int(self.visit_counts[i][a])
+            node.children[a] = child
+        node._root_value = float(self.root_values[i])
+        node.value = lambda: node._root_value if total else 0
+        return node
+
+
+def _validate(config):
+    A = len(config.action_space)
+    if list(config.action_space) != list(range(A)):
+        raise NotImplementedError("config.action_space must be list(range(n)) (the game files only edit its length)")
+    P = len(config.players)
+    if list(config.players) != list(range(P)):
+        raise NotImplementedError("config.players must be list(range(n))")
+    if P > 2:
+        raise NotImplementedError("More than two player mode not implemented.")  # self_play.py:429-430
+
+
+class BatchedMCTS:
+    """
+    MCTS.run (self_play.py:260-361) for B roots at once.  One instance owns the
+    device arena for up to ``max_trees`` roots of a given network.
+    """
+
+    def __init__(self, config, model, max_trees, num_simulations=None, mode=None):
+        _validate(config)
+        self.config = config
+        self.model = model
+        self.backend = model.backend
+        self.max_trees = int(max_trees)
+        self.num_simulations = int(config.num_simulations if num_simulations is None else num_simulations)
+        self.A = len(config.action_space)
+        n = self.num_simulations + 1
+        # host tables with Python's own math (the reference's exact values, self_play.py:384-391)
+        self._pbc = (ctypes.c_double * n)(
+            *[math.log((k + config.pb_c_base + 1) / config.pb_c_base) + config.pb_c_init for k in range(n)]
+        )
+        self._sqrt = (ctypes.c_double * n)(*[math.sqrt(k) for k in range(n)])
+        self._handles = {}
+        self._arena = None
+        self._mode = mode
+        self._buffers = {}
+
+    def __del__(self):
+        try:
+            for h in self._handles.values():
+                self.backend.lib.mzx_search_destroy(h)
+            self._handles = {}
+        except Exception:
+            pass
+
+    def handle(self, num_trees):
+        if num_trees not in self._handles:
+            lib = self.backend.lib
+            c = _lib.SearchConfig()
+            c.num_trees = num_trees
+            c.num_simulations = self.num_simulations
+            c.action_space_size = self.A
+            c.num_players = len(self.config.players)
+            c.support_size = self.config.support_size
+            c.tape_words = TAPE_WORDS
+            c.discount = float(self.config.discount)
+            c.root_exploration_fraction = float(self.config.root_exploration_fraction)
+            c.h_pb_c_table = ctypes.cast(self._pbc, ctypes.POINTER(ctypes.c_double))
+            c.h_sqrt_table = ctypes.cast(self._sqrt, ctypes.POINTER(ctypes.c_double))
+            h = ctypes.c_void_p()
+            net = self.model.handle if self.model is not None else None
+            lib.check(lib.mzx_search_create(ctypes.byref(c), net, ctypes.byref(h)))
+            if self._mode is not None:
+                lib.check(lib.mzx_search_set_mode(h, int(self._mode)))
+            self._handles[num_trees] = h
+        return self._handles[num_trees]
+
+    def arena(self, num_trees):
+        need = self.backend.lib.mzx_search_arena_bytes(self.handle(num_trees))
+        if self._arena is None or self._arena.numel() < need:
+            big = self.backend.lib.mzx_search_arena_bytes(self.handle(self.max_trees)) if num_trees <= self.max_trees else need
+            self._arena = self.backend.zeros((max(need, big),), torch.uint8)
+        return self._arena
+
+    def _buf(self, name, shape, dtype):
+        key = (name, tuple(shape), dtype)
+        if key not in self._buffers:
+            self._buffers[key] = self.backend.empty(shape, dtype)
+        return self._buffers[key]
+
+    def make_io(self, B, observations, legal, to_play, noise, tape):
+        """Upload one move's inputs; returns (io struct, output tensors)."""
+        be = self.backend
+        dev = lambda a, dt: torch.as_tensor(a).to(dt).contiguous().to(be.device, non_blocking=True)
+        t_obs = dev(observations, torch.float32)
+        t_legal = dev(legal, torch.int32)
+        t_tp = dev(to_play, torch.int32)
+        t_noise = None if noise is None else dev(noise, torch.float64)
+        t_tape = dev(tape.view(numpy.int32) if isinstance(tape, numpy.ndarray) else tape, torch.int32)
+        out = dict(
+            visits=self._buf("visits", (B, self.A), torch.int32), root_value=self._buf("rv", (B,), torch.float64),
+            predicted=self._buf("rpv", (B,), torch.float64), info=self._buf("info", (B, 4), torch.int32),
+        )
+        io = _lib.SearchIO(be.ptr(t_obs), be.ptr(t_legal), be.ptr(t_tp), be.ptr(t_noise), be.ptr(t_tape),
+                           be.ptr(out["visits"]), be.ptr(out["root_value"]), be.ptr(out["predicted"]),
+                           be.ptr(out["info"]))
+        keep = (t_obs, t_legal, t_tp, t_noise, t_tape)
+        return io, out, keep
+
+    def run(self, observations, legal_actions, to_play, add_exploration_noise, rngs):
+        """
+        observations: B stacked observations; legal_actions: B lists; to_play: B ints;
+        rngs: B numpy RandomState-like objects (dirichlet / randint / get_state / set_state).
+        """
+        cfg, A = self.config, self.A
+        B = len(legal_actions)
+        assert len(rngs) == B and len(to_play) == B
+        legal = numpy.full((B, A), -1, numpy.int32)
+        noise = numpy.zeros((B, A), numpy.float64) if add_exploration_noise else None
+        tape = numpy.zeros((B, TAPE_WORDS), numpy.uint32)
+        states = []
+        for i, acts in enumerate(legal_actions):
+            # self_play.py:296-301
+            assert acts, f"Legal actions should not be an empty array. Got {acts}."
+            assert set(acts).issubset(set(cfg.action_space)), "Legal actions should be a subset of the action space."
+            assert len(set(acts)) == len(acts), "Legal actions must not repeat."
+            legal[i, : len(acts)] = acts
+            if add_exploration_noise:
+                noise[i, : len(acts)] = rngs[i].dirichlet([cfg.root_dirichlet_alpha] * len(acts))
+            states.append(rngs[i].get_state())
+            tape[i] = rngs[i].randint(0, 2 ** 32, size=TAPE_WORDS, dtype=numpy.uint32)
+        obs = numpy.ascontiguousarray(numpy.asarray(observations, dtype=numpy.float32).reshape(B, -1))
+        lib = self.backend.lib
+        io, out, keep = self.make_io(B, obs, legal, numpy.asarray(to_play, numpy.int32), noise, tape)
+        arena = self.arena(B)
+        lib.check(lib.mzx_search_run(self.handle(B), ctypes.byref(io), self.backend.ptr(arena), arena.numel(),
+                                     self.backend.stream()))
+        visits = out["visits"].cpu().numpy()
+        info = out["info"].cpu().numpy()
+        result = SearchResult(visits, out["root_value"].cpu().numpy(), out["predicted"].cpu().numpy(), info,
+                              [list(a) for a in legal_actions])
+        if (info[:, 1] != 0).any():
+            raise _lib.MzxError(f"search flagged trees {numpy.nonzero(info[:, 1])[0][:8]} (flags {set(info[:, 1])}): "
+                                "tie tape or node arena exhausted")
+        for i in range(B):  # rewind, then consume exactly what the device consumed
+            rngs[i].set_state(states[i])
+            if info[i, 2]:
+                rngs[i].randint(0, 2 ** 32, size=int(info[i, 2]), dtype=numpy.uint32)
+        return result
+
+
+class MCTS:
+    """self_play.py:249-361 -- single-root form, same signature and return value."""
+
+    def __init__(self, config):
+        self.config = config
+
+    def run(self, model, observation, legal_actions, to_play, add_exploration_noise, override_root_with=None):
+        if override_root_with:
+            raise NotImplementedError("override_root_with (diagnose tooling) is not on the accelerated path yet")
+        engine = getattr(model, "_mcts_engine", None)
+        if engine is None or engine.config is not self.config:
+            engine = BatchedMCTS(self.config, model, 1)
+            model._mcts_engine = engine
+        res = engine.run([observation], [list(legal_actions)], [to_play], add_exploration_noise,
+                         [numpy.random.mtrand._rand])
+        extra_info = {
+            "max_tree_depth": int(res.max_tree_depth[0]),
+            "root_predicted_value": float(res.root_predicted_values[0]),
+        }
+        return res.root(0), extra_info
+
+
+def _remote(method, *args):
+    """Call a storage/replay method that may be a Ray actor method (``.remote``) or a plain one."""
+    if hasattr(method, "remote"):
+        import ray
+        return ray.get(method.remote(*args))
+    return method(*args)
+
+
+class SelfPlay:
+    """
+    self_play.py:11-245.  ``num_games`` (new, default 1) is the number of games
+    this process plays in lock-step on its GPU; game i is seeded ``seed + i``.
+    """
+
+    def __init__(self, initial_checkpoint, Game, config, seed, num_games=1, _backend=None):
+        _validate(config)
+        self.config = config
+        self.num_games = int(num_games)
+        self.games = [Game(seed + i) for i in range(self.num_games)]
+        self.game = self.games[0]
+
+        # Fix random generator seed (self_play.py:21-23)
+        numpy.random.seed(seed)
+        torch.manual_seed(seed)
+        self.rngs = [numpy.random.mtrand._rand] + [numpy.random.RandomState(seed + i) for i in range(1, self.num_games)]
+
+        # Initialize the network (self_play.py:25-29)
+        self.model = models.MuZeroNetwork(self.config, _backend=_backend)
+        self.model.set_weights(initial_checkpoint["weights"])
+        self.model.eval()
+        self.engine = BatchedMCTS(self.config, self.model, self.num_games)
+        self.stats = {"searches": 0, "simulations": 0, "search_seconds": 0.0}
+
+    # ------------------------------------------------------------------ loops
+    def continuous_self_play(self, shared_storage, replay_buffer, test_mode=False):
+        # self_play.py:31-108
+        get = lambda key: _remote(shared_storage.get_info, key)
+        while get("training_step") < self.config.training_steps and not get("terminate"):
+            self.model.set_weights(get("weights"))
+            if not test_mode:
+                histories = self.play_games(
+                    self.config.visit_softmax_temperature_fn(trained_steps=get("training_step")),
+                    self.config.temperature_threshold, False, "self", 0,
+                )
+                for game_history in histories:
+                    _remote(replay_buffer.save_game, game_history, shared_storage)
+            else:
+                game_history = self.play_game(
+                    0, self.config.temperature_threshold, False,
+                    "self" if len(self.config.players) == 1 else self.config.opponent, self.config.muzero_player,
+                )
+                _remote(shared_storage.set_info, {
+                    "episode_length": len(game_history.action_history) - 1,
+                    "total_reward": sum(game_history.reward_history),
+                    "mean_value": numpy.mean([value for value in game_history.root_values if value]),
+                })
+                if 1 < len(self.config.players):
+                    _remote(shared_storage.set_info, {
+                        "muzero_reward": sum(
+                            reward for i, reward in enumerate(game_history.reward_history)
+                            if game_history.to_play_history[i - 1] == self.config.muzero_player),
+                        "opponent_reward": sum(
+                            reward for i, reward in enumerate(game_history.reward_history)
+                            if game_history.to_play_history[i - 1] != self.config.muzero_player),
+                    })
+            if not test_mode and self.config.self_play_delay:
+                time.sleep(self.config.self_play_delay)
+            if not test_mode and self.config.ratio:
+                while (get("training_step") / max(1, get("num_played_steps")) < self.config.ratio
+                       and get("training_step") < self.config.training_steps and not get("terminate")):
+                    time.sleep(0.5)
+        self.close_game()
+
+    def play_game(self, temperature, temperature_threshold, render, opponent, muzero_player):
+        """self_play.py:110-183: one game (game slot 0, process-global numpy stream)."""
+        return self._play([0], temperature, temperature_threshold, render, opponent, muzero_player)[0]
+
+    def play_games(self, temperature, temperature_threshold, render, opponent, muzero_player):
+        """All ``num_games`` games of this shard in lock-step; returns their GameHistory list."""
+        return self._play(list(range(self.num_games)), temperature, temperature_threshold, render, opponent,
+                          muzero_player)
+
+    def _play(self, slots, temperature, temperature_threshold, render, opponent, muzero_player):
+        cfg = self.config
+        A = len(cfg.action_space)
+        histories = {}
+        observations = {}
+        for s in slots:
+            gh = GameHistory()
+            observation = self.games[s].reset()
+            gh.action_history.append(0)
+            gh.observation_history.append(observation)
+            gh.reward_history.append(0)
+            gh.to_play_history.append(self.games[s].to_play())
+            histories[s] = gh
+            observations[s] = observation
+            if render:
+                self.games[s].render()
+        active = list(slots)
+        while active:
+            searching, stacked = [], []
+            for s in active:
+                observation, gh = observations[s], histories[s]
+                # self_play.py:132-137
+                assert len(numpy.array(observation).shape) == 3, \
+                    f"Observation should be 3 dimensionnal instead of {len(numpy.array(observation).shape)} dimensionnal. Got observation of shape: {numpy.array(observation).shape}"
+                assert numpy.array(observation).shape == cfg.observation_shape, \
+                    f"Observation should match the observation_shape defined in MuZeroConfig. Expected {cfg.observation_shape} but got {numpy.array(observation).shape}."
+                st = gh.get_stacked_observations(-1, cfg.stacked_observations, A)
+                if opponent == "self" or muzero_player == self.games[s].to_play():
+                    searching.append(s)
+                    stacked.append(st)
+                else:
+                    stacked_for_opponent = st
+            result = None
+            if searching:
+                t0 = time.perf_counter()
+                result = self.engine.run(
+                    stacked, [self.games[s].legal_actions() for s in searching],
+                    [self.games[s].to_play() for s in searching], True, [self.rngs[s] for s in searching],
+                )
+                self.stats["search_seconds"] += time.perf_counter() - t0
+                self.stats["searches"] += len(searching)
+                self.stats["simulations"] += len(searching) * self.engine.num_simulations
+            still = []
+            for s in active:
+                gh, game = histories[s], self.games[s]
+                if s in searching:
+                    root = result.root(searching.index(s))
+                    t = temperature if not temperature_threshold or len(gh.action_history) < temperature_threshold else 0
+                    action = self._select_action(root, t, self.rngs[s])
+                    if render:
+                        print(f'Tree depth: {result.max_tree_depth[searching.index(s)]}')
+                        print(f"Root value for player {game.to_play()}: {root.value():.2f}")
+                else:
+                    action, root = self.select_opponent_action(opponent, stacked_for_opponent, game)
+                observation, reward, done = game.step(action)
+                if render:
+                    print(f"Played action: {game.action_to_string(action)}")
+                    game.render()
+                gh.store_search_statistics(root, cfg.action_space)
+                gh.action_history.append(action)
+                gh.observation_history.append(observation)
+                gh.reward_history.append(reward)
+                gh.to_play_history.append(game.to_play())
+                observations[s] = observation
+                if not done and len(gh.action_history) <= cfg.max_moves:
+                    still.append(s)
+            active = still
+        return [histories[s] for s in slots]
+
+    def close_game(self):
+        for g in self.games:
+            g.close()
+
+    def select_opponent_action(self, opponent, stacked_observations, game=None):
+        """self_play.py:188-220"""
+        game = self.game if game is None else game
+        if opponent == "human":
+            root, mcts_info = MCTS(self.config).run(self.model, stacked_observations, game.legal_actions(),
+                                                    game.to_play(), True)
+            print(f'Tree depth: {mcts_info["max_tree_depth"]}')
+            print(f"Root value for player {game.to_play()}: {root.value():.2f}")
+            print(f"Player {game.to_play()} turn. MuZero suggests {game.action_to_string(self.select_action(root, 0))}")
+            return game.human_to_action(), root
+        elif opponent == "expert":
+            return game.expert_agent(), None
+        elif opponent == "random":
+            assert game.legal_actions(), f"Legal actions should not be an empty array. Got {game.legal_actions()}."
+            assert set(game.legal_actions()).issubset(set(self.config.action_space)), \
+                "Legal actions should be a subset of the action space."
+            return numpy.random.choice(game.legal_actions()), None
+        else:
+            raise NotImplementedError(
+                'Wrong argument: "opponent" argument should be "self", "human", "expert" or "random"'
+            )
+
+    @staticmethod
+    def _select_action(node, temperature, rng):
+        visit_counts = numpy.array([child.visit_count for child in node.children.values()], dtype="int32")
+        actions = [action for action in node.children.keys()]
+        if temperature == 0:
+            action = actions[numpy.argmax(visit_counts)]
+        elif temperature == float("inf"):
+            action = rng.choice(actions)
+        else:
+            # See paper appendix Data Generation
+            dist = visit_counts ** (1 / temperature)
+            dist = dist / sum(dist)
+            action = rng.choice(actions, p=dist)
+        return action
+
+    @staticmethod
+    def select_action(node, temperature):
+        """self_play.py:222-245 (process-global numpy stream, like the reference)."""
+        return SelfPlay._select_action(node, temperature, numpy.random.mtrand._rand)

@@ -1,0 +1,96 @@
+"""
+CPU check of the generic search path end to end (network programs + tree
+operators + host driver) through tests/hostcheck, against the reference traces:
+fp32 heads within 1e-4, visit counts / root values expected identical
+(tolerance mode of SURVEY.md section 8c').  GPU twins: test_gpu_parity.py.
+"""
+import json
+import os
+
+import numpy
+import pytest
+import torch
+
+import hostcheck
+import lockstep
+from conftest import GOLDEN
+from mzx import configs, models, self_play, synthetic
+
+NET_FOR_GAME = {"cartpole": "net_fc_cartpole.npz", "tictactoe": "net_resnet_tictactoe.npz",
+                "connect4": "net_resnet_connect4.npz"}
+
+
+@pytest.fixture(scope="module")
+def backend():
+    return hostcheck.backend()
+
+
+def build_model(backend, cfg, weight_seed, zero_keys=()):
+    net = models.MuZeroNetwork(cfg, _backend=backend)
+    sd = synthetic.fill_state_dict(net.state_dict(), weight_seed)
+    for k in zero_keys:
+        sd[k] = torch.zeros_like(sd[k])
+    net.set_weights(sd)
+    return net
+
+
+@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties"])
+def test_search_matches_reference(backend, name):
+    z, meta, cfg = lockstep.load_fixture(name)
+    cfg.num_simulations = meta["num_simulations"]
+    net = build_model(backend, cfg, meta["weight_seed"], meta.get("zero_keys", ()))
+    cases = meta["cases"]
+    B = len(cases)
+    engine = self_play.BatchedMCTS(cfg, net, B)
+    rngs = [numpy.random.RandomState(c["rng_seed"]) for c in cases]
+    obs = [z[f"c{c}_obs"] for c in range(B)]
+    res = engine.run(obs, [c["legal"] for c in cases], [c["to_play"] for c in cases], True, rngs)
+    A = len(cfg.action_space)
+    for c, case in enumerate(cases):
+        g = lambda k: z[f"c{c}_{k}"]
+        want = numpy.zeros(A, numpy.int32)
+        for s, a in enumerate(case["legal"]):
+            ch = g("child")[0, s]
+            want[a] = g("visit")[ch] if ch >= 0 else 0
+        assert numpy.array_equal(res.visit_counts[c], want), (name, c)
+        # decoded scalars: the inverse value transform (sqrt(1+eps*..)-1) cancels ~4 digits, so two
+        # fp32 evaluations of logits that agree to 1e-6 differ by ~1e-5 RELATIVE after decoding
+        want_rv = g("value_sum")[0] / g("visit")[0]
+        assert abs(res.root_values[c] - want_rv) < 1e-4 * max(1.0, abs(want_rv))
+        want_pv = float(g("root_predicted_value"))
+        assert abs(res.root_predicted_values[c] - want_pv) < 1e-4 * max(1.0, abs(want_pv))
+        assert res.max_tree_depth[c] == int(g("max_tree_depth"))
+        # the host stream must end where the reference's global stream ended
+        ref = numpy.random.RandomState(case["rng_seed"])
+        ref.dirichlet([cfg.root_dirichlet_alpha] * len(case["legal"]))
+        if res.tape_used[c]:
+            ref.randint(0, 2 ** 32, size=int(res.tape_used[c]), dtype=numpy.uint32)
+        assert ref.get_state()[2] == rngs[c].get_state()[2]
+        assert numpy.array_equal(ref.get_state()[1], rngs[c].get_state()[1])
+
+
+def load_game(name):
+    z = numpy.load(os.path.join(GOLDEN, f"game_{name}.npz"))
+    return z, json.loads(str(z["meta"]))
+
+
+@pytest.mark.parametrize("name", ["tictactoe", "connect4", "cartpole_synth"])
+def test_whole_game_matches_reference(backend, name):
+    """SelfPlay.play_game: same GameHistory as the reference actor with the same seed."""
+    z, meta = load_game(name)
+    cfg = configs.BY_NAME[meta["game"]](**meta["overrides"])
+    if meta["synthetic_game"]:
+        Game = synthetic.make_synthetic_game(cfg.observation_shape, len(cfg.action_space), len(cfg.players))
+    else:
+        Game = pytest.importorskip("games_fixture").GAMES[meta["game"]]
+    template = models.MuZeroNetwork(cfg, _backend=backend).state_dict()
+    weights = synthetic.fill_state_dict(template, meta["weight_seed"])
+    sp = self_play.SelfPlay({"weights": weights}, Game, cfg, meta["seed"], _backend=backend)
+    gh = sp.play_game(meta["temperature"], cfg.temperature_threshold, False, "self", 0)
+    assert [int(a) for a in gh.action_history] == z["action_history"].tolist()
+    assert [float(r) for r in gh.reward_history] == z["reward_history"].tolist()
+    assert [int(p) for p in gh.to_play_history] == z["to_play_history"].tolist()
+    assert numpy.array_equal(numpy.array(gh.child_visits, numpy.float64), z["child_visits"])
+    assert numpy.allclose(numpy.array(gh.root_values, numpy.float64), z["root_values"], atol=1e-4, rtol=1e-4)
+    for a, b in zip(gh.observation_history, z["observation_history"]):
+        assert numpy.array_equal(numpy.array(a, dtype=numpy.float64), b)
