@@ -1,0 +1,48 @@
+"""
+Builds the gfx950 shared library ``mzx/libmzx.so`` from ``csrc/`` with hipcc.
+
+In-tree and explicit (no JIT cache): the built .so travels to the GPU box with
+the repository snapshot.  hipcc cross-compiles for gfx950 without a GPU.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+OUT = os.path.join(HERE, "mzx", "libmzx.so")
+
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17",
+    "-ffp-contract=off",      # tree statistics must not be fused (bit-exact binary64)
+    "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+]
+
+
+def sources():
+    return sorted(
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".hip"))
+    )
+
+
+def up_to_date():
+    if not os.path.isfile(OUT):
+        return False
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "mzx.h"), __file__]
+    return all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and up_to_date():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-x", "hip"] + sources() + ["-o", OUT]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,163 @@
+"""
+GPU parity tests proper (-m gpu): the HIP path, called through the C ABI
+(include/mzx.h via mzx._lib), against
+  * traces of the unmodified reference (tests/golden/*): lock-step tree
+    arithmetic BIT-EXACT; network heads within 1e-4; end-to-end visit counts
+    identical; whole games identical;
+  * the CPU oracle on seeded inputs at BASELINE.json's full size (C2: 4096 trees x
+    50 simulations) through size-independent invariants + a sampled tree-by-tree
+    comparison.
+"""
+import json
+import os
+
+import numpy
+import pytest
+import torch
+
+import lockstep
+import test_hostcheck_search as common
+from conftest import GOLDEN
+from mzx import _lib, configs, models, self_play, synthetic
+from oracle import mcts_oracle, net_oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # BASELINE.json north_star: policy/value logits within 1e-4 of the CPU reference
+
+
+@pytest.fixture(scope="module")
+def backend():
+    return _lib.default_backend()
+
+
+def test_native_library_is_loaded(backend):
+    assert backend.lib.mzx_is_device_build() == 1
+    with open("/proc/self/maps") as f:
+        assert "libmzx.so" in f.read()
+
+
+@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties"])
+def test_lockstep_tree_bit_exact(backend, name):
+    got = lockstep.run_fixture(backend, name)
+    if name == "cartpole_ties":
+        assert (got["info"][:, 2] > 3).all()
+
+
+@pytest.mark.parametrize("name", ["fc_cartpole", "fc_cartpole_pretrained", "fc_cartpole_stacked",
+                                  "resnet_tictactoe", "resnet_connect4", "resnet_breakout"])
+def test_network_heads_within_tolerance(backend, name):
+    z = numpy.load(os.path.join(GOLDEN, f"net_{name}.npz"))
+    meta = json.loads(str(z["meta"]))
+    cfg = configs.BY_NAME[meta["game"]](**meta["overrides"])
+    net = models.MuZeroNetwork(cfg)
+    assert [k for k, _, _ in meta["keys"]] == list(net.state_dict().keys())
+    if "flat_weights" in z.files:
+        sd, off = {}, 0
+        for k, t in net.state_dict().items():
+            if t.dtype.is_floating_point:
+                sd[k] = torch.from_numpy(z["flat_weights"][off:off + t.numel()].reshape(tuple(t.shape)).copy())
+                off += t.numel()
+    else:
+        sd = synthetic.fill_state_dict(net.state_dict(), meta["weight_seed"])
+    net.set_weights(sd)
+    o = net.initial_inference(torch.tensor(z["obs"]))
+    r1 = net.recurrent_inference(o[3], torch.tensor(z["act1"]))
+    r2 = net.recurrent_inference(r1[3], torch.tensor(z["act2"]))
+    o1 = net.initial_inference(torch.tensor(z["obs"][:1]))
+    for tag, res in (("init", o), ("rec1", r1), ("rec2", r2), ("init_b1", o1)):
+        for key, t in zip(("value", "reward", "policy", "hidden"), res):
+            ref, got = z[f"{tag}_{key}"], t.cpu().numpy()
+            assert got.shape == ref.shape
+            if key == "reward" and tag.startswith("init"):
+                assert numpy.array_equal(got, ref)  # -inf / 0 pattern exactly
+            else:
+                assert numpy.abs(got - ref).max() < TOL, (name, tag, key)
+        vs = models.support_to_scalar(res[0], cfg.support_size).cpu().numpy()
+        assert numpy.allclose(vs, z[f"{tag}_value_scalar"], atol=TOL, rtol=TOL)
+    # get_weights round trip in reference format
+    back = net.get_weights()
+    for k, v in sd.items():
+        assert torch.equal(back[k], v)
+
+
+@pytest.mark.parametrize("mode", ["generic", "fused"])
+@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties"])
+def test_search_matches_reference(backend, name, mode, monkeypatch):
+    if mode == "generic":
+        orig = self_play.BatchedMCTS.__init__
+        monkeypatch.setattr(self_play.BatchedMCTS, "__init__",
+                            lambda self, *a, **k: orig(self, *a, **{**k, "mode": 0}))
+    elif name != "cartpole" and name != "cartpole_ties":
+        pytest.skip("fused kernel covers fully connected networks")
+    common.test_search_matches_reference(backend, name)
+
+
+@pytest.mark.parametrize("name", ["tictactoe", "connect4", "cartpole_synth"])
+def test_whole_game_matches_reference(backend, name):
+    common.test_whole_game_matches_reference(backend, name)
+
+
+def _tree_invariants(cfg, res, S):
+    assert (res.visit_counts.sum(1) == S).all()          # every simulation passes the root once
+    assert (res.visit_counts >= 0).all()
+    assert (res.flags == 0).all()
+    assert (res.max_tree_depth >= 1).all() and (res.max_tree_depth <= S).all()
+    assert (res.sum_depth >= S).all() and (res.sum_depth <= res.max_tree_depth.astype(numpy.int64) * S).all()
+    assert numpy.isfinite(res.root_values).all()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_full_size_c2_cartpole(backend, mode):
+    """BASELINE config C2: CartPole-FC, 4096 trees x 50 simulations on one GPU."""
+    cfg = configs.cartpole()
+    B, S = 4096, cfg.num_simulations
+    net = models.MuZeroNetwork(cfg)
+    sd = synthetic.fill_state_dict(net.state_dict(), 11)
+    net.set_weights(sd)
+    engine = self_play.BatchedMCTS(cfg, net, B, mode=0 if mode == 0 else None)
+    if mode == 1 and not backend.lib.mzx_search_fused_supported(engine.handle(B)):
+        pytest.skip("fused kernel not available")
+    obs = synthetic.observations(B, cfg.observation_shape, seed=123)
+    legal = [list(cfg.action_space)] * B
+    rngs = [numpy.random.RandomState(1000 + i) for i in range(B)]
+    res = engine.run(list(obs), legal, [0] * B, True, rngs)
+    _tree_invariants(cfg, res, S)
+    # determinism: same inputs, same streams -> identical outputs
+    res2 = engine.run(list(obs), legal, [0] * B, True, [numpy.random.RandomState(1000 + i) for i in range(B)])
+    assert numpy.array_equal(res.visit_counts, res2.visit_counts)
+    assert numpy.array_equal(res.root_values.view(numpy.int64), res2.root_values.view(numpy.int64))
+    # sampled trees against the CPU oracle (reference network arithmetic on the host)
+    onet = net_oracle.make_oracle_network(cfg, sd)
+    sample = list(range(0, B, 64))
+    same = 0
+    for i in sample:
+        ev = net_oracle.NetworkEvaluator(onet, cfg.support_size)
+        tree = mcts_oracle.run_search(cfg, ev, obs[i], legal[i], 0, True, numpy.random.RandomState(1000 + i))
+        same += int(tree.root_visit_counts(cfg.action_space) == list(res.visit_counts[i]))
+        rv = tree.node_value(0)
+        if tree.root_visit_counts(cfg.action_space) == list(res.visit_counts[i]):
+            assert abs(res.root_values[i] - rv) < TOL * max(1.0, abs(rv))
+    # fp32 network arithmetic is not bit-reproducible across implementations; a near-tie may flip
+    # one simulation on rare trees -- report the match rate, require it to be essentially all
+    print(f"visit-count match rate vs oracle: {same}/{len(sample)}")
+    assert same >= len(sample) - 1
+
+
+def test_generic_and_fused_agree(backend):
+    cfg = configs.cartpole()
+    B = 512
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 17))
+    obs = synthetic.observations(B, cfg.observation_shape, seed=9)
+    legal = [list(cfg.action_space)] * B
+    outs = []
+    for mode in (0, None):
+        engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
+        if mode is None and not backend.lib.mzx_search_fused_supported(engine.handle(B)):
+            pytest.skip("fused kernel not available")
+        outs.append(engine.run(list(obs), legal, [0] * B, True, [numpy.random.RandomState(7 + i) for i in range(B)]))
+    match = (outs[0].visit_counts == outs[1].visit_counts).all(1).mean()
+    print("generic vs fused identical visit counts:", match)
+    assert match > 0.99
+    assert numpy.allclose(outs[0].root_predicted_values, outs[1].root_predicted_values, atol=TOL, rtol=TOL)
