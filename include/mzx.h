@@ -161,11 +161,20 @@ typedef struct mzx_search_io {
  * num_simulations x {select, recurrent_inference, expand, backpropagate}. */
 int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_t arena_bytes, void* stream);
 
-/* Which implementation mzx_search_run uses: 0 = generic operator-per-kernel path
- * (any configuration), 1 = fused LDS-resident persistent kernel (fully connected
- * networks that fit; mzx_search_fused_supported tells).  Default: 1 when supported. */
+/* Which implementation mzx_search_run uses, a set of flags:
+ *   1  fused LDS-resident whole-search kernel (fully connected networks that fit;
+ *      mzx_search_fused_supported tells); 0 = generic operator-per-kernel path
+ *   2  (fused) also export the finished trees to the arena so mzx_search_dump works
+ *   4  (fused) force the LDS-weight engine even when a register-resident
+ *      specialisation matches the network shape
+ *   8  (fused) cycle-profile build: per-tree phase cycle counters are left in the
+ *      network-workspace region of the arena (mzx_search_arena_offsets)
+ * Default: 1 when supported, else 0. */
 int mzx_search_fused_supported(const mzx_search* s);
 int mzx_search_set_mode(mzx_search* s, int32_t mode);
+/* Byte offsets inside the arena (diagnostics): out[0..6] = tables, trees, hidden states,
+ * network workspace, bytes per tree, workspace bytes, total bytes. */
+int mzx_search_arena_offsets(const mzx_search* s, int64_t out[8]);
 
 /* Lock-step interface (parity harness, SURVEY.md section 8c'): the tree arithmetic
  * alone, with the network outputs supplied by the caller in binary64.

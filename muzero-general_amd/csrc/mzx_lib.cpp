@@ -192,10 +192,17 @@ int64_t mzx_search_arena_bytes(const mzx_search* s) { return s ? s->arena_bytes 
 
 int mzx_search_fused_supported(const mzx_search* s) { return s ? s->fused_ok : 0; }
 
+int mzx_search_arena_offsets(const mzx_search* s, int64_t out[8]) {
+  if (!s || !out) { set_error("null argument"); return MZX_ERR_INVALID; }
+  out[0] = s->off_tables; out[1] = s->off_trees; out[2] = s->off_hidden; out[3] = s->off_ws;
+  out[4] = s->L.tree_bytes; out[5] = s->ws_floats * 4; out[6] = s->arena_bytes; out[7] = 0;
+  return MZX_OK;
+}
+
 int mzx_search_set_mode(mzx_search* s, int32_t mode) {
   if (!s) { set_error("null search handle"); return MZX_ERR_INVALID; }
-  if (mode == 1 && !s->fused_ok) { set_error("fused search kernel does not support this configuration"); return MZX_ERR_INVALID; }
-  if (mode != 0 && mode != 1) { set_error("mode must be 0 or 1"); return MZX_ERR_INVALID; }
+  if (mode < 0 || mode > 15) { set_error("mode is a 4-bit flag set"); return MZX_ERR_INVALID; }
+  if ((mode & 1) && !s->fused_ok) { set_error("fused search kernel does not support this configuration"); return MZX_ERR_INVALID; }
   s->mode = mode;
   return MZX_OK;
 }
@@ -219,7 +226,7 @@ int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_
     return MZX_ERR_INVALID;
   }
 #ifndef MZX_HOSTCHECK
-  if (s->mode == 1) return fused_fc_run(s, io, d_arena, (stream_t)stream);
+  if (s->mode & 1) return fused_fc_run(s, io, d_arena, (stream_t)stream);
 #endif
   return search_run_generic(s, io, d_arena, (stream_t)stream);
 }

@@ -14,8 +14,11 @@
 //
 // A node is addressed by its CANONICAL INDEX: root = 0, the leaf expanded by
 // simulation k is k+1.  A child slot is (node, position in the node's action
-// list).  Statistics of a child live in the child NODE (reachable through
-// child[node][slot]); a slot with child < 0 has visit_count 0.
+// list).  Layout: the statistics a SELECTION needs about a child -- visit count,
+// q = reward + discount * (+-value()), prior, link -- are stored in the PARENT's
+// slot arrays, so one level of the walk reads A contiguous slots of one node
+// (no pointer chase through child nodes); value_sum / visit / reward / to_play
+// also live per node for back-propagation and for the root.
 //
 // The same functions are compiled (a) for gfx950 by hipcc and (b) for the host
 // by g++ in tests/hostcheck (test-only build used by the CPU test-suite; the
@@ -61,11 +64,12 @@ struct SearchParams {
   const double* sqrt_table;  // [N+1]: sqrt(n)
 };
 
-// Byte layout of one tree inside the arena (all offsets multiples of 8).
+// Byte layout of one tree (all offsets multiples of 8).
 struct TreeLayout {
   int32_t N, A;
-  int64_t off_value_sum, off_q, off_reward, off_prior, off_mm;
-  int64_t off_visit, off_to_play, off_parent, off_parent_slot, off_child, off_root_actions, off_meta;
+  int64_t off_value_sum, off_reward, off_prior, off_sq, off_mm;                        // binary64
+  int64_t off_visit, off_to_play, off_parent, off_parent_slot, off_svisit, off_child;   // int32
+  int64_t off_root_actions, off_meta;
   int64_t tree_bytes;
 
   MZX_HD static inline int64_t align8(int64_t x) { return (x + 7) & ~int64_t(7); }
@@ -76,14 +80,15 @@ struct TreeLayout {
     L.A = A;
     int64_t o = 0;
     L.off_value_sum = o; o += int64_t(8) * N;
-    L.off_q = o;         o += int64_t(8) * N;
     L.off_reward = o;    o += int64_t(8) * N;
     L.off_prior = o;     o += int64_t(8) * N * A;
+    L.off_sq = o;        o += int64_t(8) * N * A;
     L.off_mm = o;        o += 16;
     L.off_visit = o;     o += align8(int64_t(4) * N);
     L.off_to_play = o;   o += align8(int64_t(4) * N);
     L.off_parent = o;    o += align8(int64_t(4) * N);
     L.off_parent_slot = o; o += align8(int64_t(4) * N);
+    L.off_svisit = o;    o += align8(int64_t(4) * N * A);
     L.off_child = o;     o += align8(int64_t(4) * N * A);
     L.off_root_actions = o; o += align8(int64_t(4) * A);
     L.off_meta = o;      o += int64_t(4) * TM_WORDS;
@@ -92,22 +97,26 @@ struct TreeLayout {
   }
 };
 
-// View of ONE tree in generic (global or host) memory.
+// View of ONE tree (global memory, LDS or host memory).
 struct TreeRef {
   char* base;
   TreeLayout L;
 
+  // per node
   MZX_HD inline double& value_sum(int n) const { return ((double*)(base + L.off_value_sum))[n]; }
-  MZX_HD inline double& q(int n) const { return ((double*)(base + L.off_q))[n]; }
   MZX_HD inline double& reward(int n) const { return ((double*)(base + L.off_reward))[n]; }
-  MZX_HD inline double& prior(int n, int s) const { return ((double*)(base + L.off_prior))[n * L.A + s]; }
-  MZX_HD inline double& mm_min() const { return ((double*)(base + L.off_mm))[0]; }
-  MZX_HD inline double& mm_max() const { return ((double*)(base + L.off_mm))[1]; }
   MZX_HD inline int32_t& visit(int n) const { return ((int32_t*)(base + L.off_visit))[n]; }
   MZX_HD inline int32_t& to_play(int n) const { return ((int32_t*)(base + L.off_to_play))[n]; }
   MZX_HD inline int32_t& parent(int n) const { return ((int32_t*)(base + L.off_parent))[n]; }
   MZX_HD inline int32_t& parent_slot(int n) const { return ((int32_t*)(base + L.off_parent_slot))[n]; }
+  // per child slot of a node
+  MZX_HD inline double& prior(int n, int s) const { return ((double*)(base + L.off_prior))[n * L.A + s]; }
+  MZX_HD inline double& slot_q(int n, int s) const { return ((double*)(base + L.off_sq))[n * L.A + s]; }
+  MZX_HD inline int32_t& slot_visit(int n, int s) const { return ((int32_t*)(base + L.off_svisit))[n * L.A + s]; }
   MZX_HD inline int32_t& child(int n, int s) const { return ((int32_t*)(base + L.off_child))[n * L.A + s]; }
+  // per tree
+  MZX_HD inline double& mm_min() const { return ((double*)(base + L.off_mm))[0]; }
+  MZX_HD inline double& mm_max() const { return ((double*)(base + L.off_mm))[1]; }
   MZX_HD inline int32_t& root_action(int s) const { return ((int32_t*)(base + L.off_root_actions))[s]; }
   MZX_HD inline int32_t& meta(int k) const { return ((int32_t*)(base + L.off_meta))[k]; }
 };
@@ -115,21 +124,23 @@ struct TreeRef {
 // ---------------------------------------------------------------------------
 // UCB score of one child slot -- self_play.py:380-404, same operation order.
 // `pbc` = log((N+base+1)/base)+init and `sq` = sqrt(N) for the PARENT's visit
-// count N come from the host tables.  The value term uses q(child) =
-// reward + discount * (+-value()), cached by backpropagate (same expression,
-// same operands => same bits as recomputing it here).
-template <class T>
-MZX_HD inline double ucb_score(const T& t, int node, int slot, double pbc, double sq, double mn, double mx) {
-  const int c = t.child(node, slot);
-  const int n = (c >= 0) ? t.visit(c) : 0;
+// count N come from the host tables; n / q / prior are the slot's visit count,
+// cached reward + discount * (+-value()) (written by backpropagate with the very
+// expression ucb_score uses, hence the same bits) and prior.
+MZX_HD inline double ucb_from(double pbc, double sq, int n, double prior, double q, double mn, double mx) {
   double pb_c = pbc * (sq / (double)(n + 1));   // pb_c *= sqrt(N) / (n + 1)
-  double score = pb_c * t.prior(node, slot);     // prior_score
+  double score = pb_c * prior;                   // prior_score
   if (n > 0) {
-    double v = t.q(c);
+    double v = q;
     if (mx > mn) v = (v - mn) / (mx - mn);        // MinMaxStats.normalize, :566-570
     score = score + v;
   }
   return score;
+}
+
+template <class T>
+MZX_HD inline double ucb_score(const T& t, int node, int slot, double pbc, double sq, double mn, double mx) {
+  return ucb_from(pbc, sq, t.slot_visit(node, slot), t.prior(node, slot), t.slot_q(node, slot), mn, mx);
 }
 
 // Masked-rejection draw in [0, n) from a tape of raw MT19937 words: exactly
@@ -195,71 +206,105 @@ MZX_HD inline int tree_select(const T& t, const SearchParams& p, const uint32_t*
   return node;
 }
 
-// Node.expand (self_play.py:451-465) for the leaf chosen by tree_select, then
-// MCTS.backpropagate (self_play.py:406-430) walking parent links leaf -> root.
-// `priors` are the fp32 softmax probabilities widened to binary64.
+// What one selection walk hands to the expansion / back-propagation of the same
+// simulation.  The generic path parks it in the tree's meta words between kernels;
+// the fused kernels keep it in registers.
+struct SelCtx { int32_t parent, slot, leaf, depth, to_play; };
+
+template <class T>
+MZX_HD inline SelCtx load_ctx(const T& t) {
+  SelCtx c;
+  c.parent = t.meta(TM_CUR_PARENT); c.slot = t.meta(TM_CUR_SLOT); c.leaf = t.meta(TM_CUR_LEAF);
+  c.depth = t.meta(TM_CUR_DEPTH); c.to_play = t.meta(TM_CUR_TO_PLAY);
+  return c;
+}
+
+// Node.expand, part 1 (self_play.py:451-458): link the selected leaf under its
+// parent and initialise its node record.  Priors / child links of the leaf's own
+// slots are written by tree_init_slot (one call per slot, any order / any lane).
+template <class T>
+MZX_HD inline void tree_attach_leaf(const T& t, const SearchParams& p, const SelCtx& c, double reward) {
+  t.child(c.parent, c.slot) = c.leaf;
+  t.parent(c.leaf) = c.parent;
+  t.parent_slot(c.leaf) = c.slot;
+  t.to_play(c.leaf) = c.to_play;
+  t.reward(c.leaf) = reward;
+  t.visit(c.leaf) = 0;
+  t.value_sum(c.leaf) = 0.0;
+  t.meta(TM_N_NODES) = c.leaf + 1;
+  if (c.depth > t.meta(TM_MAX_DEPTH)) t.meta(TM_MAX_DEPTH) = c.depth;
+  t.meta(TM_SUM_DEPTH) += c.depth;
+}
+
+// Node.expand, part 2 (self_play.py:460-465): child slot `s` of `node` starts
+// unvisited with the given prior (fp32 softmax probability widened to binary64).
+template <class T>
+MZX_HD inline void tree_init_slot(const T& t, int node, int s, double prior) {
+  t.prior(node, s) = prior;
+  t.slot_q(node, s) = 0.0;
+  t.slot_visit(node, s) = 0;
+  t.child(node, s) = -1;
+}
+
+// Statistics update of ONE path node given the value arriving from below
+// (self_play.py:411-417 / :420-427); returns the value to pass upward.  Mirrors
+// (visit, q) into the parent's slot arrays for the next selection.
+template <class T>
+MZX_HD inline double tree_update_node(const T& t, const SearchParams& p, int n, double value, int leaf_to_play,
+                                      double& mn, double& mx) {
+  const double disc = p.discount;
+  const double r = t.reward(n);
+  double vs, qv, up;
+  const int vc = t.visit(n) + 1;
+  if (p.num_players == 1) {
+    vs = t.value_sum(n) + value;
+    qv = r + disc * (vs / (double)vc);
+    up = r + disc * value;
+  } else {
+    const bool same = (t.to_play(n) == leaf_to_play);
+    vs = t.value_sum(n) + (same ? value : -value);
+    qv = r + disc * (-(vs / (double)vc));
+    up = (same ? -r : r) + disc * value;
+  }
+  t.value_sum(n) = vs;
+  t.visit(n) = vc;
+  const int par = t.parent(n);
+  if (par >= 0) {
+    const int ps = t.parent_slot(n);
+    t.slot_visit(par, ps) = vc;
+    t.slot_q(par, ps) = qv;
+  }
+  if (qv > mx) mx = qv;   // MinMaxStats.update, :562-564
+  if (qv < mn) mn = qv;
+  return up;
+}
+
+// MCTS.backpropagate (self_play.py:406-430): walk parent links leaf -> root.
+template <class T>
+MZX_HD inline void tree_backprop(const T& t, const SearchParams& p, const SelCtx& c, double value) {
+  double mn = t.mm_min(), mx = t.mm_max();
+  for (int n = c.leaf; n >= 0; n = t.parent(n)) value = tree_update_node(t, p, n, value, c.to_play, mn, mx);
+  t.mm_min() = mn;
+  t.mm_max() = mx;
+}
+
+// expand + backpropagate of one simulation (self_play.py:345-353).
 template <class T, class PriorFn>
 MZX_HD inline void tree_expand_backprop(const T& t, const SearchParams& p, double value, double reward,
                                         PriorFn prior_of_slot) {
-  const int parent = t.meta(TM_CUR_PARENT), slot = t.meta(TM_CUR_SLOT);
-  const int leaf = t.meta(TM_CUR_LEAF), to_play = t.meta(TM_CUR_TO_PLAY), depth = t.meta(TM_CUR_DEPTH);
-  t.child(parent, slot) = leaf;
-  t.parent(leaf) = parent;
-  t.parent_slot(leaf) = slot;
-  t.to_play(leaf) = to_play;
-  t.reward(leaf) = reward;
-  t.visit(leaf) = 0;
-  t.value_sum(leaf) = 0.0;
-  t.q(leaf) = 0.0;
-  for (int s = 0; s < p.num_actions; ++s) {
-    t.prior(leaf, s) = prior_of_slot(s);
-    t.child(leaf, s) = -1;
-  }
-  t.meta(TM_N_NODES) = leaf + 1;
-  if (depth > t.meta(TM_MAX_DEPTH)) t.meta(TM_MAX_DEPTH) = depth;
-  t.meta(TM_SUM_DEPTH) += depth;
-
-  double mn = t.mm_min(), mx = t.mm_max();
-  const double disc = p.discount;
-  if (p.num_players == 1) {
-    for (int n = leaf; n >= 0; n = t.parent(n)) {
-      const double vs = t.value_sum(n) + value;
-      const int vc = t.visit(n) + 1;
-      t.value_sum(n) = vs;
-      t.visit(n) = vc;
-      const double r = t.reward(n);
-      const double qv = r + disc * (vs / (double)vc);
-      t.q(n) = qv;
-      if (qv > mx) mx = qv;
-      if (qv < mn) mn = qv;
-      value = r + disc * value;
-    }
-  } else {
-    for (int n = leaf; n >= 0; n = t.parent(n)) {
-      const bool same = (t.to_play(n) == to_play);
-      const double vs = t.value_sum(n) + (same ? value : -value);
-      const int vc = t.visit(n) + 1;
-      t.value_sum(n) = vs;
-      t.visit(n) = vc;
-      const double r = t.reward(n);
-      const double qv = r + disc * (-(vs / (double)vc));
-      t.q(n) = qv;
-      if (qv > mx) mx = qv;
-      if (qv < mn) mn = qv;
-      value = (same ? -r : r) + disc * value;
-    }
-  }
-  t.mm_min() = mn;
-  t.mm_max() = mx;
+  const SelCtx c = load_ctx(t);
+  tree_attach_leaf(t, p, c, reward);
+  for (int s = 0; s < p.num_actions; ++s) tree_init_slot(t, c.leaf, s, prior_of_slot(s));
+  tree_backprop(t, p, c, value);
 }
 
 // Root creation: Node(0) + root.expand(legal_actions, ...) + add_exploration_noise
 // (self_play.py:276-314, :467-476).  `legal` is the game's legal_actions() list
 // in ITS order (slot i = legal[i]; the reference's children dict keeps that
 // order), padded with -1 up to num_actions.  `noise` (slot order) may be null.
-template <class T, class PriorFn>
-MZX_HD inline void tree_init_root(const T& t, const SearchParams& p, const int32_t* legal, int to_play,
-                                  double root_reward, PriorFn prior_of_slot, const double* noise) {
+template <class T>
+MZX_HD inline int tree_init_root_record(const T& t, const SearchParams& p, const int32_t* legal, int to_play,
+                                        double root_reward) {
   for (int k = 0; k < TM_WORDS; ++k) t.meta(k) = 0;
   t.mm_min() = MZX_INF;
   t.mm_max() = -MZX_INF;
@@ -270,24 +315,44 @@ MZX_HD inline void tree_init_root(const T& t, const SearchParams& p, const int32
   t.meta(TM_N_NODES) = 1;
   t.visit(0) = 0;
   t.value_sum(0) = 0.0;
-  t.q(0) = 0.0;
   t.reward(0) = root_reward;
   t.to_play(0) = to_play;
   t.parent(0) = -1;
   t.parent_slot(0) = -1;
-  const double frac = p.exploration_fraction;
-  for (int s = 0; s < p.num_actions; ++s) {
-    double pr = 0.0;
-    if (s < nroot) {
-      pr = prior_of_slot(s);
-      if (noise) pr = pr * (1.0 - frac) + noise[s] * frac;  // :476
-    }
-    t.prior(0, s) = pr;
-    t.child(0, s) = -1;
-  }
+  return nroot;
 }
 
-// fp32 helpers shared by the kernels that turn network heads into tree inputs.
+// prior of root slot s after exploration noise (self_play.py:476); `pr` = softmax prior.
+MZX_HD inline double root_noisy_prior(double pr, const double* noise, int s, double frac) {
+  return noise ? pr * (1.0 - frac) + noise[s] * frac : pr;
+}
+
+template <class T, class PriorFn>
+MZX_HD inline void tree_init_root(const T& t, const SearchParams& p, const int32_t* legal, int to_play,
+                                  double root_reward, PriorFn prior_of_slot, const double* noise) {
+  const int nroot = tree_init_root_record(t, p, legal, to_play, root_reward);
+  for (int s = 0; s < p.num_actions; ++s)
+    tree_init_slot(t, 0, s, s < nroot ? root_noisy_prior(prior_of_slot(s), noise, s, p.exploration_fraction) : 0.0);
+}
+
+// ---------------------------------------------------------------------------
+// fp32 helpers that turn network heads into tree inputs.
+//
+// Reductions use ONE canonical order everywhere (generic per-thread operators
+// and the 16-lanes-per-tree fused kernels): element i belongs to lane i % 16,
+// a lane accumulates its elements in increasing i, and the 16 lane partials are
+// combined by the butterfly  xor 1, xor 2, half-mirror (i <-> 7-i), mirror
+// (i <-> 15-i) -- what the fused kernels do with DPP.  Hence both paths produce
+// bit-identical decoded values / priors on the device.
+
+// Lane 0's result of the 16-lane butterfly sum of v[0..15].
+MZX_HD inline float butterfly16_sum(const float* v) {
+  const float q0 = (v[0] + v[1]) + (v[2] + v[3]);
+  const float q1 = (v[7] + v[6]) + (v[5] + v[4]);
+  const float q3 = (v[15] + v[14]) + (v[13] + v[12]);
+  const float q2 = (v[8] + v[9]) + (v[10] + v[11]);
+  return (q0 + q1) + (q3 + q2);
+}
 
 // Inverse of the value scaling h(x) (models.py:660-665), fp32, same op order as the
 // reference's tensor expression.  NOTE x = 0 gives sign(0) * (tiny negative) = -0.0f:
@@ -305,33 +370,34 @@ MZX_HD inline float support_inverse_transform(float x) {
   return sgn * t;
 }
 
-// models.support_to_scalar (models.py:645-666) for one row of 2*support+1 logits.
-MZX_HD inline float support_to_scalar(const float* logits, int support_size) {
-  const int F = 2 * support_size + 1;
-  float m = logits[0];
-  for (int i = 1; i < F; ++i) m = fmaxf(m, logits[i]);
-  float den = 0.f, num = 0.f;
-  for (int i = 0; i < F; ++i) {
-    const float e = mzx_expf(logits[i] - m);
-    den += e;
-  }
-  for (int i = 0; i < F; ++i) {
-    const float pr = mzx_expf(logits[i] - m) / den;
-    num += (float)(i - support_size) * pr;
-  }
-  return support_inverse_transform(num);
-}
-
-// fp32 softmax statistics over a subset of logits (Node.expand, self_play.py:460-462).
+// fp32 softmax statistics over n logits (Node.expand, self_play.py:460-462).
 struct SoftmaxStats { float m, den; };
 template <class LogitFn>
 MZX_HD inline SoftmaxStats softmax_stats(int n, LogitFn logit) {
   SoftmaxStats s;
   s.m = logit(0);
   for (int i = 1; i < n; ++i) s.m = fmaxf(s.m, logit(i));
-  s.den = 0.f;
-  for (int i = 0; i < n; ++i) s.den += mzx_expf(logit(i) - s.m);
+  float lane[16];
+  for (int j = 0; j < 16; ++j) {
+    float acc = 0.f;
+    for (int i = j; i < n; i += 16) acc += mzx_expf(logit(i) - s.m);
+    lane[j] = acc;
+  }
+  s.den = butterfly16_sum(lane);
   return s;
+}
+
+// models.support_to_scalar (models.py:645-666) for one row of 2*support+1 logits.
+MZX_HD inline float support_to_scalar(const float* logits, int support_size) {
+  const int F = 2 * support_size + 1;
+  const SoftmaxStats st = softmax_stats(F, [&](int i) { return logits[i]; });
+  float lane[16];
+  for (int j = 0; j < 16; ++j) {
+    float acc = 0.f;
+    for (int i = j; i < F; i += 16) acc += (float)(i - support_size) * (mzx_expf(logits[i] - st.m) / st.den);
+    lane[j] = acc;
+  }
+  return support_inverse_transform(butterfly16_sum(lane));
 }
 
 }  // namespace mzx

@@ -221,6 +221,30 @@ class BatchedMCTS:
             self._arena = self.backend.zeros((max(need, big),), torch.uint8)
         return self._arena
 
+    def export_trees(self, num_trees):
+        """
+        Canonical-order copy of the trees of the last ``run`` (diagnose tooling / parity tests):
+        dict of numpy arrays visit [B][N], value_sum, reward, to_play, parent, child [B][N][A],
+        prior, minmax [B][2], n_nodes [B].  With the fused kernel this needs mode flag 2.
+        """
+        be, lib, B, N, A = self.backend, self.backend.lib, num_trees, self.num_simulations + 1, self.A
+        t = dict(
+            visit=be.zeros((B, N), torch.int32), value_sum=be.zeros((B, N), torch.float64),
+            reward=be.zeros((B, N), torch.float64), to_play=be.zeros((B, N), torch.int32),
+            parent=be.zeros((B, N), torch.int32), child=be.zeros((B, N, A), torch.int32),
+            prior=be.zeros((B, N, A), torch.float64), minmax=be.zeros((B, 2), torch.float64),
+            n_nodes=be.zeros((B,), torch.int32),
+        )
+        d = _lib.TreeDump(*[be.ptr(t[k]) for k in ("visit", "value_sum", "reward", "to_play", "parent", "child",
+                                                   "prior", "minmax", "n_nodes")])
+        lib.check(lib.mzx_search_dump(self.handle(B), ctypes.byref(d), be.ptr(self.arena(B)), be.stream()))
+        return {k: v.cpu().numpy() for k, v in t.items()}
+
+    def arena_offsets(self, num_trees):
+        out = (ctypes.c_int64 * 8)()
+        self.backend.lib.check(self.backend.lib.mzx_search_arena_offsets(self.handle(num_trees), ctypes.byref(out)))
+        return dict(zip(("tables", "trees", "hidden", "workspace", "tree_bytes", "workspace_bytes", "total"), out))
+
     def _buf(self, name, shape, dtype):
         key = (name, tuple(shape), dtype)
         if key not in self._buffers:

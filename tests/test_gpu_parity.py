@@ -144,20 +144,60 @@ def test_full_size_c2_cartpole(backend, mode):
     assert same >= len(sample) - 1
 
 
-def test_generic_and_fused_agree(backend):
-    cfg = configs.cartpole()
-    B = 512
+@pytest.mark.parametrize("players", [1, 2])
+def test_generic_and_fused_trees_bit_identical(backend, players):
+    """
+    The fused kernels (register-resident SmallNet and LDS-weight LdsNet engines) against the
+    generic one-kernel-per-operator path ON THE DEVICE: same inline tree arithmetic, same
+    canonical fp32 reduction order -> every node statistic must agree bit for bit.
+    """
+    cfg = configs.cartpole(players=list(range(players)))
+    B = 256
     net = models.MuZeroNetwork(cfg)
     net.set_weights(synthetic.fill_state_dict(net.state_dict(), 17))
     obs = synthetic.observations(B, cfg.observation_shape, seed=9)
+    rs = numpy.random.RandomState(3)
+    legal = [list(cfg.action_space) if i % 5 else [int(rs.randint(0, 2))] for i in range(B)]  # some single-action roots
+    to_play = [int(i % players) for i in range(B)]
+    outs = {}
+    for name, mode in (("generic", 0), ("fused-small", 3), ("fused-lds", 7)):
+        engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
+        res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(7 + i) for i in range(B)])
+        outs[name] = (res, engine.export_trees(B))
+    ref_res, ref_tree = outs["generic"]
+    for name in ("fused-small", "fused-lds"):
+        res, tree = outs[name]
+        assert numpy.array_equal(res.visit_counts, ref_res.visit_counts), name
+        assert numpy.array_equal(res.root_values.view(numpy.int64), ref_res.root_values.view(numpy.int64)), name
+        assert numpy.array_equal(res.root_predicted_values.view(numpy.int64),
+                                 ref_res.root_predicted_values.view(numpy.int64)), name
+        assert numpy.array_equal(res.max_tree_depth, ref_res.max_tree_depth) and numpy.array_equal(res.tape_used, ref_res.tape_used)
+        for k, v in ref_tree.items():
+            a, b = tree[k], v
+            if a.dtype == numpy.float64:
+                a, b = a.view(numpy.int64), b.view(numpy.int64)
+            assert numpy.array_equal(a, b), (name, k)
+
+
+def test_fused_lds_engine_other_shapes(backend):
+    """A fully connected shape no register specialisation covers (wider, deeper, 3 actions, stacked obs)."""
+    cfg = configs.cartpole(action_space=list(range(3)), stacked_observations=2, encoding_size=10,
+                           fc_representation_layers=[12], fc_dynamics_layers=[24, 12], fc_reward_layers=[20],
+                           fc_value_layers=[], fc_policy_layers=[33], num_simulations=30)
+    B = 96
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 23))
+    obs = synthetic.observations(B, net.input_shape, seed=4)
     legal = [list(cfg.action_space)] * B
     outs = []
-    for mode in (0, None):
+    for mode in (0, 3):
         engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
-        if mode is None and not backend.lib.mzx_search_fused_supported(engine.handle(B)):
-            pytest.skip("fused kernel not available")
-        outs.append(engine.run(list(obs), legal, [0] * B, True, [numpy.random.RandomState(7 + i) for i in range(B)]))
-    match = (outs[0].visit_counts == outs[1].visit_counts).all(1).mean()
-    print("generic vs fused identical visit counts:", match)
-    assert match > 0.99
-    assert numpy.allclose(outs[0].root_predicted_values, outs[1].root_predicted_values, atol=TOL, rtol=TOL)
+        assert backend.lib.mzx_search_fused_supported(engine.handle(B))
+        res = engine.run(list(obs), legal, [0] * B, True, [numpy.random.RandomState(70 + i) for i in range(B)])
+        outs.append((res, engine.export_trees(B)))
+    assert numpy.array_equal(outs[0][0].visit_counts, outs[1][0].visit_counts)
+    for k, v in outs[0][1].items():
+        a, b = outs[1][1][k], v
+        if a.dtype == numpy.float64:
+            a, b = a.view(numpy.int64), b.view(numpy.int64)
+        assert numpy.array_equal(a, b), k
