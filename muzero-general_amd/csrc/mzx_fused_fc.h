@@ -6,27 +6,33 @@
 // Reference semantics: MCTS.run /root/reference/self_play.py:260-361 and
 // MuZeroFullyConnectedNetwork models.py:80-195.  The tree arithmetic is the SAME
 // inline code as the generic path (mzx_tree.h, proven bit-exact against the
-// reference in lock-step); the fp32 reductions follow the canonical 16-lane
-// order defined there, so this kernel and the generic operators agree bit for
-// bit on the device (tests compare the exported trees).
+// reference in lock-step) or a lane-parallel rearrangement of it that performs
+// the identical binary64 operations per node; the fp32 reductions follow the
+// canonical 16-lane order defined there.  Hence this kernel and the generic
+// operators agree bit for bit on the device (tests compare the exported trees).
 //
 // Mapping (wave64, one 256-thread workgroup per CU):
 //   * a tree owns a ROW of 16 lanes (one DPP row); a wavefront carries 4 trees, a
 //     workgroup 16 (fewer if LDS is short).  Wavefronts never synchronise with
 //     each other after the staging barrier: each wave free-runs its 4 trees.
 //   * tree statistics (binary64), child links, priors and per-node hidden states
-//     live in that tree's LDS slab for the whole launch; HBM sees only the
+//     live in that tree's LDS slab for the whole launch; per-tree scalars (min-max
+//     bounds, node count, tape cursor) stay in registers.  HBM sees only the
 //     inputs and the final visit counts.
 //   * selection: lane s scores child slot s (one LDS read of A contiguous slots per
-//     level), the argmax is a binary64 DPP butterfly + a wavefront ballot whose
-//     16-bit row field yields the maximiser count / index (ties -> numpy-exact
-//     draw from the tape).  Expansion: lane a writes slot a.  Back-propagation:
-//     lane 0 (latency chain).
+//     level); argmax = binary64 DPP butterfly + a wavefront ballot whose 16-bit
+//     row field gives the maximiser count / index (ties -> numpy-exact draw from
+//     the tape).  The winner's link, visit count and pb_c / sqrt table entries are
+//     handed to the next level by DPP row broadcasts, so a level costs ONE LDS
+//     round trip.  Lane d remembers the node at depth d of the walk.
+//   * expansion: lane a writes child slot a.  Back-propagation: lane d updates the
+//     path node at depth d; the discounted value chain (the only true recurrence)
+//     runs as DPP-broadcast steps; min-max by a binary64 butterfly when it moves.
 //   * network, two engines behind one interface:
 //       - SmallNet<...>: every weight a lane needs sits in its REGISTERS for the
-//         whole launch; a layer is K x {v_mov_dpp row_newbcast:k, v_fmac}: the
-//         activations never leave the register file (single-hidden-layer MLPs up to
-//         16 wide: the CartPole-class networks);
+//         whole launch; a layer is K x v_fmac_f32_dpp row_newbcast:k -- activations
+//         never leave the register file (single-hidden-layer MLPs up to 16 wide:
+//         the CartPole-class networks);
 //       - LdsNet: any fully connected configuration up to 64-wide layers; weights
 //         staged in LDS, activations exchanged through a per-tree LDS scratch.
 #pragma once
@@ -95,6 +101,10 @@ __device__ __forceinline__ double dpp_d(double v) {
 }
 template <int K>
 __device__ __forceinline__ float bcast(float v) { return dpp_f<DPP_BCAST0 + K>(v); }
+template <int K>
+__device__ __forceinline__ int bcast_i(int v) { return dpp_i<DPP_BCAST0 + K>(v); }
+template <int K>
+__device__ __forceinline__ double bcast_d(double v) { return dpp_d<DPP_BCAST0 + K>(v); }
 
 // canonical butterfly (mzx_tree.h): xor 1, xor 2, half-mirror, mirror; own + partner
 __device__ __forceinline__ float row_sum(float v) {
@@ -118,13 +128,45 @@ __device__ __forceinline__ float row_min(float v) {
   v = fminf(v, dpp_f<DPP_MIRROR>(v));
   return v;
 }
+// binary64 max / min over the first W lanes of the row (W = 2, 4 or 16; the other lanes hold
+// the neutral element); exact, so the order of the butterfly does not matter
+template <int W>
 __device__ __forceinline__ double row_max_d(double v) {
   double o;
   o = dpp_d<DPP_XOR1>(v); v = (o > v) ? o : v;
-  o = dpp_d<DPP_XOR2>(v); v = (o > v) ? o : v;
-  o = dpp_d<DPP_HALF_MIRROR>(v); v = (o > v) ? o : v;
-  o = dpp_d<DPP_MIRROR>(v); v = (o > v) ? o : v;
+  if constexpr (W > 2) { o = dpp_d<DPP_XOR2>(v); v = (o > v) ? o : v; }
+  if constexpr (W > 4) {
+    o = dpp_d<DPP_HALF_MIRROR>(v); v = (o > v) ? o : v;
+    o = dpp_d<DPP_MIRROR>(v); v = (o > v) ? o : v;
+  }
   return v;
+}
+__device__ __forceinline__ double row_min_d16(double v) {
+  double o;
+  o = dpp_d<DPP_XOR1>(v); v = (o < v) ? o : v;
+  o = dpp_d<DPP_XOR2>(v); v = (o < v) ? o : v;
+  o = dpp_d<DPP_HALF_MIRROR>(v); v = (o < v) ? o : v;
+  o = dpp_d<DPP_MIRROR>(v); v = (o < v) ? o : v;
+  return v;
+}
+// value held by lane `slot` (< W, row-uniform) of this row
+template <int W>
+__device__ __forceinline__ int pick_i(int v, int slot) {
+  static_assert(W == 2 || W == 4, "DPP pick is unrolled for 2 or 4 candidates");
+  int r = bcast_i<0>(v);
+  r = (slot == 1) ? bcast_i<1>(v) : r;
+  if constexpr (W > 2) {
+    r = (slot == 2) ? bcast_i<2>(v) : r;
+    r = (slot == 3) ? bcast_i<3>(v) : r;
+  }
+  return r;
+}
+template <int W>
+__device__ __forceinline__ double pick_d(double v, int slot) {
+  return __hiloint2double(pick_i<W>(__double2hiint(v), slot), pick_i<W>(__double2loint(v), slot));
+}
+__device__ __forceinline__ unsigned row_bits(unsigned long long ballot, int row_in_wave) {
+  return (unsigned)(ballot >> (row_in_wave * FUSED_ROW)) & 0xFFFFu;
 }
 
 // support_to_scalar (models.py:645-666), canonical lane order: this lane holds
@@ -144,62 +186,150 @@ __device__ __forceinline__ float row_decode2(float l0, float l1, int F, int supp
 }
 
 // ---------------------------------------------------------------------------
-// lane-parallel selection walk (tree_select of mzx_tree.h, lane s = child slot s)
-struct RowSel { SelCtx c; int action; };
+// per-tree scalars kept in registers (row-uniform) for the whole launch
+struct RowState {
+  double mn, mx;                       // MinMaxStats
+  int32_t n_nodes, tape_pos, flags, ties, max_depth, sum_depth, root_n, root_to_play;
+};
 
+__device__ __forceinline__ void store_state(const TreeRef& t, const RowState& st) {
+  t.mm_min() = st.mn; t.mm_max() = st.mx;
+  t.meta(TM_N_NODES) = st.n_nodes; t.meta(TM_TAPE_POS) = st.tape_pos; t.meta(TM_FLAGS) = st.flags;
+  t.meta(TM_TIE_DRAWS) = st.ties; t.meta(TM_MAX_DEPTH) = st.max_depth; t.meta(TM_SUM_DEPTH) = st.sum_depth;
+  t.meta(TM_ROOT_N) = st.root_n;
+}
+
+struct RowSel {
+  SelCtx c;
+  int action;
+  // this lane's share of the search path: lane d holds the node at depth d (root = 0, new leaf = depth)
+  int my_node, my_parent, my_pslot;
+};
+
+// Lane-parallel selection walk (tree_select of mzx_tree.h; lane s = child slot s).
+template <int AW>
 __device__ __forceinline__ RowSel row_select(const TreeRef& t, const SearchParams& p, const uint32_t* tape, int sub,
-                                             int row_in_wave) {
+                                             int row_in_wave, int sim, RowState& st) {
+  RowSel r;
   int node = 0, depth = 0, slot = 0;
-  int vtp = t.to_play(0);
-  const double mn = t.mm_min(), mx = t.mm_max();
-  const int root_n = t.meta(TM_ROOT_N);
-  int32_t tape_pos = t.meta(TM_TAPE_POS), flags = t.meta(TM_FLAGS), ties = t.meta(TM_TIE_DRAWS);
+  int vtp = st.root_to_play;
+  int N = sim;  // every finished simulation visited the root once
+  double pbc = p.pbc_table[N], sq = p.sqrt_table[N];
+  r.my_node = 0; r.my_parent = -1; r.my_pslot = -1;
   for (;;) {
     ++depth;
-    const int nc = (node == 0) ? root_n : p.num_actions;
-    const int N = t.visit(node);
-    const double pbc = p.pbc_table[N], sq = p.sqrt_table[N];
+    const int nc = (node == 0) ? st.root_n : p.num_actions;
     const bool valid = sub < nc;
     const int s = valid ? sub : 0;
-    const double sc = valid ? ucb_from(pbc, sq, t.slot_visit(node, s), t.prior(node, s), t.slot_q(node, s), mn, mx)
-                            : -MZX_INF;
-    const double best = row_max_d(sc);
-    const unsigned long long bal = __ballot(valid && sc == best);
-    const unsigned bits = (unsigned)(bal >> (row_in_wave * FUSED_ROW)) & 0xFFFFu;
+    const int n = t.slot_visit(node, s);
+    const int c = t.child(node, s);
+    const double sc = valid ? ucb_from(pbc, sq, n, t.prior(node, s), t.slot_q(node, s), st.mn, st.mx) : -MZX_INF;
+    // tables of the child's visit count, in case this slot wins (off the critical path)
+    const double pbc_c = p.pbc_table[n], sq_c = p.sqrt_table[n];
+    const double best = row_max_d<AW>(sc);
+    const unsigned bits = row_bits(__ballot(valid && sc == best), row_in_wave);
     const int nbest = __popc(bits);
     if (nbest <= 1) {
       slot = nbest ? (__ffs(bits) - 1) : 0;
     } else {  // numpy.random.choice(ties): k-th maximiser in slot order
-      ++ties;
-      int k = tape_draw(tape, p.tape_words, tape_pos, flags, nbest);
+      ++st.ties;
+      int k = tape_draw(tape, p.tape_words, st.tape_pos, st.flags, nbest);
       unsigned b = bits;
       for (; k > 0; --k) b &= b - 1;
       slot = __ffs(b) - 1;
     }
     vtp = (vtp + 1 < p.num_players) ? vtp + 1 : 0;
-    const int nxt = t.child(node, slot);
-    if (nxt < 0) break;
-    node = nxt;
+    int cw;
+    if constexpr (AW <= 4) cw = pick_i<AW>(c, slot); else cw = t.child(node, slot);
+    if (sub == depth) { r.my_parent = node; r.my_pslot = slot; r.my_node = cw; }
+    if (cw < 0) break;
+    if constexpr (AW <= 4) {
+      N = pick_i<AW>(n, slot); pbc = pick_d<AW>(pbc_c, slot); sq = pick_d<AW>(sq_c, slot);
+    } else {
+      N = t.slot_visit(node, slot); pbc = p.pbc_table[N]; sq = p.sqrt_table[N];
+    }
+    node = cw;
   }
-  RowSel r;
-  int leaf = t.meta(TM_N_NODES);
-  if (leaf >= p.num_nodes) { flags |= TF_NODE_OVERFLOW; leaf = p.num_nodes - 1; }
-  if (sub == 0) {
-    t.meta(TM_TAPE_POS) = tape_pos;
-    t.meta(TM_FLAGS) = flags;
-    t.meta(TM_TIE_DRAWS) = ties;
-  }
+  int leaf = st.n_nodes;
+  if (leaf >= p.num_nodes) { st.flags |= TF_NODE_OVERFLOW; leaf = p.num_nodes - 1; }
+  if (sub == depth) r.my_node = leaf;
   r.c.parent = node; r.c.slot = slot; r.c.leaf = leaf; r.c.depth = depth; r.c.to_play = vtp;
   r.action = (node == 0) ? t.root_action(slot) : slot;
   return r;
+}
+
+// Leaf attachment + back-propagation of one simulation (tree_attach_leaf + tree_backprop of
+// mzx_tree.h), one path node per lane: identical binary64 operations per node, the value
+// recurrence evaluated leaf -> root exactly in the reference's order.
+template <int J>
+__device__ __forceinline__ void chain_step(double r_eff, double disc, int depth, int sub, double& val, double& my_in) {
+  if (J <= depth) {  // row-uniform
+    const double rj = bcast_d<J>(r_eff);
+    if (sub == J) my_in = val;
+    val = rj + disc * val;
+  }
+  if constexpr (J > 1) chain_step<J - 1>(r_eff, disc, depth, sub, val, my_in);
+}
+
+__device__ __forceinline__ void row_backprop(const TreeRef& t, const SearchParams& p, const RowSel& r, int sub,
+                                             int row_in_wave, double value, double reward, RowState& st) {
+  const int depth = r.c.depth, P = p.num_players;
+  st.n_nodes = r.c.leaf + 1;
+  if (depth > st.max_depth) st.max_depth = depth;
+  st.sum_depth += depth;
+  if (depth >= FUSED_ROW) {  // path longer than a row: serial walk on lane 0 (rare)
+    if (sub == 0) {
+      store_state(t, st);
+      t.child(r.c.parent, r.c.slot) = r.c.leaf;
+      t.parent(r.c.leaf) = r.c.parent; t.parent_slot(r.c.leaf) = r.c.slot; t.to_play(r.c.leaf) = r.c.to_play;
+      t.reward(r.c.leaf) = reward; t.visit(r.c.leaf) = 0; t.value_sum(r.c.leaf) = 0.0;
+      tree_backprop(t, p, r.c, value);
+    }
+    wave_sync();
+    st.mn = t.mm_min(); st.mx = t.mm_max();
+    return;
+  }
+  const bool active = sub <= depth, is_leaf = sub == depth;
+  const int n = r.my_node;
+  double rr = reward, vs = 0.0;
+  int vc = 0, tp = r.c.to_play;
+  if (active && !is_leaf) {
+    rr = t.reward(n); vs = t.value_sum(n); vc = t.visit(n);
+    if (P == 2) tp = t.to_play(n);
+  }
+  const bool same = (tp == r.c.to_play);
+  const double r_eff = (P == 1 || !same) ? rr : -rr;  // value = (+-reward) + discount * value
+  double val = value, my_in = value;
+  chain_step<FUSED_ROW - 1>(r_eff, p.discount, depth, sub, val, my_in);
+  if (sub == 0) my_in = val;
+  double qv = 0.0;
+  if (active) {
+    const double vs2 = vs + ((P == 1 || same) ? my_in : -my_in);
+    const int vc2 = vc + 1;
+    const double mean = vs2 / (double)vc2;
+    qv = rr + p.discount * ((P == 1) ? mean : -mean);
+    t.value_sum(n) = vs2;
+    t.visit(n) = vc2;
+    if (sub > 0) { t.slot_visit(r.my_parent, r.my_pslot) = vc2; t.slot_q(r.my_parent, r.my_pslot) = qv; }
+    if (is_leaf) {
+      t.child(r.my_parent, r.my_pslot) = n;
+      t.parent(n) = r.my_parent; t.parent_slot(n) = r.my_pslot; t.to_play(n) = r.c.to_play; t.reward(n) = reward;
+    }
+  }
+  // MinMaxStats.update over the path (pure min / max: order-free)
+  if (row_bits(__ballot(active && (qv > st.mx || qv < st.mn)), row_in_wave)) {
+    const double hi = row_max_d<16>(active ? qv : -MZX_INF), lo = row_min_d16(active ? qv : MZX_INF);
+    if (hi > st.mx) st.mx = hi;
+    if (lo < st.mn) st.mn = lo;
+  }
 }
 
 // ---------------------------------------------------------------------------
 // Network engines.  Interface (all calls are row-collective, `sub` = lane in row):
 //   stage(a, smem, tid)   workgroup-wide staging before the one __syncthreads()
 //   setup(a, smem, sub)   per-lane setup after it
-//   initial(obs, h_out, scr, sub, value, policy)         models.py:172-190
-//   recurrent(h_in, action, h_out, scr, sub, value, reward, policy)  models.py:192-195
+//   initial(obs, h_out, scr, sub, out)                      models.py:172-190
+//   recurrent(h_in, action, h_out, scr, sub, out)           models.py:192-195
 // value/reward come back decoded (support_to_scalar) in every lane; `policy` is
 // the logit of action `sub` (undefined for sub >= A); h_out[0..E) receives the
 // min-max scaled state.
@@ -288,6 +418,58 @@ struct LdsNet {
 };
 
 // ---- SmallNet: register-resident weights, DPP-broadcast activations -------------
+//
+// acc += x[lane k of my row] * w[k] for k = 0..K-1, in that order, as one fused
+// multiply-add each: v_fmac_f32_dpp with the row_newbcast:k operand swizzle, i.e.
+// the sequential fmaf chain of LinearOp.  `x` is produced by plain VALU code right
+// before the block, hence the leading 2 wait states (VALU write -> DPP read hazard,
+// which hipcc does not track through an asm statement).
+#define MZX_FD(ACC, W, K) "v_fmac_f32_dpp " ACC ", %[x], " W " row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+
+__device__ __forceinline__ float dot8_bcast(float x, const float (&w)[8]) {
+  float acc = 0.f;
+  asm("s_nop 1\n\t"
+      MZX_FD("%[a]", "%[w0]", 0) MZX_FD("%[a]", "%[w1]", 1) MZX_FD("%[a]", "%[w2]", 2) MZX_FD("%[a]", "%[w3]", 3)
+      MZX_FD("%[a]", "%[w4]", 4) MZX_FD("%[a]", "%[w5]", 5) MZX_FD("%[a]", "%[w6]", 6) MZX_FD("%[a]", "%[w7]", 7)
+      : [a] "+v"(acc)
+      : [x] "v"(x), [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]),
+        [w6] "v"(w[6]), [w7] "v"(w[7]));
+  return acc;
+}
+__device__ __forceinline__ float dot16_bcast(float x, const float (&w)[16]) {
+  float acc = 0.f;
+  asm("s_nop 1\n\t"
+      MZX_FD("%[a]", "%[w0]", 0) MZX_FD("%[a]", "%[w1]", 1) MZX_FD("%[a]", "%[w2]", 2) MZX_FD("%[a]", "%[w3]", 3)
+      MZX_FD("%[a]", "%[w4]", 4) MZX_FD("%[a]", "%[w5]", 5) MZX_FD("%[a]", "%[w6]", 6) MZX_FD("%[a]", "%[w7]", 7)
+      MZX_FD("%[a]", "%[w8]", 8) MZX_FD("%[a]", "%[w9]", 9) MZX_FD("%[a]", "%[w10]", 10) MZX_FD("%[a]", "%[w11]", 11)
+      MZX_FD("%[a]", "%[w12]", 12) MZX_FD("%[a]", "%[w13]", 13) MZX_FD("%[a]", "%[w14]", 14) MZX_FD("%[a]", "%[w15]", 15)
+      : [a] "+v"(acc)
+      : [x] "v"(x), [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]),
+        [w6] "v"(w[6]), [w7] "v"(w[7]), [w8] "v"(w[8]), [w9] "v"(w[9]), [w10] "v"(w[10]), [w11] "v"(w[11]),
+        [w12] "v"(w[12]), [w13] "v"(w[13]), [w14] "v"(w[14]), [w15] "v"(w[15]));
+  return acc;
+}
+// two neurons of one layer sharing the input (two independent fmac chains interleaved)
+__device__ __forceinline__ void dot16x2_bcast(float x, const float (&u)[16], const float (&v)[16], float& ru, float& rv) {
+  float a = 0.f, b = 0.f;
+#define MZX_FD2(K) MZX_FD("%[a]", "%[u" #K "]", K) MZX_FD("%[b]", "%[v" #K "]", K)
+  asm("s_nop 1\n\t"
+      MZX_FD2(0) MZX_FD2(1) MZX_FD2(2) MZX_FD2(3) MZX_FD2(4) MZX_FD2(5) MZX_FD2(6) MZX_FD2(7)
+      : [a] "+v"(a), [b] "+v"(b)
+      : [x] "v"(x), [u0] "v"(u[0]), [u1] "v"(u[1]), [u2] "v"(u[2]), [u3] "v"(u[3]), [u4] "v"(u[4]), [u5] "v"(u[5]),
+        [u6] "v"(u[6]), [u7] "v"(u[7]), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]),
+        [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7]));
+  asm("s_nop 1\n\t"
+      MZX_FD2(8) MZX_FD2(9) MZX_FD2(10) MZX_FD2(11) MZX_FD2(12) MZX_FD2(13) MZX_FD2(14) MZX_FD2(15)
+      : [a] "+v"(a), [b] "+v"(b)
+      : [x] "v"(x), [u8] "v"(u[8]), [u9] "v"(u[9]), [u10] "v"(u[10]), [u11] "v"(u[11]), [u12] "v"(u[12]),
+        [u13] "v"(u[13]), [u14] "v"(u[14]), [u15] "v"(u[15]), [v8] "v"(v[8]), [v9] "v"(v[9]), [v10] "v"(v[10]),
+        [v11] "v"(v[11]), [v12] "v"(v[12]), [v13] "v"(v[13]), [v14] "v"(v[14]), [v15] "v"(v[15]));
+#undef MZX_FD2
+  ru = a;
+  rv = b;
+}
+
 template <int K, int I = 0>
 __device__ __forceinline__ float fma_bcast(float x, const float (&w)[K], float acc) {
   if constexpr (I < K) {
@@ -297,6 +479,18 @@ __device__ __forceinline__ float fma_bcast(float x, const float (&w)[K], float a
     return acc;
   }
 }
+template <int K>
+__device__ __forceinline__ float dot_bcast(float x, const float (&w)[K]) {
+  if constexpr (K == 8) return dot8_bcast(x, w);
+  else if constexpr (K == 16) return dot16_bcast(x, w);
+  else return fma_bcast<K>(x, w, 0.f);
+}
+template <int K>
+__device__ __forceinline__ void dot2_bcast(float x, const float (&u)[K], const float (&v)[K], float& ru, float& rv) {
+  if constexpr (K == 16) dot16x2_bcast(x, u, v, ru, rv);
+  else { ru = fma_bcast<K>(x, u, 0.f); rv = fma_bcast<K>(x, v, 0.f); }
+}
+
 template <int K>
 __device__ __forceinline__ void load_row(float (&w)[K], float& b, const float* flat, int woff, int boff, int o, int O) {
   const bool ok = o < O;
@@ -350,12 +544,12 @@ struct SmallNet {
   }
   // prediction heads from the scaled state (lane k holds element k)
   __device__ __forceinline__ void heads(float hn, int sub, NetOut& o) const {
-    const float p1 = mzx_elu(fma_bcast<E>(hn, w_p1, 0.f) + b_p1);
-    const float v1 = mzx_elu(fma_bcast<E>(hn, w_v1, 0.f) + b_v1);
-    o.policy = fma_bcast<HP>(p1, w_p2, 0.f) + b_p2;
-    const float va = fma_bcast<HV>(v1, w_v2a, 0.f) + b_v2a;
-    const float vb = fma_bcast<HV>(v1, w_v2b, 0.f) + b_v2b;
-    o.value = row_decode2(va, vb, F, support, sub);
+    const float p1 = mzx_elu(dot_bcast<E>(hn, w_p1) + b_p1);
+    const float v1 = mzx_elu(dot_bcast<E>(hn, w_v1) + b_v1);
+    o.policy = dot_bcast<HP>(p1, w_p2) + b_p2;
+    float va, vb;
+    dot2_bcast<HV>(v1, w_v2a, w_v2b, va, vb);
+    o.value = row_decode2(va + b_v2a, vb + b_v2b, F, support, sub);
   }
   __device__ __forceinline__ void initial(const float* obs, float* h_out, float*, int sub, NetOut& o) const {
     float acc = 0.f;
@@ -374,13 +568,13 @@ struct SmallNet {
 #pragma unroll
     for (int x = 1; x < A; ++x) col = (action == x) ? w_d1[E + x] : col;
     const float d1 = mzx_elu((acc + col) + b_d1);
-    const float s = fma_bcast<HD>(d1, w_d2, 0.f) + b_d2;          // next state, unscaled (lane k < E)
-    const float r1 = mzx_elu(fma_bcast<E>(s, w_r1, 0.f) + b_r1);   // reward head reads the UNscaled state
-    const float ra = fma_bcast<HR>(r1, w_r2a, 0.f) + b_r2a;
-    const float rb = fma_bcast<HR>(r1, w_r2b, 0.f) + b_r2b;
+    const float s = dot_bcast<HD>(d1, w_d2) + b_d2;                // next state, unscaled (lane k < E)
+    const float r1 = mzx_elu(dot_bcast<E>(s, w_r1) + b_r1);         // reward head reads the UNscaled state
+    float ra, rb;
+    dot2_bcast<HR>(r1, w_r2a, w_r2b, ra, rb);
     const float hn = scale(s, sub);
     if (sub < E) h_out[sub] = hn;
-    o.reward = row_decode2(ra, rb, F, support, sub);
+    o.reward = row_decode2(ra + b_r2a, rb + b_r2b, F, support, sub);
     heads(hn, sub, o);
   }
 };
@@ -395,7 +589,9 @@ struct SmallNet {
     t_last = _t;                                                \
   }
 
-template <class Net, bool PROFILE>
+// AW = lanes that can hold a child slot in this instantiation: 2, 4 (DPP hand-off of the
+// winner) or 16 (LDS re-read); chosen on the host from the action-space size.
+template <class Net, int AW, bool PROFILE>
 __global__ void __launch_bounds__(256) fused_fc_search_kernel(const FusedFcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -432,6 +628,7 @@ __global__ void __launch_bounds__(256) fused_fc_search_kernel(const FusedFcArgs 
   p.pbc_table = tables;
   p.sqrt_table = tables + (a.p.num_nodes + 1);
   const uint32_t* tape = (const uint32_t*)a.io.d_tape + (size_t)tree * p.tape_words;
+  RowState st;
   MZX_PROF(0)
 
   // ---- initial_inference (models.py:172-190) + root expansion (self_play.py:286-314, :467-476)
@@ -449,18 +646,21 @@ __global__ void __launch_bounds__(256) fused_fc_search_kernel(const FusedFcArgs 
     const float m = row_max(l);
     const float e = in ? mzx_expf(l - m) : 0.f;
     const float den = row_sum(e);
+    st.root_to_play = a.io.d_to_play[tree];
     if (sub == 0) {
-      tree_init_root_record(t, p, lg, a.io.d_to_play[tree], (double)support_inverse_transform(0.0f));
+      tree_init_root_record(t, p, lg, st.root_to_play, (double)support_inverse_transform(0.0f));
       if (a.io.d_root_predicted_value) a.io.d_root_predicted_value[tree] = (double)o.value;
     }
     if (sub < A) tree_init_slot(t, 0, sub, in ? root_noisy_prior((double)(e / den), nz, sub, p.exploration_fraction) : 0.0);
+    st.mn = MZX_INF; st.mx = -MZX_INF;
+    st.n_nodes = 1; st.tape_pos = 0; st.flags = 0; st.ties = 0; st.max_depth = 0; st.sum_depth = 0; st.root_n = nroot;
     wave_sync();
   }
   MZX_PROF(1)
 
   // ---- simulations (self_play.py:319-355)
   for (int sim = 0; sim < p.num_sims; ++sim) {
-    const RowSel sel = row_select(t, p, tape, sub, row_in_wave);
+    const RowSel sel = row_select<AW>(t, p, tape, sub, row_in_wave, sim, st);
     MZX_PROF(2)
     NetOut o;
     net.recurrent(hidden + sel.c.parent * E, sel.action, hidden + sel.c.leaf * E, scr, sub, o);
@@ -472,27 +672,25 @@ __global__ void __launch_bounds__(256) fused_fc_search_kernel(const FusedFcArgs 
     const float den = row_sum(e);
     if (in) tree_init_slot(t, sel.c.leaf, sub, (double)(e / den));
     MZX_PROF(4)
-    if (sub == 0) {
-      tree_attach_leaf(t, p, sel.c, (double)o.reward);
-      tree_backprop(t, p, sel.c, (double)o.value);
-    }
+    row_backprop(t, p, sel, sub, row_in_wave, (double)o.value, (double)o.reward, st);
     wave_sync();
     MZX_PROF(5)
   }
 
   // ---- results (FinalizeOp)
   if (sub == 0) {
+    store_state(t, st);
     for (int x = 0; x < A; ++x) a.io.d_visit_counts[(size_t)tree * A + x] = 0;
-    const int nroot = t.meta(TM_ROOT_N);
-    for (int s = 0; s < nroot; ++s) a.io.d_visit_counts[(size_t)tree * A + t.root_action(s)] = t.slot_visit(0, s);
+    for (int s = 0; s < st.root_n; ++s) a.io.d_visit_counts[(size_t)tree * A + t.root_action(s)] = t.slot_visit(0, s);
     const int vc = t.visit(0);
     a.io.d_root_value[tree] = (vc == 0) ? 0.0 : t.value_sum(0) / (double)vc;
-    a.io.d_info[tree * 4 + 0] = t.meta(TM_MAX_DEPTH);
-    a.io.d_info[tree * 4 + 1] = t.meta(TM_FLAGS);
-    a.io.d_info[tree * 4 + 2] = t.meta(TM_TAPE_POS);
-    a.io.d_info[tree * 4 + 3] = t.meta(TM_SUM_DEPTH);
+    a.io.d_info[tree * 4 + 0] = st.max_depth;
+    a.io.d_info[tree * 4 + 1] = st.flags;
+    a.io.d_info[tree * 4 + 2] = st.tape_pos;
+    a.io.d_info[tree * 4 + 3] = st.sum_depth;
   }
   if (a.export_trees) {  // parity / diagnose export: LDS slab -> arena (same layout as the generic path)
+    wave_sync();
     const int words = (int)(a.L.tree_bytes / 4);
     uint32_t* dst = (uint32_t*)(a.export_trees + (size_t)tree * a.L.tree_bytes);
     const uint32_t* src = (const uint32_t*)slab;
@@ -587,20 +785,28 @@ inline FusedPlan fused_plan(const mzx_search* s, bool allow_small = true) {
 
 inline int fused_fc_supported(const mzx_search* s) { return fused_plan(s).ok; }
 
-template <class Net, bool PROFILE>
+template <class Net, int AW, bool PROFILE>
 inline int fused_launch(const FusedPlan& P, unsigned grid, stream_t stream) {
   static bool attr_set = false;  // one per instantiation
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)fused_fc_search_kernel<Net, PROFILE>,
+    hipError_t e = hipFuncSetAttribute((const void*)fused_fc_search_kernel<Net, AW, PROFILE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BUDGET);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((fused_fc_search_kernel<Net, PROFILE>), dim3(grid), dim3(P.args.trees_per_block * FUSED_ROW),
-                     (size_t)P.lds_bytes, stream, P.args);
+  hipLaunchKernelGGL((fused_fc_search_kernel<Net, AW, PROFILE>), dim3(grid),
+                     dim3(P.args.trees_per_block * FUSED_ROW), (size_t)P.lds_bytes, stream, P.args);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("fused kernel launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
   return MZX_OK;
+}
+
+template <class Net, bool PROFILE>
+inline int fused_launch_aw(const FusedPlan& P, unsigned grid, stream_t stream) {
+  const int A = P.args.p.num_actions;
+  if (A <= 2) return fused_launch<Net, 2, PROFILE>(P, grid, stream);
+  if (A <= 4) return fused_launch<Net, 4, PROFILE>(P, grid, stream);
+  return fused_launch<Net, 16, PROFILE>(P, grid, stream);
 }
 
 // mode bits: 1 = fused, 2 = export trees to the arena, 4 = force LdsNet, 8 = cycle-profile build
@@ -620,12 +826,14 @@ inline int fused_fc_run(mzx_search* s, const mzx_search_io* io, void* d_arena, s
     P.args.export_hidden = (float*)((char*)d_arena + s->off_hidden);
   }
   if (profile) P.args.prof = (uint32_t*)((char*)d_arena + s->off_ws);
-  const bool small = P.small != 0;
   const int tpb = P.args.trees_per_block;
   const unsigned grid = (unsigned)((s->p.num_trees + tpb - 1) / tpb);
-  if (small) return profile ? fused_launch<SmallNetCartpole, true>(P, grid, stream)
-                            : fused_launch<SmallNetCartpole, false>(P, grid, stream);
-  return profile ? fused_launch<LdsNet, true>(P, grid, stream) : fused_launch<LdsNet, false>(P, grid, stream);
+  if (P.small) {
+    // SmallNetCartpole has A = 2
+    return profile ? fused_launch<SmallNetCartpole, 2, true>(P, grid, stream)
+                   : fused_launch<SmallNetCartpole, 2, false>(P, grid, stream);
+  }
+  return profile ? fused_launch_aw<LdsNet, true>(P, grid, stream) : fused_launch_aw<LdsNet, false>(P, grid, stream);
 }
 
 #endif  // !MZX_HOSTCHECK

@@ -179,9 +179,10 @@ def test_generic_and_fused_trees_bit_identical(backend, players):
             assert numpy.array_equal(a, b), (name, k)
 
 
-def test_fused_lds_engine_other_shapes(backend):
-    """A fully connected shape no register specialisation covers (wider, deeper, 3 actions, stacked obs)."""
-    cfg = configs.cartpole(action_space=list(range(3)), stacked_observations=2, encoding_size=10,
+@pytest.mark.parametrize("num_actions", [3, 6, 16])
+def test_fused_lds_engine_other_shapes(backend, num_actions):
+    """Fully connected shapes no register specialisation covers (wider, deeper, more actions, stacked obs)."""
+    cfg = configs.cartpole(action_space=list(range(num_actions)), stacked_observations=2, encoding_size=10,
                            fc_representation_layers=[12], fc_dynamics_layers=[24, 12], fc_reward_layers=[20],
                            fc_value_layers=[], fc_policy_layers=[33], num_simulations=30)
     B = 96
