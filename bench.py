@@ -225,6 +225,14 @@ def main():
         L = mean_leaf_depth
         bytes_per_sim = 28 * A * L + 29 * (L + 1) + (8 * A + 16) + 8 * Hf
         achieved = bytes_per_sim * B * S / (launch_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        try:  # PMC-measured HBM bytes per launch of this kernel (collected by a separate rocprofv3 --pmc run)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                entry = json.load(f).get(f"{args.workload}:{'fused-lds' if fused else 'generic-per-op'}")
+            if entry and B == default_trees:
+                traffic, traffic_src = entry["bytes"], entry["source"]
+        except (OSError, ValueError):
+            pass
         line = {
             "metric": "mcts_simulations_per_sec", "value": value, "unit": "sims/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -240,7 +248,8 @@ def main():
             "weight_broadcast_ms": broadcast_ms,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": bytes_per_sim * B * S,
                 "kernel": "mzx::fused_fc_search" if fused else "whole step (one kernel per operator)",
                 "launch_ms": launch_ms, "algorithmic_bytes_per_sim": bytes_per_sim,
                 "note": "tree bytes per simulation x B x S / HIP-event time of one search launch; trees live in "
