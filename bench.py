@@ -35,6 +35,7 @@ import numpy  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense FP32-input MFMA peak (= FP32 vector peak), same guide
 
 WORKLOADS = {
     # name: (config factory name, overrides, trees per GPU, description)
@@ -53,6 +54,8 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--trees", type=int, default=None, help="trees per GPU (default: the workload's)")
     ap.add_argument("--mode", default="auto", choices=["auto", "generic", "fused"])
+    ap.add_argument("--net-mode", default="fused", choices=["fused", "per-operator"],
+                    help="residual networks: fused MFMA engine (default) or one kernel per operator")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=None)
     return ap.parse_args()
@@ -154,6 +157,9 @@ def main():
     torch.cuda.synchronize()
     broadcast_ms = (time.perf_counter() - t_b0) * 1e3
 
+    if args.net_mode == "per-operator":
+        net.set_mode(0)
+    net_fused = bool(net.fused_supported()) and args.net_mode == "fused"
     mode = {"auto": None, "generic": 0, "fused": 1}[args.mode]
     engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
     handle = engine.handle(B)
@@ -212,7 +218,7 @@ def main():
     launch_ms = float(numpy.mean([a.elapsed_time(b) for a, b in ev]))
 
     # sanity: the timed work is real (every tree ran S simulations, no flags)
-    for _, out, _ in sets[: min(n_sets, max(args.steps + args.warmup, 1))]:
+    for _, out, _ in sets[: min(n_sets, max(args.steps, args.warmup, 1))]:
         visits, info = out["visits"].cpu().numpy(), out["info"].cpu().numpy()
         assert (visits.sum(1) == S).all(), "a tree did not complete its simulations"
         assert (info[:, 1] == 0).all(), "search flagged an overflow"
@@ -229,10 +235,37 @@ def main():
         try:  # PMC-measured HBM bytes per launch of this kernel (collected by a separate rocprofv3 --pmc run)
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 entry = json.load(f).get(f"{args.workload}:{'fused-lds' if fused else 'generic-per-op'}")
+            if not fused and net_fused:
+                entry = None
             if entry and B == default_trees:
                 traffic, traffic_src = entry["bytes"], entry["source"]
         except (OSError, ValueError):
             pass
+        kernel_name = "fused-lds" if fused else ("per-sim launches + fused-mfma network" if net_fused else "generic-per-op")
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": bytes_per_sim * B * S,
+            "kernel": "mzx::fused_fc_search" if fused else "whole step (one kernel per operator)",
+            "launch_ms": launch_ms, "algorithmic_bytes_per_sim": bytes_per_sim,
+            "note": "tree bytes per simulation x B x S / HIP-event time of one search launch; trees live in "
+                    "LDS in the fused kernel, so this is algorithmic traffic, not HBM traffic (DESIGN.md)",
+        }
+        if cfg.network == "resnet":  # dense contractions: FP32 MFMA roofline
+            f_init = int(lib.mzx_net_flops(net.handle, 0))
+            f_rec = int(lib.mzx_net_flops(net.handle, 1))
+            flops = B * (f_init + S * f_rec)
+            tf = flops / (launch_ms * 1e-3) / 1e12
+            roofline = {
+                "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "whole step: select / rz_network_kernel (fused MFMA network) / expand+backprop per simulation"
+                          if net_fused else "whole step (one kernel per operator)",
+                "launch_ms": launch_ms, "flops_per_simulation": f_rec, "flops_initial_inference": f_init,
+                "flops_per_step": flops, "tree_bytes_per_sim": bytes_per_sim,
+                "note": "network FLOPs (2 x MAC of every conv / linear layer, as the reference's modules count) of one "
+                        "step / HIP-event time of the step, vs the dense FP32-input MFMA peak",
+            }
         line = {
             "metric": "mcts_simulations_per_sec", "value": value, "unit": "sims/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -240,21 +273,13 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": description, "trees_per_gpu": B, "num_simulations": S, "action_space": A,
-                "network": cfg.network, "search_kernel": "fused-lds" if fused else "generic-per-op",
+                "network": cfg.network, "search_kernel": kernel_name,
                 "tree_statistics_dtype": "f64", "weights": "synthetic seed 0 (RCCL-broadcast flat buffer)",
                 "mean_leaf_depth": L,
             },
             "selfplay_steps_per_sec": world * B * args.steps / elapsed,
             "weight_broadcast_ms": broadcast_ms,
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": bytes_per_sim * B * S,
-                "kernel": "mzx::fused_fc_search" if fused else "whole step (one kernel per operator)",
-                "launch_ms": launch_ms, "algorithmic_bytes_per_sim": bytes_per_sim,
-                "note": "tree bytes per simulation x B x S / HIP-event time of one search launch; trees live in "
-                        "LDS in the fused kernel, so this is algorithmic traffic, not HBM traffic (DESIGN.md)",
-            },
+            "roofline": roofline,
         }
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_cores)

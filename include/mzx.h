@@ -90,11 +90,21 @@ int64_t mzx_net_hidden_size(const mzx_net* net);     /* floats per encoded state
 int64_t mzx_net_input_size(const mzx_net* net);      /* floats per stacked observation */
 int64_t mzx_net_derived_floats(const mzx_net* net);  /* folded-BatchNorm buffer size */
 int64_t mzx_net_workspace_floats(const mzx_net* net, int32_t max_batch);
+/* 2 x multiply-accumulates of one sample's initial_inference (recurrent = 0) or
+ * recurrent_inference (1): convolutions and linear layers, as the reference's modules count. */
+int64_t mzx_net_flops(const mzx_net* net, int32_t recurrent);
 
 /* AbstractNetwork.set_weights (models.py:72-73): bind the flat device buffer
  * (kept alive by the caller) and derive folded BatchNorm terms into d_derived. */
 int mzx_net_set_weights(mzx_net* net, const float* d_flat, int64_t n_floats,
                         float* d_derived, int64_t derived_floats, void* stream);
+
+/* Residual networks run on the fused MFMA engine (one launch per inference, activations
+ * resident in LDS) where the configuration allows it.  mzx_net_fused_supported: bit 0 =
+ * initial_inference, bit 1 = recurrent_inference.  mzx_net_set_mode(0) forces one kernel per
+ * operator (the correctness reference of the tuned engine), 1 (default) re-enables it. */
+int mzx_net_fused_supported(const mzx_net* net);
+int mzx_net_set_mode(mzx_net* net, int32_t mode);
 
 /* initial_inference(observation) (models.py:172-190 / :601-618).
  * d_observation [batch][input_size]; outputs value_logits [batch][2s+1],
@@ -111,6 +121,16 @@ int mzx_net_recurrent_inference(mzx_net* net, const float* d_hidden, const int32
                                 int32_t batch, float* d_value_logits, float* d_reward_logits,
                                 float* d_policy_logits, float* d_next_hidden,
                                 float* d_workspace, int64_t workspace_floats, void* stream);
+
+/* Diagnostics (parity bisection, no reference counterpart): run the first n_ops operators of
+ * initial_inference (recurrent = 0) or recurrent_inference (1) on the per-operator (fused = 0)
+ * or fused (1) engine and copy the LAST operator's output tensor, dense per sample, to d_out.
+ * d_scratch: (hidden_size + 2 * (2 * support_size + 1) + action_space_size) * batch floats. */
+int mzx_net_num_operators(const mzx_net* net, int32_t recurrent);
+int mzx_net_debug_prefix(mzx_net* net, int32_t recurrent, int32_t fused, int32_t n_ops, const float* d_input,
+                         const int32_t* d_action, int32_t batch, float* d_out, int64_t out_floats,
+                         float* d_scratch, int64_t scratch_floats, float* d_workspace, int64_t workspace_floats,
+                         void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Batched search: replaces MCTS(config).run(...) -- self_play.py:249-430 -- for

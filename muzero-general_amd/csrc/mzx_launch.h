@@ -5,6 +5,8 @@
 // so that B trees spread over B/64 compute units instead of B/256.
 // tests/hostcheck: a serial loop (test infrastructure only).
 #pragma once
+#include <string.h>
+
 #include "mzx_platform.h"
 
 namespace mzx {
@@ -21,6 +23,11 @@ inline int launch(const Op& op, stream_t) {
 }
 
 inline int copy_h2d(void* dst, const void* src, size_t bytes, stream_t) {
+  memcpy(dst, src, bytes);
+  return 0;
+}
+
+inline int copy_d2d(void* dst, const void* src, size_t bytes, stream_t) {
   memcpy(dst, src, bytes);
   return 0;
 }
@@ -48,6 +55,10 @@ inline int launch(const Op& op, stream_t stream) {
 
 inline int copy_h2d(void* dst, const void* src, size_t bytes, stream_t stream) {
   return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+}
+
+inline int copy_d2d(void* dst, const void* src, size_t bytes, stream_t stream) {
+  return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
 }
 
 inline const char* runtime_error_string(int e) { return hipGetErrorString((hipError_t)e); }

@@ -58,6 +58,7 @@ int mzx_net_create(const mzx_net_config* cfg, mzx_net** out) {
   net->cfg = *cfg;
   NetBuilder b(net);
   if (!b.build()) { delete net; return MZX_ERR_INVALID; }
+  rz_plan(net);
   *out = net;
   return MZX_OK;
 }
@@ -68,7 +69,11 @@ int32_t mzx_net_num_tensors(const mzx_net* net) { return net ? (int32_t)net->ten
 int64_t mzx_net_num_params(const mzx_net* net) { return net ? net->num_params : 0; }
 int64_t mzx_net_hidden_size(const mzx_net* net) { return net ? net->hidden_size : 0; }
 int64_t mzx_net_input_size(const mzx_net* net) { return net ? net->input_size : 0; }
-int64_t mzx_net_derived_floats(const mzx_net* net) { return net ? (net->derived_floats > 0 ? net->derived_floats : 1) : 0; }
+static int64_t derived_total(const mzx_net* net) {
+  const int64_t n = net->rz.ok ? net->rz.derived_floats : net->derived_floats;
+  return n > 0 ? n : 1;
+}
+int64_t mzx_net_derived_floats(const mzx_net* net) { return net ? derived_total(net) : 0; }
 int64_t mzx_net_workspace_floats(const mzx_net* net, int32_t max_batch) {
   if (!net || max_batch < 1) return 0;
   return net->act_floats * net->n_temp * (int64_t)max_batch;
@@ -92,7 +97,7 @@ int mzx_net_set_weights(mzx_net* net, const float* d_flat, int64_t n_floats, flo
     set_error("flat weight buffer has %lld floats, network expects %lld", (long long)n_floats, (long long)net->num_params);
     return MZX_ERR_INVALID;
   }
-  if (derived_floats < net->derived_floats) { set_error("derived buffer too small"); return MZX_ERR_WORKSPACE; }
+  if (derived_floats < derived_total(net)) { set_error("derived buffer too small"); return MZX_ERR_WORKSPACE; }
   net->d_flat = d_flat;
   net->d_derived = d_derived;
   for (const BnRef& r : net->bns) {
@@ -101,7 +106,48 @@ int mzx_net_set_weights(mzx_net* net, const float* d_flat, int64_t n_floats, flo
     op.alpha = d_derived + r.alpha; op.beta = d_derived + r.beta; op.channels = r.channels;
     MZX_TRY_LAUNCH(launch<256>(op, (stream_t)stream));
   }
+  if (net->rz.ok) {  // MFMA-fragment-ordered weights + program tables of the fused residual engine
+    for (const RzPack& p : net->rz.packs) {
+      RzPackOp op;
+      op.W = d_flat + p.src; op.out = d_derived + p.dst;
+      op.taps = p.taps; op.cin = p.cin; op.cin4 = p.cin4; op.cout = p.cout; op.nchunks = p.nchunks; op.ntiles = p.ntiles;
+      MZX_TRY_LAUNCH(launch<256>(op, (stream_t)stream));
+    }
+    for (const RzProgram* R : {&net->rz.initial, &net->rz.recurrent})
+      if (R->ok) MZX_TRY_LAUNCH(copy_h2d(d_derived + R->dev_off, R->ops, sizeof(RzOp) * R->n_ops, (stream_t)stream));
+  }
   return MZX_OK;
+}
+
+int mzx_net_fused_supported(const mzx_net* net) {
+  if (!net || !net->rz.ok) return 0;
+  return (net->rz.initial.ok ? 1 : 0) | (net->rz.recurrent.ok ? 2 : 0);
+}
+
+int mzx_net_set_mode(mzx_net* net, int32_t mode) {
+  if (!net) { set_error("null network handle"); return MZX_ERR_INVALID; }
+  if (mode != 0 && mode != 1) { set_error("network mode is 0 (one kernel per operator) or 1 (fused engine)"); return MZX_ERR_INVALID; }
+  net->rz_mode = mode;
+  return MZX_OK;
+}
+
+int64_t mzx_net_flops(const mzx_net* net, int32_t recurrent) {
+  if (!net) return 0;
+  int64_t macs = 0;
+  for (const OpDesc& d : (recurrent ? net->prog_recurrent : net->prog_initial)) {
+    switch (d.kind) {
+      case OP_CONV3: macs += (int64_t)d.cout * d.hout * d.wout * d.cin * 9; break;
+      case OP_CONV1: macs += (int64_t)d.cout * d.hin * d.cin; break;
+      case OP_LINEAR: macs += (int64_t)d.out_features * d.w_stride; break;
+      default: break;
+    }
+  }
+  return 2 * macs;
+}
+
+int mzx_net_num_operators(const mzx_net* net, int32_t recurrent) {
+  if (!net) return 0;
+  return (int)(recurrent ? net->prog_recurrent.size() : net->prog_initial.size());
 }
 
 static int check_net_call(const mzx_net* net, int32_t batch, int64_t workspace_floats) {
@@ -125,7 +171,7 @@ int mzx_net_initial_inference(mzx_net* net, const float* d_observation, int32_t 
   NetBuffers nb;
   nb.in = d_observation; nb.action = nullptr; nb.hidden = d_hidden; nb.value = d_value_logits;
   nb.reward = nullptr; nb.policy = d_policy_logits; nb.workspace = d_workspace;
-  rc = run_program(net, net->prog_initial, nb, batch, (stream_t)stream);
+  rc = run_network(net, false, nb, batch, (stream_t)stream);
   if (rc) return rc;
   if (d_reward_logits) {
     RewardFillOp f;
@@ -147,7 +193,23 @@ int mzx_net_recurrent_inference(mzx_net* net, const float* d_hidden, const int32
   NetBuffers nb;
   nb.in = d_hidden; nb.action = d_action; nb.hidden = d_next_hidden; nb.value = d_value_logits;
   nb.reward = d_reward_logits; nb.policy = d_policy_logits; nb.workspace = d_workspace;
-  return run_program(net, net->prog_recurrent, nb, batch, (stream_t)stream);
+  return run_network(net, true, nb, batch, (stream_t)stream);
+}
+
+int mzx_net_debug_prefix(mzx_net* net, int32_t recurrent, int32_t fused, int32_t n_ops, const float* d_input,
+                         const int32_t* d_action, int32_t batch, float* d_out, int64_t out_floats, float* d_scratch,
+                         int64_t scratch_floats, float* d_workspace, int64_t workspace_floats, void* stream) {
+  int rc = check_net_call(net, batch, workspace_floats);
+  if (rc) return rc;
+  const int64_t need = (net->hidden_size + 2 * net->full_support + net->cfg.action_space_size) * (int64_t)batch;
+  if (!d_input || !d_out || !d_scratch || scratch_floats < need) { set_error("debug_prefix: missing / short buffer (%lld scratch floats)", (long long)need); return MZX_ERR_WORKSPACE; }
+  NetBuffers nb;
+  nb.in = d_input; nb.action = d_action; nb.workspace = d_workspace;
+  nb.hidden = d_scratch;
+  nb.value = nb.hidden + net->hidden_size * batch;
+  nb.reward = nb.value + (int64_t)net->full_support * batch;
+  nb.policy = nb.reward + (int64_t)net->full_support * batch;
+  return run_network_prefix(net, recurrent != 0, fused != 0, n_ops, nb, batch, d_out, out_floats, (stream_t)stream);
 }
 
 // ----------------------------------------------------------------- search

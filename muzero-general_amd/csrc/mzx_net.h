@@ -16,6 +16,7 @@
 #include "../../include/mzx.h"
 #include "mzx_launch.h"
 #include "mzx_ops.h"
+#include "mzx_resnet_plan.h"
 
 namespace mzx {
 
@@ -63,6 +64,8 @@ struct mzx_net {
   int32_t hc = 0, hh = 0, hw = 0;  // hidden state dims (resnet)
   const float* d_flat = nullptr;
   float* d_derived = nullptr;
+  mzx::RzPlan rz;          // fused residual-network engine (mzx_resnet_fused.h)
+  int32_t rz_mode = 1;     // 0: one kernel per operator, 1: fused engine where planned
 };
 
 namespace mzx {

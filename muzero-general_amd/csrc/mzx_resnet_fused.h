@@ -1,0 +1,705 @@
+// mzx_resnet_fused.h -- the residual MuZero network (models.py:206-623) as ONE gfx950
+// kernel per inference: every convolution / 1x1 head convolution / head MLP layer of
+// initial_inference or recurrent_inference is an FP32 MFMA GEMM whose A operand (the
+// activations of a tile of trees) never leaves LDS between layers.
+//
+// Reference semantics (file:line relative to /root/reference), eval mode:
+//   conv3x3 :206-209, ResidualBlock :213-229, RepresentationNetwork :300-349,
+//   DynamicsNetwork :352-389 (reward head :369-389), PredictionNetwork :392-433,
+//   MuZeroResidualNetwork.{representation,dynamics,prediction} :522-599 (per-plane
+//   min-max scaling, action plane = action / |A|), mlp :630-642.
+//
+// Tiling (wave64, 256-thread workgroup = 4 waves, one workgroup per tile of T trees):
+//   * activations: three rotating LDS slots [T][Cbuf][PS] in a zero-haloed plane layout
+//     ((H+2) x (W+2) floats per plane, plane stride PS = 16 mod 32 so that the two
+//     16-lane halves of a ds_read_b32 group hit complementary banks); head tensors are
+//     small flat LDS regions.  Halo cells and pad planes are written once (zero) and
+//     never again, so a 3x3 tap is a constant address offset -- no bounds tests.
+//   * every layer is D[M x N] = A[M x K] . B[K x N] on v_mfma_f32_16x16x4_f32:
+//       3x3 conv : M = T*H*W (tree, position), K = 9 * Cin (tap-major), N = Cout
+//       1x1 conv : same rows, K = Cin
+//       Linear   : M = T (trees), K = in_features, N = out_features
+//     lane l feeds A[row l&15][k l>>4] with ONE ds_read_b32 at (row base + tap offset +
+//     k * plane stride); B fragments come pre-packed in lane order from the derived
+//     buffer (built once per set_weights), 16 K-deep per global_load_dwordx4, double
+//     buffered in registers; N tiles are spread over the waves first (each wave then
+//     streams a disjoint quarter of the weights exactly once), M tiles next; a wave
+//     keeps up to 8 accumulator tiles so one B fragment feeds up to 8 MFMAs.
+//   * epilogue per layer in registers: folded BatchNorm (alpha, beta), bias, residual
+//     (read from its LDS slot), ReLU / ELU, then the D fragment (col = lane & 15,
+//     row = 4 * (lane >> 4) + r) goes back to LDS in the layout the next layer reads.
+//   * exactness: the f32 MFMA is a k-ordered fmaf chain (bitwise); only the summation
+//     ORDER differs from ATen's, i.e. fp32 round-off (tests: 1e-4 absolute on all heads).
+//
+// MFMA is used because these are genuine dense contractions (C3 231 kFLOP, C4 40.4 MFLOP,
+// C5 1.5 MFLOP per simulation); roofline: FP32 matrix peak 157.3 TFLOP/s.
+#pragma once
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+
+#include "mzx_net.h"
+
+namespace mzx {
+
+constexpr int RZ_LDS_BUDGET = 160 * 1024 - 1024;
+
+// ---------------------------------------------------------------------------
+// weight packing (runs once per set_weights; element functor, also built by hostcheck)
+
+struct RzPackOp {
+  const float* W;   // [cout][cin][taps]
+  float* out;       // [ntiles][nchunks][64 lanes][4]
+  int32_t taps, cin, cin4, cout, nchunks, ntiles;
+
+  MZX_HD size_t size() const { return (size_t)ntiles * nchunks * 256; }
+  MZX_HD void operator()(size_t i) const {
+    const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    const int c = (int)((i >> 8) % nchunks), nt = (int)((i >> 8) / nchunks);
+    const int k = 16 * c + 4 * j + (lane >> 4);       // K index of K-step 4c + j, B row lane >> 4
+    const int n = nt * 16 + (lane & 15);
+    const int cp = cin4 * 4;
+    const int tap = k / cp, ci = k % cp;
+    float v = 0.f;
+    if (tap < taps && ci < cin && n < cout) v = W[((int64_t)n * cin + ci) * taps + tap];
+    out[i] = v;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// host planner: operator program (mzx_net.h) -> fused program
+
+inline int rz_round4(int x) { return (x + 3) & ~3; }
+
+inline bool rz_fusable(const OpDesc& d, int h, int w) {
+  switch (d.kind) {
+    case OP_CONV3: return d.stride == 1 && d.hin == h && d.win == w;
+    case OP_CONV1: return d.hin == h * w;
+    case OP_LINEAR: return !d.use_action;
+    case OP_SCALE: return d.len == h * w;
+    default: return false;
+  }
+}
+
+struct RzInst { int id, def, last, spatial, size, slot, off, tstride; };
+
+inline int64_t rz_add_pack(RzPlan& P, int64_t src, int taps, int cin, int cout, int64_t& cursor) {
+  const int cin4 = rz_round4(cin) / 4;
+  for (const RzPack& p : P.packs)
+    if (p.src == src && p.taps == taps && p.cin == cin && p.cout == cout) return p.dst;
+  RzPack p;
+  p.src = src; p.taps = taps; p.cin = cin; p.cin4 = cin4; p.cout = cout;
+  p.nchunks = (taps * cin4 + 3) / 4;
+  p.ntiles = (cout + 15) / 16;
+  p.dst = cursor;
+  cursor += (int64_t)p.ntiles * p.nchunks * 256;
+  P.packs.push_back(p);
+  return p.dst;
+}
+
+// Builds `R` from `prog`; returns false if the program cannot be fused.  `flat_cursor` = per-tree
+// float offset where this program's flat regions start (after the three spatial slots).
+inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog, RzPlan& P, RzProgram& R,
+                             int64_t& pack_cursor, int& flat_floats, int& max_cin) {
+  const int h = net->hh, w = net->hw, HW = h * w;
+  const int n = (int)prog.size();
+  int first = n;
+  while (first > 0 && rz_fusable(prog[first - 1], h, w)) --first;
+  if (first >= n) return false;
+  // the fused part may read exactly one tensor it does not produce
+  std::vector<RzInst> inst;
+  std::map<int, int> cur;
+  auto use = [&](int id, int at) -> int {
+    auto it = cur.find(id);
+    if (it == cur.end()) return -1;
+    inst[it->second].last = at;
+    return it->second;
+  };
+  std::vector<int> in_i(n, -1), res_i(n, -1), out_i(n, -1);
+  int ext = -1;
+  for (int i = first; i < n; ++i) {
+    const OpDesc& d = prog[i];
+    const bool in_spatial = (d.kind != OP_LINEAR);
+    int a = use(d.in, i);
+    if (a < 0) {
+      if (ext >= 0 || !in_spatial) return false;
+      RzInst e{d.in, first - 1, i, 1, 0, -1, 0, 0};
+      e.size = (d.kind == OP_CONV3) ? d.cin - (d.use_action ? 1 : 0) : (d.kind == OP_SCALE ? d.groups_per_sample : d.cin);
+      inst.push_back(e);
+      ext = (int)inst.size() - 1;
+      cur[d.in] = ext;
+      a = ext;
+    }
+    in_i[i] = a;
+    if (d.kind == OP_CONV3 && d.res != -100) {
+      const int r = use(d.res, i);
+      if (r < 0) return false;
+      res_i[i] = r;
+    }
+    RzInst o{d.out, i, i, 0, 0, -1, 0, 0};
+    switch (d.kind) {
+      case OP_CONV3: o.spatial = 1; o.size = d.cout; break;
+      case OP_SCALE: o.spatial = 1; o.size = d.groups_per_sample; break;
+      case OP_CONV1: o.spatial = 0; o.size = d.cout * HW; break;
+      default: o.spatial = 0; o.size = d.out_features; break;
+    }
+    inst.push_back(o);
+    out_i[i] = (int)inst.size() - 1;
+    cur[d.out] = out_i[i];
+  }
+  if (ext < 0) return false;
+  // outputs stay live to the end
+  for (RzInst& s : inst)
+    if (s.id == BUF_VALUE || s.id == BUF_REWARD || s.id == BUF_POLICY) s.last = n;
+  // slot / region allocation
+  for (size_t k = 0; k < inst.size(); ++k) {
+    RzInst& s = inst[k];
+    if (s.spatial) {
+      bool busy[3] = {false, false, false};
+      for (size_t j = 0; j < inst.size(); ++j) {
+        const RzInst& t = inst[j];
+        if (j != k && t.spatial && t.slot >= 0 && t.def < s.def && t.last >= s.def) busy[t.slot] = true;
+      }
+      s.slot = -1;
+      for (int q = 0; q < 3; ++q) if (!busy[q]) { s.slot = q; break; }
+      if (s.slot < 0) return false;
+    } else {
+      s.tstride = rz_round4(s.size) + 4;
+      s.off = flat_floats;
+      flat_floats += s.tstride;
+    }
+  }
+  if (n - first > RZ_MAX_OPS) return false;
+  R.first = first;
+  R.ext_buf = inst[ext].id;
+  R.n_ops = n - first;
+  R.in_channels = inst[ext].size;
+  R.use_action = (prog[first].kind == OP_CONV3 && prog[first].use_action) ? 1 : 0;
+  max_cin = std::max(max_cin, R.in_channels + R.use_action);
+  // region offsets are resolved to "slot index" (spatial, negative encoding below) until the
+  // geometry is known: store slot in in_off and patch in rz_finish_program
+  for (int i = first; i < n; ++i) {
+    const OpDesc& d = prog[i];
+    RzOp& o = R.ops[i - first];
+    memset(&o, 0, sizeof(o));
+    o.res_off = -1; o.alpha_off = -1; o.beta_off = -1; o.bias_off = -1;
+    const RzInst& si = inst[in_i[i]];
+    const RzInst& so = inst[out_i[i]];
+    switch (d.kind) {
+      case OP_CONV3:
+        o.kind = RZ_GEMM; o.rows = RZ_ROWS_POS; o.taps = 9;
+        o.in_off = si.slot; o.out_off = so.slot; o.out_layout = RZ_OUT_PADDED;
+        if (res_i[i] >= 0) o.res_off = inst[res_i[i]].slot;
+        o.cin4 = rz_round4(d.cin) / 4; o.cout = d.cout;
+        if (d.bn.channels) { o.alpha_off = (int32_t)d.bn.alpha; o.beta_off = (int32_t)d.bn.beta; }
+        o.act = d.relu ? RZ_ACT_RELU : RZ_ACT_NONE;
+        o.w_off = (int32_t)rz_add_pack(P, d.w, 9, d.cin, d.cout, pack_cursor);
+        if (o.cin4 >= 256 || 9 * o.cin4 + 4 >= 4096) return false;   // reciprocal range of the kernel's K-step decode
+        max_cin = std::max(max_cin, std::max(d.cin, d.cout));
+        break;
+      case OP_CONV1:
+        o.kind = RZ_GEMM; o.rows = RZ_ROWS_POS; o.taps = 1;
+        o.in_off = si.slot; o.out_off = so.off; o.out_tstride = so.tstride; o.out_layout = RZ_OUT_FLAT;
+        o.cin4 = rz_round4(d.cin) / 4; o.cout = d.cout;
+        o.bias_off = (int32_t)d.b;
+        o.w_off = (int32_t)rz_add_pack(P, d.w, 1, d.cin, d.cout, pack_cursor);
+        max_cin = std::max(max_cin, d.cin);
+        break;
+      case OP_LINEAR:
+        if (d.w_stride != d.in_features) return false;
+        o.kind = RZ_GEMM; o.rows = RZ_ROWS_TREE; o.taps = 1;
+        o.in_off = si.off; o.in_tstride = si.tstride;
+        o.out_off = so.off; o.out_tstride = so.tstride; o.out_layout = RZ_OUT_FLAT;
+        o.cin4 = rz_round4(d.in_features) / 4; o.cout = d.out_features;
+        o.bias_off = (int32_t)d.b;
+        o.act = d.elu ? RZ_ACT_ELU : RZ_ACT_NONE;
+        o.w_off = (int32_t)rz_add_pack(P, d.w, 1, d.in_features, d.out_features, pack_cursor);
+        if (o.cin4 * 4 > si.tstride) return false;
+        break;
+      default:  // OP_SCALE
+        o.kind = RZ_SCALE; o.rows = RZ_ROWS_POS;
+        o.in_off = si.slot; o.out_off = so.slot; o.out_layout = RZ_OUT_PADDED;
+        o.channels = d.groups_per_sample;
+        o.store_hidden = (d.out == BUF_HIDDEN) ? 1 : 0;
+        max_cin = std::max(max_cin, d.groups_per_sample);
+        break;
+    }
+    if (o.kind == RZ_GEMM) o.nchunks = (o.taps * o.cin4 + 3) / 4;
+    const int which = (d.out == BUF_VALUE) ? 0 : (d.out == BUF_REWARD) ? 1 : (d.out == BUF_POLICY) ? 2 : -1;
+    if (which >= 0) {
+      if (so.spatial) return false;
+      R.out_off[which] = so.off; R.out_ts[which] = so.tstride; R.out_n[which] = so.size;
+    }
+  }
+  R.in_off = inst[ext].slot;
+  R.ok = 1;
+  return true;
+}
+
+inline int64_t rz_lds_bytes(const RzGeometry& g, int T) {
+  const int mpad = (T * g.HW + 15) & ~15;
+  return 4 * ((int64_t)2 * mpad + (int64_t)2 * T * g.Cbuf + (int64_t)T * g.tree_floats);
+}
+
+// slot indices -> per-tree float offsets, flat offsets -> behind the three slots
+inline void rz_finish_program(const RzGeometry& g, RzProgram& R) {
+  if (!R.ok) return;
+  const int flat0 = 3 * g.slot_ts;
+  for (int i = 0; i < R.n_ops; ++i) {
+    RzOp& o = R.ops[i];
+    const bool in_spatial = !(o.kind == RZ_GEMM && o.rows == RZ_ROWS_TREE);
+    if (in_spatial) { o.in_off *= g.slot_ts; o.in_tstride = g.slot_ts; } else { o.in_off += flat0; }
+    if (o.out_layout == RZ_OUT_PADDED) { o.out_off *= g.slot_ts; o.out_tstride = g.slot_ts; } else { o.out_off += flat0; }
+    if (o.res_off >= 0) o.res_off *= g.slot_ts;
+  }
+  R.in_off *= g.slot_ts;
+  for (int k = 0; k < 3; ++k) if (R.out_off[k] >= 0) R.out_off[k] += flat0;
+}
+
+// Plans both programs of a residual network; called by mzx_net_create after NetBuilder::build.
+inline void rz_plan(mzx_net* net) {
+  RzPlan& P = net->rz;
+  P = RzPlan();
+  if (net->cfg.network != 1) return;
+  const int h = net->hh, w = net->hw;
+  if (h < 1 || w < 1 || h * w > RZ_MAX_ROWS) return;
+  int64_t cursor = (net->derived_floats + 3) & ~int64_t(3);
+  int flat_i = 0, flat_r = 0, max_cin = 4;
+  const bool oi = rz_build_program(net, net->prog_initial, P, P.initial, cursor, flat_i, max_cin);
+  const bool orr = rz_build_program(net, net->prog_recurrent, P, P.recurrent, cursor, flat_r, max_cin);
+  if (!oi) P.initial.ok = 0;
+  if (!orr) P.recurrent.ok = 0;
+  if (!oi && !orr) { P.packs.clear(); return; }
+  RzGeometry& g = P.g;
+  g.H = h; g.W = w; g.HW = h * w; g.PW = w + 2;
+  g.Cbuf = rz_round4(max_cin);
+  const int flat = std::max(flat_i, flat_r);
+  const int min_ps = (h + 2) * (w + 2);
+  const int candidates[2] = {min_ps + ((16 - min_ps % 32) + 32) % 32, min_ps};
+  for (int ps : candidates) {
+    g.PS = ps;
+    g.slot_ts = g.Cbuf * ps;
+    g.tree_floats = 3 * g.slot_ts + flat;
+    g.max_trees = 0;
+    for (int T = 1; T <= RZ_MAX_TREES && T * g.HW <= RZ_MAX_ROWS; ++T)
+      if (rz_lds_bytes(g, T) <= RZ_LDS_BUDGET) g.max_trees = T;
+    if (g.max_trees >= 1) break;
+  }
+  if (g.max_trees < 1) { P = RzPlan(); return; }
+  rz_finish_program(g, P.initial);
+  rz_finish_program(g, P.recurrent);
+  // program tables behind the packed weights
+  const int64_t table_floats = (int64_t)(sizeof(RzOp) * RZ_MAX_OPS + 15) / 16 * 4;
+  P.initial.dev_off = cursor; cursor += table_floats;
+  P.recurrent.dev_off = cursor; cursor += table_floats;
+  P.derived_floats = cursor;
+  P.ok = 1;
+}
+
+// Per-sample indirection through the search arena's hidden-state store [B][nodes][Hf]:
+// sample b reads node in_node[b] and writes node out_node[b] (null: dense [B][Hf] tensors).
+struct NetIndex {
+  const int32_t* in_node = nullptr;    // null: node 0
+  const int32_t* out_node = nullptr;   // null: node 0
+  int32_t in_nodes = 1, out_nodes = 1; // nodes per sample of nb.in / nb.hidden (1 = dense tensors)
+};
+
+struct RzArgs {
+  const RzOp* ops;
+  int32_t n_ops, T, batch, num_actions;
+  int32_t H, W, HW, PW, PS, Cbuf, slot_ts, tree_floats, mpad;
+  int32_t in_off, in_channels, use_action;
+  int32_t out_off[3], out_ts[3], out_n[3];
+  int32_t hidden_floats;          // C * H * W
+  int32_t in_nodes, out_nodes;    // nodes per sample of the in / hidden-out tensors (1 = dense)
+  int32_t dump_op;                // >= 0: stop after this op and copy its output to `dump`
+  const float* in;
+  const int32_t* in_node;
+  const int32_t* out_node;
+  const int32_t* action;
+  float* hidden_out;
+  float* outs[3];                 // value, reward, policy logits (nullable)
+  float* dump;
+  const float* flat;
+  const float* derived;
+};
+
+#ifndef MZX_HOSTCHECK
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct RzCtx {
+  float* reg;           // workgroup LDS regions (offset T * off)
+  const int* rowaddr;   // [mpad] padded-layout address of row m = (tree, position): t * slot_ts + (y+1) * PW + x + 1
+  const int* rowtp;     // [mpad] (t << 16) | position, -1 for rows beyond T * HW
+  float* scratch;       // [2 * T * Cbuf]
+  int T, lane, wave, tid;
+};
+
+// One group of up to MT row tiles x one column tile of a layer GEMM, K-loop + epilogue.
+template <int MT>
+__device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, const RzCtx& cx, int nt, int mt0,
+                                              int mt_step) {
+  const int lane = cx.lane, T = cx.T;
+  const bool pos_rows = (op.rows == RZ_ROWS_POS);
+  const int rows = pos_rows ? T * a.HW : T;
+  const int kstride = pos_rows ? a.PS : 1;
+  const float* in = cx.reg + T * op.in_off;
+  f32x4 acc[MT];
+  int abase[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int m = (mt0 + i * mt_step) * 16 + (lane & 15);
+    if (m >= rows) m = 0;
+    const int ra = pos_rows ? cx.rowaddr[m] : m * op.in_tstride;
+    abase[i] = ra + (lane >> 4) * kstride;
+  }
+  const f32x4* wp = (const f32x4*)(a.derived + op.w_off) + (size_t)nt * op.nchunks * 64 + lane;
+  // K-step ks -> (tap, channel group): branch-free scalar arithmetic (tap = ks / cin4 by a 20-bit
+  // reciprocal, exact for ks < 4096 and cin4 < 256 -- the planner checks both).  K-steps of the
+  // zero-padded tail of the last chunk clamp to the last tap: they re-read valid addresses against
+  // zero weights.
+  const unsigned magic = ((1u << 20) + (unsigned)op.cin4 - 1) / (unsigned)op.cin4;
+  const int last_tap = op.taps - 1;
+  const int pw9 = (op.taps == 9) ? a.PW : 0, one9 = (op.taps == 9) ? 1 : 0;
+  auto load_a = [&](int c, float (&dst)[4][MT]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ks = 4 * c + j;
+      const int traw = (op.taps == 9) ? (int)(((unsigned)ks * magic) >> 20) : (ks >= op.cin4 ? 1 : 0);
+      const int cg = ks - traw * op.cin4;
+      const int tap = traw < last_tap ? traw : last_tap;
+      const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;                 // tap / 3, tap % 3 for tap < 9
+      const int off = (ty - 1) * pw9 + (tx - 1) * one9 + cg * 4 * kstride;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) dst[j][i] = in[abase[i] + off];
+    }
+  };
+  // software pipeline: the A fragments and the B fragment of chunk c+1 are in flight while the
+  // 4 * MT MFMAs of chunk c issue
+  float a_cur[4][MT], a_nxt[4][MT];
+  f32x4 bq = wp[0];
+  load_a(0, a_cur);
+  for (int c = 0; c < op.nchunks; ++c) {
+    const int cn = (c + 1 < op.nchunks) ? c + 1 : c;
+    const f32x4 bn = wp[(size_t)cn * 64];
+    load_a(cn, a_nxt);
+    __builtin_amdgcn_sched_barrier(0);   // loads of chunk c+1 stay ahead of the MFMAs of chunk c
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float bj = bq[j];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][i], bj, acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a_cur[j][i] = a_nxt[j][i];
+    bq = bn;
+  }
+  // ---- epilogue
+  const int n = nt * 16 + (lane & 15);
+  const bool nv = n < op.cout;
+  float al = 1.f, be = 0.f, bi = 0.f;
+  if (nv && op.alpha_off >= 0) { al = a.derived[op.alpha_off + n]; be = a.derived[op.beta_off + n]; }
+  if (nv && op.bias_off >= 0) bi = a.flat[op.bias_off + n];
+  float* out = cx.reg + T * op.out_off;
+  const float* res = (op.res_off >= 0) ? cx.reg + T * op.res_off : nullptr;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = (mt0 + i * mt_step) * 16 + (lane >> 4) * 4 + r;
+      if (m >= rows || !nv) continue;
+      float v = acc[i][r];
+      if (op.alpha_off >= 0) v = v * al + be;
+      if (op.bias_off >= 0) v = v + bi;
+      int ra = 0, t = m, p = 0;
+      if (pos_rows) { ra = cx.rowaddr[m]; const int tp = cx.rowtp[m]; t = tp >> 16; p = tp & 0xFFFF; }
+      if (res) v += res[ra + n * a.PS];
+      if (op.act == RZ_ACT_RELU) v = fmaxf(v, 0.f);
+      else if (op.act == RZ_ACT_ELU) v = mzx_elu(v);
+      const int idx = (op.out_layout == RZ_OUT_PADDED) ? ra + n * a.PS
+                                                       : t * op.out_tstride + (pos_rows ? n * a.HW + p : n);
+      out[idx] = v;
+    }
+  }
+}
+
+__device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const RzCtx& cx) {
+  const int rows = (op.rows == RZ_ROWS_POS) ? cx.T * a.HW : cx.T;
+  const int mt_total = (rows + 15) >> 4, nt_total = (op.cout + 15) >> 4;
+  const int waves_n = nt_total >= 4 ? 4 : (nt_total >= 2 ? 2 : 1);
+  const int waves_m = 4 / waves_n;
+  const int wn = cx.wave % waves_n, wm = cx.wave / waves_n;
+  for (int nt = wn; nt < nt_total; nt += waves_n) {
+    for (int mt0 = wm; mt0 < mt_total; mt0 += waves_m * 8) {
+      const int cnt = min(8, (mt_total - mt0 + waves_m - 1) / waves_m);   // wave-uniform
+      switch (cnt) {
+        case 1: rz_gemm_tiles<1>(op, a, cx, nt, mt0, waves_m); break;
+        case 2: rz_gemm_tiles<2>(op, a, cx, nt, mt0, waves_m); break;
+        case 3: rz_gemm_tiles<3>(op, a, cx, nt, mt0, waves_m); break;
+        case 4: rz_gemm_tiles<4>(op, a, cx, nt, mt0, waves_m); break;
+        case 5: rz_gemm_tiles<5>(op, a, cx, nt, mt0, waves_m); break;
+        case 6: rz_gemm_tiles<6>(op, a, cx, nt, mt0, waves_m); break;
+        case 7: rz_gemm_tiles<7>(op, a, cx, nt, mt0, waves_m); break;
+        default: rz_gemm_tiles<8>(op, a, cx, nt, mt0, waves_m); break;
+      }
+    }
+  }
+}
+
+// per-plane min-max scaling (models.py:527-553, :574-599) + hidden-state store
+__device__ __forceinline__ void rz_scale(const RzOp& op, const RzArgs& a, const RzCtx& cx, int b0, int ntree) {
+  const int T = cx.T, C = op.channels;
+  const float* in = cx.reg + T * op.in_off;
+  float* out = cx.reg + T * op.out_off;
+  for (int idx = cx.tid; idx < T * C; idx += 256) {
+    const int t = idx / C, c = idx - t * C;
+    const float* pl = in + t * a.slot_ts + c * a.PS;
+    float lo = pl[a.PW + 1], hi = lo;
+    for (int y = 0; y < a.H; ++y)
+      for (int x = 0; x < a.W; ++x) {
+        const float v = pl[(y + 1) * a.PW + x + 1];
+        lo = fminf(lo, v); hi = fmaxf(hi, v);
+      }
+    float sc = hi - lo;
+    if (sc < 1e-5f) sc += 1e-5f;
+    cx.scratch[2 * idx] = lo;
+    cx.scratch[2 * idx + 1] = sc;
+  }
+  __syncthreads();
+  const int per_tree = C * a.HW;
+  for (int idx = cx.tid; idx < T * per_tree; idx += 256) {
+    const int t = idx / per_tree, rem = idx - t * per_tree;
+    const int c = rem / a.HW, p = rem - c * a.HW;
+    const int ra = cx.rowaddr[t * a.HW + p] + c * a.PS;
+    const float y = (in[ra] - cx.scratch[2 * (t * C + c)]) / cx.scratch[2 * (t * C + c) + 1];
+    out[ra] = y;
+    if (op.store_hidden && t < ntree && a.hidden_out) {
+      const int64_t s = b0 + t;
+      const int64_t node = a.out_node ? a.out_node[s] : 0;
+      a.hidden_out[(s * a.out_nodes + node) * a.hidden_floats + rem] = y;
+    }
+  }
+}
+
+// One workgroup per CU by design (LDS-resident activations): tell the scheduler that registers are
+// free (1 wave per SIMD) so that it keeps the prefetch distance of the software pipeline.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) rz_network_kernel(const RzArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float rz_lds[];
+  const int tid = threadIdx.x, T = a.T;
+  const int b0 = blockIdx.x * T;
+  const int ntree = min(T, a.batch - b0);
+  int* rowaddr = (int*)rz_lds;
+  int* rowtp = rowaddr + a.mpad;
+  float* scratch = (float*)(rowtp + a.mpad);
+  float* reg = scratch + 2 * T * a.Cbuf;
+  RzCtx cx;
+  cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.scratch = scratch;
+  cx.T = T; cx.lane = tid & 63; cx.wave = tid >> 6; cx.tid = tid;
+
+  // ---- zero every region (halo cells, pad planes and pad words stay zero for the whole launch)
+  for (int i = tid; i < T * a.tree_floats; i += 256) reg[i] = 0.f;
+  for (int m = tid; m < a.mpad; m += 256) {
+    if (m < T * a.HW) {
+      const int t = m / a.HW, p = m - t * a.HW;
+      const int y = p / a.W, x = p - y * a.W;
+      rowaddr[m] = t * a.slot_ts + (y + 1) * a.PW + x + 1;
+      rowtp[m] = (t << 16) | p;
+    } else {
+      rowaddr[m] = a.PW + 1;
+      rowtp[m] = -1;
+    }
+  }
+  __syncthreads();
+
+  // ---- input tensor [in_channels][H][W] per sample (+ the action plane of the dynamics input)
+  {
+    float* dst = reg + T * a.in_off;
+    const int per_tree = a.in_channels * a.HW;
+    for (int idx = tid; idx < ntree * per_tree; idx += 256) {
+      const int t = idx / per_tree, rem = idx - t * per_tree;
+      const int c = rem / a.HW, p = rem - c * a.HW;
+      const int64_t s = b0 + t;
+      const int64_t node = a.in_node ? a.in_node[s] : 0;
+      dst[rowaddr[t * a.HW + p] + c * a.PS] = a.in[(s * a.in_nodes + node) * per_tree + rem];
+    }
+    if (a.use_action) {
+      for (int idx = tid; idx < ntree * a.HW; idx += 256) {
+        const int t = idx / a.HW;
+        dst[rowaddr[idx] + a.in_channels * a.PS] = (float)a.action[b0 + t] / (float)a.num_actions;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- the layers
+  for (int o = 0; o < a.n_ops; ++o) {
+    const RzOp op = a.ops[o];   // wave-uniform: lives in scalar registers
+    if (op.kind == RZ_GEMM) rz_gemm(op, a, cx);
+    else rz_scale(op, a, cx, b0, ntree);
+    __syncthreads();
+    if (o == a.dump_op) {  // diagnostics: the output tensor of op `o`, dense per sample
+      const float* src = reg + T * op.out_off;
+      if (op.out_layout == RZ_OUT_PADDED) {
+        const int C = (op.kind == RZ_GEMM) ? op.cout : op.channels;
+        const int per_tree = C * a.HW;
+        for (int idx = tid; idx < ntree * per_tree; idx += 256) {
+          const int t = idx / per_tree, rem = idx - t * per_tree;
+          const int c = rem / a.HW, p = rem - c * a.HW;
+          a.dump[(int64_t)(b0 + t) * per_tree + rem] = src[rowaddr[t * a.HW + p] + c * a.PS];
+        }
+      } else {
+        const int nfl = (op.rows == RZ_ROWS_POS) ? op.cout * a.HW : op.cout;
+        for (int idx = tid; idx < ntree * nfl; idx += 256) {
+          const int t = idx / nfl, rem = idx - t * nfl;
+          a.dump[(int64_t)(b0 + t) * nfl + rem] = src[t * op.out_tstride + rem];
+        }
+      }
+      return;
+    }
+  }
+
+  // ---- head logits
+  for (int k = 0; k < 3; ++k) {
+    if (!a.outs[k] || a.out_off[k] < 0) continue;
+    const float* src = reg + T * a.out_off[k];
+    const int nfl = a.out_n[k];
+    for (int idx = tid; idx < ntree * nfl; idx += 256) {
+      const int t = idx / nfl, rem = idx - t * nfl;
+      a.outs[k][(int64_t)(b0 + t) * nfl + rem] = src[t * a.out_ts[k] + rem];
+    }
+  }
+}
+
+inline int rz_choose_trees(const RzGeometry& g, int batch) {
+  int T = (batch + 255) / 256;          // one workgroup per CU when the batch allows
+  if (T < 1) T = 1;
+  if (T > g.max_trees) T = g.max_trees;
+  return T;
+}
+
+// Launches the fused part of a program.  `in` = the tensor feeding it (observation, parent hidden
+// state or the stem's output).
+inline int rz_launch(const mzx_net* net, const RzProgram& R, const float* in, const NetBuffers& nb, int batch,
+                     const NetIndex* ix, stream_t stream, int dump_op = -1, float* dump = nullptr) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)rz_network_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+    attr_set = true;
+  }
+  const RzGeometry& g = net->rz.g;
+  RzArgs a;
+  memset(&a, 0, sizeof(a));
+  a.ops = (const RzOp*)(net->d_derived + R.dev_off);
+  a.n_ops = R.n_ops;
+  a.T = rz_choose_trees(g, batch);
+  a.batch = batch;
+  a.num_actions = net->cfg.action_space_size;
+  a.H = g.H; a.W = g.W; a.HW = g.HW; a.PW = g.PW; a.PS = g.PS; a.Cbuf = g.Cbuf; a.slot_ts = g.slot_ts;
+  a.tree_floats = g.tree_floats;
+  a.mpad = (a.T * g.HW + 15) & ~15;
+  a.in_off = R.in_off; a.in_channels = R.in_channels; a.use_action = R.use_action;
+  for (int k = 0; k < 3; ++k) { a.out_off[k] = R.out_off[k]; a.out_ts[k] = R.out_ts[k]; a.out_n[k] = R.out_n[k]; }
+  a.hidden_floats = (int32_t)net->hidden_size;
+  a.in_nodes = ix ? ix->in_nodes : 1;
+  a.out_nodes = ix ? ix->out_nodes : 1;
+  a.dump_op = dump_op;
+  a.in = in;
+  a.in_node = ix ? ix->in_node : nullptr;
+  a.out_node = ix ? ix->out_node : nullptr;
+  a.action = nb.action;
+  a.hidden_out = nb.hidden;
+  a.outs[0] = nb.value; a.outs[1] = nb.reward; a.outs[2] = nb.policy;
+  a.dump = dump;
+  a.flat = net->d_flat;
+  a.derived = net->d_derived;
+  const unsigned grid = (unsigned)((batch + a.T - 1) / a.T);
+  hipLaunchKernelGGL(rz_network_kernel, dim3(grid), dim3(256), (size_t)rz_lds_bytes(g, a.T), stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("fused network launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+  return MZX_OK;
+}
+
+#endif  // !MZX_HOSTCHECK
+
+// True when inference `recurrent` of `net` runs on the fused engine.
+inline bool rz_enabled(const mzx_net* net, bool recurrent) {
+#ifdef MZX_HOSTCHECK
+  (void)net; (void)recurrent;
+  return false;
+#else
+  if (!net->rz.ok || !net->rz_mode) return false;
+  return recurrent ? net->rz.recurrent.ok != 0 : net->rz.initial.ok != 0;
+#endif
+}
+
+// initial_inference / recurrent_inference of any network: the fused engine where it applies
+// (preceded by the per-operator kernels of a down-sampling stem), else one kernel per operator.
+// With `ix`, sample b reads hidden-state node ix->in_node[b] of nb.in ([batch][ix->in_nodes][..])
+// and writes node ix->out_node[b] of nb.hidden ([batch][ix->out_nodes][hidden]); only the fused
+// engine implements that, callers check rz_enabled first.
+inline int run_network(const mzx_net* net, bool recurrent, const NetBuffers& nb, int batch, stream_t stream,
+                       const NetIndex* ix = nullptr) {
+  const std::vector<OpDesc>& prog = recurrent ? net->prog_recurrent : net->prog_initial;
+#ifndef MZX_HOSTCHECK
+  if (rz_enabled(net, recurrent)) {
+    const RzProgram& R = recurrent ? net->rz.recurrent : net->rz.initial;
+    const float* in = nb.in;
+    if (R.first > 0) {
+      const std::vector<OpDesc> stem(prog.begin(), prog.begin() + R.first);
+      const int rc = run_program(net, stem, nb, batch, stream);
+      if (rc) return rc;
+      in = resolve(net, nb, R.ext_buf, batch);
+    }
+    return rz_launch(net, R, in, nb, batch, ix, stream);
+  }
+#endif
+  if (ix && (ix->in_nodes != 1 || ix->out_nodes != 1)) { set_error("indexed inference needs the fused engine"); return MZX_ERR_INVALID; }
+  return run_program(net, prog, nb, batch, stream);
+}
+
+// Diagnostics: run the first n_ops operators of a program on either engine and copy the output
+// tensor of the last one (dense per sample) to d_out.
+inline int run_network_prefix(const mzx_net* net, bool recurrent, bool fused, int n_ops, const NetBuffers& nb, int batch,
+                              float* d_out, int64_t out_floats, stream_t stream) {
+  const std::vector<OpDesc>& prog = recurrent ? net->prog_recurrent : net->prog_initial;
+  if (n_ops < 1 || n_ops > (int)prog.size()) { set_error("n_ops out of range"); return MZX_ERR_INVALID; }
+  const OpDesc& last = prog[n_ops - 1];
+  int64_t per = 0;
+  switch (last.kind) {
+    case OP_LINEAR: per = last.out_features; break;
+    case OP_CONV3: case OP_POOL: per = (int64_t)last.cout * last.hout * last.wout; break;
+    case OP_CONV1: per = (int64_t)last.cout * last.hin; break;
+    default: per = (int64_t)last.groups_per_sample * last.len; break;
+  }
+  if (out_floats < per * batch) { set_error("prefix output buffer too small (%lld floats per sample)", (long long)per); return MZX_ERR_WORKSPACE; }
+#ifndef MZX_HOSTCHECK
+  if (fused) {
+    const RzProgram& R = recurrent ? net->rz.recurrent : net->rz.initial;
+    if (!net->rz.ok || !R.ok || n_ops <= R.first) { set_error("fused engine does not cover this operator"); return MZX_ERR_INVALID; }
+    const float* in = nb.in;
+    if (R.first > 0) {
+      const std::vector<OpDesc> stem(prog.begin(), prog.begin() + R.first);
+      const int rc = run_program(net, stem, nb, batch, stream);
+      if (rc) return rc;
+      in = resolve(net, nb, R.ext_buf, batch);
+    }
+    return rz_launch(net, R, in, nb, batch, nullptr, stream, n_ops - 1 - R.first, d_out);
+  }
+#else
+  if (fused) { set_error("no fused engine in this build"); return MZX_ERR_INVALID; }
+#endif
+  const std::vector<OpDesc> head(prog.begin(), prog.begin() + n_ops);
+  const int rc = run_program(net, head, nb, batch, stream);
+  if (rc) return rc;
+  const float* src = resolve(net, nb, last.out, batch);
+  return copy_d2d(d_out, src, sizeof(float) * per * batch, stream) ? MZX_ERR_RUNTIME : MZX_OK;
+}
+
+}  // namespace mzx

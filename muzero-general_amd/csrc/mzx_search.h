@@ -8,7 +8,7 @@
 #pragma once
 #include <vector>
 
-#include "mzx_net.h"
+#include "mzx_resnet_fused.h"
 
 struct mzx_search {
   mzx_search_config cfg;
@@ -116,10 +116,16 @@ inline int search_run_generic(mzx_search* s, const mzx_search_io* io, void* d_ar
   int rc = ensure_tables(s, d_arena, stream);
   if (rc) return rc;
 
+  // With the fused network engine the per-node hidden states are read from / written to the arena
+  // store [B][N][Hf] directly (NetIndex); the per-operator engine goes through dense staging copies.
+  const bool ix_init = rz_enabled(net, false), ix_rec = rz_enabled(net, true);
+  NetIndex ix;
+  ix.in_nodes = 1; ix.out_nodes = s->p.num_nodes;   // root: dense observation in, node 0 out
+
   NetBuffers nb;
-  nb.in = io->d_observation; nb.action = nullptr; nb.hidden = v.dense_out;
+  nb.in = io->d_observation; nb.action = nullptr; nb.hidden = ix_init ? v.arena.hidden : v.dense_out;
   nb.value = v.value; nb.reward = v.reward; nb.policy = v.policy; nb.workspace = v.ws;
-  rc = run_program(net, net->prog_initial, nb, B, stream);
+  rc = run_network(net, false, nb, B, stream, ix_init ? &ix : nullptr);
   if (rc) return rc;
 
   RootInitOp ri;
@@ -130,8 +136,10 @@ inline int search_run_generic(mzx_search* s, const mzx_search_io* io, void* d_ar
 
   HiddenMoveOp mv;
   mv.arena = v.arena; mv.num_trees = B; mv.num_nodes = s->p.num_nodes; mv.hidden_size = s->p.hidden_size;
-  mv.dense = v.dense_out; mv.node = nullptr; mv.to_arena = 1;
-  MZX_TRY_LAUNCH(launch<256>(mv, stream));
+  if (!ix_init) {
+    mv.dense = v.dense_out; mv.node = nullptr; mv.to_arena = 1;
+    MZX_TRY_LAUNCH(launch<256>(mv, stream));
+  }
 
   SelectOp sel;
   sel.arena = v.arena; sel.p = v.p; sel.tape = io->d_tape;
@@ -139,13 +147,25 @@ inline int search_run_generic(mzx_search* s, const mzx_search_io* io, void* d_ar
   ExpandBackpropOp eb;
   eb.arena = v.arena; eb.p = v.p; eb.value_logits = v.value; eb.reward_logits = v.reward; eb.policy_logits = v.policy;
   eb.ext_value = nullptr; eb.ext_reward = nullptr; eb.ext_priors = nullptr;
-  nb.in = v.dense_in; nb.action = v.sel_action;
+  nb.action = v.sel_action;
+  if (ix_rec) {
+    nb.in = v.arena.hidden; nb.hidden = v.arena.hidden;
+    ix.in_node = v.sel_parent; ix.out_node = v.sel_leaf; ix.in_nodes = s->p.num_nodes; ix.out_nodes = s->p.num_nodes;
+  } else {
+    nb.in = v.dense_in; nb.hidden = v.dense_out;
+  }
 
   for (int k = 0; k < s->p.num_sims; ++k) {
     MZX_TRY_LAUNCH(launch<64>(sel, stream));
+    if (ix_rec) {
+      rc = run_network(net, true, nb, B, stream, &ix);
+      if (rc) return rc;
+      MZX_TRY_LAUNCH(launch<64>(eb, stream));
+      continue;
+    }
     mv.dense = v.dense_in; mv.node = v.sel_parent; mv.to_arena = 0;
     MZX_TRY_LAUNCH(launch<256>(mv, stream));
-    rc = run_program(net, net->prog_recurrent, nb, B, stream);
+    rc = run_network(net, true, nb, B, stream);
     if (rc) return rc;
     MZX_TRY_LAUNCH(launch<64>(eb, stream));
     mv.dense = v.dense_out; mv.node = v.sel_leaf; mv.to_arena = 1;

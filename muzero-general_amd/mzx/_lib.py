@@ -74,7 +74,13 @@ PROTOTYPES = {
     "mzx_net_input_size": (c_i64, [c_vp]),
     "mzx_net_derived_floats": (c_i64, [c_vp]),
     "mzx_net_workspace_floats": (c_i64, [c_vp, c_i32]),
+    "mzx_net_flops": (c_i64, [c_vp, c_i32]),
     "mzx_net_set_weights": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "mzx_net_fused_supported": (ctypes.c_int, [c_vp]),
+    "mzx_net_set_mode": (ctypes.c_int, [c_vp, c_i32]),
+    "mzx_net_num_operators": (ctypes.c_int, [c_vp, c_i32]),
+    "mzx_net_debug_prefix": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64,
+                                            c_vp, c_i64, c_vp]),
     "mzx_net_initial_inference": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mzx_net_recurrent_inference": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mzx_search_create": (ctypes.c_int, [ctypes.POINTER(SearchConfig), c_vp, ctypes.POINTER(c_vp)]),

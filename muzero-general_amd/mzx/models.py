@@ -228,6 +228,33 @@ class HipNetwork:
                 raise AssertionError(key)
         return sd
 
+    # ---- engine selection / diagnostics (no reference counterpart) ----
+    def fused_supported(self):
+        """bit 0: initial_inference, bit 1: recurrent_inference run on the fused MFMA engine."""
+        return int(self.backend.lib.mzx_net_fused_supported(self.handle))
+
+    def set_mode(self, mode):
+        """0 = one kernel per operator, 1 = fused engine where available (default)."""
+        self.backend.lib.check(self.backend.lib.mzx_net_set_mode(self.handle, int(mode)))
+
+    def num_operators(self, recurrent):
+        return int(self.backend.lib.mzx_net_num_operators(self.handle, int(bool(recurrent))))
+
+    def debug_prefix(self, recurrent, fused, n_ops, x, action=None):
+        """Output tensor [batch, -1] of operator n_ops-1 of the chosen program on the chosen engine."""
+        b, lib = self.backend, self.backend.lib
+        x = self._prepare(x, self.hidden_size if recurrent else self.input_size)
+        n = x.shape[0]
+        act = None if action is None else action.to(b.device).reshape(-1).to(torch.int32).contiguous()
+        cap = max(self.hidden_size, self.input_size, 4096) * 64
+        out = b.zeros((n, cap), torch.float32)
+        scratch = b.empty(((self.hidden_size + 2 * self.full_support_size + self.action_space_size) * n,), torch.float32)
+        ws = self._ws(n)
+        lib.check(lib.mzx_net_debug_prefix(self.handle, int(bool(recurrent)), int(bool(fused)), int(n_ops), b.ptr(x),
+                                           b.ptr(act), n, b.ptr(out), out.numel(), b.ptr(scratch), scratch.numel(),
+                                           b.ptr(ws), ws.numel(), b.stream()))
+        return out
+
     # ---- inference ----
     def _ws(self, batch):
         if self._workspace is None or self._ws_batch < batch:
