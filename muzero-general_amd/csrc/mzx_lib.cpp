@@ -110,7 +110,13 @@ int mzx_net_set_weights(mzx_net* net, const float* d_flat, int64_t n_floats, flo
     for (const RzPack& p : net->rz.packs) {
       RzPackOp op;
       op.W = d_flat + p.src; op.out = d_derived + p.dst;
-      op.taps = p.taps; op.cin = p.cin; op.cin4 = p.cin4; op.cout = p.cout; op.nchunks = p.nchunks; op.ntiles = p.ntiles;
+      op.taps = p.taps; op.cin = p.cin; op.cin_total = p.cin_total; op.cchunks = p.cchunks; op.cout = p.cout;
+      op.nchunks = p.nchunks; op.ntiles = p.ntiles;
+      MZX_TRY_LAUNCH(launch<256>(op, (stream_t)stream));
+    }
+    for (const RzAsum& q : net->rz.asums) {
+      RzAsumOp op;
+      op.W = d_flat + q.src; op.out = d_derived + q.dst; op.cout = q.cout; op.cin_total = q.cin_total; op.H = q.H; op.Wd = q.W;
       MZX_TRY_LAUNCH(launch<256>(op, (stream_t)stream));
     }
     for (const RzProgram* R : {&net->rz.initial, &net->rz.recurrent})

@@ -10,24 +10,32 @@
 //   min-max scaling, action plane = action / |A|), mlp :630-642.
 //
 // Tiling (wave64, 256-thread workgroup = 4 waves, one workgroup per tile of T trees):
-//   * activations: three rotating LDS slots [T][Cbuf][PS] in a zero-haloed plane layout
-//     ((H+2) x (W+2) floats per plane, plane stride PS = 16 mod 32 so that the two
-//     16-lane halves of a ds_read_b32 group hit complementary banks); head tensors are
-//     small flat LDS regions.  Halo cells and pad planes are written once (zero) and
-//     never again, so a 3x3 tap is a constant address offset -- no bounds tests.
+//   * activations: three rotating LDS slots in a position-major, zero-haloed layout
+//     [T][(H+2)*(W+2)][Cs] (channels innermost, Cs = 8 mod 16 floats so that the 16-byte
+//     reads of 16 consecutive rows fall on distinct LDS slots); head tensors are small
+//     flat regions.  Halo positions and pad channels are written once (zero) and never
+//     again, so a 3x3 tap is a constant address offset -- no bounds tests.
 //   * every layer is D[M x N] = A[M x K] . B[K x N] on v_mfma_f32_16x16x4_f32:
-//       3x3 conv : M = T*H*W (tree, position), K = 9 * Cin (tap-major), N = Cout
+//       3x3 conv : M = T*H*W (tree, position), K = 9 taps x Cin, N = Cout
 //       1x1 conv : same rows, K = Cin
 //       Linear   : M = T (trees), K = in_features, N = out_features
-//     lane l feeds A[row l&15][k l>>4] with ONE ds_read_b32 at (row base + tap offset +
-//     k * plane stride); B fragments come pre-packed in lane order from the derived
-//     buffer (built once per set_weights), 16 K-deep per global_load_dwordx4, double
-//     buffered in registers; N tiles are spread over the waves first (each wave then
-//     streams a disjoint quarter of the weights exactly once), M tiles next; a wave
-//     keeps up to 8 accumulator tiles so one B fragment feeds up to 8 MFMAs.
-//   * epilogue per layer in registers: folded BatchNorm (alpha, beta), bias, residual
-//     (read from its LDS slot), ReLU / ELU, then the D fragment (col = lane & 15,
-//     row = 4 * (lane >> 4) + r) goes back to LDS in the layout the next layer reads.
+//     K is walked in 16-channel chunks: lane l = (row l&15, group g = l>>4) reads channels
+//     4g..4g+3 of its row with ONE ds_read_b128 and uses them as the A operand of four
+//     consecutive K-steps (K-step j = channels {4g + j}); the B fragments are pre-packed
+//     in the same permuted order (RzPackOp), one 16-byte load per lane per chunk --
+//     from an LDS-resident copy of the program's whole weight image when it fits beside the
+//     activations (small nets: every weight is read from HBM/L2 once per workgroup), else
+//     straight from L2 with the next chunk in flight.  Chunks are double-buffered in
+//     registers (ping-pong, no copies); N tiles are spread over the waves first (each wave
+//     then streams a disjoint part of the weights exactly once), M tiles next; a wave keeps
+//     up to 8 accumulator tiles so one B fragment feeds up to 8 MFMAs.
+//   * the dynamics input's action plane (models.py:557-572) is not materialised: it is
+//     constant inside the board, so its contribution is action/|A| x (sum of the in-board
+//     taps of its weights), a [Cout][H*W] table built per set_weights and added in the
+//     epilogue -- K stays a multiple of 16 (Cin = C, not C + 1).
+//   * epilogue per layer in registers: action term, folded BatchNorm (alpha, beta), bias,
+//     residual (read from its LDS slot), ReLU / ELU, then the D fragment (col = lane & 15,
+//     row = 4 * (lane >> 4) + r) goes back to LDS (16 lanes = 16 consecutive channels).
 //   * exactness: the f32 MFMA is a k-ordered fmaf chain (bitwise); only the summation
 //     ORDER differs from ATen's, i.e. fp32 round-off (tests: 1e-4 absolute on all heads).
 //
@@ -49,21 +57,45 @@ constexpr int RZ_LDS_BUDGET = 160 * 1024 - 1024;
 // weight packing (runs once per set_weights; element functor, also built by hostcheck)
 
 struct RzPackOp {
-  const float* W;   // [cout][cin][taps]
+  const float* W;   // [cout][cin_total][taps]
   float* out;       // [ntiles][nchunks][64 lanes][4]
-  int32_t taps, cin, cin4, cout, nchunks, ntiles;
+  int32_t taps, cin, cin_total, cchunks, cout, nchunks, ntiles;
 
   MZX_HD size_t size() const { return (size_t)ntiles * nchunks * 256; }
   MZX_HD void operator()(size_t i) const {
     const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
     const int c = (int)((i >> 8) % nchunks), nt = (int)((i >> 8) / nchunks);
-    const int k = 16 * c + 4 * j + (lane >> 4);       // K index of K-step 4c + j, B row lane >> 4
+    const int tap = c / cchunks, cc = c % cchunks;
+    const int ci = cc * 16 + 4 * (lane >> 4) + j;      // K-step j of the chunk, B row lane >> 4
     const int n = nt * 16 + (lane & 15);
-    const int cp = cin4 * 4;
-    const int tap = k / cp, ci = k % cp;
     float v = 0.f;
-    if (tap < taps && ci < cin && n < cout) v = W[((int64_t)n * cin + ci) * taps + tap];
+    if (ci < cin && n < cout) v = W[((int64_t)n * cin_total + ci) * taps + tap];
     out[i] = v;
+  }
+};
+
+// out[co][pos] = sum over the 3x3 taps that stay inside the board of W[co][cin_total - 1][ky][kx]
+struct RzAsumOp {
+  const float* W;
+  float* out;
+  int32_t cout, cin_total, H, Wd;
+
+  MZX_HD size_t size() const { return (size_t)cout * H * Wd; }
+  MZX_HD void operator()(size_t i) const {
+    const int p = (int)(i % (H * Wd)), co = (int)(i / (H * Wd));
+    const int y = p / Wd, x = p % Wd;
+    const float* w = W + ((int64_t)co * cin_total + (cin_total - 1)) * 9;
+    float acc = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = y + ky - 1;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = x + kx - 1;
+        if (ix < 0 || ix >= Wd) continue;
+        acc += w[ky * 3 + kx];
+      }
+    }
+    out[i] = acc;
   }
 };
 
@@ -71,6 +103,7 @@ struct RzPackOp {
 // host planner: operator program (mzx_net.h) -> fused program
 
 inline int rz_round4(int x) { return (x + 3) & ~3; }
+inline int rz_round16(int x) { return (x + 15) & ~15; }
 
 inline bool rz_fusable(const OpDesc& d, int h, int w) {
   switch (d.kind) {
@@ -84,24 +117,27 @@ inline bool rz_fusable(const OpDesc& d, int h, int w) {
 
 struct RzInst { int id, def, last, spatial, size, slot, off, tstride; };
 
-inline int64_t rz_add_pack(RzPlan& P, int64_t src, int taps, int cin, int cout, int64_t& cursor) {
-  const int cin4 = rz_round4(cin) / 4;
-  for (const RzPack& p : P.packs)
-    if (p.src == src && p.taps == taps && p.cin == cin && p.cout == cout) return p.dst;
+// packs are deduplicated inside one program; every program owns a contiguous weight image
+inline int32_t rz_add_pack(RzPlan& P, size_t first_pack, int64_t w_base, int64_t src, int taps, int cin, int cin_total,
+                           int cout, int64_t& cursor) {
+  for (size_t k = first_pack; k < P.packs.size(); ++k) {
+    const RzPack& p = P.packs[k];
+    if (p.src == src && p.taps == taps && p.cin == cin && p.cout == cout) return (int32_t)(p.dst - w_base);
+  }
   RzPack p;
-  p.src = src; p.taps = taps; p.cin = cin; p.cin4 = cin4; p.cout = cout;
-  p.nchunks = (taps * cin4 + 3) / 4;
+  p.src = src; p.taps = taps; p.cin = cin; p.cin_total = cin_total; p.cout = cout;
+  p.cchunks = rz_round16(cin) / 16;
+  p.nchunks = taps * p.cchunks;
   p.ntiles = (cout + 15) / 16;
   p.dst = cursor;
   cursor += (int64_t)p.ntiles * p.nchunks * 256;
   P.packs.push_back(p);
-  return p.dst;
+  return (int32_t)(p.dst - w_base);
 }
 
-// Builds `R` from `prog`; returns false if the program cannot be fused.  `flat_cursor` = per-tree
-// float offset where this program's flat regions start (after the three spatial slots).
+// Builds `R` from `prog`; returns false if the program cannot be fused.
 inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog, RzPlan& P, RzProgram& R,
-                             int64_t& pack_cursor, int& flat_floats, int& max_cin) {
+                             int64_t& cursor, int& max_c) {
   const int h = net->hh, w = net->hw, HW = h * w;
   const int n = (int)prog.size();
   int first = n;
@@ -153,6 +189,7 @@ inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog
   for (RzInst& s : inst)
     if (s.id == BUF_VALUE || s.id == BUF_REWARD || s.id == BUF_POLICY) s.last = n;
   // slot / region allocation
+  int flat_floats = 0;
   for (size_t k = 0; k < inst.size(); ++k) {
     RzInst& s = inst[k];
     if (s.spatial) {
@@ -165,7 +202,7 @@ inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog
       for (int q = 0; q < 3; ++q) if (!busy[q]) { s.slot = q; break; }
       if (s.slot < 0) return false;
     } else {
-      s.tstride = rz_round4(s.size) + 4;
+      s.tstride = rz_round16(s.size) + 8;   // whole 16-deep K chunks readable; 8 mod 16 spreads the rows over LDS slots
       s.off = flat_floats;
       flat_floats += s.tstride;
     }
@@ -176,70 +213,92 @@ inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog
   R.n_ops = n - first;
   R.in_channels = inst[ext].size;
   R.use_action = (prog[first].kind == OP_CONV3 && prog[first].use_action) ? 1 : 0;
-  max_cin = std::max(max_cin, R.in_channels + R.use_action);
-  // region offsets are resolved to "slot index" (spatial, negative encoding below) until the
-  // geometry is known: store slot in in_off and patch in rz_finish_program
+  R.flat_floats = flat_floats;
+  R.w_base = cursor;
+  max_c = std::max(max_c, R.in_channels);
+  const size_t first_pack = P.packs.size();
+  // spatial region offsets hold the SLOT index until the geometry is known (rz_finish_program)
   for (int i = first; i < n; ++i) {
     const OpDesc& d = prog[i];
     RzOp& o = R.ops[i - first];
     memset(&o, 0, sizeof(o));
-    o.res_off = -1; o.alpha_off = -1; o.beta_off = -1; o.bias_off = -1;
+    o.res_off = -1; o.alpha_off = -1; o.beta_off = -1; o.bias_off = -1; o.asum_off = -1;
     const RzInst& si = inst[in_i[i]];
     const RzInst& so = inst[out_i[i]];
     switch (d.kind) {
-      case OP_CONV3:
+      case OP_CONV3: {
+        const int cin = d.cin - (d.use_action ? 1 : 0);   // the action plane is folded into the epilogue
         o.kind = RZ_GEMM; o.rows = RZ_ROWS_POS; o.taps = 9;
         o.in_off = si.slot; o.out_off = so.slot; o.out_layout = RZ_OUT_PADDED;
         if (res_i[i] >= 0) o.res_off = inst[res_i[i]].slot;
-        o.cin4 = rz_round4(d.cin) / 4; o.cout = d.cout;
+        o.cchunks = rz_round16(cin) / 16; o.cout = d.cout;
         if (d.bn.channels) { o.alpha_off = (int32_t)d.bn.alpha; o.beta_off = (int32_t)d.bn.beta; }
         o.act = d.relu ? RZ_ACT_RELU : RZ_ACT_NONE;
-        o.w_off = (int32_t)rz_add_pack(P, d.w, 9, d.cin, d.cout, pack_cursor);
-        if (o.cin4 >= 256 || 9 * o.cin4 + 4 >= 4096) return false;   // reciprocal range of the kernel's K-step decode
-        max_cin = std::max(max_cin, std::max(d.cin, d.cout));
+        o.w_off = rz_add_pack(P, first_pack, R.w_base, d.w, 9, cin, d.cin, d.cout, cursor);
+        if (o.cchunks >= 256 || 9 * o.cchunks >= 4096) return false;   // reciprocal range of the kernel's chunk decode
+        max_c = std::max(max_c, std::max(cin, d.cout));
         break;
+      }
       case OP_CONV1:
         o.kind = RZ_GEMM; o.rows = RZ_ROWS_POS; o.taps = 1;
         o.in_off = si.slot; o.out_off = so.off; o.out_tstride = so.tstride; o.out_layout = RZ_OUT_FLAT;
-        o.cin4 = rz_round4(d.cin) / 4; o.cout = d.cout;
+        o.cchunks = rz_round16(d.cin) / 16; o.cout = d.cout;
         o.bias_off = (int32_t)d.b;
-        o.w_off = (int32_t)rz_add_pack(P, d.w, 1, d.cin, d.cout, pack_cursor);
-        max_cin = std::max(max_cin, d.cin);
+        o.w_off = rz_add_pack(P, first_pack, R.w_base, d.w, 1, d.cin, d.cin, d.cout, cursor);
+        max_c = std::max(max_c, d.cin);
         break;
       case OP_LINEAR:
         if (d.w_stride != d.in_features) return false;
         o.kind = RZ_GEMM; o.rows = RZ_ROWS_TREE; o.taps = 1;
         o.in_off = si.off; o.in_tstride = si.tstride;
         o.out_off = so.off; o.out_tstride = so.tstride; o.out_layout = RZ_OUT_FLAT;
-        o.cin4 = rz_round4(d.in_features) / 4; o.cout = d.out_features;
+        o.cchunks = rz_round16(d.in_features) / 16; o.cout = d.out_features;
         o.bias_off = (int32_t)d.b;
         o.act = d.elu ? RZ_ACT_ELU : RZ_ACT_NONE;
-        o.w_off = (int32_t)rz_add_pack(P, d.w, 1, d.in_features, d.out_features, pack_cursor);
-        if (o.cin4 * 4 > si.tstride) return false;
+        o.w_off = rz_add_pack(P, first_pack, R.w_base, d.w, 1, d.in_features, d.in_features, d.out_features, cursor);
+        if (o.cchunks * 16 > si.tstride) return false;
         break;
       default:  // OP_SCALE
         o.kind = RZ_SCALE; o.rows = RZ_ROWS_POS;
         o.in_off = si.slot; o.out_off = so.slot; o.out_layout = RZ_OUT_PADDED;
         o.channels = d.groups_per_sample;
         o.store_hidden = (d.out == BUF_HIDDEN) ? 1 : 0;
-        max_cin = std::max(max_cin, d.groups_per_sample);
+        max_c = std::max(max_c, d.groups_per_sample);
         break;
     }
-    if (o.kind == RZ_GEMM) o.nchunks = (o.taps * o.cin4 + 3) / 4;
+    if (o.kind == RZ_GEMM) o.nchunks = o.taps * o.cchunks;
     const int which = (d.out == BUF_VALUE) ? 0 : (d.out == BUF_REWARD) ? 1 : (d.out == BUF_POLICY) ? 2 : -1;
     if (which >= 0) {
       if (so.spatial) return false;
       R.out_off[which] = so.off; R.out_ts[which] = so.tstride; R.out_n[which] = so.size;
     }
   }
+  R.w_floats = (int32_t)(cursor - R.w_base);
+  if (R.use_action) {  // action-plane tap sums of the first convolution
+    const OpDesc& d = prog[first];
+    RzAsum s;
+    s.src = d.w; s.dst = cursor; s.cout = d.cout; s.cin_total = d.cin; s.H = h; s.W = w;
+    R.ops[0].asum_off = (int32_t)cursor;
+    cursor += rz_round4(d.cout * HW);
+    P.asums.push_back(s);
+  }
   R.in_off = inst[ext].slot;
   R.ok = 1;
   return true;
 }
 
-inline int64_t rz_lds_bytes(const RzGeometry& g, int T) {
-  const int mpad = (T * g.HW + 15) & ~15;
-  return 4 * ((int64_t)2 * mpad + (int64_t)2 * T * g.Cbuf + (int64_t)T * g.tree_floats);
+// LDS floats of a workgroup of T trees: row tables, scratch, regions, optionally the weight image
+inline int64_t rz_lds_floats(const RzGeometry& g, const RzProgram& R, int T, bool weights_in_lds) {
+  const int mpad = rz_round16(T * g.HW);
+  const int64_t scratch = rz_round4(2 * T * g.Cs + T);
+  return (int64_t)2 * mpad + scratch + (int64_t)T * (3 * g.slot_ts + R.flat_floats) + (weights_in_lds ? R.w_floats : 0);
+}
+
+inline int rz_max_trees(const RzGeometry& g, const RzProgram& R, bool weights_in_lds) {
+  int best = 0;
+  for (int T = 1; T <= RZ_MAX_TREES && T * g.HW <= RZ_MAX_ROWS; ++T)
+    if (4 * rz_lds_floats(g, R, T, weights_in_lds) <= RZ_LDS_BUDGET) best = T;
+  return best;
 }
 
 // slot indices -> per-tree float offsets, flat offsets -> behind the three slots
@@ -255,6 +314,7 @@ inline void rz_finish_program(const RzGeometry& g, RzProgram& R) {
   }
   R.in_off *= g.slot_ts;
   for (int k = 0; k < 3; ++k) if (R.out_off[k] >= 0) R.out_off[k] += flat0;
+  if (rz_max_trees(g, R, false) < 1) R.ok = 0;
 }
 
 // Plans both programs of a residual network; called by mzx_net_create after NetBuilder::build.
@@ -265,30 +325,17 @@ inline void rz_plan(mzx_net* net) {
   const int h = net->hh, w = net->hw;
   if (h < 1 || w < 1 || h * w > RZ_MAX_ROWS) return;
   int64_t cursor = (net->derived_floats + 3) & ~int64_t(3);
-  int flat_i = 0, flat_r = 0, max_cin = 4;
-  const bool oi = rz_build_program(net, net->prog_initial, P, P.initial, cursor, flat_i, max_cin);
-  const bool orr = rz_build_program(net, net->prog_recurrent, P, P.recurrent, cursor, flat_r, max_cin);
-  if (!oi) P.initial.ok = 0;
-  if (!orr) P.recurrent.ok = 0;
-  if (!oi && !orr) { P.packs.clear(); return; }
+  int max_c = 4;
+  if (!rz_build_program(net, net->prog_initial, P, P.initial, cursor, max_c)) P.initial.ok = 0;
+  if (!rz_build_program(net, net->prog_recurrent, P, P.recurrent, cursor, max_c)) P.recurrent.ok = 0;
+  if (!P.initial.ok && !P.recurrent.ok) { P = RzPlan(); return; }
   RzGeometry& g = P.g;
-  g.H = h; g.W = w; g.HW = h * w; g.PW = w + 2;
-  g.Cbuf = rz_round4(max_cin);
-  const int flat = std::max(flat_i, flat_r);
-  const int min_ps = (h + 2) * (w + 2);
-  const int candidates[2] = {min_ps + ((16 - min_ps % 32) + 32) % 32, min_ps};
-  for (int ps : candidates) {
-    g.PS = ps;
-    g.slot_ts = g.Cbuf * ps;
-    g.tree_floats = 3 * g.slot_ts + flat;
-    g.max_trees = 0;
-    for (int T = 1; T <= RZ_MAX_TREES && T * g.HW <= RZ_MAX_ROWS; ++T)
-      if (rz_lds_bytes(g, T) <= RZ_LDS_BUDGET) g.max_trees = T;
-    if (g.max_trees >= 1) break;
-  }
-  if (g.max_trees < 1) { P = RzPlan(); return; }
+  g.H = h; g.W = w; g.HW = h * w; g.PW = w + 2; g.PP = (h + 2) * (w + 2);
+  g.Cs = rz_round16(max_c) + 8;
+  g.slot_ts = g.PP * g.Cs;
   rz_finish_program(g, P.initial);
   rz_finish_program(g, P.recurrent);
+  if (!P.initial.ok && !P.recurrent.ok) { P = RzPlan(); return; }
   // program tables behind the packed weights
   const int64_t table_floats = (int64_t)(sizeof(RzOp) * RZ_MAX_OPS + 15) / 16 * 4;
   P.initial.dev_off = cursor; cursor += table_floats;
@@ -308,12 +355,13 @@ struct NetIndex {
 struct RzArgs {
   const RzOp* ops;
   int32_t n_ops, T, batch, num_actions;
-  int32_t H, W, HW, PW, PS, Cbuf, slot_ts, tree_floats, mpad;
+  int32_t H, W, HW, PW, Cs, slot_ts, tree_floats, mpad, scratch_floats;
   int32_t in_off, in_channels, use_action;
   int32_t out_off[3], out_ts[3], out_n[3];
   int32_t hidden_floats;          // C * H * W
   int32_t in_nodes, out_nodes;    // nodes per sample of the in / hidden-out tensors (1 = dense)
   int32_t dump_op;                // >= 0: stop after this op and copy its output to `dump`
+  int32_t w_floats;               // size of the program's weight image
   const float* in;
   const int32_t* in_node;
   const int32_t* out_node;
@@ -323,6 +371,7 @@ struct RzArgs {
   float* dump;
   const float* flat;
   const float* derived;
+  const float* weights;           // the program's weight image (global)
 };
 
 #ifndef MZX_HOSTCHECK
@@ -330,21 +379,21 @@ struct RzArgs {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct RzCtx {
-  float* reg;           // workgroup LDS regions (offset T * off)
-  const int* rowaddr;   // [mpad] padded-layout address of row m = (tree, position): t * slot_ts + (y+1) * PW + x + 1
+  float* reg;           // workgroup LDS regions (region r of the program starts at T * r.off)
+  const int* rowaddr;   // [mpad] activation address of row m = (tree, position): t * slot_ts + ((y+1) * PW + x + 1) * Cs
   const int* rowtp;     // [mpad] (t << 16) | position, -1 for rows beyond T * HW
-  float* scratch;       // [2 * T * Cbuf]
+  float* scratch;       // [2 * T * Cs] min-max scratch, then actval[T] = action / |A| per tree
+  const float* wlds;    // LDS copy of the weight image (WLDS kernels)
   int T, lane, wave, tid;
 };
 
-// One group of up to MT row tiles x one column tile of a layer GEMM, K-loop + epilogue.
-template <int MT>
+// One group of MT row tiles x one column tile of a layer GEMM: K loop + epilogue.
+template <int MT, bool WLDS>
 __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, const RzCtx& cx, int nt, int mt0,
                                               int mt_step) {
   const int lane = cx.lane, T = cx.T;
   const bool pos_rows = (op.rows == RZ_ROWS_POS);
   const int rows = pos_rows ? T * a.HW : T;
-  const int kstride = pos_rows ? a.PS : 1;
   const float* in = cx.reg + T * op.in_off;
   f32x4 acc[MT];
   int abase[MT];
@@ -353,51 +402,44 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
     acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     int m = (mt0 + i * mt_step) * 16 + (lane & 15);
     if (m >= rows) m = 0;
-    const int ra = pos_rows ? cx.rowaddr[m] : m * op.in_tstride;
-    abase[i] = ra + (lane >> 4) * kstride;
+    abase[i] = (pos_rows ? cx.rowaddr[m] : m * op.in_tstride) + 4 * (lane >> 4);
   }
-  const f32x4* wp = (const f32x4*)(a.derived + op.w_off) + (size_t)nt * op.nchunks * 64 + lane;
-  // K-step ks -> (tap, channel group): branch-free scalar arithmetic (tap = ks / cin4 by a 20-bit
-  // reciprocal, exact for ks < 4096 and cin4 < 256 -- the planner checks both).  K-steps of the
-  // zero-padded tail of the last chunk clamp to the last tap: they re-read valid addresses against
-  // zero weights.
-  const unsigned magic = ((1u << 20) + (unsigned)op.cin4 - 1) / (unsigned)op.cin4;
-  const int last_tap = op.taps - 1;
-  const int pw9 = (op.taps == 9) ? a.PW : 0, one9 = (op.taps == 9) ? 1 : 0;
-  auto load_a = [&](int c, float (&dst)[4][MT]) {
+  const f32x4* wp = (const f32x4*)((WLDS ? cx.wlds : a.weights) + op.w_off) + (size_t)nt * op.nchunks * 64 + lane;
+  // chunk c -> (tap, 16-channel chunk of the tap): tap = c / cchunks by a 20-bit reciprocal, exact for
+  // c < 4096 and cchunks < 256 (the planner checks both)
+  const unsigned magic = ((1u << 20) + (unsigned)op.cchunks - 1) / (unsigned)op.cchunks;
+  const int pw9 = (op.taps == 9) ? a.PW * a.Cs : 0, one9 = (op.taps == 9) ? a.Cs : 0;
+  const int last = op.nchunks - 1;
+  auto load = [&](int c, f32x4 (&av)[MT], f32x4& bv) {
+    const bool tail = c > last;   // one chunk past the end (odd chunk counts): zero B, valid addresses
+    c = c < last ? c : last;
+    const int tap = (op.taps == 9) ? (int)(((unsigned)c * magic) >> 20) : 0;
+    const int cc = c - tap * op.cchunks;
+    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;                 // tap / 3, tap % 3 for tap < 9
+    const int off = (ty - 1) * pw9 + (tx - 1) * one9 + cc * 16;
+    bv = wp[(size_t)c * 64];
+    if (tail) bv = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ks = 4 * c + j;
-      const int traw = (op.taps == 9) ? (int)(((unsigned)ks * magic) >> 20) : (ks >= op.cin4 ? 1 : 0);
-      const int cg = ks - traw * op.cin4;
-      const int tap = traw < last_tap ? traw : last_tap;
-      const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;                 // tap / 3, tap % 3 for tap < 9
-      const int off = (ty - 1) * pw9 + (tx - 1) * one9 + cg * 4 * kstride;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) dst[j][i] = in[abase[i] + off];
-    }
+    for (int i = 0; i < MT; ++i) av[i] = *(const f32x4*)(in + abase[i] + off);
   };
-  // software pipeline: the A fragments and the B fragment of chunk c+1 are in flight while the
-  // 4 * MT MFMAs of chunk c issue
-  float a_cur[4][MT], a_nxt[4][MT];
-  f32x4 bq = wp[0];
-  load_a(0, a_cur);
-  for (int c = 0; c < op.nchunks; ++c) {
-    const int cn = (c + 1 < op.nchunks) ? c + 1 : c;
-    const f32x4 bn = wp[(size_t)cn * 64];
-    load_a(cn, a_nxt);
-    __builtin_amdgcn_sched_barrier(0);   // loads of chunk c+1 stay ahead of the MFMAs of chunk c
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float bj = bq[j];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][i], bj, acc[i], 0, 0, 0);
-    }
+  auto compute = [&](const f32x4 (&av)[MT], const f32x4& bv) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a_cur[j][i] = a_nxt[j][i];
-    bq = bn;
+      for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][j], bv[j], acc[i], 0, 0, 0);
+  };
+  // ping-pong software pipeline: the operands of chunk c+1 are in flight while the 4 * MT MFMAs of chunk c issue
+  f32x4 a0[MT], a1[MT], b0, b1;
+  load(0, a0, b0);
+  for (int c = 0; c < op.nchunks; c += 2) {
+    load(c + 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(c + 2, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
   }
   // ---- epilogue
   const int n = nt * 16 + (lane & 15);
@@ -407,6 +449,7 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
   if (nv && op.bias_off >= 0) bi = a.flat[op.bias_off + n];
   float* out = cx.reg + T * op.out_off;
   const float* res = (op.res_off >= 0) ? cx.reg + T * op.res_off : nullptr;
+  const float* actval = cx.scratch + 2 * T * a.Cs;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -414,20 +457,21 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
       const int m = (mt0 + i * mt_step) * 16 + (lane >> 4) * 4 + r;
       if (m >= rows || !nv) continue;
       float v = acc[i][r];
-      if (op.alpha_off >= 0) v = v * al + be;
-      if (op.bias_off >= 0) v = v + bi;
       int ra = 0, t = m, p = 0;
       if (pos_rows) { ra = cx.rowaddr[m]; const int tp = cx.rowtp[m]; t = tp >> 16; p = tp & 0xFFFF; }
-      if (res) v += res[ra + n * a.PS];
+      if (op.asum_off >= 0) v += actval[t] * a.derived[op.asum_off + n * a.HW + p];
+      if (op.alpha_off >= 0) v = v * al + be;
+      if (op.bias_off >= 0) v = v + bi;
+      if (res) v += res[ra + n];
       if (op.act == RZ_ACT_RELU) v = fmaxf(v, 0.f);
       else if (op.act == RZ_ACT_ELU) v = mzx_elu(v);
-      const int idx = (op.out_layout == RZ_OUT_PADDED) ? ra + n * a.PS
-                                                       : t * op.out_tstride + (pos_rows ? n * a.HW + p : n);
+      const int idx = (op.out_layout == RZ_OUT_PADDED) ? ra + n : t * op.out_tstride + (pos_rows ? n * a.HW + p : n);
       out[idx] = v;
     }
   }
 }
 
+template <bool WLDS>
 __device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const RzCtx& cx) {
   const int rows = (op.rows == RZ_ROWS_POS) ? cx.T * a.HW : cx.T;
   const int mt_total = (rows + 15) >> 4, nt_total = (op.cout + 15) >> 4;
@@ -438,14 +482,14 @@ __device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const R
     for (int mt0 = wm; mt0 < mt_total; mt0 += waves_m * 8) {
       const int cnt = min(8, (mt_total - mt0 + waves_m - 1) / waves_m);   // wave-uniform
       switch (cnt) {
-        case 1: rz_gemm_tiles<1>(op, a, cx, nt, mt0, waves_m); break;
-        case 2: rz_gemm_tiles<2>(op, a, cx, nt, mt0, waves_m); break;
-        case 3: rz_gemm_tiles<3>(op, a, cx, nt, mt0, waves_m); break;
-        case 4: rz_gemm_tiles<4>(op, a, cx, nt, mt0, waves_m); break;
-        case 5: rz_gemm_tiles<5>(op, a, cx, nt, mt0, waves_m); break;
-        case 6: rz_gemm_tiles<6>(op, a, cx, nt, mt0, waves_m); break;
-        case 7: rz_gemm_tiles<7>(op, a, cx, nt, mt0, waves_m); break;
-        default: rz_gemm_tiles<8>(op, a, cx, nt, mt0, waves_m); break;
+        case 1: rz_gemm_tiles<1, WLDS>(op, a, cx, nt, mt0, waves_m); break;
+        case 2: rz_gemm_tiles<2, WLDS>(op, a, cx, nt, mt0, waves_m); break;
+        case 3: rz_gemm_tiles<3, WLDS>(op, a, cx, nt, mt0, waves_m); break;
+        case 4: rz_gemm_tiles<4, WLDS>(op, a, cx, nt, mt0, waves_m); break;
+        case 5: rz_gemm_tiles<5, WLDS>(op, a, cx, nt, mt0, waves_m); break;
+        case 6: rz_gemm_tiles<6, WLDS>(op, a, cx, nt, mt0, waves_m); break;
+        case 7: rz_gemm_tiles<7, WLDS>(op, a, cx, nt, mt0, waves_m); break;
+        default: rz_gemm_tiles<8, WLDS>(op, a, cx, nt, mt0, waves_m); break;
       }
     }
   }
@@ -458,11 +502,11 @@ __device__ __forceinline__ void rz_scale(const RzOp& op, const RzArgs& a, const 
   float* out = cx.reg + T * op.out_off;
   for (int idx = cx.tid; idx < T * C; idx += 256) {
     const int t = idx / C, c = idx - t * C;
-    const float* pl = in + t * a.slot_ts + c * a.PS;
-    float lo = pl[a.PW + 1], hi = lo;
+    const float* pl = in + t * a.slot_ts + c;
+    float lo = pl[(a.PW + 1) * a.Cs], hi = lo;
     for (int y = 0; y < a.H; ++y)
       for (int x = 0; x < a.W; ++x) {
-        const float v = pl[(y + 1) * a.PW + x + 1];
+        const float v = pl[((y + 1) * a.PW + x + 1) * a.Cs];
         lo = fminf(lo, v); hi = fmaxf(hi, v);
       }
     float sc = hi - lo;
@@ -475,7 +519,7 @@ __device__ __forceinline__ void rz_scale(const RzOp& op, const RzArgs& a, const 
   for (int idx = cx.tid; idx < T * per_tree; idx += 256) {
     const int t = idx / per_tree, rem = idx - t * per_tree;
     const int c = rem / a.HW, p = rem - c * a.HW;
-    const int ra = cx.rowaddr[t * a.HW + p] + c * a.PS;
+    const int ra = cx.rowaddr[t * a.HW + p] + c;
     const float y = (in[ra] - cx.scratch[2 * (t * C + c)]) / cx.scratch[2 * (t * C + c) + 1];
     out[ra] = y;
     if (op.store_hidden && t < ntree && a.hidden_out) {
@@ -488,6 +532,7 @@ __device__ __forceinline__ void rz_scale(const RzOp& op, const RzArgs& a, const 
 
 // One workgroup per CU by design (LDS-resident activations): tell the scheduler that registers are
 // free (1 wave per SIMD) so that it keeps the prefetch distance of the software pipeline.
+template <bool WLDS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) rz_network_kernel(const RzArgs a) {
   extern __shared__ __attribute__((aligned(16))) float rz_lds[];
   const int tid = threadIdx.x, T = a.T;
@@ -496,27 +541,38 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   int* rowaddr = (int*)rz_lds;
   int* rowtp = rowaddr + a.mpad;
   float* scratch = (float*)(rowtp + a.mpad);
-  float* reg = scratch + 2 * T * a.Cbuf;
+  float* reg = scratch + a.scratch_floats;
+  float* wlds = reg + T * a.tree_floats;
   RzCtx cx;
-  cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.scratch = scratch;
+  cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.scratch = scratch; cx.wlds = wlds;
   cx.T = T; cx.lane = tid & 63; cx.wave = tid >> 6; cx.tid = tid;
 
-  // ---- zero every region (halo cells, pad planes and pad words stay zero for the whole launch)
-  for (int i = tid; i < T * a.tree_floats; i += 256) reg[i] = 0.f;
+  // ---- weight image -> LDS (every weight leaves L2 once per workgroup), 16 bytes per lane per load
+  if (WLDS) {
+    const f32x4* src = (const f32x4*)a.weights;
+    f32x4* dst = (f32x4*)wlds;
+    for (int i = tid; i < a.w_floats / 4; i += 256) dst[i] = src[i];
+  }
+  // ---- zero every region (halo positions, pad channels and pad words stay zero for the whole launch)
+  {
+    f32x4* z = (f32x4*)reg;
+    for (int i = tid; i < T * a.tree_floats / 4; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   for (int m = tid; m < a.mpad; m += 256) {
     if (m < T * a.HW) {
       const int t = m / a.HW, p = m - t * a.HW;
       const int y = p / a.W, x = p - y * a.W;
-      rowaddr[m] = t * a.slot_ts + (y + 1) * a.PW + x + 1;
+      rowaddr[m] = t * a.slot_ts + ((y + 1) * a.PW + x + 1) * a.Cs;
       rowtp[m] = (t << 16) | p;
     } else {
-      rowaddr[m] = a.PW + 1;
+      rowaddr[m] = (a.PW + 1) * a.Cs;
       rowtp[m] = -1;
     }
   }
+  if (tid < T) scratch[2 * T * a.Cs + tid] = (a.use_action && tid < ntree) ? (float)a.action[b0 + tid] / (float)a.num_actions : 0.f;
   __syncthreads();
 
-  // ---- input tensor [in_channels][H][W] per sample (+ the action plane of the dynamics input)
+  // ---- input tensor [in_channels][H][W] per sample -> position-major LDS layout
   {
     float* dst = reg + T * a.in_off;
     const int per_tree = a.in_channels * a.HW;
@@ -525,13 +581,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
       const int c = rem / a.HW, p = rem - c * a.HW;
       const int64_t s = b0 + t;
       const int64_t node = a.in_node ? a.in_node[s] : 0;
-      dst[rowaddr[t * a.HW + p] + c * a.PS] = a.in[(s * a.in_nodes + node) * per_tree + rem];
-    }
-    if (a.use_action) {
-      for (int idx = tid; idx < ntree * a.HW; idx += 256) {
-        const int t = idx / a.HW;
-        dst[rowaddr[idx] + a.in_channels * a.PS] = (float)a.action[b0 + t] / (float)a.num_actions;
-      }
+      dst[rowaddr[t * a.HW + p] + c] = a.in[(s * a.in_nodes + node) * per_tree + rem];
     }
   }
   __syncthreads();
@@ -539,7 +589,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   // ---- the layers
   for (int o = 0; o < a.n_ops; ++o) {
     const RzOp op = a.ops[o];   // wave-uniform: lives in scalar registers
-    if (op.kind == RZ_GEMM) rz_gemm(op, a, cx);
+    if (op.kind == RZ_GEMM) rz_gemm<WLDS>(op, a, cx);
     else rz_scale(op, a, cx, b0, ntree);
     __syncthreads();
     if (o == a.dump_op) {  // diagnostics: the output tensor of op `o`, dense per sample
@@ -550,7 +600,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         for (int idx = tid; idx < ntree * per_tree; idx += 256) {
           const int t = idx / per_tree, rem = idx - t * per_tree;
           const int c = rem / a.HW, p = rem - c * a.HW;
-          a.dump[(int64_t)(b0 + t) * per_tree + rem] = src[rowaddr[t * a.HW + p] + c * a.PS];
+          a.dump[(int64_t)(b0 + t) * per_tree + rem] = src[rowaddr[t * a.HW + p] + c];
         }
       } else {
         const int nfl = (op.rows == RZ_ROWS_POS) ? op.cout * a.HW : op.cout;
@@ -575,41 +625,54 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   }
 }
 
-inline int rz_choose_trees(const RzGeometry& g, int batch) {
-  int T = (batch + 255) / 256;          // one workgroup per CU when the batch allows
+// Trees per workgroup and whether the weight image is LDS-resident, for a batch.
+inline void rz_choose(const RzGeometry& g, const RzProgram& R, int batch, int& T, bool& wlds) {
+  T = (batch + 255) / 256;          // one workgroup per CU when the batch allows
   if (T < 1) T = 1;
-  if (T > g.max_trees) T = g.max_trees;
-  return T;
+  const int tmax = rz_max_trees(g, R, false);
+  if (T > tmax) T = tmax;
+  wlds = 4 * rz_lds_floats(g, R, T, true) <= RZ_LDS_BUDGET;
+}
+
+template <bool WLDS>
+inline int rz_launch_k(const RzArgs& a, unsigned grid, size_t lds_bytes, stream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)rz_network_kernel<WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(rz_network_kernel<WLDS>, dim3(grid), dim3(256), lds_bytes, stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("fused network launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+  return MZX_OK;
 }
 
 // Launches the fused part of a program.  `in` = the tensor feeding it (observation, parent hidden
 // state or the stem's output).
 inline int rz_launch(const mzx_net* net, const RzProgram& R, const float* in, const NetBuffers& nb, int batch,
                      const NetIndex* ix, stream_t stream, int dump_op = -1, float* dump = nullptr) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)rz_network_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
-    attr_set = true;
-  }
   const RzGeometry& g = net->rz.g;
   RzArgs a;
   memset(&a, 0, sizeof(a));
+  bool wlds = false;
+  rz_choose(g, R, batch, a.T, wlds);
   a.ops = (const RzOp*)(net->d_derived + R.dev_off);
   a.n_ops = R.n_ops;
-  a.T = rz_choose_trees(g, batch);
   a.batch = batch;
   a.num_actions = net->cfg.action_space_size;
-  a.H = g.H; a.W = g.W; a.HW = g.HW; a.PW = g.PW; a.PS = g.PS; a.Cbuf = g.Cbuf; a.slot_ts = g.slot_ts;
-  a.tree_floats = g.tree_floats;
-  a.mpad = (a.T * g.HW + 15) & ~15;
+  a.H = g.H; a.W = g.W; a.HW = g.HW; a.PW = g.PW; a.Cs = g.Cs; a.slot_ts = g.slot_ts;
+  a.tree_floats = 3 * g.slot_ts + R.flat_floats;
+  a.mpad = rz_round16(a.T * g.HW);
+  a.scratch_floats = rz_round4(2 * a.T * g.Cs + a.T);
   a.in_off = R.in_off; a.in_channels = R.in_channels; a.use_action = R.use_action;
   for (int k = 0; k < 3; ++k) { a.out_off[k] = R.out_off[k]; a.out_ts[k] = R.out_ts[k]; a.out_n[k] = R.out_n[k]; }
   a.hidden_floats = (int32_t)net->hidden_size;
   a.in_nodes = ix ? ix->in_nodes : 1;
   a.out_nodes = ix ? ix->out_nodes : 1;
   a.dump_op = dump_op;
+  a.w_floats = R.w_floats;
   a.in = in;
   a.in_node = ix ? ix->in_node : nullptr;
   a.out_node = ix ? ix->out_node : nullptr;
@@ -619,11 +682,10 @@ inline int rz_launch(const mzx_net* net, const RzProgram& R, const float* in, co
   a.dump = dump;
   a.flat = net->d_flat;
   a.derived = net->d_derived;
+  a.weights = net->d_derived + R.w_base;
   const unsigned grid = (unsigned)((batch + a.T - 1) / a.T);
-  hipLaunchKernelGGL(rz_network_kernel, dim3(grid), dim3(256), (size_t)rz_lds_bytes(g, a.T), stream, a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { set_error("fused network launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
-  return MZX_OK;
+  const size_t lds = (size_t)4 * rz_lds_floats(g, R, a.T, wlds);
+  return wlds ? rz_launch_k<true>(a, grid, lds, stream) : rz_launch_k<false>(a, grid, lds, stream);
 }
 
 #endif  // !MZX_HOSTCHECK

@@ -26,24 +26,33 @@ struct RzOp {
   int32_t out_off, out_tstride, out_layout;   // RzOut
   int32_t res_off;       // residual input (padded layout), -1: none
   int32_t taps;          // 9 (3x3, padding 1) or 1
-  int32_t cin4;          // input channels padded to a multiple of 4, / 4  (= K-steps per tap)
+  int32_t cchunks;       // 16-channel K chunks per tap (input channels padded to a multiple of 16)
   int32_t cout;
-  int32_t nchunks;       // ceil(taps * cin4 / 4): 16-deep K chunks of packed B fragments
-  int32_t w_off;         // float offset of the packed B fragments in the derived buffer
+  int32_t nchunks;       // taps * cchunks
+  int32_t w_off;         // float offset of the packed B fragments inside the program's weight image
   int32_t alpha_off, beta_off;   // folded BatchNorm (derived buffer), -1: none
   int32_t bias_off;      // bias (flat weight buffer), -1: none
+  int32_t asum_off;      // dynamics input convolution: border-aware tap sums of the action plane's weights
+                         // [cout][H*W] (derived buffer), -1: none
   int32_t act;           // RzAct
   int32_t channels;      // RZ_SCALE: planes per tree
   int32_t store_hidden;  // RZ_SCALE: also write the scaled state to the caller's hidden-state output
-  int32_t pad_;
 };
 
-// One packed weight tensor (deduplicated by source offset): B fragments of a GEMM
-// in v_mfma_f32_16x16x4_f32 lane order, K = (tap, channel) tap-major.
+// One packed weight tensor: B fragments of a GEMM in v_mfma_f32_16x16x4_f32 lane order,
+// K = (tap, 16-channel chunk); inside a chunk K-step j holds channels {4 g + j : g = 0..3}
+// so that ONE 16-byte LDS read per lane (channels 4g .. 4g+3 of its row) feeds four K-steps.
 struct RzPack {
-  int64_t src;           // flat-buffer offset of W[cout][cin][taps]
+  int64_t src;           // flat-buffer offset of W[cout][cin_total][taps]
   int64_t dst;           // derived-buffer offset
-  int32_t taps, cin, cin4, cout, nchunks, ntiles;
+  int32_t taps, cin, cin_total, cchunks, cout, nchunks, ntiles;   // cin = channels packed (<= cin_total)
+};
+
+// sum over the in-board taps of W[co][action channel][ky][kx], per output position
+struct RzAsum {
+  int64_t src;           // flat-buffer offset of W[cout][cin_total][3][3]
+  int64_t dst;           // derived-buffer offset of [cout][H*W]
+  int32_t cout, cin_total, H, W;
 };
 
 struct RzProgram {
@@ -54,20 +63,21 @@ struct RzProgram {
   RzOp ops[RZ_MAX_OPS];
   int32_t in_off = 0;           // region receiving the input tensor
   int32_t in_channels = 0;      // channels of the input tensor
-  int32_t use_action = 0;       // 1: plane `in_channels` of the input region = action / |A|
+  int32_t use_action = 0;       // 1: the first op adds the action plane's contribution (asum_off)
   int32_t out_off[3] = {-1, -1, -1};   // value, reward, policy logits (flat regions, per-tree stride = out_ts)
   int32_t out_ts[3] = {0, 0, 0};
   int32_t out_n[3] = {0, 0, 0};
   int64_t dev_off = 0;          // derived-buffer float offset of the uploaded RzOp table
+  int64_t w_base = 0;           // derived-buffer float offset of this program's contiguous weight image
+  int32_t w_floats = 0;
+  int32_t flat_floats = 0;      // per-tree floats of the flat regions
 };
 
 struct RzGeometry {
   int32_t H = 0, W = 0, HW = 0, PW = 0;   // board, padded row width W + 2
-  int32_t PS = 0;                         // plane stride (floats) of the padded layout
-  int32_t Cbuf = 0;                       // planes per tree of a spatial slot
-  int32_t slot_ts = 0;                    // Cbuf * PS
-  int32_t tree_floats = 0;                // LDS floats per tree (3 slots + flat regions)
-  int32_t max_trees = 0;                  // trees per workgroup the LDS budget admits
+  int32_t PP = 0;                         // padded positions per tree (H + 2) * (W + 2)
+  int32_t Cs = 0;                         // channel stride of the position-major (NHWC) activation layout
+  int32_t slot_ts = 0;                    // PP * Cs
 };
 
 struct RzPlan {
@@ -75,7 +85,8 @@ struct RzPlan {
   RzGeometry g;
   RzProgram initial, recurrent;
   std::vector<RzPack> packs;
-  int64_t derived_floats = 0;             // packed weights + program tables appended to the derived buffer
+  std::vector<RzAsum> asums;
+  int64_t derived_floats = 0;             // packed weights + tables appended to the derived buffer
 };
 
 }  // namespace mzx

@@ -80,8 +80,10 @@ def test_network_heads_within_tolerance(backend, name, engine):
                 assert numpy.array_equal(got, ref)  # -inf / 0 pattern exactly
             else:
                 assert numpy.abs(got - ref).max() < TOL, (name, tag, key)
+        # decoded scalar: the inverse value transform computes sqrt(1 + 0.004 (|x| + 1.001)) - 1 in fp32, which
+        # cancels ~3 digits -- two evaluations of logits that agree to 1e-6 differ by up to ~1e-4 after decoding
         vs = models.support_to_scalar(res[0], cfg.support_size).cpu().numpy()
-        assert numpy.allclose(vs, z[f"{tag}_value_scalar"], atol=TOL, rtol=TOL)
+        assert numpy.allclose(vs, z[f"{tag}_value_scalar"], atol=3 * TOL, rtol=3 * TOL)
     # get_weights round trip in reference format
     back = net.get_weights()
     for k, v in sd.items():
