@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--trees", type=int, default=None, help="trees per GPU (default: the workload's)")
     ap.add_argument("--mode", default="auto", choices=["auto", "generic", "fused"])
-    ap.add_argument("--net-mode", default="fused", choices=["fused", "per-operator"],
+    ap.add_argument("--net-mode", default="fused", choices=["fused", "fused-4wave", "per-operator"],
                     help="residual networks: fused MFMA engine (default) or one kernel per operator")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=None)
@@ -159,7 +159,9 @@ def main():
 
     if args.net_mode == "per-operator":
         net.set_mode(0)
-    net_fused = bool(net.fused_supported()) and args.net_mode == "fused"
+    elif args.net_mode == "fused-4wave" and net.fused_supported():
+        net.set_mode(2)
+    net_fused = bool(net.fused_supported()) and args.net_mode != "per-operator"
     mode = {"auto": None, "generic": 0, "fused": 1}[args.mode]
     engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
     handle = engine.handle(B)

@@ -125,6 +125,8 @@ int mzx_net_recurrent_inference(mzx_net* net, const float* d_hidden, const int32
 /* Diagnostics (parity bisection, no reference counterpart): run the first n_ops operators of
  * initial_inference (recurrent = 0) or recurrent_inference (1) on the per-operator (fused = 0)
  * or fused (1) engine and copy the LAST operator's output tensor, dense per sample, to d_out.
+ * fused = 2: run the whole fused program and write workgroup 0's shader-clock stamps (uint64: after
+ * staging, after the input load, after every operator, at the end) to d_out instead.
  * d_scratch: (hidden_size + 2 * (2 * support_size + 1) + action_space_size) * batch floats. */
 int mzx_net_num_operators(const mzx_net* net, int32_t recurrent);
 int mzx_net_debug_prefix(mzx_net* net, int32_t recurrent, int32_t fused, int32_t n_ops, const float* d_input,

@@ -111,7 +111,7 @@ int mzx_net_set_weights(mzx_net* net, const float* d_flat, int64_t n_floats, flo
       RzPackOp op;
       op.W = d_flat + p.src; op.out = d_derived + p.dst;
       op.taps = p.taps; op.cin = p.cin; op.cin_total = p.cin_total; op.cchunks = p.cchunks; op.cout = p.cout;
-      op.nchunks = p.nchunks; op.ntiles = p.ntiles;
+      op.nchunks = p.nchunks; op.wchunks = p.wchunks; op.ntiles = p.ntiles;
       MZX_TRY_LAUNCH(launch<256>(op, (stream_t)stream));
     }
     for (const RzAsum& q : net->rz.asums) {
@@ -119,8 +119,13 @@ int mzx_net_set_weights(mzx_net* net, const float* d_flat, int64_t n_floats, flo
       op.W = d_flat + q.src; op.out = d_derived + q.dst; op.cout = q.cout; op.cin_total = q.cin_total; op.H = q.H; op.Wd = q.W;
       MZX_TRY_LAUNCH(launch<256>(op, (stream_t)stream));
     }
+    for (const RzCopy& c : net->rz.copies) {
+      RzCopyOp op;
+      op.src = (c.from_derived ? (const float*)d_derived : d_flat) + c.src; op.dst = d_derived + c.dst; op.n = c.n; op.npad = c.npad;
+      MZX_TRY_LAUNCH(launch<256>(op, (stream_t)stream));
+    }
     for (const RzProgram* R : {&net->rz.initial, &net->rz.recurrent})
-      if (R->ok) MZX_TRY_LAUNCH(copy_h2d(d_derived + R->dev_off, R->ops, sizeof(RzOp) * R->n_ops, (stream_t)stream));
+      if (R->ok) MZX_TRY_LAUNCH(copy_h2d(d_derived + R->small_base, R->ops, sizeof(RzOp) * R->n_ops, (stream_t)stream));
   }
   return MZX_OK;
 }
@@ -132,8 +137,9 @@ int mzx_net_fused_supported(const mzx_net* net) {
 
 int mzx_net_set_mode(mzx_net* net, int32_t mode) {
   if (!net) { set_error("null network handle"); return MZX_ERR_INVALID; }
-  if (mode != 0 && mode != 1) { set_error("network mode is 0 (one kernel per operator) or 1 (fused engine)"); return MZX_ERR_INVALID; }
-  net->rz_mode = mode;
+  if (mode != 0 && mode != 1 && mode != 2) { set_error("network mode is 0 (one kernel per operator), 1 (fused engine) or 2 (fused, 4-wave workgroups)"); return MZX_ERR_INVALID; }
+  net->rz_mode = mode ? 1 : 0;
+  net->rz_waves = (mode == 2) ? 4 : 0;
   return MZX_OK;
 }
 
@@ -215,7 +221,7 @@ int mzx_net_debug_prefix(mzx_net* net, int32_t recurrent, int32_t fused, int32_t
   nb.value = nb.hidden + net->hidden_size * batch;
   nb.reward = nb.value + (int64_t)net->full_support * batch;
   nb.policy = nb.reward + (int64_t)net->full_support * batch;
-  return run_network_prefix(net, recurrent != 0, fused != 0, n_ops, nb, batch, d_out, out_floats, (stream_t)stream);
+  return run_network_prefix(net, recurrent != 0, fused, n_ops, nb, batch, d_out, out_floats, (stream_t)stream);
 }
 
 // ----------------------------------------------------------------- search

@@ -66,6 +66,7 @@ struct mzx_net {
   float* d_derived = nullptr;
   mzx::RzPlan rz;          // fused residual-network engine (mzx_resnet_fused.h)
   int32_t rz_mode = 1;     // 0: one kernel per operator, 1: fused engine where planned
+  int32_t rz_waves = 0;    // 0: automatic, 4: force 256-thread workgroups (A/B measurements)
 };
 
 namespace mzx {

@@ -58,13 +58,14 @@ constexpr int RZ_LDS_BUDGET = 160 * 1024 - 1024;
 
 struct RzPackOp {
   const float* W;   // [cout][cin_total][taps]
-  float* out;       // [ntiles][nchunks][64 lanes][4]
-  int32_t taps, cin, cin_total, cchunks, cout, nchunks, ntiles;
+  float* out;       // [ntiles][wchunks][64 lanes][4], chunks >= nchunks are zero
+  int32_t taps, cin, cin_total, cchunks, cout, nchunks, wchunks, ntiles;
 
-  MZX_HD size_t size() const { return (size_t)ntiles * nchunks * 256; }
+  MZX_HD size_t size() const { return (size_t)ntiles * wchunks * 256; }
   MZX_HD void operator()(size_t i) const {
     const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
-    const int c = (int)((i >> 8) % nchunks), nt = (int)((i >> 8) / nchunks);
+    const int c = (int)((i >> 8) % wchunks), nt = (int)((i >> 8) / wchunks);
+    if (c >= nchunks) { out[i] = 0.f; return; }
     const int tap = c / cchunks, cc = c % cchunks;
     const int ci = cc * 16 + 4 * (lane >> 4) + j;      // K-step j of the chunk, B row lane >> 4
     const int n = nt * 16 + (lane & 15);
@@ -72,6 +73,14 @@ struct RzPackOp {
     if (ci < cin && n < cout) v = W[((int64_t)n * cin_total + ci) * taps + tap];
     out[i] = v;
   }
+};
+
+struct RzCopyOp {
+  const float* src;
+  float* dst;
+  int32_t n, npad;
+  MZX_HD size_t size() const { return (size_t)npad; }
+  MZX_HD void operator()(size_t i) const { dst[i] = ((int)i < n) ? src[i] : 0.f; }
 };
 
 // out[co][pos] = sum over the 3x3 taps that stay inside the board of W[co][cin_total - 1][ky][kx]
@@ -128,9 +137,10 @@ inline int32_t rz_add_pack(RzPlan& P, size_t first_pack, int64_t w_base, int64_t
   p.src = src; p.taps = taps; p.cin = cin; p.cin_total = cin_total; p.cout = cout;
   p.cchunks = rz_round16(cin) / 16;
   p.nchunks = taps * p.cchunks;
+  p.wchunks = ((p.nchunks + 1) & ~1) + 4;
   p.ntiles = (cout + 15) / 16;
   p.dst = cursor;
-  cursor += (int64_t)p.ntiles * p.nchunks * 256;
+  cursor += (int64_t)p.ntiles * p.wchunks * 256;
   P.packs.push_back(p);
   return (int32_t)(p.dst - w_base);
 }
@@ -232,7 +242,7 @@ inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog
         o.in_off = si.slot; o.out_off = so.slot; o.out_layout = RZ_OUT_PADDED;
         if (res_i[i] >= 0) o.res_off = inst[res_i[i]].slot;
         o.cchunks = rz_round16(cin) / 16; o.cout = d.cout;
-        if (d.bn.channels) { o.alpha_off = (int32_t)d.bn.alpha; o.beta_off = (int32_t)d.bn.beta; }
+        if (d.bn.channels) { o.alpha_off = (int32_t)d.bn.alpha; o.beta_off = (int32_t)d.bn.beta; }   // patched below
         o.act = d.relu ? RZ_ACT_RELU : RZ_ACT_NONE;
         o.w_off = rz_add_pack(P, first_pack, R.w_base, d.w, 9, cin, d.cin, d.cout, cursor);
         if (o.cchunks >= 256 || 9 * o.cchunks >= 4096) return false;   // reciprocal range of the kernel's chunk decode
@@ -266,7 +276,11 @@ inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog
         max_c = std::max(max_c, d.groups_per_sample);
         break;
     }
-    if (o.kind == RZ_GEMM) o.nchunks = o.taps * o.cchunks;
+    if (o.kind == RZ_GEMM) {
+      o.nchunks = o.taps * o.cchunks;
+      o.wchunks = ((o.nchunks + 1) & ~1) + 4;
+      o.magic = ((1u << 20) + (uint32_t)o.cchunks - 1) / (uint32_t)o.cchunks;
+    }
     const int which = (d.out == BUF_VALUE) ? 0 : (d.out == BUF_REWARD) ? 1 : (d.out == BUF_POLICY) ? 2 : -1;
     if (which >= 0) {
       if (so.spatial) return false;
@@ -274,24 +288,46 @@ inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog
     }
   }
   R.w_floats = (int32_t)(cursor - R.w_base);
-  if (R.use_action) {  // action-plane tap sums of the first convolution
+  // small image: RzOp table, then the epilogue parameters of every GEMM (padded to whole column tiles), then
+  // the action-plane tap sums of the first convolution
+  R.small_base = cursor;
+  cursor += rz_round4((int)(sizeof(RzOp) / 4) * R.n_ops);
+  auto param = [&](int64_t src, int from_derived, int nvals) -> int32_t {
+    RzCopy c;
+    c.src = src; c.dst = cursor; c.n = nvals; c.npad = rz_round16(nvals); c.from_derived = from_derived;
+    P.copies.push_back(c);
+    cursor += c.npad;
+    return (int32_t)(c.dst - R.small_base);
+  };
+  for (int i = 0; i < R.n_ops; ++i) {
+    RzOp& o = R.ops[i];
+    if (o.kind != RZ_GEMM) continue;
+    if (o.alpha_off >= 0) { o.alpha_off = param(o.alpha_off, 1, o.cout); o.beta_off = param(o.beta_off, 1, o.cout); }
+    if (o.bias_off >= 0) o.bias_off = param(o.bias_off, 0, o.cout);
+  }
+  if (R.use_action) {
     const OpDesc& d = prog[first];
     RzAsum s;
     s.src = d.w; s.dst = cursor; s.cout = d.cout; s.cin_total = d.cin; s.H = h; s.W = w;
-    R.ops[0].asum_off = (int32_t)cursor;
+    R.ops[0].asum_off = (int32_t)(cursor - R.small_base);
     cursor += rz_round4(d.cout * HW);
     P.asums.push_back(s);
   }
+  R.small_floats = (int32_t)(cursor - R.small_base);
   R.in_off = inst[ext].slot;
   R.ok = 1;
   return true;
 }
 
+// min-max scratch [2 * T * Cs], actval [T], cycle stamps of the profiling mode [2 * (RZ_MAX_OPS + 4)]
+inline int rz_scratch_floats(const RzGeometry& g, int T) { return rz_round4(2 * T * g.Cs + T) + 2 * (RZ_MAX_OPS + 4); }
+
 // LDS floats of a workgroup of T trees: row tables, scratch, regions, optionally the weight image
 inline int64_t rz_lds_floats(const RzGeometry& g, const RzProgram& R, int T, bool weights_in_lds) {
   const int mpad = rz_round16(T * g.HW);
-  const int64_t scratch = rz_round4(2 * T * g.Cs + T);
-  return (int64_t)2 * mpad + scratch + (int64_t)T * (3 * g.slot_ts + R.flat_floats) + (weights_in_lds ? R.w_floats : 0);
+  const int64_t scratch = rz_scratch_floats(g, T);
+  return (int64_t)2 * mpad + scratch + R.small_floats + (int64_t)T * (3 * g.slot_ts + R.flat_floats) +
+         (weights_in_lds ? R.w_floats : 0);
 }
 
 inline int rz_max_trees(const RzGeometry& g, const RzProgram& R, bool weights_in_lds) {
@@ -336,10 +372,6 @@ inline void rz_plan(mzx_net* net) {
   rz_finish_program(g, P.initial);
   rz_finish_program(g, P.recurrent);
   if (!P.initial.ok && !P.recurrent.ok) { P = RzPlan(); return; }
-  // program tables behind the packed weights
-  const int64_t table_floats = (int64_t)(sizeof(RzOp) * RZ_MAX_OPS + 15) / 16 * 4;
-  P.initial.dev_off = cursor; cursor += table_floats;
-  P.recurrent.dev_off = cursor; cursor += table_floats;
   P.derived_floats = cursor;
   P.ok = 1;
 }
@@ -353,15 +385,16 @@ struct NetIndex {
 };
 
 struct RzArgs {
-  const RzOp* ops;
   int32_t n_ops, T, batch, num_actions;
   int32_t H, W, HW, PW, Cs, slot_ts, tree_floats, mpad, scratch_floats;
+  uint32_t magic_hw, magic_w;     // ceil(2^32 / HW), ceil(2^32 / W): divisions by multiplication
   int32_t in_off, in_channels, use_action;
   int32_t out_off[3], out_ts[3], out_n[3];
   int32_t hidden_floats;          // C * H * W
   int32_t in_nodes, out_nodes;    // nodes per sample of the in / hidden-out tensors (1 = dense)
-  int32_t dump_op;                // >= 0: stop after this op and copy its output to `dump`
-  int32_t w_floats;               // size of the program's weight image
+  int32_t dump_op;                // >= 0: stop after this op and copy its output to `dump`; -2: cycle profile
+                                  // (workgroup 0 writes s_memtime stamps after staging, input load and each op)
+  int32_t w_floats, small_floats; // sizes of the program's weight image / small image
   const float* in;
   const int32_t* in_node;
   const int32_t* out_node;
@@ -369,9 +402,8 @@ struct RzArgs {
   float* hidden_out;
   float* outs[3];                 // value, reward, policy logits (nullable)
   float* dump;
-  const float* flat;
-  const float* derived;
   const float* weights;           // the program's weight image (global)
+  const float* small;             // the program's small image (global): RzOp table, epilogue parameters
 };
 
 #ifndef MZX_HOSTCHECK
@@ -384,8 +416,14 @@ struct RzCtx {
   const int* rowtp;     // [mpad] (t << 16) | position, -1 for rows beyond T * HW
   float* scratch;       // [2 * T * Cs] min-max scratch, then actval[T] = action / |A| per tree
   const float* wlds;    // LDS copy of the weight image (WLDS kernels)
+  const float* simg;    // LDS copy of the small image
   int T, lane, wave, tid;
 };
+
+// x / d for 0 <= x < 2^32 / d with magic = ceil(2^32 / d) (d >= 2), no division instruction
+__device__ __forceinline__ int rz_div(int x, int d, unsigned magic) {
+  return d == 1 ? x : (int)__umulhi((unsigned)x, magic);
+}
 
 // One group of MT row tiles x one column tile of a layer GEMM: K loop + epilogue.
 template <int MT, bool WLDS>
@@ -404,49 +442,63 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
     if (m >= rows) m = 0;
     abase[i] = (pos_rows ? cx.rowaddr[m] : m * op.in_tstride) + 4 * (lane >> 4);
   }
-  const f32x4* wp = (const f32x4*)((WLDS ? cx.wlds : a.weights) + op.w_off) + (size_t)nt * op.nchunks * 64 + lane;
+  const f32x4* wp = (const f32x4*)((WLDS ? cx.wlds : a.weights) + op.w_off) + (size_t)nt * op.wchunks * 64 + lane;
   // chunk c -> (tap, 16-channel chunk of the tap): tap = c / cchunks by a 20-bit reciprocal, exact for
   // c < 4096 and cchunks < 256 (the planner checks both)
-  const unsigned magic = ((1u << 20) + (unsigned)op.cchunks - 1) / (unsigned)op.cchunks;
+  const unsigned magic = op.magic;
   const int pw9 = (op.taps == 9) ? a.PW * a.Cs : 0, one9 = (op.taps == 9) ? a.Cs : 0;
   const int last = op.nchunks - 1;
-  auto load = [&](int c, f32x4 (&av)[MT], f32x4& bv) {
-    const bool tail = c > last;   // one chunk past the end (odd chunk counts): zero B, valid addresses
-    c = c < last ? c : last;
-    const int tap = (op.taps == 9) ? (int)(((unsigned)c * magic) >> 20) : 0;
-    const int cc = c - tap * op.cchunks;
-    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;                 // tap / 3, tap % 3 for tap < 9
-    const int off = (ty - 1) * pw9 + (tx - 1) * one9 + cc * 16;
-    bv = wp[(size_t)c * 64];
-    if (tail) bv = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < MT; ++i) av[i] = *(const f32x4*)(in + abase[i] + off);
-  };
   auto compute = [&](const f32x4 (&av)[MT], const f32x4& bv) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][j], bv[j], acc[i], 0, 0, 0);
   };
-  // ping-pong software pipeline: the operands of chunk c+1 are in flight while the 4 * MT MFMAs of chunk c issue
-  f32x4 a0[MT], a1[MT], b0, b1;
-  load(0, a0, b0);
-  for (int c = 0; c < op.nchunks; c += 2) {
-    load(c + 1, a1, b1);
+  // software pipeline: A fragments (LDS) one chunk ahead, B fragments (L2 or LDS) two chunks ahead of the
+  // 4 * MT MFMAs being issued; two chunks per iteration, ping-pong registers
+  auto load_a = [&](int c, f32x4 (&av)[MT]) {
+    c = c < last ? c : last;
+    const int tap = (op.taps == 9) ? (int)(((unsigned)c * magic) >> 20) : 0;
+    const int cc = c - tap * op.cchunks;
+    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;                 // tap / 3, tap % 3 for tap < 9
+    const int off = (ty - 1) * pw9 + (tx - 1) * one9 + cc * 16;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) av[i] = *(const f32x4*)(in + abase[i] + off);
+  };
+  auto load_b = [&](int c, f32x4& bv) { bv = wp[(size_t)c * 64]; };   // chunks past the end are stored as zeros
+  f32x4 a0[MT], a1[MT], b0, b1, b2, b3;
+  load_b(0, b0);
+  load_b(1, b1);
+  load_a(0, a0);
+  for (int c = 0; c < op.nchunks; c += 4) {   // four chunks per trip: no register copies in the rotation
+    load_b(c + 2, b2);
+    load_b(c + 3, b3);
+    load_a(c + 1, a1);
     __builtin_amdgcn_sched_barrier(0);
     compute(a0, b0);
     __builtin_amdgcn_sched_barrier(0);
-    load(c + 2, a0, b0);
+    load_a(c + 2, a0);
     __builtin_amdgcn_sched_barrier(0);
     compute(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 2 >= op.nchunks) break;
+    load_b(c + 4, b0);
+    load_b(c + 5, b1);
+    load_a(c + 3, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(a0, b2);
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(c + 4, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(a1, b3);
     __builtin_amdgcn_sched_barrier(0);
   }
   // ---- epilogue
   const int n = nt * 16 + (lane & 15);
   const bool nv = n < op.cout;
   float al = 1.f, be = 0.f, bi = 0.f;
-  if (nv && op.alpha_off >= 0) { al = a.derived[op.alpha_off + n]; be = a.derived[op.beta_off + n]; }
-  if (nv && op.bias_off >= 0) bi = a.flat[op.bias_off + n];
+  if (op.alpha_off >= 0) { al = cx.simg[op.alpha_off + n]; be = cx.simg[op.beta_off + n]; }   // padded to whole tiles
+  if (op.bias_off >= 0) bi = cx.simg[op.bias_off + n];
   float* out = cx.reg + T * op.out_off;
   const float* res = (op.res_off >= 0) ? cx.reg + T * op.res_off : nullptr;
   const float* actval = cx.scratch + 2 * T * a.Cs;
@@ -459,7 +511,7 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
       float v = acc[i][r];
       int ra = 0, t = m, p = 0;
       if (pos_rows) { ra = cx.rowaddr[m]; const int tp = cx.rowtp[m]; t = tp >> 16; p = tp & 0xFFFF; }
-      if (op.asum_off >= 0) v += actval[t] * a.derived[op.asum_off + n * a.HW + p];
+      if (op.asum_off >= 0) v += actval[t] * cx.simg[op.asum_off + n * a.HW + p];
       if (op.alpha_off >= 0) v = v * al + be;
       if (op.bias_off >= 0) v = v + bi;
       if (res) v += res[ra + n];
@@ -471,16 +523,36 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
   }
 }
 
-template <bool WLDS>
+// operator descriptor o of the LDS-resident table, made wave-uniform (scalar registers)
+__device__ __forceinline__ RzOp rz_fetch_op(const float* simg, int o) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4* p = (const i32x4*)simg + o * 6;
+  i32x4 v[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[k] = p[k];            // six independent 16-byte LDS reads, one wait
+  RzOp op;
+  int* q = (int*)&op;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[4 * k + j] = __builtin_amdgcn_readfirstlane(v[k][j]);
+  return op;
+}
+
+template <bool WLDS, int NW>
 __device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const RzCtx& cx) {
   const int rows = (op.rows == RZ_ROWS_POS) ? cx.T * a.HW : cx.T;
   const int mt_total = (rows + 15) >> 4, nt_total = (op.cout + 15) >> 4;
-  const int waves_n = nt_total >= 4 ? 4 : (nt_total >= 2 ? 2 : 1);
-  const int waves_m = 4 / waves_n;
-  const int wn = cx.wave % waves_n, wm = cx.wave / waves_n;
+  // column tiles over the waves first (a power of two of them), row tiles over the rest
+  int lg_n = 0;
+  while ((2 << lg_n) <= NW && (2 << lg_n) <= nt_total) ++lg_n;
+  const int waves_n = 1 << lg_n, waves_m = NW >> lg_n;
+  int lg_m = 0;
+  while ((1 << lg_m) < waves_m) ++lg_m;
+  const int wn = cx.wave & (waves_n - 1), wm = cx.wave >> lg_n;
   for (int nt = wn; nt < nt_total; nt += waves_n) {
     for (int mt0 = wm; mt0 < mt_total; mt0 += waves_m * 8) {
-      const int cnt = min(8, (mt_total - mt0 + waves_m - 1) / waves_m);   // wave-uniform
+      const int cnt = min(8, (mt_total - mt0 + waves_m - 1) >> lg_m);   // wave-uniform
       switch (cnt) {
         case 1: rz_gemm_tiles<1, WLDS>(op, a, cx, nt, mt0, waves_m); break;
         case 2: rz_gemm_tiles<2, WLDS>(op, a, cx, nt, mt0, waves_m); break;
@@ -496,72 +568,85 @@ __device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const R
 }
 
 // per-plane min-max scaling (models.py:527-553, :574-599) + hidden-state store
+template <int NW>
 __device__ __forceinline__ void rz_scale(const RzOp& op, const RzArgs& a, const RzCtx& cx, int b0, int ntree) {
+  constexpr int NT = NW * 64;
   const int T = cx.T, C = op.channels;
   const float* in = cx.reg + T * op.in_off;
   float* out = cx.reg + T * op.out_off;
-  for (int idx = cx.tid; idx < T * C; idx += 256) {
-    const int t = idx / C, c = idx - t * C;
-    const float* pl = in + t * a.slot_ts + c;
-    float lo = pl[(a.PW + 1) * a.Cs], hi = lo;
-    for (int y = 0; y < a.H; ++y)
-      for (int x = 0; x < a.W; ++x) {
-        const float v = pl[((y + 1) * a.PW + x + 1) * a.Cs];
-        lo = fminf(lo, v); hi = fmaxf(hi, v);
-      }
-    float sc = hi - lo;
-    if (sc < 1e-5f) sc += 1e-5f;
-    cx.scratch[2 * idx] = lo;
-    cx.scratch[2 * idx + 1] = sc;
+  for (int t = 0; t < T; ++t) {
+    for (int c = cx.tid; c < C; c += NT) {
+      const float* pl = in + t * a.slot_ts + c;
+      float lo = pl[(a.PW + 1) * a.Cs], hi = lo;
+      for (int y = 0; y < a.H; ++y)
+        for (int x = 0; x < a.W; ++x) {
+          const float v = pl[((y + 1) * a.PW + x + 1) * a.Cs];
+          lo = fminf(lo, v); hi = fmaxf(hi, v);
+        }
+      float sc = hi - lo;
+      if (sc < 1e-5f) sc += 1e-5f;
+      cx.scratch[2 * (t * C + c)] = lo;
+      cx.scratch[2 * (t * C + c) + 1] = sc;
+    }
   }
   __syncthreads();
   const int per_tree = C * a.HW;
-  for (int idx = cx.tid; idx < T * per_tree; idx += 256) {
-    const int t = idx / per_tree, rem = idx - t * per_tree;
-    const int c = rem / a.HW, p = rem - c * a.HW;
-    const int ra = cx.rowaddr[t * a.HW + p] + c;
-    const float y = (in[ra] - cx.scratch[2 * (t * C + c)]) / cx.scratch[2 * (t * C + c) + 1];
-    out[ra] = y;
-    if (op.store_hidden && t < ntree && a.hidden_out) {
-      const int64_t s = b0 + t;
-      const int64_t node = a.out_node ? a.out_node[s] : 0;
-      a.hidden_out[(s * a.out_nodes + node) * a.hidden_floats + rem] = y;
+  for (int t = 0; t < T; ++t) {
+    const int64_t s = b0 + t;
+    const int64_t node = (op.store_hidden && t < ntree && a.out_node) ? a.out_node[s] : 0;
+    float* hid = a.hidden_out + (s * a.out_nodes + node) * a.hidden_floats;
+    for (int rem = cx.tid; rem < per_tree; rem += NT) {
+      const int c = rz_div(rem, a.HW, a.magic_hw), p = rem - c * a.HW;
+      const int ra = cx.rowaddr[t * a.HW + p] + c;
+      const float y = (in[ra] - cx.scratch[2 * (t * C + c)]) / cx.scratch[2 * (t * C + c) + 1];
+      out[ra] = y;
+      if (op.store_hidden && t < ntree && a.hidden_out) hid[rem] = y;
     }
   }
 }
 
 // One workgroup per CU by design (LDS-resident activations): tell the scheduler that registers are
 // free (1 wave per SIMD) so that it keeps the prefetch distance of the software pipeline.
-template <bool WLDS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) rz_network_kernel(const RzArgs a) {
+template <bool WLDS, int NW>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
+rz_network_kernel(const RzArgs a) {
+  constexpr int NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float rz_lds[];
+  const unsigned long long t_entry = __builtin_readcyclecounter();
   const int tid = threadIdx.x, T = a.T;
   const int b0 = blockIdx.x * T;
   const int ntree = min(T, a.batch - b0);
   int* rowaddr = (int*)rz_lds;
   int* rowtp = rowaddr + a.mpad;
   float* scratch = (float*)(rowtp + a.mpad);
-  float* reg = scratch + a.scratch_floats;
+  float* simg = scratch + a.scratch_floats;
+  float* reg = simg + a.small_floats;
   float* wlds = reg + T * a.tree_floats;
   RzCtx cx;
-  cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.scratch = scratch; cx.wlds = wlds;
+  cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.scratch = scratch; cx.wlds = wlds; cx.simg = simg;
   cx.T = T; cx.lane = tid & 63; cx.wave = tid >> 6; cx.tid = tid;
 
+  // ---- small image (operator table, epilogue parameters) -> LDS, always: no layer waits on HBM/L2 latency
+  {
+    const f32x4* src = (const f32x4*)a.small;
+    f32x4* dst = (f32x4*)simg;
+    for (int i = tid; i < a.small_floats / 4; i += NT) dst[i] = src[i];
+  }
   // ---- weight image -> LDS (every weight leaves L2 once per workgroup), 16 bytes per lane per load
   if (WLDS) {
     const f32x4* src = (const f32x4*)a.weights;
     f32x4* dst = (f32x4*)wlds;
-    for (int i = tid; i < a.w_floats / 4; i += 256) dst[i] = src[i];
+    for (int i = tid; i < a.w_floats / 4; i += NT) dst[i] = src[i];
   }
   // ---- zero every region (halo positions, pad channels and pad words stay zero for the whole launch)
   {
     f32x4* z = (f32x4*)reg;
-    for (int i = tid; i < T * a.tree_floats / 4; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < T * a.tree_floats / 4; i += NT) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int m = tid; m < a.mpad; m += 256) {
+  for (int m = tid; m < a.mpad; m += NT) {
     if (m < T * a.HW) {
-      const int t = m / a.HW, p = m - t * a.HW;
-      const int y = p / a.W, x = p - y * a.W;
+      const int t = rz_div(m, a.HW, a.magic_hw), p = m - t * a.HW;
+      const int y = rz_div(p, a.W, a.magic_w), x = p - y * a.W;
       rowaddr[m] = t * a.slot_ts + ((y + 1) * a.PW + x + 1) * a.Cs;
       rowtp[m] = (t << 16) | p;
     } else {
@@ -571,43 +656,48 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   }
   if (tid < T) scratch[2 * T * a.Cs + tid] = (a.use_action && tid < ntree) ? (float)a.action[b0 + tid] / (float)a.num_actions : 0.f;
   __syncthreads();
+  unsigned long long* stamps = (unsigned long long*)(scratch + a.scratch_floats - 2 * (RZ_MAX_OPS + 4));   // LDS
+  const bool prof = (a.dump_op == -2) && blockIdx.x == 0 && tid == 0;
+  if (prof) { stamps[0] = t_entry; stamps[1] = __builtin_readcyclecounter(); }
 
   // ---- input tensor [in_channels][H][W] per sample -> position-major LDS layout
   {
     float* dst = reg + T * a.in_off;
     const int per_tree = a.in_channels * a.HW;
-    for (int idx = tid; idx < ntree * per_tree; idx += 256) {
-      const int t = idx / per_tree, rem = idx - t * per_tree;
-      const int c = rem / a.HW, p = rem - c * a.HW;
+    for (int t = 0; t < ntree; ++t) {
       const int64_t s = b0 + t;
       const int64_t node = a.in_node ? a.in_node[s] : 0;
-      dst[rowaddr[t * a.HW + p] + c] = a.in[(s * a.in_nodes + node) * per_tree + rem];
+      const float* src = a.in + (s * a.in_nodes + node) * per_tree;
+      for (int rem = tid; rem < per_tree; rem += NT) {
+        const int c = rz_div(rem, a.HW, a.magic_hw), p = rem - c * a.HW;
+        dst[rowaddr[t * a.HW + p] + c] = src[rem];
+      }
     }
   }
   __syncthreads();
+  if (prof) stamps[2] = __builtin_readcyclecounter();
 
   // ---- the layers
   for (int o = 0; o < a.n_ops; ++o) {
-    const RzOp op = a.ops[o];   // wave-uniform: lives in scalar registers
-    if (op.kind == RZ_GEMM) rz_gemm<WLDS>(op, a, cx);
-    else rz_scale(op, a, cx, b0, ntree);
+    const RzOp op = rz_fetch_op(simg, o);   // wave-uniform: lives in scalar registers
+    if (op.kind == RZ_GEMM) rz_gemm<WLDS, NW>(op, a, cx);
+    else rz_scale<NW>(op, a, cx, b0, ntree);
     __syncthreads();
+    if (prof) stamps[3 + o] = __builtin_readcyclecounter();
     if (o == a.dump_op) {  // diagnostics: the output tensor of op `o`, dense per sample
       const float* src = reg + T * op.out_off;
       if (op.out_layout == RZ_OUT_PADDED) {
         const int C = (op.kind == RZ_GEMM) ? op.cout : op.channels;
         const int per_tree = C * a.HW;
-        for (int idx = tid; idx < ntree * per_tree; idx += 256) {
-          const int t = idx / per_tree, rem = idx - t * per_tree;
-          const int c = rem / a.HW, p = rem - c * a.HW;
-          a.dump[(int64_t)(b0 + t) * per_tree + rem] = src[rowaddr[t * a.HW + p] + c];
-        }
+        for (int t = 0; t < ntree; ++t)
+          for (int rem = tid; rem < per_tree; rem += NT) {
+            const int c = rz_div(rem, a.HW, a.magic_hw), p = rem - c * a.HW;
+            a.dump[(int64_t)(b0 + t) * per_tree + rem] = src[rowaddr[t * a.HW + p] + c];
+          }
       } else {
         const int nfl = (op.rows == RZ_ROWS_POS) ? op.cout * a.HW : op.cout;
-        for (int idx = tid; idx < ntree * nfl; idx += 256) {
-          const int t = idx / nfl, rem = idx - t * nfl;
-          a.dump[(int64_t)(b0 + t) * nfl + rem] = src[t * op.out_tstride + rem];
-        }
+        for (int t = 0; t < ntree; ++t)
+          for (int rem = tid; rem < nfl; rem += NT) a.dump[(int64_t)(b0 + t) * nfl + rem] = src[t * op.out_tstride + rem];
       }
       return;
     }
@@ -618,10 +708,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     if (!a.outs[k] || a.out_off[k] < 0) continue;
     const float* src = reg + T * a.out_off[k];
     const int nfl = a.out_n[k];
-    for (int idx = tid; idx < ntree * nfl; idx += 256) {
-      const int t = idx / nfl, rem = idx - t * nfl;
-      a.outs[k][(int64_t)(b0 + t) * nfl + rem] = src[t * a.out_ts[k] + rem];
-    }
+    for (int t = 0; t < ntree; ++t)
+      for (int rem = tid; rem < nfl; rem += NT) a.outs[k][(int64_t)(b0 + t) * nfl + rem] = src[t * a.out_ts[k] + rem];
+  }
+  if (prof) {
+    stamps[3 + a.n_ops] = __builtin_readcyclecounter();
+    for (int k = 0; k < a.n_ops + 4; ++k) ((unsigned long long*)a.dump)[k] = stamps[k];
   }
 }
 
@@ -634,16 +726,16 @@ inline void rz_choose(const RzGeometry& g, const RzProgram& R, int batch, int& T
   wlds = 4 * rz_lds_floats(g, R, T, true) <= RZ_LDS_BUDGET;
 }
 
-template <bool WLDS>
+template <bool WLDS, int NW>
 inline int rz_launch_k(const RzArgs& a, unsigned grid, size_t lds_bytes, stream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)rz_network_kernel<WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)rz_network_kernel<WLDS, NW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
     attr_set = true;
   }
-  hipLaunchKernelGGL(rz_network_kernel<WLDS>, dim3(grid), dim3(256), lds_bytes, stream, a);
+  hipLaunchKernelGGL((rz_network_kernel<WLDS, NW>), dim3(grid), dim3(NW * 64), lds_bytes, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("fused network launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
   return MZX_OK;
@@ -658,14 +750,13 @@ inline int rz_launch(const mzx_net* net, const RzProgram& R, const float* in, co
   memset(&a, 0, sizeof(a));
   bool wlds = false;
   rz_choose(g, R, batch, a.T, wlds);
-  a.ops = (const RzOp*)(net->d_derived + R.dev_off);
   a.n_ops = R.n_ops;
   a.batch = batch;
   a.num_actions = net->cfg.action_space_size;
   a.H = g.H; a.W = g.W; a.HW = g.HW; a.PW = g.PW; a.Cs = g.Cs; a.slot_ts = g.slot_ts;
   a.tree_floats = 3 * g.slot_ts + R.flat_floats;
   a.mpad = rz_round16(a.T * g.HW);
-  a.scratch_floats = rz_round4(2 * a.T * g.Cs + a.T);
+  a.scratch_floats = rz_scratch_floats(g, a.T);
   a.in_off = R.in_off; a.in_channels = R.in_channels; a.use_action = R.use_action;
   for (int k = 0; k < 3; ++k) { a.out_off[k] = R.out_off[k]; a.out_ts[k] = R.out_ts[k]; a.out_n[k] = R.out_n[k]; }
   a.hidden_floats = (int32_t)net->hidden_size;
@@ -673,6 +764,7 @@ inline int rz_launch(const mzx_net* net, const RzProgram& R, const float* in, co
   a.out_nodes = ix ? ix->out_nodes : 1;
   a.dump_op = dump_op;
   a.w_floats = R.w_floats;
+  a.small_floats = R.small_floats;
   a.in = in;
   a.in_node = ix ? ix->in_node : nullptr;
   a.out_node = ix ? ix->out_node : nullptr;
@@ -680,12 +772,18 @@ inline int rz_launch(const mzx_net* net, const RzProgram& R, const float* in, co
   a.hidden_out = nb.hidden;
   a.outs[0] = nb.value; a.outs[1] = nb.reward; a.outs[2] = nb.policy;
   a.dump = dump;
-  a.flat = net->d_flat;
-  a.derived = net->d_derived;
   a.weights = net->d_derived + R.w_base;
+  a.small = net->d_derived + R.small_base;
   const unsigned grid = (unsigned)((batch + a.T - 1) / a.T);
   const size_t lds = (size_t)4 * rz_lds_floats(g, R, a.T, wlds);
-  return wlds ? rz_launch_k<true>(a, grid, lds, stream) : rz_launch_k<false>(a, grid, lds, stream);
+  a.magic_hw = (uint32_t)((0x100000000ull + (uint64_t)g.HW - 1) / (uint64_t)g.HW);
+  a.magic_w = (uint32_t)((0x100000000ull + (uint64_t)g.W - 1) / (uint64_t)g.W);
+  // two waves per SIMD when the layer GEMMs have enough tiles to feed eight waves (big boards / wide
+  // networks): latencies of one wave (weight prefetch, epilogue, barriers) hide behind the other's MFMAs
+  const int tiles = ((a.T * g.HW + 15) / 16) * ((net->cfg.channels + 15) / 16);
+  const bool eight = tiles >= 16 && net->rz_waves != 4;
+  if (wlds) return eight ? rz_launch_k<true, 8>(a, grid, lds, stream) : rz_launch_k<true, 4>(a, grid, lds, stream);
+  return eight ? rz_launch_k<false, 8>(a, grid, lds, stream) : rz_launch_k<false, 4>(a, grid, lds, stream);
 }
 
 #endif  // !MZX_HOSTCHECK
@@ -728,7 +826,7 @@ inline int run_network(const mzx_net* net, bool recurrent, const NetBuffers& nb,
 
 // Diagnostics: run the first n_ops operators of a program on either engine and copy the output
 // tensor of the last one (dense per sample) to d_out.
-inline int run_network_prefix(const mzx_net* net, bool recurrent, bool fused, int n_ops, const NetBuffers& nb, int batch,
+inline int run_network_prefix(const mzx_net* net, bool recurrent, int fused, int n_ops, const NetBuffers& nb, int batch,
                               float* d_out, int64_t out_floats, stream_t stream) {
   const std::vector<OpDesc>& prog = recurrent ? net->prog_recurrent : net->prog_initial;
   if (n_ops < 1 || n_ops > (int)prog.size()) { set_error("n_ops out of range"); return MZX_ERR_INVALID; }
@@ -740,6 +838,7 @@ inline int run_network_prefix(const mzx_net* net, bool recurrent, bool fused, in
     case OP_CONV1: per = (int64_t)last.cout * last.hin; break;
     default: per = (int64_t)last.groups_per_sample * last.len; break;
   }
+  if (fused == 2) per = 0;
   if (out_floats < per * batch) { set_error("prefix output buffer too small (%lld floats per sample)", (long long)per); return MZX_ERR_WORKSPACE; }
 #ifndef MZX_HOSTCHECK
   if (fused) {
@@ -751,6 +850,10 @@ inline int run_network_prefix(const mzx_net* net, bool recurrent, bool fused, in
       const int rc = run_program(net, stem, nb, batch, stream);
       if (rc) return rc;
       in = resolve(net, nb, R.ext_buf, batch);
+    }
+    if (fused == 2) {  // cycle profile of the whole fused program: stamps (uint64) land in d_out
+      if (out_floats < 2 * (R.n_ops + 4)) { set_error("profile buffer too small"); return MZX_ERR_WORKSPACE; }
+      return rz_launch(net, R, in, nb, batch, nullptr, stream, -2, d_out);
     }
     return rz_launch(net, R, in, nb, batch, nullptr, stream, n_ops - 1 - R.first, d_out);
   }

@@ -29,15 +29,20 @@ struct RzOp {
   int32_t cchunks;       // 16-channel K chunks per tap (input channels padded to a multiple of 16)
   int32_t cout;
   int32_t nchunks;       // taps * cchunks
+  int32_t wchunks;       // chunks stored per column tile: nchunks rounded up to even, + 4 zero chunks, so that the
+                         // two-chunk pipeline steps and the B prefetch (up to 4 chunks ahead) never need a tail test
   int32_t w_off;         // float offset of the packed B fragments inside the program's weight image
-  int32_t alpha_off, beta_off;   // folded BatchNorm (derived buffer), -1: none
-  int32_t bias_off;      // bias (flat weight buffer), -1: none
-  int32_t asum_off;      // dynamics input convolution: border-aware tap sums of the action plane's weights
-                         // [cout][H*W] (derived buffer), -1: none
+  // epilogue parameters: float offsets inside the program's SMALL image (LDS-resident), -1: none
+  int32_t alpha_off, beta_off;   // folded BatchNorm, padded to whole column tiles
+  int32_t bias_off;      // bias, padded to whole column tiles
+  int32_t asum_off;      // dynamics input convolution: border-aware tap sums of the action plane's weights [cout][H*W]
   int32_t act;           // RzAct
   int32_t channels;      // RZ_SCALE: planes per tree
   int32_t store_hidden;  // RZ_SCALE: also write the scaled state to the caller's hidden-state output
+  uint32_t magic;        // ceil(2^20 / cchunks): chunk -> tap decode without a division
+  int32_t pad_[2];       // sizeof(RzOp) = 96: six 16-byte words (fetched with six wide LDS reads)
 };
+static_assert(sizeof(RzOp) == 96, "RzOp is fetched as six 16-byte words");
 
 // One packed weight tensor: B fragments of a GEMM in v_mfma_f32_16x16x4_f32 lane order,
 // K = (tap, 16-channel chunk); inside a chunk K-step j holds channels {4 g + j : g = 0..3}
@@ -45,7 +50,14 @@ struct RzOp {
 struct RzPack {
   int64_t src;           // flat-buffer offset of W[cout][cin_total][taps]
   int64_t dst;           // derived-buffer offset
-  int32_t taps, cin, cin_total, cchunks, cout, nchunks, ntiles;   // cin = channels packed (<= cin_total)
+  int32_t taps, cin, cin_total, cchunks, cout, nchunks, wchunks, ntiles;   // cin = channels packed (<= cin_total)
+};
+
+// n floats copied (zero-padded to npad) into a program's small image: folded BatchNorm terms, biases
+struct RzCopy {
+  int64_t src;           // offset in the flat weight buffer (from_derived = 0) or the derived buffer (1)
+  int64_t dst;           // derived-buffer offset
+  int32_t n, npad, from_derived;
 };
 
 // sum over the in-board taps of W[co][action channel][ky][kx], per output position
@@ -67,9 +79,12 @@ struct RzProgram {
   int32_t out_off[3] = {-1, -1, -1};   // value, reward, policy logits (flat regions, per-tree stride = out_ts)
   int32_t out_ts[3] = {0, 0, 0};
   int32_t out_n[3] = {0, 0, 0};
-  int64_t dev_off = 0;          // derived-buffer float offset of the uploaded RzOp table
-  int64_t w_base = 0;           // derived-buffer float offset of this program's contiguous weight image
+  // program image in the derived buffer: [packed weights: w_floats][small image: RzOp table, epilogue
+  // parameters, action tap sums: small_floats].  The small image is always staged into LDS.
+  int64_t w_base = 0;
   int32_t w_floats = 0;
+  int64_t small_base = 0;
+  int32_t small_floats = 0;
   int32_t flat_floats = 0;      // per-tree floats of the flat regions
 };
 
@@ -86,6 +101,7 @@ struct RzPlan {
   RzProgram initial, recurrent;
   std::vector<RzPack> packs;
   std::vector<RzAsum> asums;
+  std::vector<RzCopy> copies;
   int64_t derived_floats = 0;             // packed weights + tables appended to the derived buffer
 };
 

@@ -250,7 +250,7 @@ class HipNetwork:
         out = b.zeros((n, cap), torch.float32)
         scratch = b.empty(((self.hidden_size + 2 * self.full_support_size + self.action_space_size) * n,), torch.float32)
         ws = self._ws(n)
-        lib.check(lib.mzx_net_debug_prefix(self.handle, int(bool(recurrent)), int(bool(fused)), int(n_ops), b.ptr(x),
+        lib.check(lib.mzx_net_debug_prefix(self.handle, int(bool(recurrent)), int(fused), int(n_ops), b.ptr(x),
                                            b.ptr(act), n, b.ptr(out), out.numel(), b.ptr(scratch), scratch.numel(),
                                            b.ptr(ws), ws.numel(), b.stream()))
         return out
