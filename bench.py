@@ -165,7 +165,10 @@ def main():
     mode = {"auto": None, "generic": 0, "fused": 1}[args.mode]
     engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
     handle = engine.handle(B)
-    fused = bool(engine.backend.lib.mzx_search_fused_supported(handle)) and mode != 0
+    fused_kind = int(engine.backend.lib.mzx_search_fused_supported(handle)) if mode != 0 else 0
+    if fused_kind == 2 and not net_fused:
+        fused_kind = 0
+    fused = fused_kind == 1
     be, lib = engine.backend, engine.backend.lib
 
     # synthetic inputs, resident in HBM: a few distinct input sets rotated over the steps
@@ -236,14 +239,17 @@ def main():
         traffic, traffic_src = None, None
         try:  # PMC-measured HBM bytes per launch of this kernel (collected by a separate rocprofv3 --pmc run)
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                entry = json.load(f).get(f"{args.workload}:{'fused-lds' if fused else 'generic-per-op'}")
-            if not fused and net_fused:
+                key = "fused-lds" if fused else ("residual-whole-search" if fused_kind == 2 else "generic-per-op")
+                entry = json.load(f).get(f"{args.workload}:{key}")
+            if not fused and fused_kind != 2 and net_fused:
                 entry = None
             if entry and B == default_trees:
                 traffic, traffic_src = entry["bytes"], entry["source"]
         except (OSError, ValueError):
             pass
-        kernel_name = "fused-lds" if fused else ("per-sim launches + fused-mfma network" if net_fused else "generic-per-op")
+        kernel_name = ("fused-lds" if fused else
+                       "residual whole-search kernel (arena trees, fused MFMA network)" if fused_kind == 2 else
+                       "per-sim launches + fused-mfma network" if net_fused else "generic-per-op")
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -261,7 +267,8 @@ def main():
             roofline = {
                 "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "whole step: select / rz_network_kernel (fused MFMA network) / expand+backprop per simulation"
+                "kernel": "whole step: root kernels + mzx::rz_search_kernel (all simulations, one launch)" if fused_kind == 2
+                          else "whole step: select / rz_network_kernel (fused MFMA network) / expand+backprop per simulation"
                           if net_fused else "whole step (one kernel per operator)",
                 "launch_ms": launch_ms, "flops_per_simulation": f_rec, "flops_initial_inference": f_init,
                 "flops_per_step": flops, "tree_bytes_per_sim": bytes_per_sim,

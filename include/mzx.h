@@ -184,8 +184,10 @@ typedef struct mzx_search_io {
 int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_t arena_bytes, void* stream);
 
 /* Which implementation mzx_search_run uses, a set of flags:
- *   1  fused LDS-resident whole-search kernel (fully connected networks that fit;
- *      mzx_search_fused_supported tells); 0 = generic operator-per-kernel path
+ *   1  whole-search kernel: every simulation of the move in one launch.  mzx_search_fused_supported
+ *      returns 1 for the LDS-resident fully connected kernel, 2 for the residual-network kernel
+ *      (trees in the arena, network on the fused MFMA engine), 0 if neither applies;
+ *      0 = generic path (select / network / expand+backpropagate launches per simulation)
  *   2  (fused) also export the finished trees to the arena so mzx_search_dump works
  *   4  (fused) force the LDS-weight engine even when a register-resident
  *      specialisation matches the network shape

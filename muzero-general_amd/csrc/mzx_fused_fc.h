@@ -23,8 +23,8 @@
 //     level); argmax = binary64 DPP butterfly + a wavefront ballot whose 16-bit
 //     row field gives the maximiser count / index (ties -> numpy-exact draw from
 //     the tape).  The winner's link, visit count and pb_c / sqrt table entries are
-//     handed to the next level by DPP row broadcasts, so a level costs ONE LDS
-//     round trip.  Lane d remembers the node at depth d of the walk.
+//     handed to the next level by DPP row broadcasts (ds_bpermute beyond 4
+//     candidates), so a level costs ONE round trip to the tree's memory.  Lane d remembers the node at depth d of the walk.
 //   * expansion: lane a writes child slot a.  Back-propagation: lane d updates the
 //     path node at depth d; the discounted value chain (the only true recurrence)
 //     runs as DPP-broadcast steps; min-max by a binary64 butterfly when it moves.
@@ -165,6 +165,13 @@ template <int W>
 __device__ __forceinline__ double pick_d(double v, int slot) {
   return __hiloint2double(pick_i<W>(__double2hiint(v), slot), pick_i<W>(__double2loint(v), slot));
 }
+// value held by lane `slot` (< 16, row-uniform) of this row, any width: one ds_bpermute (no memory access)
+__device__ __forceinline__ int perm_i(int v, int slot, int row_in_wave) {
+  return __builtin_amdgcn_ds_bpermute((row_in_wave * FUSED_ROW + slot) << 2, v);
+}
+__device__ __forceinline__ double perm_d(double v, int slot, int row_in_wave) {
+  return __hiloint2double(perm_i(__double2hiint(v), slot, row_in_wave), perm_i(__double2loint(v), slot, row_in_wave));
+}
 __device__ __forceinline__ unsigned row_bits(unsigned long long ballot, int row_in_wave) {
   return (unsigned)(ballot >> (row_in_wave * FUSED_ROW)) & 0xFFFFu;
 }
@@ -240,13 +247,13 @@ __device__ __forceinline__ RowSel row_select(const TreeRef& t, const SearchParam
     }
     vtp = (vtp + 1 < p.num_players) ? vtp + 1 : 0;
     int cw;
-    if constexpr (AW <= 4) cw = pick_i<AW>(c, slot); else cw = t.child(node, slot);
+    if constexpr (AW <= 4) cw = pick_i<AW>(c, slot); else cw = perm_i(c, slot, row_in_wave);
     if (sub == depth) { r.my_parent = node; r.my_pslot = slot; r.my_node = cw; }
     if (cw < 0) break;
     if constexpr (AW <= 4) {
       N = pick_i<AW>(n, slot); pbc = pick_d<AW>(pbc_c, slot); sq = pick_d<AW>(sq_c, slot);
     } else {
-      N = t.slot_visit(node, slot); pbc = p.pbc_table[N]; sq = p.sqrt_table[N];
+      N = perm_i(n, slot, row_in_wave); pbc = perm_d(pbc_c, slot, row_in_wave); sq = perm_d(sq_c, slot, row_in_wave);
     }
     node = cw;
   }

@@ -11,6 +11,7 @@
 #include "mzx_search.h"
 #ifndef MZX_HOSTCHECK
 #include "mzx_fused_fc.h"
+#include "mzx_resnet_search.h"
 #endif
 
 namespace mzx {
@@ -253,7 +254,7 @@ int mzx_search_create(const mzx_search_config* cfg, mzx_net* net, mzx_search** o
   s->cfg.h_sqrt_table = nullptr;
   search_plan(s);
 #ifndef MZX_HOSTCHECK
-  s->fused_ok = fused_fc_supported(s);
+  s->fused_ok = fused_fc_supported(s) ? 1 : (rz_search_supported(s) ? 2 : 0);
 #endif
   s->mode = s->fused_ok ? 1 : 0;
   *out = s;
@@ -300,7 +301,8 @@ int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_
     return MZX_ERR_INVALID;
   }
 #ifndef MZX_HOSTCHECK
-  if (s->mode & 1) return fused_fc_run(s, io, d_arena, (stream_t)stream);
+  if ((s->mode & 1) && s->fused_ok == 1) return fused_fc_run(s, io, d_arena, (stream_t)stream);
+  if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) return rz_search_run(s, io, d_arena, (stream_t)stream);
 #endif
   return search_run_generic(s, io, d_arena, (stream_t)stream);
 }

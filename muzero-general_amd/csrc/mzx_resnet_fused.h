@@ -137,7 +137,7 @@ inline int32_t rz_add_pack(RzPlan& P, size_t first_pack, int64_t w_base, int64_t
   p.src = src; p.taps = taps; p.cin = cin; p.cin_total = cin_total; p.cout = cout;
   p.cchunks = rz_round16(cin) / 16;
   p.nchunks = taps * p.cchunks;
-  p.wchunks = ((p.nchunks + 1) & ~1) + 4;
+  p.wchunks = (p.nchunks + 1) & ~1;
   p.ntiles = (cout + 15) / 16;
   p.dst = cursor;
   cursor += (int64_t)p.ntiles * p.wchunks * 256;
@@ -278,7 +278,7 @@ inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog
     }
     if (o.kind == RZ_GEMM) {
       o.nchunks = o.taps * o.cchunks;
-      o.wchunks = ((o.nchunks + 1) & ~1) + 4;
+      o.wchunks = (o.nchunks + 1) & ~1;
       o.magic = ((1u << 20) + (uint32_t)o.cchunks - 1) / (uint32_t)o.cchunks;
     }
     const int which = (d.out == BUF_VALUE) ? 0 : (d.out == BUF_REWARD) ? 1 : (d.out == BUF_POLICY) ? 2 : -1;
@@ -465,7 +465,9 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
 #pragma unroll
     for (int i = 0; i < MT; ++i) av[i] = *(const f32x4*)(in + abase[i] + off);
   };
-  auto load_b = [&](int c, f32x4& bv) { bv = wp[(size_t)c * 64]; };   // chunks past the end are stored as zeros
+  // an odd chunk count is stored with one trailing zero chunk; prefetches beyond it re-read the last chunk
+  const int wlast = op.wchunks - 1;
+  auto load_b = [&](int c, f32x4& bv) { bv = wp[(size_t)(c < wlast ? c : wlast) * 64]; };
   f32x4 a0[MT], a1[MT], b0, b1, b2, b3;
   load_b(0, b0);
   load_b(1, b1);
@@ -569,7 +571,8 @@ __device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const R
 
 // per-plane min-max scaling (models.py:527-553, :574-599) + hidden-state store
 template <int NW>
-__device__ __forceinline__ void rz_scale(const RzOp& op, const RzArgs& a, const RzCtx& cx, int b0, int ntree) {
+__device__ __forceinline__ void rz_scale(const RzOp& op, const RzArgs& a, const RzCtx& cx, int b0, int ntree,
+                                         const int32_t* out_node, bool local) {
   constexpr int NT = NW * 64;
   const int T = cx.T, C = op.channels;
   const float* in = cx.reg + T * op.in_off;
@@ -593,7 +596,7 @@ __device__ __forceinline__ void rz_scale(const RzOp& op, const RzArgs& a, const 
   const int per_tree = C * a.HW;
   for (int t = 0; t < T; ++t) {
     const int64_t s = b0 + t;
-    const int64_t node = (op.store_hidden && t < ntree && a.out_node) ? a.out_node[s] : 0;
+    const int64_t node = (op.store_hidden && t < ntree && out_node) ? out_node[local ? t : s] : 0;
     float* hid = a.hidden_out + (s * a.out_nodes + node) * a.hidden_floats;
     for (int rem = cx.tid; rem < per_tree; rem += NT) {
       const int c = rz_div(rem, a.HW, a.magic_hw), p = rem - c * a.HW;
@@ -607,42 +610,45 @@ __device__ __forceinline__ void rz_scale(const RzOp& op, const RzArgs& a, const 
 
 // One workgroup per CU by design (LDS-resident activations): tell the scheduler that registers are
 // free (1 wave per SIMD) so that it keeps the prefetch distance of the software pipeline.
-template <bool WLDS, int NW>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
-rz_network_kernel(const RzArgs a) {
-  constexpr int NT = NW * 64;
-  extern __shared__ __attribute__((aligned(16))) float rz_lds[];
-  const unsigned long long t_entry = __builtin_readcyclecounter();
-  const int tid = threadIdx.x, T = a.T;
-  const int b0 = blockIdx.x * T;
-  const int ntree = min(T, a.batch - b0);
-  int* rowaddr = (int*)rz_lds;
+// LDS carve of a workgroup (offsets follow rz_lds_floats)
+template <int NW>
+__device__ __forceinline__ RzCtx rz_carve(const RzArgs& a, float* lds) {
+  RzCtx cx;
+  int* rowaddr = (int*)lds;
   int* rowtp = rowaddr + a.mpad;
   float* scratch = (float*)(rowtp + a.mpad);
   float* simg = scratch + a.scratch_floats;
   float* reg = simg + a.small_floats;
-  float* wlds = reg + T * a.tree_floats;
-  RzCtx cx;
-  cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.scratch = scratch; cx.wlds = wlds; cx.simg = simg;
-  cx.T = T; cx.lane = tid & 63; cx.wave = tid >> 6; cx.tid = tid;
+  cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.scratch = scratch; cx.simg = simg;
+  cx.wlds = reg + a.T * a.tree_floats;
+  cx.T = a.T; cx.tid = threadIdx.x; cx.lane = threadIdx.x & 63; cx.wave = threadIdx.x >> 6;
+  return cx;
+}
 
-  // ---- small image (operator table, epilogue parameters) -> LDS, always: no layer waits on HBM/L2 latency
+// Once per launch: program image -> LDS, regions zeroed, row tables built.  Ends with a barrier.
+template <bool WLDS, int NW>
+__device__ __forceinline__ void rz_setup(const RzArgs& a, const RzCtx& cx) {
+  constexpr int NT = NW * 64;
+  const int tid = cx.tid, T = cx.T;
+  // small image (operator table, epilogue parameters) -> LDS, always: no layer waits on HBM/L2 latency
   {
     const f32x4* src = (const f32x4*)a.small;
-    f32x4* dst = (f32x4*)simg;
+    f32x4* dst = (f32x4*)cx.simg;
     for (int i = tid; i < a.small_floats / 4; i += NT) dst[i] = src[i];
   }
-  // ---- weight image -> LDS (every weight leaves L2 once per workgroup), 16 bytes per lane per load
+  // weight image -> LDS (every weight leaves L2 once per workgroup), 16 bytes per lane per load
   if (WLDS) {
     const f32x4* src = (const f32x4*)a.weights;
-    f32x4* dst = (f32x4*)wlds;
+    f32x4* dst = (f32x4*)cx.wlds;
     for (int i = tid; i < a.w_floats / 4; i += NT) dst[i] = src[i];
   }
-  // ---- zero every region (halo positions, pad channels and pad words stay zero for the whole launch)
+  // zero every region (halo positions, pad channels and pad words stay zero for the whole launch)
   {
-    f32x4* z = (f32x4*)reg;
+    f32x4* z = (f32x4*)cx.reg;
     for (int i = tid; i < T * a.tree_floats / 4; i += NT) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  int* rowaddr = (int*)cx.rowaddr;
+  int* rowtp = (int*)cx.rowtp;
   for (int m = tid; m < a.mpad; m += NT) {
     if (m < T * a.HW) {
       const int t = rz_div(m, a.HW, a.magic_hw), p = m - t * a.HW;
@@ -654,34 +660,61 @@ rz_network_kernel(const RzArgs a) {
       rowtp[m] = -1;
     }
   }
-  if (tid < T) scratch[2 * T * a.Cs + tid] = (a.use_action && tid < ntree) ? (float)a.action[b0 + tid] / (float)a.num_actions : 0.f;
   __syncthreads();
-  unsigned long long* stamps = (unsigned long long*)(scratch + a.scratch_floats - 2 * (RZ_MAX_OPS + 4));   // LDS
-  const bool prof = (a.dump_op == -2) && blockIdx.x == 0 && tid == 0;
-  if (prof) { stamps[0] = t_entry; stamps[1] = __builtin_readcyclecounter(); }
+}
 
-  // ---- input tensor [in_channels][H][W] per sample -> position-major LDS layout
-  {
-    float* dst = reg + T * a.in_off;
-    const int per_tree = a.in_channels * a.HW;
-    for (int t = 0; t < ntree; ++t) {
-      const int64_t s = b0 + t;
-      const int64_t node = a.in_node ? a.in_node[s] : 0;
-      const float* src = a.in + (s * a.in_nodes + node) * per_tree;
-      for (int rem = tid; rem < per_tree; rem += NT) {
-        const int c = rz_div(rem, a.HW, a.magic_hw), p = rem - c * a.HW;
-        dst[rowaddr[t * a.HW + p] + c] = src[rem];
-      }
+// Input tensors [in_channels][H][W] of the workgroup's trees -> position-major LDS layout, and the
+// per-tree action value action / |A| of the dynamics input.  `in_node` / `action` are indexed by the
+// tree's slot in the workgroup when `local` (LDS arrays of the search kernel), else by sample.
+// Ends with a barrier.
+template <int NW>
+__device__ __forceinline__ void rz_load_input(const RzArgs& a, const RzCtx& cx, int b0, int ntree, const int32_t* in_node,
+                                              const int32_t* action, bool local) {
+  constexpr int NT = NW * 64;
+  const int tid = cx.tid, T = cx.T;
+  if (tid < T) {
+    const int k = local ? tid : b0 + tid;
+    cx.scratch[2 * T * a.Cs + tid] = (a.use_action && tid < ntree) ? (float)action[k] / (float)a.num_actions : 0.f;
+  }
+  float* dst = cx.reg + T * a.in_off;
+  const int per_tree = a.in_channels * a.HW;
+  for (int t = 0; t < ntree; ++t) {
+    const int64_t s = b0 + t;
+    const int64_t node = in_node ? in_node[local ? t : s] : 0;
+    const float* src = a.in + (s * a.in_nodes + node) * per_tree;
+    for (int rem = tid; rem < per_tree; rem += NT) {
+      const int c = rz_div(rem, a.HW, a.magic_hw), p = rem - c * a.HW;
+      dst[cx.rowaddr[t * a.HW + p] + c] = src[rem];
     }
   }
   __syncthreads();
+}
+
+template <bool WLDS, int NW>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
+rz_network_kernel(const RzArgs a) {
+  constexpr int NT = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) float rz_lds[];
+  const unsigned long long t_entry = __builtin_readcyclecounter();
+  const int tid = threadIdx.x, T = a.T;
+  const int b0 = blockIdx.x * T;
+  const int ntree = min(T, a.batch - b0);
+  const RzCtx cx = rz_carve<NW>(a, rz_lds);
+  float* reg = cx.reg;
+  const int* rowaddr = cx.rowaddr;
+  rz_setup<WLDS, NW>(a, cx);
+  unsigned long long* stamps = (unsigned long long*)(cx.scratch + a.scratch_floats - 2 * (RZ_MAX_OPS + 4));   // LDS
+  const bool prof = (a.dump_op == -2) && blockIdx.x == 0 && tid == 0;
+  if (prof) { stamps[0] = t_entry; stamps[1] = __builtin_readcyclecounter(); }
+
+  rz_load_input<NW>(a, cx, b0, ntree, a.in_node, a.action, false);
   if (prof) stamps[2] = __builtin_readcyclecounter();
 
   // ---- the layers
   for (int o = 0; o < a.n_ops; ++o) {
-    const RzOp op = rz_fetch_op(simg, o);   // wave-uniform: lives in scalar registers
+    const RzOp op = rz_fetch_op(cx.simg, o);   // wave-uniform: lives in scalar registers
     if (op.kind == RZ_GEMM) rz_gemm<WLDS, NW>(op, a, cx);
-    else rz_scale<NW>(op, a, cx, b0, ntree);
+    else rz_scale<NW>(op, a, cx, b0, ntree, a.out_node, false);
     __syncthreads();
     if (prof) stamps[3 + o] = __builtin_readcyclecounter();
     if (o == a.dump_op) {  // diagnostics: the output tensor of op `o`, dense per sample
@@ -741,15 +774,25 @@ inline int rz_launch_k(const RzArgs& a, unsigned grid, size_t lds_bytes, stream_
   return MZX_OK;
 }
 
-// Launches the fused part of a program.  `in` = the tensor feeding it (observation, parent hidden
-// state or the stem's output).
-inline int rz_launch(const mzx_net* net, const RzProgram& R, const float* in, const NetBuffers& nb, int batch,
-                     const NetIndex* ix, stream_t stream, int dump_op = -1, float* dump = nullptr) {
+struct RzLaunch { RzArgs a; bool wlds; bool eight; unsigned grid; size_t lds; };
+
+// Everything of a launch that depends on (network, program, batch); `extra_lds_floats` = LDS the caller
+// adds behind the engine's own image (search kernel).
+inline RzLaunch rz_prepare(const mzx_net* net, const RzProgram& R, const float* in, const NetBuffers& nb, int batch,
+                           const NetIndex* ix, int64_t extra_lds_floats_per_tree = 0, int64_t extra_lds_floats = 0) {
   const RzGeometry& g = net->rz.g;
-  RzArgs a;
+  RzLaunch L;
+  RzArgs& a = L.a;
   memset(&a, 0, sizeof(a));
   bool wlds = false;
   rz_choose(g, R, batch, a.T, wlds);
+  if (extra_lds_floats_per_tree || extra_lds_floats) {
+    auto fits = [&](int T, bool w) {
+      return 4 * (rz_lds_floats(g, R, T, w) + extra_lds_floats_per_tree * T + extra_lds_floats) <= RZ_LDS_BUDGET;
+    };
+    while (a.T > 1 && !fits(a.T, false)) --a.T;
+    wlds = fits(a.T, true);
+  }
   a.n_ops = R.n_ops;
   a.batch = batch;
   a.num_actions = net->cfg.action_space_size;
@@ -762,7 +805,7 @@ inline int rz_launch(const mzx_net* net, const RzProgram& R, const float* in, co
   a.hidden_floats = (int32_t)net->hidden_size;
   a.in_nodes = ix ? ix->in_nodes : 1;
   a.out_nodes = ix ? ix->out_nodes : 1;
-  a.dump_op = dump_op;
+  a.dump_op = -1;
   a.w_floats = R.w_floats;
   a.small_floats = R.small_floats;
   a.in = in;
@@ -771,19 +814,30 @@ inline int rz_launch(const mzx_net* net, const RzProgram& R, const float* in, co
   a.action = nb.action;
   a.hidden_out = nb.hidden;
   a.outs[0] = nb.value; a.outs[1] = nb.reward; a.outs[2] = nb.policy;
-  a.dump = dump;
+  a.dump = nullptr;
   a.weights = net->d_derived + R.w_base;
   a.small = net->d_derived + R.small_base;
-  const unsigned grid = (unsigned)((batch + a.T - 1) / a.T);
-  const size_t lds = (size_t)4 * rz_lds_floats(g, R, a.T, wlds);
+  L.grid = (unsigned)((batch + a.T - 1) / a.T);
+  L.lds = (size_t)4 * rz_lds_floats(g, R, a.T, wlds);
   a.magic_hw = (uint32_t)((0x100000000ull + (uint64_t)g.HW - 1) / (uint64_t)g.HW);
   a.magic_w = (uint32_t)((0x100000000ull + (uint64_t)g.W - 1) / (uint64_t)g.W);
   // two waves per SIMD when the layer GEMMs have enough tiles to feed eight waves (big boards / wide
   // networks): latencies of one wave (weight prefetch, epilogue, barriers) hide behind the other's MFMAs
   const int tiles = ((a.T * g.HW + 15) / 16) * ((net->cfg.channels + 15) / 16);
-  const bool eight = tiles >= 16 && net->rz_waves != 4;
-  if (wlds) return eight ? rz_launch_k<true, 8>(a, grid, lds, stream) : rz_launch_k<true, 4>(a, grid, lds, stream);
-  return eight ? rz_launch_k<false, 8>(a, grid, lds, stream) : rz_launch_k<false, 4>(a, grid, lds, stream);
+  L.eight = tiles >= 16 && net->rz_waves != 4;
+  L.wlds = wlds;
+  return L;
+}
+
+// Launches the fused part of a program.  `in` = the tensor feeding it (observation, parent hidden
+// state or the stem's output).
+inline int rz_launch(const mzx_net* net, const RzProgram& R, const float* in, const NetBuffers& nb, int batch,
+                     const NetIndex* ix, stream_t stream, int dump_op = -1, float* dump = nullptr) {
+  RzLaunch L = rz_prepare(net, R, in, nb, batch, ix);
+  L.a.dump_op = dump_op;
+  L.a.dump = dump;
+  if (L.wlds) return L.eight ? rz_launch_k<true, 8>(L.a, L.grid, L.lds, stream) : rz_launch_k<true, 4>(L.a, L.grid, L.lds, stream);
+  return L.eight ? rz_launch_k<false, 8>(L.a, L.grid, L.lds, stream) : rz_launch_k<false, 4>(L.a, L.grid, L.lds, stream);
 }
 
 #endif  // !MZX_HOSTCHECK

@@ -29,8 +29,8 @@ struct RzOp {
   int32_t cchunks;       // 16-channel K chunks per tap (input channels padded to a multiple of 16)
   int32_t cout;
   int32_t nchunks;       // taps * cchunks
-  int32_t wchunks;       // chunks stored per column tile: nchunks rounded up to even, + 4 zero chunks, so that the
-                         // two-chunk pipeline steps and the B prefetch (up to 4 chunks ahead) never need a tail test
+  int32_t wchunks;       // chunks stored per column tile: nchunks rounded up to even (the pad chunk is zero) --
+                         // the pipeline consumes chunks in pairs
   int32_t w_off;         // float offset of the packed B fragments inside the program's weight image
   // epilogue parameters: float offsets inside the program's SMALL image (LDS-resident), -1: none
   int32_t alpha_off, beta_off;   // folded BatchNorm, padded to whole column tiles

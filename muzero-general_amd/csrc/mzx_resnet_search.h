@@ -1,0 +1,208 @@
+// mzx_resnet_search.h -- all simulations of a move in ONE launch for residual networks:
+// num_simulations x {select, recurrent_inference, expand, backpropagate} of
+// MCTS.run (/root/reference/self_play.py:319-355) with the network of
+// mzx_resnet_fused.h (models.py:555-623) inside the same kernel.
+//
+// A workgroup owns T trees for the whole search (no inter-workgroup traffic, no grid
+// barrier).  Tree t is walked lane-parallel by 16-lane row t of the workgroup with the
+// SAME code as the fully connected kernel (row_select / row_backprop of mzx_fused_fc.h,
+// i.e. the binary64 operations of mzx_tree.h in the reference's order): lane s scores
+// child slot s, binary64 DPP argmax + wave ballot, tie draws from the tape, lane d
+// back-propagates path node d.  The trees and the per-node hidden states stay in the
+// caller's arena (HBM; L2-resident at these sizes: C4 40 KB per tree + 2.1 MB of hidden
+// states); the selected parents' states are gathered into the LDS activation slots, all
+// four waves (or eight) then run the layer GEMMs on the MFMA pipes, the scaled next
+// states go straight back to the arena and the head logits are decoded in registers
+// (support_to_scalar / softmax in the canonical 16-lane order) by the row that owns the
+// tree.  The operator table, epilogue parameters and -- when they fit -- the weights are
+// staged into LDS once per MOVE instead of once per simulation.
+//
+// The root (initial_inference + root expansion) and the result gathering remain the
+// kernels of the generic path: 4 launches per move instead of 3 * num_simulations + 4.
+#pragma once
+#include "mzx_fused_fc.h"
+
+namespace mzx {
+
+#ifndef MZX_HOSTCHECK
+
+struct RzSearchArgs {
+  RzArgs net;            // recurrent program (in / hidden_out = the arena's hidden-state store)
+  SearchParams p;        // pbc_table / sqrt_table: global (arena), copied to LDS by the kernel
+  TreeLayout L;
+  char* trees;           // arena: [num_trees][L.tree_bytes]
+  const uint32_t* tape;  // [num_trees][tape_words]
+  int32_t num_sims, sim0;
+};
+
+// floats of LDS the search adds behind the network engine's image: selection hand-off, tables
+inline int64_t rz_search_extra_floats(const SearchParams& p) { return 64 + 4 * (int64_t)(p.num_nodes + 1) + 4; }
+
+__device__ __forceinline__ void load_state(const TreeRef& t, RowState& st) {
+  st.mn = t.mm_min(); st.mx = t.mm_max();
+  st.n_nodes = t.meta(TM_N_NODES); st.tape_pos = t.meta(TM_TAPE_POS); st.flags = t.meta(TM_FLAGS);
+  st.ties = t.meta(TM_TIE_DRAWS); st.max_depth = t.meta(TM_MAX_DEPTH); st.sum_depth = t.meta(TM_SUM_DEPTH);
+  st.root_n = t.meta(TM_ROOT_N); st.root_to_play = t.to_play(0);
+}
+
+template <bool WLDS, int NW, int AW>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
+rz_search_kernel(const RzSearchArgs sa) {
+  constexpr int NT = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) float rz_lds[];
+  const RzArgs& a = sa.net;
+  const int tid = threadIdx.x, T = a.T;
+  const int b0 = blockIdx.x * T;
+  const int ntree = min(T, a.batch - b0);
+  const RzCtx cx = rz_carve<NW>(a, rz_lds);
+  float* extra = (float*)cx.wlds + (WLDS ? a.w_floats : 0);
+  int32_t* sel_parent = (int32_t*)extra;
+  int32_t* sel_action = sel_parent + 16;
+  int32_t* sel_leaf = sel_action + 16;
+  double* tables = (double*)(extra + 64);
+  rz_setup<WLDS, NW>(a, cx);
+  const int ntab = 2 * (sa.p.num_nodes + 1);
+  for (int i = tid; i < ntab; i += NT) tables[i] = sa.p.pbc_table[i];   // pbc[N+1] then sqrt[N+1], contiguous
+  SearchParams p = sa.p;
+  p.pbc_table = tables;
+  p.sqrt_table = tables + (sa.p.num_nodes + 1);
+
+  // tree <-> 16-lane row
+  const int sub = tid & (FUSED_ROW - 1), row = tid / FUSED_ROW, row_in_wave = row & 3;
+  const bool row_valid = row < ntree;   // the other rows idle through the tree phases, all lanes run the network
+  const int tree = b0 + (row_valid ? row : 0);
+  TreeRef t;
+  t.base = sa.trees + (size_t)tree * sa.L.tree_bytes;
+  t.L = sa.L;
+  const uint32_t* tape = sa.tape + (size_t)tree * p.tape_words;
+  RowState st;
+  if (row_valid) load_state(t, st);
+  const int F = a.out_n[0], A = a.out_n[2];
+  __syncthreads();
+
+  for (int sim = 0; sim < sa.num_sims; ++sim) {
+    // ---- selection (self_play.py:325-334)
+    RowSel sel;
+    if (row_valid) {
+      sel = row_select<AW>(t, p, tape, sub, row_in_wave, sa.sim0 + sim, st);
+      if (sub == 0) { sel_parent[row] = sel.c.parent; sel_action[row] = sel.action; sel_leaf[row] = sel.c.leaf; }
+    }
+    __syncthreads();
+
+    // ---- recurrent_inference on the T selected (parent state, action) pairs (models.py:620-623)
+    rz_load_input<NW>(a, cx, b0, ntree, sel_parent, sel_action, true);
+    for (int o = 0; o < a.n_ops; ++o) {
+      const RzOp op = rz_fetch_op(cx.simg, o);
+      if (op.kind == RZ_GEMM) rz_gemm<WLDS, NW>(op, a, cx);
+      else rz_scale<NW>(op, a, cx, b0, ntree, sel_leaf, true);
+      __syncthreads();
+    }
+
+    // ---- decode, expand, back-propagate (self_play.py:343-353), the row that owns the tree
+    if (row_valid) {
+      const float* vl = cx.reg + T * a.out_off[0] + row * a.out_ts[0];
+      const float* rl = cx.reg + T * a.out_off[1] + row * a.out_ts[1];
+      const float* pl = cx.reg + T * a.out_off[2] + row * a.out_ts[2];
+      const float value = row_decode2(sub < F ? vl[sub] : 0.f, sub + 16 < F ? vl[sub + 16] : 0.f, F, p.support_size, sub);
+      const float reward = row_decode2(sub < F ? rl[sub] : 0.f, sub + 16 < F ? rl[sub + 16] : 0.f, F, p.support_size, sub);
+      const bool in = sub < A;
+      const float lg = in ? pl[sub] : 0.f;
+      const float m = row_max(in ? lg : -MZX_INF);
+      const float e = in ? mzx_expf(lg - m) : 0.f;
+      const float den = row_sum(e);
+      if (in) tree_init_slot(t, sel.c.leaf, sub, (double)(e / den));
+      row_backprop(t, p, sel, sub, row_in_wave, (double)value, (double)reward, st);
+    }
+    __syncthreads();
+  }
+  if (row_valid && sub == 0) store_state(t, st);
+}
+
+template <bool WLDS, int NW, int AW>
+inline int rz_search_launch_k(const RzSearchArgs& sa, unsigned grid, size_t lds_bytes, stream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)rz_search_kernel<WLDS, NW, AW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((rz_search_kernel<WLDS, NW, AW>), dim3(grid), dim3(NW * 64), lds_bytes, stream, sa);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("residual search kernel launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+  return MZX_OK;
+}
+
+template <bool WLDS, int NW>
+inline int rz_search_launch_aw(const RzSearchArgs& sa, unsigned grid, size_t lds, stream_t stream) {
+  if (sa.p.num_actions <= 4) return rz_search_launch_k<WLDS, NW, 4>(sa, grid, lds, stream);
+  return rz_search_launch_k<WLDS, NW, 16>(sa, grid, lds, stream);
+}
+
+inline bool rz_search_supported(const mzx_search* s) {
+  const mzx_net* net = s->net;
+  if (!net || !net->rz.ok || !net->rz.recurrent.ok) return false;
+  if (s->p.num_actions > FUSED_ROW || 2 * s->p.support_size + 1 > 2 * FUSED_ROW) return false;
+  const RzProgram& R = net->rz.recurrent;
+  // at least one tree per workgroup must fit beside the search's own LDS
+  return 4 * (rz_lds_floats(net->rz.g, R, 1, false) + rz_search_extra_floats(s->p)) <= RZ_LDS_BUDGET;
+}
+
+// MCTS.run for B roots, residual network: root by the generic kernels, all simulations in one launch.
+inline int rz_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream) {
+  const ArenaView v = arena_view(s, d_arena);
+  mzx_net* net = s->net;
+  const int B = s->p.num_trees;
+  int rc = ensure_tables(s, d_arena, stream);
+  if (rc) return rc;
+
+  // ---- root: initial_inference (hidden state -> arena node 0) + root expansion
+  const bool ix_init = rz_enabled(net, false);
+  NetIndex ix;
+  ix.in_nodes = 1; ix.out_nodes = s->p.num_nodes;
+  NetBuffers nb;
+  nb.in = io->d_observation; nb.action = nullptr; nb.hidden = ix_init ? v.arena.hidden : v.dense_out;
+  nb.value = v.value; nb.reward = v.reward; nb.policy = v.policy; nb.workspace = v.ws;
+  rc = run_network(net, false, nb, B, stream, ix_init ? &ix : nullptr);
+  if (rc) return rc;
+  RootInitOp ri;
+  ri.arena = v.arena; ri.p = v.p; ri.value_logits = v.value; ri.policy_logits = v.policy; ri.ext_priors = nullptr; ri.ext_root_reward = nullptr;
+  ri.legal = io->d_legal_actions; ri.to_play = io->d_to_play; ri.noise = io->d_noise;
+  ri.root_predicted_value = io->d_root_predicted_value;
+  MZX_TRY_LAUNCH(launch<64>(ri, stream));
+  if (!ix_init) {
+    HiddenMoveOp mv;
+    mv.arena = v.arena; mv.num_trees = B; mv.num_nodes = s->p.num_nodes; mv.hidden_size = s->p.hidden_size;
+    mv.dense = v.dense_out; mv.node = nullptr; mv.to_arena = 1;
+    MZX_TRY_LAUNCH(launch<256>(mv, stream));
+  }
+
+  // ---- every simulation, one launch
+  if (s->p.num_sims > 0) {
+    const RzProgram& R = net->rz.recurrent;
+    NetBuffers nr;
+    nr.in = v.arena.hidden; nr.action = nullptr; nr.hidden = v.arena.hidden;
+    nr.value = nullptr; nr.reward = nullptr; nr.policy = nullptr; nr.workspace = nullptr;
+    NetIndex ir;
+    ir.in_nodes = s->p.num_nodes; ir.out_nodes = s->p.num_nodes;
+    const int64_t extra = rz_search_extra_floats(s->p);
+    RzLaunch L = rz_prepare(net, R, nr.in, nr, B, &ir, 0, extra);
+    RzSearchArgs sa;
+    sa.net = L.a;
+    sa.p = v.p;
+    sa.L = s->L;
+    sa.trees = v.arena.trees;
+    sa.tape = io->d_tape;
+    sa.num_sims = s->p.num_sims;
+    sa.sim0 = 0;
+    const size_t lds = L.lds + (size_t)4 * extra;
+    if (L.wlds) rc = L.eight ? rz_search_launch_aw<true, 8>(sa, L.grid, lds, stream) : rz_search_launch_aw<true, 4>(sa, L.grid, lds, stream);
+    else rc = L.eight ? rz_search_launch_aw<false, 8>(sa, L.grid, lds, stream) : rz_search_launch_aw<false, 4>(sa, L.grid, lds, stream);
+    if (rc) return rc;
+  }
+  return search_finish(s, io, d_arena, stream);
+}
+
+#endif  // !MZX_HOSTCHECK
+
+}  // namespace mzx

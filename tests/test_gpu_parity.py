@@ -97,9 +97,7 @@ def test_search_matches_reference(backend, name, mode, monkeypatch):
         orig = self_play.BatchedMCTS.__init__
         monkeypatch.setattr(self_play.BatchedMCTS, "__init__",
                             lambda self, *a, **k: orig(self, *a, **{**k, "mode": 0}))
-    elif name != "cartpole" and name != "cartpole_ties":
-        pytest.skip("fused kernel covers fully connected networks")
-    common.test_search_matches_reference(backend, name)
+    common.test_search_matches_reference(backend, name)   # whole-search kernel (fully connected or residual)
 
 
 @pytest.mark.parametrize("name", ["tictactoe", "connect4", "cartpole_synth"])
@@ -319,3 +317,37 @@ def test_search_with_fused_resnet_matches_per_operator_search(backend, name):
     print(f"visit-count match rate fused vs per-operator: {same:.3f}")
     assert same >= 0.95
     assert numpy.abs(res[0].root_values - res[1].root_values).max() < 1e-3
+
+
+@pytest.mark.parametrize("name,B", [("tictactoe", 70), ("connect4", 19), ("odd", 33), ("breakout", 9)])
+def test_residual_whole_search_kernel_bit_identical_to_generic(backend, name, B):
+    """
+    Every simulation in one launch (mzx_resnet_search.h: lane-parallel tree walks on arena-resident trees +
+    fused MFMA network) against the generic path (one select / network / expand+backpropagate launch per
+    simulation, one thread per tree) ON THE DEVICE: same network kernels, same binary64 tree arithmetic,
+    same canonical fp32 reduction order -> every node statistic must agree bit for bit.
+    """
+    cfg = RESNET_CASES[name]()
+    cfg.num_simulations = 30
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 12))
+    obs = synthetic.observations(B, net.input_shape, seed=6)
+    rs = numpy.random.RandomState(2)
+    A = len(cfg.action_space)
+    legal = [sorted(rs.choice(A, size=rs.randint(1, A + 1), replace=False).tolist()) for _ in range(B)]
+    to_play = [int(i % len(cfg.players)) for i in range(B)]
+    outs = {}
+    for mode in (0, 1):
+        engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
+        assert backend.lib.mzx_search_fused_supported(engine.handle(B)) == 2
+        res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(90 + i) for i in range(B)])
+        outs[mode] = (res, engine.export_trees(B))
+    (r0, t0), (r1, t1) = outs[0], outs[1]
+    assert numpy.array_equal(r0.visit_counts, r1.visit_counts)
+    assert numpy.array_equal(r0.root_values.view(numpy.int64), r1.root_values.view(numpy.int64))
+    assert numpy.array_equal(r0.max_tree_depth, r1.max_tree_depth) and numpy.array_equal(r0.tape_used, r1.tape_used)
+    for k, v in t0.items():
+        a, b = t1[k], v
+        if a.dtype == numpy.float64:
+            a, b = a.view(numpy.int64), b.view(numpy.int64)
+        assert numpy.array_equal(a, b), (name, k)
