@@ -42,6 +42,7 @@
 // MFMA is used because these are genuine dense contractions (C3 231 kFLOP, C4 40.4 MFLOP,
 // C5 1.5 MFLOP per simulation); roofline: FP32 matrix peak 157.3 TFLOP/s.
 #pragma once
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -776,6 +777,11 @@ inline int rz_launch_k(const RzArgs& a, unsigned grid, size_t lds_bytes, stream_
 
 struct RzLaunch { RzArgs a; bool wlds; bool eight; unsigned grid; size_t lds; };
 
+inline int rz_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
 // Everything of a launch that depends on (network, program, batch); `extra_lds_floats` = LDS the caller
 // adds behind the engine's own image (search kernel).
 inline RzLaunch rz_prepare(const mzx_net* net, const RzProgram& R, const float* in, const NetBuffers& nb, int batch,
@@ -786,7 +792,12 @@ inline RzLaunch rz_prepare(const mzx_net* net, const RzProgram& R, const float* 
   memset(&a, 0, sizeof(a));
   bool wlds = false;
   rz_choose(g, R, batch, a.T, wlds);
-  if (extra_lds_floats_per_tree || extra_lds_floats) {
+  // tuning knobs for A/B measurements (bench / profiling only): trees per workgroup, waves per workgroup.
+  // Measured on MI355X (profiles/r01_rz_tiling_ab.txt): the defaults below win on C3 and C4; splitting a CU
+  // between two smaller workgroups loses more M-tile efficiency and weight reuse than it hides.
+  const int force_T = rz_env_int("MZX_RZ_TREES", 0);
+  if (force_T > 0 && force_T < a.T) a.T = force_T;
+  {
     auto fits = [&](int T, bool w) {
       return 4 * (rz_lds_floats(g, R, T, w) + extra_lds_floats_per_tree * T + extra_lds_floats) <= RZ_LDS_BUDGET;
     };
@@ -825,6 +836,9 @@ inline RzLaunch rz_prepare(const mzx_net* net, const RzProgram& R, const float* 
   // networks): latencies of one wave (weight prefetch, epilogue, barriers) hide behind the other's MFMAs
   const int tiles = ((a.T * g.HW + 15) / 16) * ((net->cfg.channels + 15) / 16);
   L.eight = tiles >= 16 && net->rz_waves != 4;
+  const int force_w = rz_env_int("MZX_RZ_WAVES", 0);
+  if (force_w == 4) L.eight = false;
+  if (force_w == 8) L.eight = true;
   L.wlds = wlds;
   return L;
 }
