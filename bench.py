@@ -58,6 +58,8 @@ def parse():
                     help="residual networks: fused MFMA engine (default) or one kernel per operator")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=None)
+    ap.add_argument("--selfplay-moves", type=int, default=4,
+                    help="moves of the end-to-end self-play leg (SelfPlay(num_games=B) on the synthetic game; 0 = skip)")
     return ap.parse_args()
 
 
@@ -123,6 +125,36 @@ def cpu_baseline(workload, seconds, cores):
         "sample": f"{sum(r[1] for r in res)} searches x {sims // max(1, sum(r[1] for r in res))} sims of the same "
                   f"workload, {cores} processes x {seconds:.0f} s, torch.set_num_threads(1) each",
         "per_core": one,
+    }
+
+
+# ----------------------------------------------------------------------------- end-to-end self-play leg
+def selfplay_leg(cfg, net, B, moves):
+    """
+    SelfPlay(num_games=B).play_games on the synthetic fixed-shape game (reference plugin surface): what a
+    user of the drop-in engine sees per process -- B Python Game.step calls, per-game numpy-compatible
+    streams (native bank), temperature sampling and GameHistory records around one batched search per move.
+    """
+    import copy
+
+    from mzx import self_play, synthetic
+
+    c = copy.copy(cfg)
+    c.max_moves = moves
+    Game = synthetic.make_synthetic_game(c.observation_shape, len(c.action_space), len(c.players))
+    sp = self_play.SelfPlay({"weights": net.get_weights()}, Game, c, 0, num_games=B)
+    sp.play_games(1.0, None, False, "self", 0)          # warm-up (allocations, kernel attributes)
+    sp.stats = {"searches": 0, "simulations": 0, "search_seconds": 0.0}
+    t0 = time.perf_counter()
+    histories = sp.play_games(1.0, None, False, "self", 0)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    steps = sum(len(h.action_history) - 1 for h in histories)
+    return {
+        "steps_per_sec": steps / wall, "sims_per_sec": steps * c.num_simulations / wall, "games": B, "moves_per_game": moves,
+        "wall_s": wall, "search_share": sp.stats["search_seconds"] / wall,
+        "note": "one host process: Python plugin Game.step x B per move + host bookkeeping + batched search "
+                "(search_share = fraction of the wall spent inside BatchedMCTS.run incl. uploads/downloads)",
     }
 
 
@@ -286,10 +318,12 @@ def main():
                 "tree_statistics_dtype": "f64", "weights": "synthetic seed 0 (RCCL-broadcast flat buffer)",
                 "mean_leaf_depth": L,
             },
-            "selfplay_steps_per_sec": world * B * args.steps / elapsed,
+            "search_steps_per_sec": world * B * args.steps / elapsed,
             "weight_broadcast_ms": broadcast_ms,
             "roofline": roofline,
         }
+        if world == 1 and args.selfplay_moves > 0:
+            line["selfplay_end_to_end"] = selfplay_leg(cfg, net, B, args.selfplay_moves)
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_cores)
         else:

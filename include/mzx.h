@@ -226,6 +226,34 @@ typedef struct mzx_tree_dump {
 } mzx_tree_dump;
 int mzx_search_dump(mzx_search* s, const mzx_tree_dump* dump, void* d_arena, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Per-game random streams (host side, no GPU): replaces the numpy.random calls of one
+ * self-play actor -- numpy.random.seed (self_play.py:22), numpy.random.dirichlet (:473), the
+ * numpy.random.choice(ties) of the search (:371, drawn on the device from the tape this produces)
+ * and SelfPlay.select_action's numpy.random.choice (:229-243) -- for a SHARD of games: stream i is
+ * numpy.random.RandomState(seed_i), bit for bit (legacy MT19937 algorithms, csrc/mzx_rng.h).
+ * All arrays are host arrays; `idx[k]` selects the stream of the k-th entry.
+ * ------------------------------------------------------------------------- */
+typedef struct mzx_rng mzx_rng;
+int mzx_rng_create(int32_t num_streams, mzx_rng** out);
+void mzx_rng_destroy(mzx_rng* r);
+/* RandomState(seeds[k]) for streams first .. first + count - 1 (0 <= seed < 2^32). */
+int mzx_rng_seed(mzx_rng* r, int32_t first, int32_t count, const uint32_t* seeds);
+/* RandomState.get_state() / set_state() of one stream: key[624], pos, has_gauss, cached_gaussian. */
+int mzx_rng_get_state(const mzx_rng* r, int32_t i, uint32_t* key, int32_t* pos, int32_t* has_gauss, double* gauss);
+int mzx_rng_set_state(mzx_rng* r, int32_t i, const uint32_t* key, int32_t pos, int32_t has_gauss, double gauss);
+/* Per-move root draws of `count` games: noise[k][0..n_legal[k]) = dirichlet([alpha] * n_legal[k])
+ * (noise == NULL: no exploration noise, nothing drawn), then tape[k][0..tape_words) = the NEXT raw
+ * 32-bit words of the stream WITHOUT consuming them (the search consumes some; see mzx_rng_advance). */
+int mzx_rng_root_draws(mzx_rng* r, const int32_t* idx, int32_t count, double alpha, const int32_t* n_legal,
+                       int32_t action_space_size, double* noise, int32_t tape_words, uint32_t* tape, int32_t n_threads);
+/* Consume words[k] raw words of stream idx[k] (what the search reported in info[2]). */
+int mzx_rng_advance(mzx_rng* r, const int32_t* idx, int32_t count, const int32_t* words);
+/* One RandomState.random_sample() per stream (numpy.random.choice(a, p=...) draws exactly one). */
+int mzx_rng_random_sample(mzx_rng* r, const int32_t* idx, int32_t count, double* out);
+/* One RandomState.randint(0, n[k]) per stream (numpy.random.choice(list of n) draws exactly that). */
+int mzx_rng_randint(mzx_rng* r, const int32_t* idx, int32_t count, const int32_t* n, int32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

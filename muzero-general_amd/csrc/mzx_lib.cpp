@@ -8,6 +8,7 @@
 #include <new>
 #include <string>
 
+#include "mzx_rng.h"
 #include "mzx_search.h"
 #ifndef MZX_HOSTCHECK
 #include "mzx_fused_fc.h"
@@ -363,6 +364,110 @@ int mzx_search_dump(mzx_search* s, const mzx_tree_dump* dump, void* d_arena, voi
   DumpOp op;
   op.arena = v.arena; op.p = v.p; op.d = *dump;
   MZX_TRY_LAUNCH(launch<64>(op, (stream_t)stream));
+  return MZX_OK;
+}
+
+// ------------------------------------------------------------- random streams
+
+static int rng_check(const mzx_rng* r, const int32_t* idx, int32_t count) {
+  if (!r || (count > 0 && !idx) || count < 0) { set_error("rng: null / negative argument"); return MZX_ERR_INVALID; }
+  const int32_t n = (int32_t)r->streams.size();
+  for (int32_t k = 0; k < count; ++k)
+    if (idx[k] < 0 || idx[k] >= n) { set_error("rng: stream index %d out of range (%d streams)", idx[k], n); return MZX_ERR_INVALID; }
+  return MZX_OK;
+}
+
+int mzx_rng_create(int32_t num_streams, mzx_rng** out) {
+  if (num_streams < 1 || !out) { set_error("mzx_rng_create: invalid argument"); return MZX_ERR_INVALID; }
+  mzx_rng* r = new (std::nothrow) mzx_rng();
+  if (!r) { set_error("out of host memory"); return MZX_ERR_RUNTIME; }
+  r->streams.resize(num_streams);
+  for (int32_t i = 0; i < num_streams; ++i) r->streams[i].seed((uint32_t)i);
+  *out = r;
+  return MZX_OK;
+}
+
+void mzx_rng_destroy(mzx_rng* r) { delete r; }
+
+int mzx_rng_seed(mzx_rng* r, int32_t first, int32_t count, const uint32_t* seeds) {
+  if (!r || !seeds || first < 0 || count < 0 || first + count > (int32_t)r->streams.size()) { set_error("mzx_rng_seed: range"); return MZX_ERR_INVALID; }
+  for (int32_t k = 0; k < count; ++k) r->streams[first + k].seed(seeds[k]);
+  return MZX_OK;
+}
+
+int mzx_rng_get_state(const mzx_rng* r, int32_t i, uint32_t* key, int32_t* pos, int32_t* has_gauss, double* gauss) {
+  if (!r || i < 0 || i >= (int32_t)r->streams.size() || !key || !pos || !has_gauss || !gauss) { set_error("mzx_rng_get_state: argument"); return MZX_ERR_INVALID; }
+  const Mt19937& m = r->streams[i];
+  memcpy(key, m.key, sizeof(m.key));
+  *pos = m.pos; *has_gauss = m.has_gauss; *gauss = m.gauss;
+  return MZX_OK;
+}
+
+int mzx_rng_set_state(mzx_rng* r, int32_t i, const uint32_t* key, int32_t pos, int32_t has_gauss, double gauss) {
+  if (!r || i < 0 || i >= (int32_t)r->streams.size() || !key || pos < 0 || pos > 624) { set_error("mzx_rng_set_state: argument"); return MZX_ERR_INVALID; }
+  Mt19937& m = r->streams[i];
+  memcpy(m.key, key, sizeof(m.key));
+  m.pos = pos; m.has_gauss = has_gauss ? 1 : 0; m.gauss = gauss;
+  return MZX_OK;
+}
+
+int mzx_rng_root_draws(mzx_rng* r, const int32_t* idx, int32_t count, double alpha, const int32_t* n_legal,
+                       int32_t action_space_size, double* noise, int32_t tape_words, uint32_t* tape, int32_t n_threads) {
+  int rc = rng_check(r, idx, count);
+  if (rc) return rc;
+  if ((noise && !n_legal) || action_space_size < 1 || tape_words < 0 || (tape_words > 0 && !tape)) { set_error("mzx_rng_root_draws: argument"); return MZX_ERR_INVALID; }
+  if (noise)
+    for (int32_t k = 0; k < count; ++k)
+      if (n_legal[k] < 1 || n_legal[k] > action_space_size) { set_error("n_legal[%d] = %d out of range", k, n_legal[k]); return MZX_ERR_INVALID; }
+  rng_parallel(count, n_threads, [=](int lo, int hi) {
+    for (int k = lo; k < hi; ++k) {
+      Mt19937& m = r->streams[idx[k]];
+      if (noise) {  // RandomState.dirichlet([alpha] * n): gammas, then multiplication by 1 / sum
+        double* out = noise + (size_t)k * action_space_size;
+        const int n = n_legal[k];
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) { out[j] = m.standard_gamma(alpha); acc = acc + out[j]; }
+        const double invacc = 1 / acc;
+        for (int j = 0; j < n; ++j) out[j] = out[j] * invacc;
+        for (int j = n; j < action_space_size; ++j) out[j] = 0.0;
+      }
+      if (tape_words > 0) {  // peek: the next raw words, generator state restored afterwards
+        Mt19937 copy = m;
+        uint32_t* t = tape + (size_t)k * tape_words;
+        for (int j = 0; j < tape_words; ++j) t[j] = copy.next32();
+      }
+    }
+  });
+  return MZX_OK;
+}
+
+int mzx_rng_advance(mzx_rng* r, const int32_t* idx, int32_t count, const int32_t* words) {
+  int rc = rng_check(r, idx, count);
+  if (rc) return rc;
+  if (count > 0 && !words) { set_error("mzx_rng_advance: null"); return MZX_ERR_INVALID; }
+  for (int32_t k = 0; k < count; ++k) {
+    Mt19937& m = r->streams[idx[k]];
+    for (int32_t j = 0; j < words[k]; ++j) m.next32();
+  }
+  return MZX_OK;
+}
+
+int mzx_rng_random_sample(mzx_rng* r, const int32_t* idx, int32_t count, double* out) {
+  int rc = rng_check(r, idx, count);
+  if (rc) return rc;
+  if (count > 0 && !out) { set_error("mzx_rng_random_sample: null"); return MZX_ERR_INVALID; }
+  for (int32_t k = 0; k < count; ++k) out[k] = r->streams[idx[k]].next_double();
+  return MZX_OK;
+}
+
+int mzx_rng_randint(mzx_rng* r, const int32_t* idx, int32_t count, const int32_t* n, int32_t* out) {
+  int rc = rng_check(r, idx, count);
+  if (rc) return rc;
+  if (count > 0 && (!n || !out)) { set_error("mzx_rng_randint: null"); return MZX_ERR_INVALID; }
+  for (int32_t k = 0; k < count; ++k) {
+    if (n[k] < 1) { set_error("randint(0, %d): empty range", n[k]); return MZX_ERR_INVALID; }
+    out[k] = (int32_t)r->streams[idx[k]].bounded((uint32_t)n[k]);
+  }
   return MZX_OK;
 }
 

@@ -95,6 +95,16 @@ PROTOTYPES = {
     "mzx_search_lockstep_apply": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mzx_search_finish": (ctypes.c_int, [c_vp, ctypes.POINTER(SearchIO), c_vp, c_vp]),
     "mzx_search_dump": (ctypes.c_int, [c_vp, ctypes.POINTER(TreeDump), c_vp, c_vp]),
+    "mzx_rng_create": (ctypes.c_int, [c_i32, ctypes.POINTER(c_vp)]),
+    "mzx_rng_destroy": (None, [c_vp]),
+    "mzx_rng_seed": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp]),
+    "mzx_rng_get_state": (ctypes.c_int, [c_vp, c_i32, c_vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
+                                         ctypes.POINTER(c_f64)]),
+    "mzx_rng_set_state": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_f64]),
+    "mzx_rng_root_draws": (ctypes.c_int, [c_vp, c_vp, c_i32, c_f64, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32]),
+    "mzx_rng_advance": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp]),
+    "mzx_rng_random_sample": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp]),
+    "mzx_rng_randint": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_vp]),
 }
 
 

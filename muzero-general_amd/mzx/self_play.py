@@ -33,7 +33,7 @@ import time
 import numpy
 import torch
 
-from . import _lib, models
+from . import _lib, _rng, models
 
 TAPE_WORDS = 64
 
@@ -273,25 +273,41 @@ class BatchedMCTS:
     def run(self, observations, legal_actions, to_play, add_exploration_noise, rngs):
         """
         observations: B stacked observations; legal_actions: B lists; to_play: B ints;
-        rngs: B numpy RandomState-like objects (dirichlet / randint / get_state / set_state).
+        rngs: B numpy RandomState-like objects (dirichlet / randint / get_state / set_state), or a pair
+        ``(StreamBank, stream indices)`` -- the native bank serves all B games with one call.
         """
         cfg, A = self.config, self.A
         B = len(legal_actions)
-        assert len(rngs) == B and len(to_play) == B
+        bank = None
+        if isinstance(rngs, tuple):
+            bank, bank_idx = rngs
+            bank_idx = numpy.ascontiguousarray(bank_idx, dtype=numpy.int32)
+            assert bank_idx.size == B
+        else:
+            assert len(rngs) == B
+        assert len(to_play) == B
         legal = numpy.full((B, A), -1, numpy.int32)
-        noise = numpy.zeros((B, A), numpy.float64) if add_exploration_noise else None
-        tape = numpy.zeros((B, TAPE_WORDS), numpy.uint32)
-        states = []
+        n_legal = numpy.empty(B, numpy.int32)
+        action_set = set(cfg.action_space)
         for i, acts in enumerate(legal_actions):
             # self_play.py:296-301
             assert acts, f"Legal actions should not be an empty array. Got {acts}."
-            assert set(acts).issubset(set(cfg.action_space)), "Legal actions should be a subset of the action space."
+            assert set(acts).issubset(action_set), "Legal actions should be a subset of the action space."
             assert len(set(acts)) == len(acts), "Legal actions must not repeat."
             legal[i, : len(acts)] = acts
-            if add_exploration_noise:
-                noise[i, : len(acts)] = rngs[i].dirichlet([cfg.root_dirichlet_alpha] * len(acts))
-            states.append(rngs[i].get_state())
-            tape[i] = rngs[i].randint(0, 2 ** 32, size=TAPE_WORDS, dtype=numpy.uint32)
+            n_legal[i] = len(acts)
+        if bank is not None:
+            noise, tape = bank.root_draws(bank_idx, cfg.root_dirichlet_alpha, n_legal, A, TAPE_WORDS,
+                                          with_noise=bool(add_exploration_noise))
+        else:
+            noise = numpy.zeros((B, A), numpy.float64) if add_exploration_noise else None
+            tape = numpy.zeros((B, TAPE_WORDS), numpy.uint32)
+            states = []
+            for i in range(B):
+                if add_exploration_noise:
+                    noise[i, : n_legal[i]] = rngs[i].dirichlet([cfg.root_dirichlet_alpha] * int(n_legal[i]))
+                states.append(rngs[i].get_state())
+                tape[i] = rngs[i].randint(0, 2 ** 32, size=TAPE_WORDS, dtype=numpy.uint32)
         obs = numpy.ascontiguousarray(numpy.asarray(observations, dtype=numpy.float32).reshape(B, -1))
         lib = self.backend.lib
         io, out, keep = self.make_io(B, obs, legal, numpy.asarray(to_play, numpy.int32), noise, tape)
@@ -305,10 +321,13 @@ class BatchedMCTS:
         if (info[:, 1] != 0).any():
             raise _lib.MzxError(f"search flagged trees {numpy.nonzero(info[:, 1])[0][:8]} (flags {set(info[:, 1])}): "
                                 "tie tape or node arena exhausted")
-        for i in range(B):  # rewind, then consume exactly what the device consumed
-            rngs[i].set_state(states[i])
-            if info[i, 2]:
-                rngs[i].randint(0, 2 ** 32, size=int(info[i, 2]), dtype=numpy.uint32)
+        if bank is not None:
+            bank.advance(bank_idx, info[:, 2])   # consume exactly what the device consumed
+        else:
+            for i in range(B):  # rewind, then consume exactly what the device consumed
+                rngs[i].set_state(states[i])
+                if info[i, 2]:
+                    rngs[i].randint(0, 2 ** 32, size=int(info[i, 2]), dtype=numpy.uint32)
         return result
 
 
@@ -358,13 +377,18 @@ class SelfPlay:
         # Fix random generator seed (self_play.py:21-23)
         numpy.random.seed(seed)
         torch.manual_seed(seed)
-        self.rngs = [numpy.random.mtrand._rand] + [numpy.random.RandomState(seed + i) for i in range(1, self.num_games)]
+        # game 0 of a single-game actor draws from the process-global stream like the reference; a shard of
+        # games uses the native stream bank, stream i = RandomState(seed + i) (muzero.py:185 seeds actor i so)
+        self.rngs = [numpy.random.mtrand._rand]
+        self.bank = None
 
         # Initialize the network (self_play.py:25-29)
         self.model = models.MuZeroNetwork(self.config, _backend=_backend)
         self.model.set_weights(initial_checkpoint["weights"])
         self.model.eval()
         self.engine = BatchedMCTS(self.config, self.model, self.num_games)
+        if self.num_games > 1:
+            self.bank = _rng.StreamBank(self.model.backend.lib, [(seed + i) & 0xFFFFFFFF for i in range(self.num_games)])
         self.stats = {"searches": 0, "simulations": 0, "search_seconds": 0.0}
 
     # ------------------------------------------------------------------ loops
@@ -453,20 +477,27 @@ class SelfPlay:
                 t0 = time.perf_counter()
                 result = self.engine.run(
                     stacked, [self.games[s].legal_actions() for s in searching],
-                    [self.games[s].to_play() for s in searching], True, [self.rngs[s] for s in searching],
+                    [self.games[s].to_play() for s in searching], True,
+                    (self.bank, searching) if self.bank is not None else [self.rngs[s] for s in searching],
                 )
                 self.stats["search_seconds"] += time.perf_counter() - t0
                 self.stats["searches"] += len(searching)
                 self.stats["simulations"] += len(searching) * self.engine.num_simulations
             still = []
+            position = {s: k for k, s in enumerate(searching)}
+            batch_actions = None
+            if self.bank is not None and searching:
+                temps = [temperature if not temperature_threshold or len(histories[s].action_history) < temperature_threshold
+                         else 0 for s in searching]
+                batch_actions = self._select_actions_bank(result, searching, temps)
             for s in active:
                 gh, game = histories[s], self.games[s]
-                if s in searching:
-                    root = result.root(searching.index(s))
+                if s in position:
+                    root = result.root(position[s])
                     t = temperature if not temperature_threshold or len(gh.action_history) < temperature_threshold else 0
-                    action = self._select_action(root, t, self.rngs[s])
+                    action = batch_actions[position[s]] if batch_actions is not None else self._select_action(root, t, self.rngs[s])
                     if render:
-                        print(f'Tree depth: {result.max_tree_depth[searching.index(s)]}')
+                        print(f'Tree depth: {result.max_tree_depth[position[s]]}')
                         print(f"Root value for player {game.to_play()}: {root.value():.2f}")
                 else:
                     action, root = self.select_opponent_action(opponent, stacked_for_opponent, game)
@@ -510,6 +541,47 @@ class SelfPlay:
             raise NotImplementedError(
                 'Wrong argument: "opponent" argument should be "self", "human", "expert" or "random"'
             )
+
+    def _select_actions_bank(self, result, searching, temps):
+        """
+        SelfPlay.select_action (self_play.py:222-245) for all searched games of a move, the draws taken from
+        the native stream bank.  Same arithmetic as the reference per game: int32 counts ** (1 / T), the
+        sequential Python ``sum``, numpy.random.choice's cumulative sum / renormalisation / right-bisection.
+        """
+        k = len(searching)
+        A = self.engine.A
+        counts = numpy.zeros((k, A), numpy.int32)     # in CHILD order (= legal-action order), zero padded
+        n = numpy.empty(k, numpy.int32)
+        for r, legal in enumerate(result.legal_actions):
+            n[r] = len(legal)
+            counts[r, : n[r]] = result.visit_counts[r][legal]
+        actions = numpy.zeros(k, numpy.int64)
+        temps = numpy.asarray(temps, dtype=numpy.float64)
+        greedy = numpy.nonzero(temps == 0)[0]
+        if greedy.size:
+            masked = numpy.where(numpy.arange(A)[None, :] < n[greedy, None], counts[greedy], -1)
+            actions[greedy] = numpy.argmax(masked, axis=1)           # first maximum, like numpy.argmax on the child list
+        uniform = numpy.nonzero(numpy.isinf(temps))[0]
+        if uniform.size:
+            actions[uniform] = self.bank.randint([searching[r] for r in uniform], n[uniform])
+        rest = numpy.nonzero((temps != 0) & ~numpy.isinf(temps))[0]
+        for t in numpy.unique(temps[rest]):
+            rows = rest[temps[rest] == t]
+            dist = counts[rows] ** (1 / float(t))                    # int32 ** float -> float64 pow, elementwise
+            total = numpy.zeros(len(rows))
+            for j in range(A):                                       # Python's sum(): left to right
+                total = total + dist[:, j]
+            dist = dist / total[:, None]
+            cdf = numpy.empty_like(dist)
+            acc = numpy.zeros(len(rows))
+            for j in range(A):                                       # ndarray.cumsum: left to right
+                acc = acc + dist[:, j]
+                cdf[:, j] = acc
+            cdf = cdf / cdf[numpy.arange(len(rows)), n[rows] - 1][:, None]
+            u = self.bank.random_sample([searching[r] for r in rows])
+            inside = numpy.arange(A)[None, :] < n[rows, None]
+            actions[rows] = ((cdf <= u[:, None]) & inside).sum(axis=1)   # searchsorted(u, side="right")
+        return [result.legal_actions[r][int(actions[r])] for r in range(k)]
 
     @staticmethod
     def _select_action(node, temperature, rng):

@@ -1,0 +1,41 @@
+"""
+A shard of B games played in lock-step (SelfPlay(num_games=B), native stream bank, one batched search
+per move) must produce, game by game, exactly the GameHistory a single-game actor seeded seed + i
+produces (the reference's i-th actor, muzero.py:185): same Dirichlet noise, same tie draws, same
+sampled actions -- for every temperature regime of SelfPlay.select_action (self_play.py:222-245).
+CPU test through tests/hostcheck (the host logic is what is under test).
+"""
+import numpy
+import pytest
+
+import hostcheck
+from mzx import configs, models, self_play, synthetic
+
+
+@pytest.fixture(scope="module")
+def backend():
+    return hostcheck.backend()
+
+
+@pytest.mark.parametrize("temperature,threshold,players,actions", [
+    (1.0, None, 1, 2), (0.5, None, 1, 3), (0.25, 4, 2, 5), (0, None, 1, 2), (float("inf"), None, 1, 4)])
+def test_shard_equals_independent_actors(backend, temperature, threshold, players, actions):
+    cfg = configs.cartpole(num_simulations=12, max_moves=7, action_space=list(range(actions)),
+                           players=list(range(players)), temperature_threshold=threshold)
+    Game = synthetic.make_synthetic_game(cfg.observation_shape, actions, players)
+    template = models.MuZeroNetwork(cfg, _backend=backend).state_dict()
+    weights = synthetic.fill_state_dict(template, 3)
+    B, seed = 6, 40
+    shard = self_play.SelfPlay({"weights": weights}, Game, cfg, seed, num_games=B, _backend=backend)
+    histories = shard.play_games(temperature, cfg.temperature_threshold, False, "self", 0)
+    assert len(histories) == B
+    for i in range(B):
+        single = self_play.SelfPlay({"weights": weights}, Game, cfg, seed + i, _backend=backend)
+        want = single.play_game(temperature, cfg.temperature_threshold, False, "self", 0)
+        got = histories[i]
+        assert [int(a) for a in got.action_history] == [int(a) for a in want.action_history], i
+        assert got.reward_history == want.reward_history and got.to_play_history == want.to_play_history
+        assert got.child_visits == want.child_visits
+        assert numpy.array_equal(numpy.array(got.root_values).view(numpy.int64), numpy.array(want.root_values).view(numpy.int64))
+        for a, b in zip(got.observation_history, want.observation_history):
+            assert numpy.array_equal(a, b)
