@@ -373,6 +373,21 @@ inline void rz_plan(mzx_net* net) {
   rz_finish_program(g, P.initial);
   rz_finish_program(g, P.recurrent);
   if (!P.initial.ok && !P.recurrent.ok) { P = RzPlan(); return; }
+  // down-sampling stem: its 3x3 convolutions (stride 1 / 2, large maps) get packed weights for rz_stem_conv_kernel
+  if (P.initial.ok && P.initial.first > 0) {
+    for (int i = 0; i < P.initial.first; ++i) {
+      const OpDesc& d = net->prog_initial[i];
+      if (d.kind != OP_CONV3 || d.use_action || d.cout > 64 || d.cin > 240) continue;
+      RzStemConv sc;
+      sc.op_index = i;
+      sc.cchunks = rz_round16(d.cin) / 16;
+      sc.nchunks = 9 * sc.cchunks;
+      sc.wchunks = (sc.nchunks + 1) & ~1;
+      sc.magic = ((1u << 20) + (uint32_t)sc.cchunks - 1) / (uint32_t)sc.cchunks;
+      sc.w_off = rz_add_pack(P, P.packs.size(), 0, d.w, 9, d.cin, d.cin, d.cout, cursor);
+      P.stem.push_back(sc);
+    }
+  }
   P.derived_floats = cursor;
   P.ok = 1;
 }
@@ -415,6 +430,7 @@ struct RzCtx {
   float* reg;           // workgroup LDS regions (region r of the program starts at T * r.off)
   const int* rowaddr;   // [mpad] activation address of row m = (tree, position): t * slot_ts + ((y+1) * PW + x + 1) * Cs
   const int* rowtp;     // [mpad] (t << 16) | position, -1 for rows beyond T * HW
+  const int* rowout;    // output / residual address of row m (the stem kernel's tiles differ from rowaddr); null: rowaddr
   float* scratch;       // [2 * T * Cs] min-max scratch, then actval[T] = action / |A| per tree
   const float* wlds;    // LDS copy of the weight image (WLDS kernels)
   const float* simg;    // LDS copy of the small image
@@ -513,7 +529,7 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
       if (m >= rows || !nv) continue;
       float v = acc[i][r];
       int ra = 0, t = m, p = 0;
-      if (pos_rows) { ra = cx.rowaddr[m]; const int tp = cx.rowtp[m]; t = tp >> 16; p = tp & 0xFFFF; }
+      if (pos_rows) { ra = (cx.rowout ? cx.rowout : cx.rowaddr)[m]; const int tp = cx.rowtp[m]; t = tp >> 16; p = tp & 0xFFFF; }
       if (op.asum_off >= 0) v += actval[t] * cx.simg[op.asum_off + n * a.HW + p];
       if (op.alpha_off >= 0) v = v * al + be;
       if (op.bias_off >= 0) v = v + bi;
@@ -620,7 +636,7 @@ __device__ __forceinline__ RzCtx rz_carve(const RzArgs& a, float* lds) {
   float* scratch = (float*)(rowtp + a.mpad);
   float* simg = scratch + a.scratch_floats;
   float* reg = simg + a.small_floats;
-  cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.scratch = scratch; cx.simg = simg;
+  cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.scratch = scratch; cx.simg = simg; cx.rowout = nullptr;
   cx.wlds = reg + a.T * a.tree_floats;
   cx.T = a.T; cx.tid = threadIdx.x; cx.lane = threadIdx.x & 63; cx.wave = threadIdx.x >> 6;
   return cx;
@@ -854,7 +870,172 @@ inline int rz_launch(const mzx_net* net, const RzProgram& R, const float* in, co
   return L.eight ? rz_launch_k<false, 8>(L.a, L.grid, L.lds, stream) : rz_launch_k<false, 4>(L.a, L.grid, L.lds, stream);
 }
 
+// ---------------------------------------------------------------------------
+// Down-sampling stem (DownSample, models.py:233-275): one 3x3 convolution (stride 1 or 2, optional folded
+// BatchNorm / residual / ReLU) on LARGE feature maps as an MFMA implicit GEMM.  A workgroup computes a
+// TH x TW tile of output positions for every output channel: the input tile with its halo is gathered
+// from the NCHW tensor into the position-major LDS layout (out-of-image cells zero), the K loop and
+// epilogue are rz_gemm_tiles, the result is staged in LDS and written back coalesced (NCHW).
+struct RzStemArgs {
+  RzOp op;                // one RZ_GEMM (rows = tile positions), in_off / out_off / res_off = LDS float offsets
+  const float* x;         // [batch][cin][hin][win]
+  const float* res;       // [batch][cout][hout][wout] or null
+  float* y;               // [batch][cout][hout][wout]
+  const float* weights;   // packed B fragments
+  const float* alpha;     // folded BatchNorm (null: none)
+  const float* beta;
+  int32_t cin, cout, hin, win, hout, wout, stride;
+  int32_t TH, TW, tiles_x, PWin, PHin, Cs, mpad;
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) rz_stem_conv_kernel(const RzStemArgs sa) {
+  extern __shared__ __attribute__((aligned(16))) float rz_lds[];
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x, b = blockIdx.y;
+  const int ty0 = (tile / sa.tiles_x) * sa.TH, tx0 = (tile % sa.tiles_x) * sa.TW;
+  const int rows = sa.TH * sa.TW;
+  int* rowaddr = (int*)rz_lds;
+  int* rowtp = rowaddr + sa.mpad;
+  int* rowout = rowtp + sa.mpad;
+  float* params = (float*)(rowout + sa.mpad);          // alpha[64], beta[64]
+  float* reg = params + 128;
+  const int in_floats = sa.PHin * sa.PWin * sa.Cs;
+  const int out_floats = rows * sa.Cs;
+  // ---- tables, parameters, input tile (+ halo), residual tile
+  for (int m = tid; m < sa.mpad; m += 256) {
+    const int ty = m / sa.TW, tx = m - ty * sa.TW;
+    const bool v = m < rows;
+    rowaddr[m] = v ? ((ty * sa.stride + 1) * sa.PWin + tx * sa.stride + 1) * sa.Cs : (sa.PWin + 1) * sa.Cs;
+    rowout[m] = v ? m * sa.Cs : 0;
+    rowtp[m] = v ? m : -1;
+  }
+  if (tid < 128) params[tid] = (tid < 64) ? ((sa.alpha && tid < sa.cout) ? sa.alpha[tid] : 1.f)
+                                          : ((sa.beta && tid - 64 < sa.cout) ? sa.beta[tid - 64] : 0.f);
+  {
+    f32x4* z = (f32x4*)reg;
+    for (int i = tid; i < (in_floats + 2 * out_floats) / 4; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  {
+    // LDS cell (iy, ix) of the haloed tile = image pixel (ty0 * stride - 1 + iy, tx0 * stride - 1 + ix)
+    const float* xb = sa.x + (size_t)b * sa.cin * sa.hin * sa.win;
+    const int gy0 = ty0 * sa.stride - 1, gx0 = tx0 * sa.stride - 1;
+    const int cells = sa.PHin * sa.PWin;
+    for (int c = 0; c < sa.cin; ++c) {
+      const float* xc = xb + (size_t)c * sa.hin * sa.win;
+      for (int i = tid; i < cells; i += 256) {
+        const int iy = i / sa.PWin, ix = i - iy * sa.PWin;
+        const int gy = gy0 + iy, gx = gx0 + ix;
+        if (gy >= 0 && gy < sa.hin && gx >= 0 && gx < sa.win) reg[i * sa.Cs + c] = xc[gy * sa.win + gx];
+      }
+    }
+    if (sa.res) {
+      float* rr = reg + in_floats + out_floats;
+      const float* rb = sa.res + (size_t)b * sa.cout * sa.hout * sa.wout;
+      for (int c = 0; c < sa.cout; ++c)
+        for (int m = tid; m < rows; m += 256) {
+          const int ty = m / sa.TW, tx = m - ty * sa.TW;
+          const int oy = ty0 + ty, ox = tx0 + tx;
+          if (oy < sa.hout && ox < sa.wout) rr[m * sa.Cs + c] = rb[((size_t)c * sa.hout + oy) * sa.wout + ox];
+        }
+    }
+  }
+  __syncthreads();
+  // ---- the GEMM: rows = tile positions, K = 9 taps x cin, N = cout
+  RzArgs a;
+  a.T = 1; a.HW = rows; a.PW = sa.PWin; a.Cs = sa.Cs; a.weights = sa.weights;
+  RzCtx cx;
+  cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.rowout = rowout; cx.scratch = params; cx.simg = params;
+  cx.wlds = nullptr; cx.T = 1; cx.tid = tid; cx.lane = tid & 63; cx.wave = tid >> 6;
+  rz_gemm<false, 4>(sa.op, a, cx);
+  __syncthreads();
+  // ---- write back, coalesced along x
+  {
+    const float* out = reg + in_floats;
+    float* yb = sa.y + (size_t)b * sa.cout * sa.hout * sa.wout;
+    for (int c = 0; c < sa.cout; ++c)
+      for (int m = tid; m < rows; m += 256) {
+        const int ty = m / sa.TW, tx = m - ty * sa.TW;
+        const int oy = ty0 + ty, ox = tx0 + tx;
+        if (oy < sa.hout && ox < sa.wout) yb[((size_t)c * sa.hout + oy) * sa.wout + ox] = out[m * sa.Cs + c];
+      }
+  }
+}
+
+// Launches one stem convolution; returns MZX_ERR_INVALID if the shape does not fit the kernel's LDS tiling
+// (the caller then uses the per-operator kernel).
+inline int rz_stem_launch(const mzx_net* net, const RzStemConv& sc, const OpDesc& d, const float* x, const float* res,
+                          float* y, int batch, stream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)rz_stem_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+    attr_set = true;
+  }
+  RzStemArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.cin = d.cin; sa.cout = d.cout; sa.hin = d.hin; sa.win = d.win; sa.hout = d.hout; sa.wout = d.wout; sa.stride = d.stride;
+  sa.Cs = rz_round16(std::max(d.cin, d.cout)) + 8;
+  // output tile: up to 256 positions (16 MFMA row tiles over 4 waves), halo'ed input tile beside it in LDS
+  sa.TW = std::min(16, d.wout);
+  sa.TH = std::min(256 / sa.TW, d.hout);
+  for (;;) {
+    sa.PHin = (sa.TH - 1) * d.stride + 3;
+    sa.PWin = (sa.TW - 1) * d.stride + 3;
+    sa.mpad = rz_round16(sa.TH * sa.TW);
+    const int64_t floats = 3 * (int64_t)sa.mpad + 128 + (int64_t)sa.PHin * sa.PWin * sa.Cs + 2 * (int64_t)sa.TH * sa.TW * sa.Cs;
+    if (4 * floats <= RZ_LDS_BUDGET) break;
+    if (sa.TH <= 1) return MZX_ERR_INVALID;
+    sa.TH = (sa.TH + 1) / 2;
+  }
+  sa.tiles_x = (d.wout + sa.TW - 1) / sa.TW;
+  const int tiles_y = (d.hout + sa.TH - 1) / sa.TH;
+  RzOp& o = sa.op;
+  o.kind = RZ_GEMM; o.rows = RZ_ROWS_POS; o.taps = 9;
+  o.in_off = 0; o.in_tstride = 0;
+  o.out_off = sa.PHin * sa.PWin * sa.Cs; o.out_tstride = 0; o.out_layout = RZ_OUT_PADDED;
+  o.res_off = res ? o.out_off + sa.TH * sa.TW * sa.Cs : -1;
+  o.cchunks = sc.cchunks; o.cout = d.cout; o.nchunks = sc.nchunks; o.wchunks = sc.wchunks; o.magic = sc.magic;
+  o.w_off = 0;
+  o.alpha_off = d.bn.channels ? 0 : -1; o.beta_off = d.bn.channels ? 64 : -1; o.bias_off = -1; o.asum_off = -1;
+  o.act = d.relu ? RZ_ACT_RELU : RZ_ACT_NONE;
+  sa.x = x; sa.res = res; sa.y = y;
+  sa.weights = net->d_derived + sc.w_off;
+  sa.alpha = d.bn.channels ? net->d_derived + d.bn.alpha : nullptr;
+  sa.beta = d.bn.channels ? net->d_derived + d.bn.beta : nullptr;
+  const size_t lds = 4 * (size_t)(3 * sa.mpad + 128 + sa.PHin * sa.PWin * sa.Cs + 2 * sa.TH * sa.TW * sa.Cs);
+  hipLaunchKernelGGL(rz_stem_conv_kernel, dim3(sa.tiles_x * tiles_y, batch), dim3(256), lds, stream, sa);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("stem convolution launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+  return MZX_OK;
+}
+
+// The operators [0, count) of initial_inference that precede the fused part: 3x3 convolutions on the MFMA
+// stem kernel, everything else (average pooling) on the per-operator kernels.
+inline int rz_run_stem(const mzx_net* net, const std::vector<OpDesc>& prog, int count, const NetBuffers& nb, int batch,
+                       stream_t stream) {
+  for (int i = 0; i < count; ++i) {
+    const OpDesc& d = prog[i];
+    const RzStemConv* sc = nullptr;
+    if (net->rz_mode == 1) for (const RzStemConv& c : net->rz.stem) if (c.op_index == i) sc = &c;
+    int rc = MZX_ERR_INVALID;
+    if (sc && d.kind == OP_CONV3) {
+      const float* res = (d.res == -100) ? nullptr : resolve(net, nb, d.res, batch);
+      rc = rz_stem_launch(net, *sc, d, resolve(net, nb, d.in, batch), res, resolve(net, nb, d.out, batch), batch, stream);
+      if (rc == MZX_ERR_RUNTIME) return rc;
+    }
+    if (rc != MZX_OK) {
+      const std::vector<OpDesc> one(prog.begin() + i, prog.begin() + i + 1);
+      rc = run_program(net, one, nb, batch, stream);
+      if (rc) return rc;
+    }
+  }
+  return MZX_OK;
+}
+
 #endif  // !MZX_HOSTCHECK
+
 
 // True when inference `recurrent` of `net` runs on the fused engine.
 inline bool rz_enabled(const mzx_net* net, bool recurrent) {
@@ -880,8 +1061,7 @@ inline int run_network(const mzx_net* net, bool recurrent, const NetBuffers& nb,
     const RzProgram& R = recurrent ? net->rz.recurrent : net->rz.initial;
     const float* in = nb.in;
     if (R.first > 0) {
-      const std::vector<OpDesc> stem(prog.begin(), prog.begin() + R.first);
-      const int rc = run_program(net, stem, nb, batch, stream);
+      const int rc = rz_run_stem(net, prog, R.first, nb, batch, stream);
       if (rc) return rc;
       in = resolve(net, nb, R.ext_buf, batch);
     }
@@ -911,11 +1091,15 @@ inline int run_network_prefix(const mzx_net* net, bool recurrent, int fused, int
 #ifndef MZX_HOSTCHECK
   if (fused) {
     const RzProgram& R = recurrent ? net->rz.recurrent : net->rz.initial;
-    if (!net->rz.ok || !R.ok || n_ops <= R.first) { set_error("fused engine does not cover this operator"); return MZX_ERR_INVALID; }
+    if (!net->rz.ok || !R.ok) { set_error("fused engine does not cover this operator"); return MZX_ERR_INVALID; }
+    if (n_ops <= R.first) {  // an operator of the down-sampling stem (MFMA stem kernel / per-operator pooling)
+      const int rc = rz_run_stem(net, prog, n_ops, nb, batch, stream);
+      if (rc) return rc;
+      return copy_d2d(d_out, resolve(net, nb, last.out, batch), sizeof(float) * per * batch, stream) ? MZX_ERR_RUNTIME : MZX_OK;
+    }
     const float* in = nb.in;
     if (R.first > 0) {
-      const std::vector<OpDesc> stem(prog.begin(), prog.begin() + R.first);
-      const int rc = run_program(net, stem, nb, batch, stream);
+      const int rc = rz_run_stem(net, prog, R.first, nb, batch, stream);
       if (rc) return rc;
       in = resolve(net, nb, R.ext_buf, batch);
     }

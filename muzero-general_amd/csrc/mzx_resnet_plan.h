@@ -95,6 +95,14 @@ struct RzGeometry {
   int32_t slot_ts = 0;                    // PP * Cs
 };
 
+// A 3x3 convolution of the down-sampling stem (large feature maps), run as its own MFMA kernel
+struct RzStemConv {
+  int32_t op_index;      // index in prog_initial
+  int64_t w_off;         // derived-buffer offset of the packed weights
+  int32_t cchunks, nchunks, wchunks;
+  uint32_t magic;
+};
+
 struct RzPlan {
   int32_t ok = 0;
   RzGeometry g;
@@ -102,6 +110,7 @@ struct RzPlan {
   std::vector<RzPack> packs;
   std::vector<RzAsum> asums;
   std::vector<RzCopy> copies;
+  std::vector<RzStemConv> stem;
   int64_t derived_floats = 0;             // packed weights + tables appended to the derived buffer
 };
 

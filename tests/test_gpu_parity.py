@@ -250,10 +250,7 @@ def test_fused_resnet_operator_by_operator(backend, name):
     for recurrent, x, a in ((0, obs, None), (1, hid, act)):
         covered = 0
         for n_ops in range(1, net.num_operators(recurrent) + 1):
-            try:
-                got = net.debug_prefix(recurrent, 1, n_ops, x, a).cpu().numpy()
-            except _lib.MzxError:
-                continue  # operator of the down-sampling stem (runs per operator in both engines)
+            got = net.debug_prefix(recurrent, 1, n_ops, x, a).cpu().numpy()
             want = net.debug_prefix(recurrent, 0, n_ops, x, a).cpu().numpy()
             err = numpy.abs(got - want).max()
             assert err < 2e-5 * (1.0 + numpy.abs(want).max()), (name, "recurrent" if recurrent else "initial", n_ops, err)
@@ -351,3 +348,58 @@ def test_residual_whole_search_kernel_bit_identical_to_generic(backend, name, B)
         if a.dtype == numpy.float64:
             a, b = a.view(numpy.int64), b.view(numpy.int64)
         assert numpy.array_equal(a, b), (name, k)
+
+
+# ----------------------------------------------------------------------------- edge cases of the whole-search kernels
+def _compare_modes(cfg, net, B, legal, to_play, noise, seeds):
+    outs = []
+    for mode in (0, 3):   # 3 = whole-search kernel + export of LDS-resident trees to the arena
+        engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
+        obs = synthetic.observations(B, net.input_shape, seed=B + 1)
+        res = engine.run(list(obs), legal, to_play, noise, [numpy.random.RandomState(s) for s in seeds])
+        outs.append((res, engine.export_trees(B)))
+    (r0, t0), (r1, t1) = outs
+    assert numpy.array_equal(r0.visit_counts, r1.visit_counts)
+    assert numpy.array_equal(r0.root_values.view(numpy.int64), r1.root_values.view(numpy.int64))
+    assert numpy.array_equal(r0.root_predicted_values.view(numpy.int64), r1.root_predicted_values.view(numpy.int64))
+    assert numpy.array_equal(r0.max_tree_depth, r1.max_tree_depth) and numpy.array_equal(r0.tape_used, r1.tape_used)
+    for k, v in t0.items():
+        a, b = t1[k], v
+        if a.dtype == numpy.float64:
+            a, b = a.view(numpy.int64), b.view(numpy.int64)
+        assert numpy.array_equal(a, b), k
+    return r1
+
+
+@pytest.mark.parametrize("net_name", ["cartpole", "tictactoe"])
+@pytest.mark.parametrize("B,S,noise", [(1, 1, True), (1, 40, False), (17, 3, True), (257, 7, False)])
+def test_whole_search_kernels_edge_shapes(backend, net_name, B, S, noise):
+    """
+    One tree, one simulation, batches that do not fill the last workgroup / wave row, no exploration noise
+    (NULL noise pointer), single-action roots: whole-search kernels == generic path, bit for bit.
+    """
+    cfg = configs.BY_NAME[net_name](num_simulations=S)
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 77))
+    A = len(cfg.action_space)
+    rs = numpy.random.RandomState(B * 131 + S)
+    legal = [[int(rs.randint(0, A))] if i % 3 == 0 else sorted(rs.choice(A, size=rs.randint(1, A + 1), replace=False).tolist())
+             for i in range(B)]
+    to_play = [int(i % len(cfg.players)) for i in range(B)]
+    res = _compare_modes(cfg, net, B, legal, to_play, noise, [500 + i for i in range(B)])
+    assert (res.visit_counts.sum(1) == S).all()
+    for i in range(B):
+        assert set(numpy.nonzero(res.visit_counts[i])[0]).issubset(set(legal[i]))
+
+
+def test_zero_simulations(backend):
+    """num_simulations = 0: the root alone (self_play.py:319 loop body never runs)."""
+    for name in ("cartpole", "tictactoe"):
+        cfg = configs.BY_NAME[name](num_simulations=0)
+        net = models.MuZeroNetwork(cfg)
+        net.set_weights(synthetic.fill_state_dict(net.state_dict(), 1))
+        B = 5
+        engine = self_play.BatchedMCTS(cfg, net, B)
+        obs = synthetic.observations(B, net.input_shape, seed=3)
+        res = engine.run(list(obs), [list(cfg.action_space)] * B, [0] * B, True, [numpy.random.RandomState(i) for i in range(B)])
+        assert (res.visit_counts == 0).all() and (res.root_values == 0).all() and (res.max_tree_depth == 0).all()
