@@ -281,6 +281,13 @@ inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog
       o.nchunks = o.taps * o.cchunks;
       o.wchunks = (o.nchunks + 1) & ~1;
       o.magic = ((1u << 20) + (uint32_t)o.cchunks - 1) / (uint32_t)o.cchunks;
+      const int nt_total = (o.cout + 15) / 16;
+      for (int k = 0; k < 2; ++k) {   // column tiles over the waves first (a power of two of them)
+        const int nw = k ? 8 : 4;
+        int lg = 0;
+        while ((2 << lg) <= nw && (2 << lg) <= nt_total) ++lg;
+        o.lg_waves_n[k] = lg;
+      }
     }
     const int which = (d.out == BUF_VALUE) ? 0 : (d.out == BUF_REWARD) ? 1 : (d.out == BUF_POLICY) ? 2 : -1;
     if (which >= 0) {
@@ -320,8 +327,9 @@ inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog
   return true;
 }
 
-// min-max scratch [2 * T * Cs], actval [T], cycle stamps of the profiling mode [2 * (RZ_MAX_OPS + 4)]
-inline int rz_scratch_floats(const RzGeometry& g, int T) { return rz_round4(2 * T * g.Cs + T) + 2 * (RZ_MAX_OPS + 4); }
+// min-max scratch [2 * T * Cs], actval [T], cycle stamps of the profiling mode
+constexpr int RZ_STAMP_WORDS = (RZ_MAX_OPS + 4) + 8 * RZ_MAX_OPS;   // uint64 stamps: per operator + 8 intra-operator each
+inline int rz_scratch_floats(const RzGeometry& g, int T) { return rz_round4(2 * T * g.Cs + T) + 2 * RZ_STAMP_WORDS; }
 
 // LDS floats of a workgroup of T trees: row tables, scratch, regions, optionally the weight image
 inline int64_t rz_lds_floats(const RzGeometry& g, const RzProgram& R, int T, bool weights_in_lds) {
@@ -429,8 +437,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct RzCtx {
   float* reg;           // workgroup LDS regions (region r of the program starts at T * r.off)
   const int* rowaddr;   // [mpad] activation address of row m = (tree, position): t * slot_ts + ((y+1) * PW + x + 1) * Cs
-  const int* rowtp;     // [mpad] (t << 16) | position, -1 for rows beyond T * HW
+  const int* rowtp;     // [mpad] (t << 16) | position (0 for rows beyond T * HW)
   const int* rowout;    // output / residual address of row m (the stem kernel's tiles differ from rowaddr); null: rowaddr
+  unsigned long long* fine;   // profiling: eight intra-operator clock stamps of wave 0 (null: off)
   float* scratch;       // [2 * T * Cs] min-max scratch, then actval[T] = action / |A| per tree
   const float* wlds;    // LDS copy of the weight image (WLDS kernels)
   const float* simg;    // LDS copy of the small image
@@ -447,6 +456,8 @@ template <int MT, bool WLDS>
 __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, const RzCtx& cx, int nt, int mt0,
                                               int mt_step) {
   const int lane = cx.lane, T = cx.T;
+#define RZ_FINE(k) if (cx.fine && cx.tid == 0) cx.fine[k] = __builtin_readcyclecounter();
+  RZ_FINE(1)
   const bool pos_rows = (op.rows == RZ_ROWS_POS);
   const int rows = pos_rows ? T * a.HW : T;
   const float* in = cx.reg + T * op.in_off;
@@ -486,6 +497,7 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
   const int wlast = op.wchunks - 1;
   auto load_b = [&](int c, f32x4& bv) { bv = wp[(size_t)(c < wlast ? c : wlast) * 64]; };
   f32x4 a0[MT], a1[MT], b0, b1, b2, b3;
+  RZ_FINE(2)
   load_b(0, b0);
   load_b(1, b1);
   load_a(0, a0);
@@ -512,62 +524,87 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
     compute(a1, b3);
     __builtin_amdgcn_sched_barrier(0);
   }
-  // ---- epilogue
+  RZ_FINE(3)
+  // ---- epilogue: every per-layer variation (BatchNorm or not, bias or not, residual or not, ReLU or not,
+  // output layout) is turned into DATA before the element loop (identity scale / zero bias / -inf floor /
+  // base + stride addressing), so the loop body is straight-line code: no branch per element
   const int n = nt * 16 + (lane & 15);
   const bool nv = n < op.cout;
   float al = 1.f, be = 0.f, bi = 0.f;
   if (op.alpha_off >= 0) { al = cx.simg[op.alpha_off + n]; be = cx.simg[op.beta_off + n]; }   // padded to whole tiles
   if (op.bias_off >= 0) bi = cx.simg[op.bias_off + n];
+  const float floor_v = (op.act == RZ_ACT_RELU) ? 0.f : -MZX_INF;
   float* out = cx.reg + T * op.out_off;
   const float* res = (op.res_off >= 0) ? cx.reg + T * op.res_off : nullptr;
   const float* actval = cx.scratch + 2 * T * a.Cs;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const int* rowo = cx.rowout ? cx.rowout : cx.rowaddr;
+  const bool padded = (op.out_layout == RZ_OUT_PADDED);
+  const bool need_tp = pos_rows && (!padded || op.asum_off >= 0);
+  const int nstride = (!padded && pos_rows) ? a.HW : 1;       // address step per output channel
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
+    // this lane's four rows are consecutive and 4-aligned: one 16-byte read per table (tables are padded
+    // to whole tiles; rows beyond the matrix hold a valid dummy address and are masked at the store)
+    const int m0 = (mt0 + i * mt_step) * 16 + (lane >> 4) * 4;
+    i32x4 ra4 = i32x4{0, 0, 0, 0}, tp4 = i32x4{0, 0, 0, 0};
+    if (pos_rows) ra4 = *(const i32x4*)(rowo + m0);
+    if (need_tp) tp4 = *(const i32x4*)(cx.rowtp + m0);
+    int base[4];
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (padded) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) base[r] = ra4[r];
+    } else if (pos_rows) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) base[r] = (tp4[r] >> 16) * op.out_tstride + (tp4[r] & 0xFFFF);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) base[r] = (m0 + r) * op.out_tstride;
+    }
+    if (res) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rs[r] = res[ra4[r] + n];
+    }
+    if (op.asum_off >= 0) {   // action plane of the dynamics input (first layer only)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[i][r] += actval[tp4[r] >> 16] * cx.simg[op.asum_off + n * a.HW + (tp4[r] & 0xFFFF)];
+    }
+    float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = (mt0 + i * mt_step) * 16 + (lane >> 4) * 4 + r;
-      if (m >= rows || !nv) continue;
-      float v = acc[i][r];
-      int ra = 0, t = m, p = 0;
-      if (pos_rows) { ra = (cx.rowout ? cx.rowout : cx.rowaddr)[m]; const int tp = cx.rowtp[m]; t = tp >> 16; p = tp & 0xFFFF; }
-      if (op.asum_off >= 0) v += actval[t] * cx.simg[op.asum_off + n * a.HW + p];
-      if (op.alpha_off >= 0) v = v * al + be;
-      if (op.bias_off >= 0) v = v + bi;
-      if (res) v += res[ra + n];
-      if (op.act == RZ_ACT_RELU) v = fmaxf(v, 0.f);
-      else if (op.act == RZ_ACT_ELU) v = mzx_elu(v);
-      const int idx = (op.out_layout == RZ_OUT_PADDED) ? ra + n : t * op.out_tstride + (pos_rows ? n * a.HW + p : n);
-      out[idx] = v;
+      float x = acc[i][r] * al + be;
+      x = x + bi;
+      x = x + rs[r];
+      v[r] = fmaxf(x, floor_v);
     }
+    if (op.act == RZ_ACT_ELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = mzx_elu(v[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (m0 + r < rows && nv) out[base[r] + n * nstride] = v[r];
   }
+  RZ_FINE(4)
+#undef RZ_FINE
 }
 
-// operator descriptor o of the LDS-resident table, made wave-uniform (scalar registers)
-__device__ __forceinline__ RzOp rz_fetch_op(const float* simg, int o) {
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
-  const i32x4* p = (const i32x4*)simg + o * 6;
-  i32x4 v[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) v[k] = p[k];            // six independent 16-byte LDS reads, one wait
-  RzOp op;
-  int* q = (int*)&op;
-#pragma unroll
-  for (int k = 0; k < 6; ++k)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) q[4 * k + j] = __builtin_amdgcn_readfirstlane(v[k][j]);
-  return op;
+// operator descriptor o: 24 scalar words straight from the program image in global memory (uniform
+// address -> s_load through the scalar cache, which keeps the 2 KB table hot across simulations)
+__device__ __forceinline__ RzOp rz_fetch_op(const float* small_global, int o) {
+  return ((const RzOp*)small_global)[o];
 }
 
 template <bool WLDS, int NW>
 __device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const RzCtx& cx) {
   const int rows = (op.rows == RZ_ROWS_POS) ? cx.T * a.HW : cx.T;
   const int mt_total = (rows + 15) >> 4, nt_total = (op.cout + 15) >> 4;
-  // column tiles over the waves first (a power of two of them), row tiles over the rest
-  int lg_n = 0;
-  while ((2 << lg_n) <= NW && (2 << lg_n) <= nt_total) ++lg_n;
-  const int waves_n = 1 << lg_n, waves_m = NW >> lg_n;
-  int lg_m = 0;
-  while ((1 << lg_m) < waves_m) ++lg_m;
+  // column tiles over the waves first (a power of two of them, precomputed), row tiles over the rest
+  const int lg_n = op.lg_waves_n[NW == 8 ? 1 : 0];
+  const int lg_m = (NW == 8 ? 3 : 2) - lg_n;
+  const int waves_n = 1 << lg_n, waves_m = 1 << lg_m;
   const int wn = cx.wave & (waves_n - 1), wm = cx.wave >> lg_n;
   for (int nt = wn; nt < nt_total; nt += waves_n) {
     for (int mt0 = wm; mt0 < mt_total; mt0 += waves_m * 8) {
@@ -637,6 +674,7 @@ __device__ __forceinline__ RzCtx rz_carve(const RzArgs& a, float* lds) {
   float* simg = scratch + a.scratch_floats;
   float* reg = simg + a.small_floats;
   cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.scratch = scratch; cx.simg = simg; cx.rowout = nullptr;
+  cx.fine = nullptr;
   cx.wlds = reg + a.T * a.tree_floats;
   cx.T = a.T; cx.tid = threadIdx.x; cx.lane = threadIdx.x & 63; cx.wave = threadIdx.x >> 6;
   return cx;
@@ -673,8 +711,8 @@ __device__ __forceinline__ void rz_setup(const RzArgs& a, const RzCtx& cx) {
       rowaddr[m] = t * a.slot_ts + ((y + 1) * a.PW + x + 1) * a.Cs;
       rowtp[m] = (t << 16) | p;
     } else {
-      rowaddr[m] = (a.PW + 1) * a.Cs;
-      rowtp[m] = -1;
+      rowaddr[m] = (a.PW + 1) * a.Cs;   // rows beyond the matrix: a valid address, never stored to
+      rowtp[m] = 0;
     }
   }
   __syncthreads();
@@ -720,7 +758,7 @@ rz_network_kernel(const RzArgs a) {
   float* reg = cx.reg;
   const int* rowaddr = cx.rowaddr;
   rz_setup<WLDS, NW>(a, cx);
-  unsigned long long* stamps = (unsigned long long*)(cx.scratch + a.scratch_floats - 2 * (RZ_MAX_OPS + 4));   // LDS
+  unsigned long long* stamps = (unsigned long long*)(cx.scratch + a.scratch_floats - 2 * RZ_STAMP_WORDS);   // LDS
   const bool prof = (a.dump_op == -2) && blockIdx.x == 0 && tid == 0;
   if (prof) { stamps[0] = t_entry; stamps[1] = __builtin_readcyclecounter(); }
 
@@ -729,10 +767,15 @@ rz_network_kernel(const RzArgs a) {
 
   // ---- the layers
   for (int o = 0; o < a.n_ops; ++o) {
-    const RzOp op = rz_fetch_op(cx.simg, o);   // wave-uniform: lives in scalar registers
-    if (op.kind == RZ_GEMM) rz_gemm<WLDS, NW>(op, a, cx);
+    RzCtx cxo = cx;
+    unsigned long long* fine = stamps + (RZ_MAX_OPS + 4) + 8 * o;   // [8] per operator, LDS
+    if (a.dump_op == -2 && blockIdx.x == 0) { cxo.fine = fine; if (tid == 0) fine[0] = __builtin_readcyclecounter(); }
+    const RzOp op = rz_fetch_op(a.small, o);   // wave-uniform: lives in scalar registers
+    if (op.kind == RZ_GEMM) rz_gemm<WLDS, NW>(op, a, cxo);
     else rz_scale<NW>(op, a, cx, b0, ntree, a.out_node, false);
+    if (cxo.fine && tid == 0) fine[5] = __builtin_readcyclecounter();
     __syncthreads();
+    if (cxo.fine && tid == 0) fine[6] = __builtin_readcyclecounter();
     if (prof) stamps[3 + o] = __builtin_readcyclecounter();
     if (o == a.dump_op) {  // diagnostics: the output tensor of op `o`, dense per sample
       const float* src = reg + T * op.out_off;
@@ -764,6 +807,7 @@ rz_network_kernel(const RzArgs a) {
   if (prof) {
     stamps[3 + a.n_ops] = __builtin_readcyclecounter();
     for (int k = 0; k < a.n_ops + 4; ++k) ((unsigned long long*)a.dump)[k] = stamps[k];
+    for (int k = 0; k < 8 * a.n_ops; ++k) ((unsigned long long*)a.dump)[RZ_MAX_OPS + 4 + k] = stamps[RZ_MAX_OPS + 4 + k];
   }
 }
 
@@ -907,7 +951,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const bool v = m < rows;
     rowaddr[m] = v ? ((ty * sa.stride + 1) * sa.PWin + tx * sa.stride + 1) * sa.Cs : (sa.PWin + 1) * sa.Cs;
     rowout[m] = v ? m * sa.Cs : 0;
-    rowtp[m] = v ? m : -1;
+    rowtp[m] = v ? m : 0;
   }
   if (tid < 128) params[tid] = (tid < 64) ? ((sa.alpha && tid < sa.cout) ? sa.alpha[tid] : 1.f)
                                           : ((sa.beta && tid - 64 < sa.cout) ? sa.beta[tid - 64] : 0.f);
@@ -946,7 +990,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   a.T = 1; a.HW = rows; a.PW = sa.PWin; a.Cs = sa.Cs; a.weights = sa.weights;
   RzCtx cx;
   cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.rowout = rowout; cx.scratch = params; cx.simg = params;
-  cx.wlds = nullptr; cx.T = 1; cx.tid = tid; cx.lane = tid & 63; cx.wave = tid >> 6;
+  cx.wlds = nullptr; cx.T = 1; cx.tid = tid; cx.lane = tid & 63; cx.wave = tid >> 6; cx.fine = nullptr;
   rz_gemm<false, 4>(sa.op, a, cx);
   __syncthreads();
   // ---- write back, coalesced along x
@@ -1104,7 +1148,7 @@ inline int run_network_prefix(const mzx_net* net, bool recurrent, int fused, int
       in = resolve(net, nb, R.ext_buf, batch);
     }
     if (fused == 2) {  // cycle profile of the whole fused program: stamps (uint64) land in d_out
-      if (out_floats < 2 * (R.n_ops + 4)) { set_error("profile buffer too small"); return MZX_ERR_WORKSPACE; }
+      if (out_floats < 2 * RZ_STAMP_WORDS) { set_error("profile buffer too small"); return MZX_ERR_WORKSPACE; }
       return rz_launch(net, R, in, nb, batch, nullptr, stream, -2, d_out);
     }
     return rz_launch(net, R, in, nb, batch, nullptr, stream, n_ops - 1 - R.first, d_out);

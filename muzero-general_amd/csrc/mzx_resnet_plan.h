@@ -40,9 +40,9 @@ struct RzOp {
   int32_t channels;      // RZ_SCALE: planes per tree
   int32_t store_hidden;  // RZ_SCALE: also write the scaled state to the caller's hidden-state output
   uint32_t magic;        // ceil(2^20 / cchunks): chunk -> tap decode without a division
-  int32_t pad_[2];       // sizeof(RzOp) = 96: six 16-byte words (fetched with six wide LDS reads)
+  int32_t lg_waves_n[2]; // log2 of the waves the column tiles are spread over, for 4- and 8-wave workgroups
 };
-static_assert(sizeof(RzOp) == 96, "RzOp is fetched as six 16-byte words");
+static_assert(sizeof(RzOp) == 96, "RzOp is fetched as 24 scalar words");
 
 // One packed weight tensor: B fragments of a GEMM in v_mfma_f32_16x16x4_f32 lane order,
 // K = (tap, 16-channel chunk); inside a chunk K-step j holds channels {4 g + j : g = 0..3}

@@ -32,12 +32,18 @@ def main():
         for _ in range(3):
             out = net.debug_prefix(recurrent, 2, n, x, a)
         torch.cuda.synchronize()
-        stamps = out.cpu().numpy().reshape(-1).view(numpy.uint64)
-        stamps = stamps[: n + 4]
+        raw = out.cpu().numpy().reshape(-1).view(numpy.uint64)
+        fine = raw[52: 52 + 8 * 48].reshape(48, 8).astype(numpy.int64)
+        stamps = raw[: n + 4]
         stamps = stamps[stamps > 0]
         d = numpy.diff(stamps.astype(numpy.int64))
         print(f"{wl} {'recurrent' if recurrent else 'initial'} batch {batch}: {len(d)} intervals, total {d.sum()} cycles")
         print("  staging %d; input load %d; ops: %s" % (d[0], d[1], " ".join(str(int(v)) for v in d[2:])))
+        print("  intra-operator (wave 0): fetch+dispatch | row bases | K loop | epilogue | tail | barrier")
+        for o in range(len(d) - 3):
+            f = fine[o]
+            if f[1] and f[4]:
+                print("   op %2d: %6d %6d %6d %6d %6d %6d" % (o, f[1] - f[0], f[2] - f[1], f[3] - f[2], f[4] - f[3], f[5] - f[4], f[6] - f[5]))
 
 
 if __name__ == "__main__":
