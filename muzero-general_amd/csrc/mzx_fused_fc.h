@@ -223,39 +223,57 @@ __device__ __forceinline__ RowSel row_select(const TreeRef& t, const SearchParam
   int N = sim;  // every finished simulation visited the root once
   double pbc = p.pbc_table[N], sq = p.sqrt_table[N];
   r.my_node = 0; r.my_parent = -1; r.my_pslot = -1;
+  // The rows of a wave walk trees of different depths: the loop is WAVE-uniform (it ends when every row
+  // has reached its leaf) and a row that is done keeps executing with its state frozen by selects --
+  // one straight-line body per level instead of a divergent loop with exec-mask bookkeeping.
+  bool done = false;
   for (;;) {
-    ++depth;
+    const int d1 = depth + 1;
     const int nc = (node == 0) ? st.root_n : p.num_actions;
     const bool valid = sub < nc;
     const int s = valid ? sub : 0;
     const int n = t.slot_visit(node, s);
     const int c = t.child(node, s);
-    const double sc = valid ? ucb_from(pbc, sq, n, t.prior(node, s), t.slot_q(node, s), st.mn, st.mx) : -MZX_INF;
+    const double u = ucb_from(pbc, sq, n, t.prior(node, s), t.slot_q(node, s), st.mn, st.mx);
+    const double sc = valid ? u : -MZX_INF;
     // tables of the child's visit count, in case this slot wins (off the critical path)
     const double pbc_c = p.pbc_table[n], sq_c = p.sqrt_table[n];
     const double best = row_max_d<AW>(sc);
     const unsigned bits = row_bits(__ballot(valid && sc == best), row_in_wave);
     const int nbest = __popc(bits);
-    if (nbest <= 1) {
-      slot = nbest ? (__ffs(bits) - 1) : 0;
-    } else {  // numpy.random.choice(ties): k-th maximiser in slot order
+    int sl = nbest ? (__ffs(bits) - 1) : 0;
+    if (nbest > 1 && !done) {  // numpy.random.choice(ties): k-th maximiser in slot order (rare after the first level)
       ++st.ties;
       int k = tape_draw(tape, p.tape_words, st.tape_pos, st.flags, nbest);
       unsigned b = bits;
       for (; k > 0; --k) b &= b - 1;
-      slot = __ffs(b) - 1;
+      sl = __ffs(b) - 1;
     }
-    vtp = (vtp + 1 < p.num_players) ? vtp + 1 : 0;
-    int cw;
-    if constexpr (AW <= 4) cw = pick_i<AW>(c, slot); else cw = perm_i(c, slot, row_in_wave);
-    if (sub == depth) { r.my_parent = node; r.my_pslot = slot; r.my_node = cw; }
-    if (cw < 0) break;
+    int cw, n_w;
+    double pbc_w, sq_w;
     if constexpr (AW <= 4) {
-      N = pick_i<AW>(n, slot); pbc = pick_d<AW>(pbc_c, slot); sq = pick_d<AW>(sq_c, slot);
+      cw = pick_i<AW>(c, sl); n_w = pick_i<AW>(n, sl); pbc_w = pick_d<AW>(pbc_c, sl); sq_w = pick_d<AW>(sq_c, sl);
     } else {
-      N = perm_i(n, slot, row_in_wave); pbc = perm_d(pbc_c, slot, row_in_wave); sq = perm_d(sq_c, slot, row_in_wave);
+      cw = perm_i(c, sl, row_in_wave); n_w = perm_i(n, sl, row_in_wave);
+      pbc_w = perm_d(pbc_c, sl, row_in_wave); sq_w = perm_d(sq_c, sl, row_in_wave);
     }
-    node = cw;
+    // commit this level unless the row already stopped
+    const bool act = !done;
+    const bool mine = act && sub == d1;
+    r.my_parent = mine ? node : r.my_parent;
+    r.my_pslot = mine ? sl : r.my_pslot;
+    r.my_node = mine ? cw : r.my_node;
+    const int nvtp = (vtp + 1 < p.num_players) ? vtp + 1 : 0;  // players turn by turn, :331-334
+    depth = act ? d1 : depth;
+    slot = act ? sl : slot;
+    vtp = act ? nvtp : vtp;
+    const bool go = act && cw >= 0;
+    N = go ? n_w : N;
+    pbc = go ? pbc_w : pbc;
+    sq = go ? sq_w : sq;
+    node = go ? cw : node;
+    done = done || (cw < 0);
+    if (__all(done)) break;
   }
   int leaf = st.n_nodes;
   if (leaf >= p.num_nodes) { st.flags |= TF_NODE_OVERFLOW; leaf = p.num_nodes - 1; }

@@ -128,14 +128,16 @@ struct TreeRef {
 // cached reward + discount * (+-value()) (written by backpropagate with the very
 // expression ucb_score uses, hence the same bits) and prior.
 MZX_HD inline double ucb_from(double pbc, double sq, int n, double prior, double q, double mn, double mx) {
-  double pb_c = pbc * (sq / (double)(n + 1));   // pb_c *= sqrt(N) / (n + 1)
-  double score = pb_c * prior;                   // prior_score
-  if (n > 0) {
-    double v = q;
-    if (mx > mn) v = (v - mn) / (mx - mn);        // MinMaxStats.normalize, :566-570
-    score = score + v;
-  }
-  return score;
+  // Straight-line form (selects, no branches: the lanes of a wave score different children): every
+  // operation the reference performs is performed with the same operands in the same order; results of
+  // the branches the reference does not take (e.g. the normalisation while max <= min, which may be
+  // inf - inf) are computed and discarded -- IEEE arithmetic does not trap.
+  const double pb_c = pbc * (sq / (double)(n + 1));            // pb_c *= sqrt(N) / (n + 1)
+  const double prior_score = pb_c * prior;
+  const double normalized = (q - mn) / (mx - mn);               // MinMaxStats.normalize, :566-570
+  const double v = (mx > mn) ? normalized : q;
+  const double with_value = prior_score + v;
+  return (n > 0) ? with_value : prior_score;
 }
 
 template <class T>
