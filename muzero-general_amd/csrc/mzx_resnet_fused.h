@@ -476,11 +476,18 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
   const unsigned magic = op.magic;
   const int pw9 = (op.taps == 9) ? a.PW * a.Cs : 0, one9 = (op.taps == 9) ? a.Cs : 0;
   const int last = op.nchunks - 1;
-  auto compute = [&](const f32x4 (&av)[MT], const f32x4& bv) {
+  // With a single row tile the MFMAs of a chunk would form one dependent chain (40-cycle accumulator
+  // latency against a 32-cycle issue interval): even and odd chunks then accumulate into two tiles that are
+  // added at the end.
+  f32x4 acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](const f32x4 (&av)[MT], const f32x4& bv, bool odd) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][j], bv[j], acc[i], 0, 0, 0);
+      for (int i = 0; i < MT; ++i) {
+        if (MT == 1 && odd) acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][j], bv[j], acc_odd, 0, 0, 0);
+        else acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][j], bv[j], acc[i], 0, 0, 0);
+      }
   };
   // software pipeline: A fragments (LDS) one chunk ahead, B fragments (L2 or LDS) two chunks ahead of the
   // 4 * MT MFMAs being issued; two chunks per iteration, ping-pong registers
@@ -496,8 +503,33 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
   // an odd chunk count is stored with one trailing zero chunk; prefetches beyond it re-read the last chunk
   const int wlast = op.wchunks - 1;
   auto load_b = [&](int c, f32x4& bv) { bv = wp[(size_t)(c < wlast ? c : wlast) * 64]; };
-  f32x4 a0[MT], a1[MT], b0, b1, b2, b3;
+  // Small tile counts (latency-bound layers of small networks): fetch everything the epilogue needs that
+  // does not depend on the accumulators -- row addresses and the residual -- BEFORE the K loop, so that
+  // these LDS round trips hide under the MFMAs instead of following them.
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  constexpr bool EARLY = (MT <= 2);
+  const int n = nt * 16 + (lane & 15);
+  const int* rowo = cx.rowout ? cx.rowout : cx.rowaddr;
+  const bool padded = (op.out_layout == RZ_OUT_PADDED);
+  const bool need_tp = pos_rows && (!padded || op.asum_off >= 0);
+  const float* res = (op.res_off >= 0) ? cx.reg + T * op.res_off : nullptr;
+  i32x4 e_ra[EARLY ? MT : 1], e_tp[EARLY ? MT : 1];
+  float e_rs[EARLY ? MT : 1][4];
+  if (EARLY) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m0 = (mt0 + i * mt_step) * 16 + (lane >> 4) * 4;
+      e_ra[i] = pos_rows ? *(const i32x4*)(rowo + m0) : i32x4{0, 0, 0, 0};
+      e_tp[i] = need_tp ? *(const i32x4*)(cx.rowtp + m0) : i32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e_rs[i][r] = res ? res[e_ra[i][r] + n] : 0.f;
+  }
   RZ_FINE(2)
+  {
+  f32x4 a0[MT], a1[MT], b0, b1, b2, b3;
   load_b(0, b0);
   load_b(1, b1);
   load_a(0, a0);
@@ -506,41 +538,37 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
     load_b(c + 3, b3);
     load_a(c + 1, a1);
     __builtin_amdgcn_sched_barrier(0);
-    compute(a0, b0);
+    compute(a0, b0, false);
     __builtin_amdgcn_sched_barrier(0);
     load_a(c + 2, a0);
     __builtin_amdgcn_sched_barrier(0);
-    compute(a1, b1);
+    compute(a1, b1, true);
     __builtin_amdgcn_sched_barrier(0);
     if (c + 2 >= op.nchunks) break;
     load_b(c + 4, b0);
     load_b(c + 5, b1);
     load_a(c + 3, a1);
     __builtin_amdgcn_sched_barrier(0);
-    compute(a0, b2);
+    compute(a0, b2, false);
     __builtin_amdgcn_sched_barrier(0);
     load_a(c + 4, a0);
     __builtin_amdgcn_sched_barrier(0);
-    compute(a1, b3);
+    compute(a1, b3, true);
     __builtin_amdgcn_sched_barrier(0);
   }
+  }
+  if (MT == 1) acc[0] = acc[0] + acc_odd;
   RZ_FINE(3)
   // ---- epilogue: every per-layer variation (BatchNorm or not, bias or not, residual or not, ReLU or not,
   // output layout) is turned into DATA before the element loop (identity scale / zero bias / -inf floor /
   // base + stride addressing), so the loop body is straight-line code: no branch per element
-  const int n = nt * 16 + (lane & 15);
   const bool nv = n < op.cout;
   float al = 1.f, be = 0.f, bi = 0.f;
   if (op.alpha_off >= 0) { al = cx.simg[op.alpha_off + n]; be = cx.simg[op.beta_off + n]; }   // padded to whole tiles
   if (op.bias_off >= 0) bi = cx.simg[op.bias_off + n];
   const float floor_v = (op.act == RZ_ACT_RELU) ? 0.f : -MZX_INF;
   float* out = cx.reg + T * op.out_off;
-  const float* res = (op.res_off >= 0) ? cx.reg + T * op.res_off : nullptr;
   const float* actval = cx.scratch + 2 * T * a.Cs;
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
-  const int* rowo = cx.rowout ? cx.rowout : cx.rowaddr;
-  const bool padded = (op.out_layout == RZ_OUT_PADDED);
-  const bool need_tp = pos_rows && (!padded || op.asum_off >= 0);
   const int nstride = (!padded && pos_rows) ? a.HW : 1;       // address step per output channel
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -548,10 +576,16 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
     // to whole tiles; rows beyond the matrix hold a valid dummy address and are masked at the store)
     const int m0 = (mt0 + i * mt_step) * 16 + (lane >> 4) * 4;
     i32x4 ra4 = i32x4{0, 0, 0, 0}, tp4 = i32x4{0, 0, 0, 0};
-    if (pos_rows) ra4 = *(const i32x4*)(rowo + m0);
-    if (need_tp) tp4 = *(const i32x4*)(cx.rowtp + m0);
-    int base[4];
     float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EARLY) {
+      ra4 = e_ra[i]; tp4 = e_tp[i];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rs[r] = e_rs[i][r];
+    } else {
+      if (pos_rows) ra4 = *(const i32x4*)(rowo + m0);
+      if (need_tp) tp4 = *(const i32x4*)(cx.rowtp + m0);
+    }
+    int base[4];
     if (padded) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) base[r] = ra4[r];
@@ -562,7 +596,7 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
 #pragma unroll
       for (int r = 0; r < 4; ++r) base[r] = (m0 + r) * op.out_tstride;
     }
-    if (res) {
+    if (!EARLY && res) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) rs[r] = res[ra4[r] + n];
     }
