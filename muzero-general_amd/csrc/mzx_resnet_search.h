@@ -33,6 +33,7 @@ struct RzSearchArgs {
   char* trees;           // arena: [num_trees][L.tree_bytes]
   const uint32_t* tape;  // [num_trees][tape_words]
   int32_t num_sims, sim0;
+  uint32_t* prof;        // nullable: [grid][8] cycles per phase, accumulated over the simulations (mode flag 8)
 };
 
 // floats of LDS the search adds behind the network engine's image: selection hand-off, tables
@@ -79,6 +80,12 @@ rz_search_kernel(const RzSearchArgs sa) {
   if (row_valid) load_state(t, st);
   const int F = a.out_n[0], A = a.out_n[2];
   __syncthreads();
+  // cycle profile (mode flag 8): thread 0 accumulates the shader clock per phase
+  uint32_t pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = 0;
+  const bool prof = sa.prof != nullptr && tid == 0;
+  if (prof) t_last = __builtin_readcyclecounter();
+#define RZS_PROF(k) if (prof) { const unsigned long long _t = __builtin_readcyclecounter(); pc[k] += (uint32_t)(_t - t_last); t_last = _t; }
 
   for (int sim = 0; sim < sa.num_sims; ++sim) {
     // ---- selection (self_play.py:325-334)
@@ -87,16 +94,20 @@ rz_search_kernel(const RzSearchArgs sa) {
       sel = row_select<AW>(t, p, tape, sub, row_in_wave, sa.sim0 + sim, st);
       if (sub == 0) { sel_parent[row] = sel.c.parent; sel_action[row] = sel.action; sel_leaf[row] = sel.c.leaf; }
     }
+    RZS_PROF(0)
     __syncthreads();
+    RZS_PROF(1)
 
     // ---- recurrent_inference on the T selected (parent state, action) pairs (models.py:620-623)
     rz_load_input<NW>(a, cx, b0, ntree, sel_parent, sel_action, true);
+    RZS_PROF(2)
     for (int o = 0; o < a.n_ops; ++o) {
       const RzOp op = rz_fetch_op(cx.simg, o);
       if (op.kind == RZ_GEMM) rz_gemm<WLDS, NW>(op, a, cx);
       else rz_scale<NW>(op, a, cx, b0, ntree, sel_leaf, true);
       __syncthreads();
     }
+    RZS_PROF(3)
 
     // ---- decode, expand, back-propagate (self_play.py:343-353), the row that owns the tree
     if (row_valid) {
@@ -113,8 +124,12 @@ rz_search_kernel(const RzSearchArgs sa) {
       if (in) tree_init_slot(t, sel.c.leaf, sub, (double)(e / den));
       row_backprop(t, p, sel, sub, row_in_wave, (double)value, (double)reward, st);
     }
+    RZS_PROF(4)
     __syncthreads();
+    RZS_PROF(5)
   }
+#undef RZS_PROF
+  if (prof) for (int k = 0; k < 8; ++k) sa.prof[blockIdx.x * 8 + k] = pc[k];
   if (row_valid && sub == 0) store_state(t, st);
 }
 
@@ -195,6 +210,8 @@ inline int rz_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, 
     sa.tape = io->d_tape;
     sa.num_sims = s->p.num_sims;
     sa.sim0 = 0;
+    // mode flag 8: per-workgroup phase cycle counters in the (otherwise unused) network workspace region
+    sa.prof = ((s->mode & 8) && s->ws_floats >= (int64_t)L.grid * 8) ? (uint32_t*)((char*)d_arena + s->off_ws) : nullptr;
     const size_t lds = L.lds + (size_t)4 * extra;
     if (L.wlds) rc = L.eight ? rz_search_launch_aw<true, 8>(sa, L.grid, lds, stream) : rz_search_launch_aw<true, 4>(sa, L.grid, lds, stream);
     else rc = L.eight ? rz_search_launch_aw<false, 8>(sa, L.grid, lds, stream) : rz_search_launch_aw<false, 4>(sa, L.grid, lds, stream);

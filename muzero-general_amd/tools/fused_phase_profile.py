@@ -21,7 +21,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trees", type=int, default=4096)
     ap.add_argument("--lds", action="store_true", help="force the LDS-weight engine")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     args = ap.parse_args()
+    if args.workload != "c2":
+        return residual(args)
     cfg = configs.cartpole()
     B = args.trees
     net = models.MuZeroNetwork(cfg)
@@ -41,6 +44,31 @@ def main():
         per = c / S if k in (2, 3, 4, 5) else c
         print(f"  {name:18s} {c:12.0f} cycles/tree  ({100 * c / total:5.1f}%)" + (f"   {per:8.0f} per simulation" if k in (2, 3, 4, 5) else ""))
     print(f"  total              {total:12.0f} cycles/tree  = {total / 2.4e3:.1f} us at 2.4 GHz")
+
+
+def residual(args):
+    """Phase cycles of the residual whole-search kernel (thread 0 of every workgroup), summed over the simulations."""
+    name, B = {"c3": ("tictactoe", 1024), "c4": ("connect4", 1024), "c5": ("breakout", 64)}[args.workload]
+    cfg = configs.BY_NAME[name](**({"num_simulations": 50} if name == "breakout" else {}))
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 0))
+    engine = self_play.BatchedMCTS(cfg, net, B, mode=1 | 8)
+    obs = synthetic.observations(B, net.input_shape, seed=123)
+    for _ in range(2):
+        res = engine.run(list(obs), [list(cfg.action_space)] * B, [0] * B, True,
+                         [numpy.random.RandomState(1000 + i) for i in range(B)])
+    torch.cuda.synchronize()
+    off = engine.arena_offsets(B)
+    raw = engine.arena(B)[off["workspace"]: off["workspace"] + 256 * 8 * 4].view(torch.int32).cpu().numpy().reshape(-1, 8)
+    raw = raw[((raw[:, :6] > 0) & (raw[:, :6] < 2 ** 29)).all(1)]   # workgroups that wrote counters (the region is shared with the stem's workspace)
+    S = cfg.num_simulations
+    names = ["select (lane-parallel, arena trees)", "barrier after select", "gather parent states -> LDS", "network layers",
+             "decode + expand + backpropagate", "barrier"]
+    mean = raw[:, :6].mean(0)
+    print(f"{args.workload}: {B} trees x {S} sims, {len(raw)} workgroups sampled, mean leaf depth {res.sum_depth.mean() / S:.2f}")
+    for k, nm in enumerate(names):
+        print(f"  {nm:38s} {mean[k] / S:10.0f} cycles per simulation  ({100 * mean[k] / mean.sum():5.1f}%)")
+    print(f"  total                                  {mean.sum() / S:10.0f} cycles per simulation = {mean.sum() / S / 2.4e3:.2f} us at 2.4 GHz")
 
 
 if __name__ == "__main__":
