@@ -191,8 +191,9 @@ int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_
  *   2  (fused) also export the finished trees to the arena so mzx_search_dump works
  *   4  (fused) force the LDS-weight engine even when a register-resident
  *      specialisation matches the network shape
- *   8  (fused) cycle-profile build: per-tree phase cycle counters are left in the
- *      network-workspace region of the arena (mzx_search_arena_offsets)
+ *   8  cycle profile: phase cycle counters are left in the network-workspace region of the
+ *      arena (mzx_search_arena_offsets): [tree][16] for the fully connected kernel (a
+ *      separate profiling instantiation), [workgroup][8] for the residual kernel
  * Default: 1 when supported, else 0. */
 int mzx_search_fused_supported(const mzx_search* s);
 int mzx_search_set_mode(mzx_search* s, int32_t mode);
