@@ -33,7 +33,7 @@ import time
 import numpy
 import torch
 
-from . import _lib, _rng, models
+from . import _lib, _rng, models, replay
 
 TAPE_WORDS = 64
 
@@ -403,6 +403,9 @@ class SelfPlay:
                     self.config.temperature_threshold, False, "self", 0,
                 )
                 for game_history in histories:
+                    # initial PER priorities, vectorised (replay_buffer.py:39-51 would loop in Python);
+                    # save_game then takes its "priorities already present" branch
+                    replay.fill_initial_priorities(game_history, self.config)
                     _remote(replay_buffer.save_game, game_history, shared_storage)
             else:
                 game_history = self.play_game(
