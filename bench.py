@@ -129,7 +129,7 @@ def cpu_baseline(workload, seconds, cores):
 
 
 # ----------------------------------------------------------------------------- end-to-end self-play leg
-def selfplay_leg(cfg, net, B, moves):
+def selfplay_leg(cfg, net, B, moves, batched=False):
     """
     SelfPlay(num_games=B).play_games on the synthetic fixed-shape game (reference plugin surface): what a
     user of the drop-in engine sees per process -- B Python Game.step calls, per-game numpy-compatible
@@ -141,7 +141,8 @@ def selfplay_leg(cfg, net, B, moves):
 
     c = copy.copy(cfg)
     c.max_moves = moves
-    Game = synthetic.make_synthetic_game(c.observation_shape, len(c.action_space), len(c.players))
+    make = synthetic.make_synthetic_batched_game if batched else synthetic.make_synthetic_game
+    Game = make(c.observation_shape, len(c.action_space), len(c.players))
     sp = self_play.SelfPlay({"weights": net.get_weights()}, Game, c, 0, num_games=B)
     sp.play_games(1.0, None, False, "self", 0)          # warm-up (allocations, kernel attributes)
     sp.stats = {"searches": 0, "simulations": 0, "search_seconds": 0.0}
@@ -153,7 +154,8 @@ def selfplay_leg(cfg, net, B, moves):
     return {
         "steps_per_sec": steps / wall, "sims_per_sec": steps * c.num_simulations / wall, "games": B, "moves_per_game": moves,
         "wall_s": wall, "search_share": sp.stats["search_seconds"] / wall,
-        "note": "one host process: Python plugin Game.step x B per move + host bookkeeping + batched search "
+        "game_protocol": "batched (one object steps the shard)" if batched else "reference plugin surface (B Game objects)",
+        "note": "one host process: plugin game stepping + host bookkeeping + batched search "
                 "(search_share = fraction of the wall spent inside BatchedMCTS.run incl. uploads/downloads)",
     }
 
@@ -324,6 +326,7 @@ def main():
         }
         if world == 1 and args.selfplay_moves > 0:
             line["selfplay_end_to_end"] = selfplay_leg(cfg, net, B, args.selfplay_moves)
+            line["selfplay_end_to_end_batched_game"] = selfplay_leg(cfg, net, B, args.selfplay_moves, batched=True)
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_cores)
         else:

@@ -289,7 +289,15 @@ class BatchedMCTS:
         legal = numpy.full((B, A), -1, numpy.int32)
         n_legal = numpy.empty(B, numpy.int32)
         action_set = set(cfg.action_space)
-        for i, acts in enumerate(legal_actions):
+        if isinstance(legal_actions, numpy.ndarray):   # batched protocol: [B][A] int32, lists padded with -1
+            legal = numpy.ascontiguousarray(legal_actions, dtype=numpy.int32)
+            assert legal.shape == (B, A), "legal_actions array must be [num_trees][len(action_space)]"
+            n_legal = (legal >= 0).sum(1).astype(numpy.int32)
+            assert (n_legal > 0).all(), "Legal actions should not be an empty array."
+            assert (legal < A).all() and ((legal >= 0) == (numpy.arange(A)[None, :] < n_legal[:, None])).all(), \
+                "Legal actions should be a subset of the action space (padded with -1 at the end)."
+            legal_actions = legal
+        for i, acts in enumerate(legal_actions if not isinstance(legal_actions, numpy.ndarray) else ()):
             # self_play.py:296-301
             assert acts, f"Legal actions should not be an empty array. Got {acts}."
             assert set(acts).issubset(action_set), "Legal actions should be a subset of the action space."
@@ -317,7 +325,7 @@ class BatchedMCTS:
         visits = out["visits"].cpu().numpy()
         info = out["info"].cpu().numpy()
         result = SearchResult(visits, out["root_value"].cpu().numpy(), out["predicted"].cpu().numpy(), info,
-                              [list(a) for a in legal_actions])
+                              legal_actions if isinstance(legal_actions, numpy.ndarray) else [list(a) for a in legal_actions])
         if (info[:, 1] != 0).any():
             raise _lib.MzxError(f"search flagged trees {numpy.nonzero(info[:, 1])[0][:8]} (flags {set(info[:, 1])}): "
                                 "tie tape or node arena exhausted")
@@ -371,8 +379,16 @@ class SelfPlay:
         _validate(config)
         self.config = config
         self.num_games = int(num_games)
-        self.games = [Game(seed + i) for i in range(self.num_games)]
-        self.game = self.games[0]
+        self.batched_game = None
+        if getattr(Game, "batched", False):
+            # optional batched plugin protocol (mzx.synthetic.make_synthetic_batched_game documents it): ONE
+            # object steps the whole shard, the per-move host work is a handful of numpy calls
+            self.batched_game = Game([seed + i for i in range(self.num_games)])
+            self.games = []
+            self.game = self.batched_game
+        else:
+            self.games = [Game(seed + i) for i in range(self.num_games)]
+            self.game = self.games[0]
 
         # Fix random generator seed (self_play.py:21-23)
         numpy.random.seed(seed)
@@ -387,7 +403,7 @@ class SelfPlay:
         self.model.set_weights(initial_checkpoint["weights"])
         self.model.eval()
         self.engine = BatchedMCTS(self.config, self.model, self.num_games)
-        if self.num_games > 1:
+        if self.num_games > 1 or self.batched_game is not None:
             self.bank = _rng.StreamBank(self.model.backend.lib, [(seed + i) & 0xFFFFFFFF for i in range(self.num_games)])
         self.stats = {"searches": 0, "simulations": 0, "search_seconds": 0.0}
 
@@ -440,6 +456,10 @@ class SelfPlay:
 
     def play_games(self, temperature, temperature_threshold, render, opponent, muzero_player):
         """All ``num_games`` games of this shard in lock-step; returns their GameHistory list."""
+        if self.batched_game is not None:
+            if opponent != "self" or render:
+                raise NotImplementedError("the batched game protocol covers self-play without rendering")
+            return self._play_batched(temperature, temperature_threshold)
         return self._play(list(range(self.num_games)), temperature, temperature_threshold, render, opponent,
                           muzero_player)
 
@@ -519,7 +539,95 @@ class SelfPlay:
             active = still
         return [histories[s] for s in slots]
 
+    def _play_batched(self, temperature, temperature_threshold):
+        """
+        play_game (self_play.py:110-183) for a shard behind the batched plugin protocol: per move ONE game
+        call, ONE search, ONE action draw for all running games; the per-game GameHistory objects
+        (field-identical to the per-object path, tests/test_selfplay_shard.py) are materialised at the end.
+        """
+        cfg, g, B = self.config, self.batched_game, self.num_games
+        A, k = len(cfg.action_space), int(cfg.stacked_observations)
+        obs = numpy.asarray(g.reset())
+        assert obs.shape == (B,) + tuple(cfg.observation_shape), \
+            f"Observation should match the observation_shape defined in MuZeroConfig. Expected {(B,) + tuple(cfg.observation_shape)} but got {obs.shape}."
+        obs_hist, act_hist, rew_hist = [obs], [numpy.zeros(B, numpy.int64)], [numpy.zeros(B, numpy.int64)]
+        tp_hist = [numpy.asarray(g.to_play()).astype(numpy.int64)]
+        visits_hist, value_hist, legal_hist, alive_hist = [], [], [], []
+        alive = numpy.ones(B, bool)
+        length = numpy.zeros(B, numpy.int64)
+        move = 0
+        while alive.any() and move + 1 <= cfg.max_moves:      # len(action_history) <= max_moves, :129
+            idx = numpy.nonzero(alive)[0]
+            stacked = self._stacked_batch(obs_hist, act_hist, k, A)[idx]
+            legal = g.legal_actions()
+            legal = legal[idx] if isinstance(legal, numpy.ndarray) else [legal[i] for i in idx]
+            t0 = time.perf_counter()
+            result = self.engine.run(stacked, legal, tp_hist[-1][idx], True, (self.bank, idx))
+            self.stats["search_seconds"] += time.perf_counter() - t0
+            self.stats["searches"] += len(idx)
+            self.stats["simulations"] += len(idx) * self.engine.num_simulations
+            t = temperature if not temperature_threshold or move + 1 < temperature_threshold else 0
+            chosen = self._select_actions_bank(result, idx, [t] * len(idx))
+            actions = numpy.zeros(B, numpy.int64)
+            actions[idx] = chosen
+            obs, reward, done = g.step(actions, alive.copy())
+            visits = numpy.zeros((B, A), numpy.int32)
+            visits[idx] = result.visit_counts
+            values = numpy.zeros(B, numpy.float64)
+            values[idx] = result.root_values
+            mask = numpy.zeros((B, A), bool)
+            if isinstance(legal, numpy.ndarray):
+                rows = numpy.repeat(idx, (legal >= 0).sum(1))
+                mask[rows, legal[legal >= 0]] = True
+            else:
+                for r, acts in zip(idx, legal):
+                    mask[r, acts] = True
+            visits_hist.append(visits); value_hist.append(values); legal_hist.append(mask); alive_hist.append(alive.copy())
+            obs_hist.append(numpy.asarray(obs)); act_hist.append(actions)
+            rew_hist.append(numpy.asarray(reward)); tp_hist.append(numpy.asarray(g.to_play()).astype(numpy.int64))
+            length[idx] += 1
+            alive = alive & ~numpy.asarray(done, bool)
+            move += 1
+        # ---- per-game records (self_play.py:479-511)
+        histories = []
+        for i in range(B):
+            n = int(length[i])
+            gh = GameHistory()
+            gh.observation_history = [obs_hist[t][i] for t in range(n + 1)]
+            gh.action_history = [0] + [int(act_hist[t][i]) for t in range(1, n + 1)]
+            gh.reward_history = [0] + [rew_hist[t][i].item() for t in range(1, n + 1)]
+            gh.to_play_history = [int(tp_hist[t][i]) for t in range(n + 1)]
+            for t in range(n):
+                v, m = visits_hist[t][i], legal_hist[t][i]
+                total = int(v.sum())
+                gh.child_visits.append([int(v[a]) / total if m[a] else 0 for a in range(A)])
+                gh.root_values.append(float(value_hist[t][i]) if total else 0)
+            histories.append(gh)
+        return histories
+
+    @staticmethod
+    def _stacked_batch(obs_hist, act_hist, k, A):
+        """GameHistory.get_stacked_observations(-1, k, A) (self_play.py:513-550) for every game of the shard."""
+        current = obs_hist[-1]
+        if k == 0:
+            return current
+        index = len(obs_hist) - 1
+        B = current.shape[0]
+        plane_shape = (B, 1) + current.shape[2:]
+        pieces = [current]
+        for past in range(index - 1, index - 1 - k, -1):
+            if past >= 0:
+                pieces.append(obs_hist[past])
+                a = act_hist[past + 1].reshape((B,) + (1,) * (current.ndim - 1))
+                pieces.append(numpy.ones(plane_shape, current.dtype) * a / A)
+            else:
+                pieces.append(numpy.zeros_like(current))
+                pieces.append(numpy.zeros(plane_shape, current.dtype))
+        return numpy.concatenate(pieces, axis=1)
+
     def close_game(self):
+        if self.batched_game is not None:
+            self.batched_game.close()
         for g in self.games:
             g.close()
 
@@ -555,9 +663,14 @@ class SelfPlay:
         A = self.engine.A
         counts = numpy.zeros((k, A), numpy.int32)     # in CHILD order (= legal-action order), zero padded
         n = numpy.empty(k, numpy.int32)
-        for r, legal in enumerate(result.legal_actions):
-            n[r] = len(legal)
-            counts[r, : n[r]] = result.visit_counts[r][legal]
+        if isinstance(result.legal_actions, numpy.ndarray):
+            legal_arr = result.legal_actions
+            n[:] = (legal_arr >= 0).sum(1)
+            counts = numpy.where(legal_arr >= 0, numpy.take_along_axis(result.visit_counts, numpy.maximum(legal_arr, 0), 1), 0).astype(numpy.int32)
+        else:
+            for r, legal in enumerate(result.legal_actions):
+                n[r] = len(legal)
+                counts[r, : n[r]] = result.visit_counts[r][legal]
         actions = numpy.zeros(k, numpy.int64)
         temps = numpy.asarray(temps, dtype=numpy.float64)
         greedy = numpy.nonzero(temps == 0)[0]
@@ -584,6 +697,8 @@ class SelfPlay:
             u = self.bank.random_sample([searching[r] for r in rows])
             inside = numpy.arange(A)[None, :] < n[rows, None]
             actions[rows] = ((cdf <= u[:, None]) & inside).sum(axis=1)   # searchsorted(u, side="right")
+        if isinstance(result.legal_actions, numpy.ndarray):
+            return result.legal_actions[numpy.arange(k), actions].astype(numpy.int64)
         return [result.legal_actions[r][int(actions[r])] for r in range(k)]
 
     @staticmethod

@@ -117,3 +117,56 @@ def make_synthetic_game(observation_shape, num_actions, num_players=1):
             return str(action_number)
 
     return SyntheticGame
+
+
+def make_synthetic_batched_game(observation_shape, num_actions, num_players=1):
+    """
+    The same environment as ``make_synthetic_game`` for a whole shard at once, through the optional BATCHED
+    plugin protocol of ``mzx.self_play.SelfPlay`` (class attribute ``batched = True``; ``Game(seeds)``;
+    ``reset() -> obs [B, *shape]``; ``step(actions [B], active=None) -> (obs, rewards [B], done [B])``;
+    ``legal_actions() -> int32 [B][A]`` padded with -1; ``to_play() -> [B]``).  Game i behaves exactly like
+    ``make_synthetic_game(...)(seeds[i])`` -- tests compare the two game by game.
+    """
+    shape = tuple(observation_shape)
+    size = int(numpy.prod(shape))
+    lane = numpy.arange(size, dtype=numpy.uint64) * numpy.uint64(2654435761)
+
+    class SyntheticBatchedGame:
+        batched = True
+
+        def __init__(self, seeds):
+            self.seeds = numpy.asarray([0 if s is None else int(s) for s in seeds], dtype=numpy.uint64)
+            self.num_games = int(self.seeds.size)
+            self._legal = numpy.tile(numpy.arange(num_actions, dtype=numpy.int32), (self.num_games, 1))
+            self.t = 0
+            self.player = 0
+            self.key = self.seeds & numpy.uint64(0xFFFFFFFF)
+
+        def _observation(self):
+            h = _hash_u32(lane[None, :] + self.key[:, None])
+            return (h.astype(numpy.float64) / 4294967296.0).astype(numpy.float32).reshape((self.num_games,) + shape)
+
+        def reset(self):
+            self.t = 0
+            self.player = 0
+            self.key = _hash_u32(self.seeds * numpy.uint64(7919) + numpy.uint64(17))
+            return self._observation()
+
+        def step(self, actions, active=None):
+            self.t += 1
+            a = numpy.asarray(actions).astype(numpy.uint64)
+            self.key = _hash_u32(self.key * numpy.uint64(31) + a * numpy.uint64(131) + numpy.uint64(self.t))
+            self.player = (self.player + 1) % num_players
+            reward = (self.key & numpy.uint64(1)).astype(numpy.int64)
+            return self._observation(), reward, numpy.zeros(self.num_games, bool)
+
+        def to_play(self):
+            return numpy.full(self.num_games, self.player, numpy.int64)
+
+        def legal_actions(self):
+            return self._legal
+
+        def close(self):
+            pass
+
+    return SyntheticBatchedGame

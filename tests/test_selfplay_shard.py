@@ -39,3 +39,30 @@ def test_shard_equals_independent_actors(backend, temperature, threshold, player
         assert numpy.array_equal(numpy.array(got.root_values).view(numpy.int64), numpy.array(want.root_values).view(numpy.int64))
         for a, b in zip(got.observation_history, want.observation_history):
             assert numpy.array_equal(a, b)
+
+
+@pytest.mark.parametrize("temperature,threshold,players,actions,stacked", [
+    (1.0, None, 1, 2, 0), (0.5, 3, 2, 5, 2), (0, None, 1, 3, 1)])
+def test_batched_game_protocol_equals_per_object_games(backend, temperature, threshold, players, actions, stacked):
+    """The optional batched plugin protocol (one object steps the shard) against the per-object Game path."""
+    cfg = configs.cartpole(num_simulations=9, max_moves=6, action_space=list(range(actions)), observation_shape=(2, 1, 3),
+                           players=list(range(players)), temperature_threshold=threshold, stacked_observations=stacked)
+    Game = synthetic.make_synthetic_game(cfg.observation_shape, actions, players)
+    Batched = synthetic.make_synthetic_batched_game(cfg.observation_shape, actions, players)
+    template = models.MuZeroNetwork(cfg, _backend=backend).state_dict()
+    weights = synthetic.fill_state_dict(template, 5)
+    B, seed = 7, 11
+    a = self_play.SelfPlay({"weights": weights}, Game, cfg, seed, num_games=B, _backend=backend)
+    b = self_play.SelfPlay({"weights": weights}, Batched, cfg, seed, num_games=B, _backend=backend)
+    ha = a.play_games(temperature, cfg.temperature_threshold, False, "self", 0)
+    hb = b.play_games(temperature, cfg.temperature_threshold, False, "self", 0)
+    for want, got in zip(ha, hb):
+        assert [int(x) for x in got.action_history] == [int(x) for x in want.action_history]
+        assert got.reward_history == want.reward_history and got.to_play_history == want.to_play_history
+        assert got.child_visits == want.child_visits
+        assert numpy.array_equal(numpy.array(got.root_values).view(numpy.int64), numpy.array(want.root_values).view(numpy.int64))
+        assert len(got.observation_history) == len(want.observation_history)
+        for x, y in zip(got.observation_history, want.observation_history):
+            assert numpy.array_equal(x, y)
+        for i in range(len(want.root_values) + 1):
+            assert numpy.array_equal(got.get_stacked_observations(i, stacked, actions), want.get_stacked_observations(i, stacked, actions))
