@@ -588,20 +588,36 @@ class SelfPlay:
             length[idx] += 1
             alive = alive & ~numpy.asarray(done, bool)
             move += 1
-        # ---- per-game records (self_play.py:479-511)
+        # ---- per-game records (self_play.py:479-511): stack once, slice per game
+        n_moves = len(visits_hist)
+        acts = numpy.stack(act_hist)                      # [n_moves + 1][B]
+        rews = numpy.stack(rew_hist)
+        tps = numpy.stack(tp_hist)
+        if n_moves:
+            vis = numpy.stack(visits_hist)                # [n_moves][B][A]
+            vals = numpy.stack(value_hist)
+            legal_mask = numpy.stack(legal_hist)
+            totals = vis.sum(2)
+            # visit_count / total: true division of small integers == Python's int / int
+            ratios = vis / numpy.maximum(totals, 1)[:, :, None]
+            all_legal = legal_mask.all(2)
         histories = []
         for i in range(B):
             n = int(length[i])
             gh = GameHistory()
             gh.observation_history = [obs_hist[t][i] for t in range(n + 1)]
-            gh.action_history = [0] + [int(act_hist[t][i]) for t in range(1, n + 1)]
-            gh.reward_history = [0] + [rew_hist[t][i].item() for t in range(1, n + 1)]
-            gh.to_play_history = [int(tp_hist[t][i]) for t in range(n + 1)]
-            for t in range(n):
-                v, m = visits_hist[t][i], legal_hist[t][i]
-                total = int(v.sum())
-                gh.child_visits.append([int(v[a]) / total if m[a] else 0 for a in range(A)])
-                gh.root_values.append(float(value_hist[t][i]) if total else 0)
+            gh.action_history = acts[: n + 1, i].tolist()
+            gh.reward_history = rews[: n + 1, i].tolist()
+            gh.to_play_history = tps[: n + 1, i].tolist()
+            if n:
+                if all_legal[:n, i].all() and (totals[:n, i] > 0).all():
+                    gh.child_visits = ratios[:n, i].tolist()
+                    gh.root_values = vals[:n, i].tolist()
+                else:
+                    for t in range(n):
+                        total = int(totals[t, i])
+                        gh.child_visits.append([int(vis[t, i, a]) / total if legal_mask[t, i, a] else 0 for a in range(A)])
+                        gh.root_values.append(float(vals[t, i]) if total else 0)
             histories.append(gh)
         return histories
 
