@@ -403,3 +403,45 @@ def test_zero_simulations(backend):
         obs = synthetic.observations(B, net.input_shape, seed=3)
         res = engine.run(list(obs), [list(cfg.action_space)] * B, [0] * B, True, [numpy.random.RandomState(i) for i in range(B)])
         assert (res.visit_counts == 0).all() and (res.root_values == 0).all() and (res.max_tree_depth == 0).all()
+
+
+@pytest.mark.parametrize("name,B", [("tictactoe", 1024), ("connect4", 1024)])
+def test_full_size_residual_configs(backend, name, B):
+    """
+    BASELINE configs C3 (tic-tac-toe, 1024 trees x 25 simulations) and C4 (connect4, 1024 x 200) at full size
+    on the whole-search kernel: size-independent invariants, determinism, and a sample of trees against the
+    CPU oracle (the reference's algorithm with its torch network).
+    """
+    cfg = configs.BY_NAME[name]()
+    S = cfg.num_simulations
+    net = models.MuZeroNetwork(cfg)
+    sd = synthetic.fill_state_dict(net.state_dict(), 21)
+    net.set_weights(sd)
+    engine = self_play.BatchedMCTS(cfg, net, B)
+    assert backend.lib.mzx_search_fused_supported(engine.handle(B)) == 2
+    obs = synthetic.observations(B, net.input_shape, seed=77)
+    rs = numpy.random.RandomState(8)
+    A = len(cfg.action_space)
+    legal = [sorted(rs.choice(A, size=rs.randint(2, A + 1), replace=False).tolist()) for _ in range(B)]
+    to_play = [int(i % 2) for i in range(B)]
+    res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(4000 + i) for i in range(B)])
+    _tree_invariants(cfg, res, S)
+    for i in range(B):
+        assert set(numpy.nonzero(res.visit_counts[i])[0]).issubset(set(legal[i]))
+    res2 = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(4000 + i) for i in range(B)])
+    assert numpy.array_equal(res.visit_counts, res2.visit_counts)
+    assert numpy.array_equal(res.root_values.view(numpy.int64), res2.root_values.view(numpy.int64))
+    onet = net_oracle.make_oracle_network(cfg, sd)
+    sample = list(range(0, B, 128))
+    same = 0
+    for i in sample:
+        ev = net_oracle.NetworkEvaluator(onet, cfg.support_size)
+        tree = mcts_oracle.run_search(cfg, ev, obs[i], legal[i], to_play[i], True, numpy.random.RandomState(4000 + i))
+        match = tree.root_visit_counts(cfg.action_space) == list(res.visit_counts[i])
+        same += int(match)
+        if match:
+            rv = tree.node_value(0)
+            assert abs(res.root_values[i] - rv) < 10 * TOL * max(1.0, abs(rv))
+    print(f"{name}: visit-count match rate vs oracle {same}/{len(sample)}")
+    # fp32 summation order differs between implementations; with 200 simulations a near-tie may flip on a tree
+    assert same >= len(sample) - 2
