@@ -408,6 +408,14 @@ struct NetIndex {
   int32_t in_nodes = 1, out_nodes = 1; // nodes per sample of nb.in / nb.hidden (1 = dense tensors)
 };
 
+// Latency experiments (profiles/r01_rz_latency_experiments.txt) are compiled in only on request: even a
+// never-taken uniform branch per layer costs a few percent on small networks.
+#ifdef MZX_RZ_EXPERIMENT
+#define RZ_DBG(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define RZ_DBG(a, bit) false
+#endif
+
 struct RzArgs {
   int32_t n_ops, T, batch, num_actions;
   int32_t H, W, HW, PW, Cs, slot_ts, tree_floats, mpad, scratch_floats;
@@ -416,7 +424,8 @@ struct RzArgs {
   int32_t out_off[3], out_ts[3], out_n[3];
   int32_t hidden_floats;          // C * H * W
   int32_t in_nodes, out_nodes;    // nodes per sample of the in / hidden-out tensors (1 = dense)
-  int32_t dbg;                    // latency experiments only (MZX_RZ_DBG): 1 skip the K loops, 2 skip the epilogues
+  int32_t dbg;                    // latency experiments (builds with -DMZX_RZ_EXPERIMENT only, env MZX_RZ_DBG):
+                                  // 1 skip the K loops, 2 skip the epilogues, 4 skip the layer GEMMs, 8 skip the barriers
   int32_t dump_op;                // >= 0: stop after this op and copy its output to `dump`; -2: cycle profile
                                   // (workgroup 0 writes s_memtime stamps after staging, input load and each op)
   int32_t w_floats, small_floats; // sizes of the program's weight image / small image
@@ -529,7 +538,7 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
       for (int r = 0; r < 4; ++r) e_rs[i][r] = res ? res[e_ra[i][r] + n] : 0.f;
   }
   RZ_FINE(2)
-  if (!(a.dbg & 1)) {
+  if (!RZ_DBG(a, 1)) {
   f32x4 a0[MT], a1[MT], b0, b1, b2, b3;
   load_b(0, b0);
   load_b(1, b1);
@@ -560,7 +569,7 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
   }
   if (MT == 1) acc[0] = acc[0] + acc_odd;
   RZ_FINE(3)
-  if (a.dbg & 2) return;
+  if (RZ_DBG(a, 2)) return;
   // ---- epilogue: every per-layer variation (BatchNorm or not, bias or not, residual or not, ReLU or not,
   // output layout) is turned into DATA before the element loop (identity scale / zero bias / -inf floor /
   // base + stride addressing), so the loop body is straight-line code: no branch per element

@@ -103,9 +103,9 @@ rz_search_kernel(const RzSearchArgs sa) {
     RZS_PROF(2)
     for (int o = 0; o < a.n_ops; ++o) {
       const RzOp op = rz_fetch_op(cx.simg, o);   // from the LDS-resident program image (measured faster than scalar loads from L2)
-      if (op.kind == RZ_GEMM) { if (!(a.dbg & 4)) rz_gemm<WLDS, NW>(op, a, cx); }
+      if (op.kind == RZ_GEMM) { if (!RZ_DBG(a, 4)) rz_gemm<WLDS, NW>(op, a, cx); }
       else rz_scale<NW>(op, a, cx, b0, ntree, sel_leaf, true);
-      if (!(a.dbg & 8)) __syncthreads();
+      if (!RZ_DBG(a, 8)) __syncthreads();
     }
     RZS_PROF(3)
 
