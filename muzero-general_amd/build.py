@@ -37,7 +37,10 @@ def build(force=False, verbose=True):
     if not force and up_to_date():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-x", "hip"] + sources() + ["-o", OUT]
+    # MZX_CXXFLAGS: extra flags, e.g. -DMZX_RZ_EXPERIMENT for the instrumented build that
+    # tools/resnet_phase_profile.py (intra-operator stamps) and the MZX_RZ_DBG latency experiments need
+    extra = os.environ.get("MZX_CXXFLAGS", "").split()
+    cmd = [hipcc] + FLAGS + extra + ["-x", "hip"] + sources() + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

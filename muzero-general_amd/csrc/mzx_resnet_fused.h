@@ -466,7 +466,11 @@ template <int MT, bool WLDS>
 __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, const RzCtx& cx, int nt, int mt0,
                                               int mt_step) {
   const int lane = cx.lane, T = cx.T;
+#ifdef MZX_RZ_EXPERIMENT
 #define RZ_FINE(k) if (cx.fine && cx.tid == 0) cx.fine[k] = __builtin_readcyclecounter();
+#else
+#define RZ_FINE(k)
+#endif
   RZ_FINE(1)
   const bool pos_rows = (op.rows == RZ_ROWS_POS);
   const int rows = pos_rows ? T * a.HW : T;

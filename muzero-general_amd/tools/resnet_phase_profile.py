@@ -2,6 +2,10 @@
 Per-operator shader-clock profile of the fused residual engine (workgroup 0), on the GPU box:
 
     python muzero-general_amd/tools/resnet_phase_profile.py c3 1024
+
+The intra-operator stamps need the instrumented build
+(MZX_CXXFLAGS=-DMZX_RZ_EXPERIMENT python muzero-general_amd/build.py --force); the per-operator totals
+work with the product build.
 """
 import os
 import sys
