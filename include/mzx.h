@@ -228,6 +228,34 @@ typedef struct mzx_tree_dump {
 int mzx_search_dump(mzx_search* s, const mzx_tree_dump* dump, void* d_arena, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Observation pipeline on the device (csrc/mzx_obs.h).
+ * mzx_obs_stack replaces GameHistory.get_stacked_observations (self_play.py:513-550) for n_out
+ * positions at once, reading a device-resident frame store instead of the Python history lists:
+ *   d_frames  [ring][num_games][channels][height][width] fp32,  d_actions [ring][num_games] int32;
+ *   the observation / action of game g at history index t live in slot t % ring
+ *   (action_history convention of the reference: index 0 holds the leading 0, self_play.py:118).
+ * Sample n is (game, index) = (d_game[n], d_time[n]); a NULL d_game means n % num_games, a NULL
+ * d_time means time0 + n / num_games.  The caller guarantees 0 <= index and that the frames
+ * index - stacked_observations .. index are present (ring >= stacked_observations + 1).
+ *   d_out [n_out][channels * (stacked + 1) + stacked][height][width] fp32 = the reference's array
+ *   after torch.tensor(...).float() (self_play.py:280-285), bit for bit.
+ * mzx_support_to_scalar = models.support_to_scalar (models.py:645-666) of `rows` rows of
+ * 2 * support_size + 1 logits -> d_out[rows] (Reanalyse's value decode, replay_buffer.py:361-367).
+ * ------------------------------------------------------------------------- */
+typedef struct mzx_obs_layout {
+  int32_t channels, height, width; /* config.observation_shape */
+  int32_t stacked_observations;    /* config.stacked_observations */
+  int32_t action_space_size;       /* len(config.action_space) */
+  int32_t num_games;               /* games interleaved in the frame store */
+  int32_t ring;                    /* history slots per game */
+} mzx_obs_layout;
+int64_t mzx_obs_stacked_floats(const mzx_obs_layout* layout); /* floats per stacked sample; 0 if invalid */
+int mzx_obs_stack(const mzx_obs_layout* layout, const float* d_frames, const int32_t* d_actions,
+                  const int32_t* d_game, const int32_t* d_time, int32_t time0, int32_t n_out, float* d_out,
+                  void* stream);
+int mzx_support_to_scalar(const float* d_logits, int32_t rows, int32_t support_size, float* d_out, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Per-game random streams (host side, no GPU): replaces the numpy.random calls of one
  * self-play actor -- numpy.random.seed (self_play.py:22), numpy.random.dirichlet (:473), the
  * numpy.random.choice(ties) of the search (:371, drawn on the device from the tape this produces)

@@ -8,6 +8,7 @@
 #include <new>
 #include <string>
 
+#include "mzx_obs.h"
 #include "mzx_rng.h"
 #include "mzx_search.h"
 #ifndef MZX_HOSTCHECK
@@ -363,6 +364,59 @@ int mzx_search_dump(mzx_search* s, const mzx_tree_dump* dump, void* d_arena, voi
   const ArenaView v = arena_view(s, d_arena);
   DumpOp op;
   op.arena = v.arena; op.p = v.p; op.d = *dump;
+  MZX_TRY_LAUNCH(launch<64>(op, (stream_t)stream));
+  return MZX_OK;
+}
+
+// ------------------------------------------------------- observation pipeline
+
+static bool obs_layout_ok(const mzx_obs_layout* L) {
+  return L && L->channels >= 1 && L->height >= 1 && L->width >= 1 && L->stacked_observations >= 0 &&
+         L->action_space_size >= 1 && L->num_games >= 1 && L->ring >= 1 &&
+         (int64_t)L->channels * (L->stacked_observations + 1) + L->stacked_observations < (1 << 20);
+}
+
+int64_t mzx_obs_stacked_floats(const mzx_obs_layout* L) {
+  if (!obs_layout_ok(L)) return 0;
+  return ((int64_t)L->channels * (L->stacked_observations + 1) + L->stacked_observations) * L->height * L->width;
+}
+
+extern "C++" {
+template <int VEC>
+static int obs_stack_launch(const mzx_obs_layout* L, const float* d_frames, const int32_t* d_actions,
+                            const int32_t* d_game, const int32_t* d_time, int32_t time0, int32_t n_out, float* d_out,
+                            stream_t stream) {
+  ObsStackOp<VEC> op;
+  op.frames = d_frames; op.actions = d_actions; op.game = d_game; op.time = d_time; op.out = d_out;
+  op.time0 = time0; op.C = L->channels; op.hwv = L->height * L->width / VEC; op.k = L->stacked_observations;
+  op.A = L->action_space_size; op.G = L->num_games; op.ring = L->ring; op.n_out = n_out;
+  op.c_out = L->channels * (L->stacked_observations + 1) + L->stacked_observations;
+  MZX_TRY_LAUNCH(launch<256>(op, stream));
+  return MZX_OK;
+}
+}  // extern "C++"
+
+int mzx_obs_stack(const mzx_obs_layout* L, const float* d_frames, const int32_t* d_actions, const int32_t* d_game,
+                  const int32_t* d_time, int32_t time0, int32_t n_out, float* d_out, void* stream) {
+  if (!obs_layout_ok(L)) { set_error("obs_stack: invalid layout"); return MZX_ERR_INVALID; }
+  if (n_out < 0 || time0 < 0) { set_error("obs_stack: negative n_out / time0"); return MZX_ERR_INVALID; }
+  if (n_out == 0) return MZX_OK;
+  if (!d_frames || !d_out || (L->stacked_observations > 0 && !d_actions)) { set_error("obs_stack: missing buffer"); return MZX_ERR_INVALID; }
+  if (!d_time && L->ring < L->stacked_observations + 1 && (int64_t)time0 + (n_out - 1) / L->num_games >= L->ring) {
+    set_error("obs_stack: ring %d cannot hold %d stacked observations at index %d", L->ring, L->stacked_observations, time0);
+    return MZX_ERR_INVALID;
+  }
+  const bool vec = (L->height * L->width) % 4 == 0 && ((uintptr_t)d_frames % 16) == 0 && ((uintptr_t)d_out % 16) == 0;
+  return vec ? obs_stack_launch<4>(L, d_frames, d_actions, d_game, d_time, time0, n_out, d_out, (stream_t)stream)
+             : obs_stack_launch<1>(L, d_frames, d_actions, d_game, d_time, time0, n_out, d_out, (stream_t)stream);
+}
+
+int mzx_support_to_scalar(const float* d_logits, int32_t rows, int32_t support_size, float* d_out, void* stream) {
+  if (rows < 0 || support_size < 0) { set_error("support_to_scalar: negative argument"); return MZX_ERR_INVALID; }
+  if (rows == 0) return MZX_OK;
+  if (!d_logits || !d_out) { set_error("support_to_scalar: missing buffer"); return MZX_ERR_INVALID; }
+  SupportToScalarOp op;
+  op.logits = d_logits; op.out = d_out; op.rows = rows; op.support_size = support_size;
   MZX_TRY_LAUNCH(launch<64>(op, (stream_t)stream));
   return MZX_OK;
 }

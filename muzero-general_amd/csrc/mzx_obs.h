@@ -1,0 +1,81 @@
+// mzx_obs.h -- observation pipeline on the device.
+//
+// GameHistory.get_stacked_observations (/root/reference/self_play.py:513-550) builds the network
+// input of a position from the game's history: the current observation followed, for the k =
+// config.stacked_observations previous positions (most recent first), by that observation and a
+// constant plane  action / len(action_space)  -- or zeros before the start of the game.  With
+// config.stacked_observations = 32 (games/atari.py:30) that is 131 planes of 96x96: 4.8 MB per
+// position, 36x the one new frame a move actually adds.  The host mirror therefore keeps the frames
+// of a shard in HBM (one upload of the NEW frame per move) and this operator assembles the stacked
+// inputs there: pure HBM-bound byte movement, one 16-byte load + store per thread.
+//
+// Frame store layout: frames[ring][G][C][H][W] fp32, actions[ring][G] int32; frame / action of game
+// g at history index t live in slot t % ring (ring >= k + 1 for self-play; ring = len(history) for
+// whole-game use such as Reanalyse, replay_buffer.py:343-360).
+// Output n: [C * (k + 1) + k][H][W], sample n = (game[n] or n % G, time[n] or time0 + n / G).
+//
+// Values: a frame element is copied; the action plane is float(double(action) / double(A)) -- numpy
+// evaluates ones_like(plane) * action / A in binary64 and the caller's torch.tensor(...).float()
+// rounds once to fp32 (self_play.py:280-285).
+#pragma once
+#include "mzx_platform.h"
+#include "mzx_tree.h"
+
+namespace mzx {
+
+template <int VEC>
+struct ObsStackOp {
+  const float* frames;
+  const int32_t* actions;
+  const int32_t* game;   // nullable
+  const int32_t* time;   // nullable
+  float* out;
+  int32_t time0, C, hwv /* H*W / VEC */, k, A, G, ring, n_out, c_out;
+
+  MZX_HD size_t size() const { return (size_t)n_out * c_out * hwv; }
+  MZX_HD void operator()(size_t i) const {
+    const int p = (int)(i % (size_t)hwv);
+    const size_t plane = i / (size_t)hwv;
+    const int c = (int)(plane % (size_t)c_out), n = (int)(plane / (size_t)c_out);
+    const int g = game ? game[n] : n % G;
+    const int t = time ? time[n] : time0 + n / G;
+    const int64_t plane_floats = (int64_t)hwv * VEC;
+    const float* src = nullptr;
+    float fill = 0.f;
+    if (c < C) {
+      src = frames + (((int64_t)(t % ring) * G + g) * C + c) * plane_floats;
+    } else {
+      const int j = (c - C) / (C + 1), r = (c - C) % (C + 1);
+      const int past = t - 1 - j;
+      if (past >= 0) {
+        if (r < C) src = frames + (((int64_t)(past % ring) * G + g) * C + r) * plane_floats;
+        else fill = (float)((double)actions[(int64_t)((past + 1) % ring) * G + g] / (double)A);
+      }
+    }
+    float* dst = out + (int64_t)plane * plane_floats + (int64_t)p * VEC;
+    if (VEC == 4) {
+      struct alignas(16) F4 { float x, y, z, w; };
+      F4 v = {fill, fill, fill, fill};
+      if (src) v = *(const F4*)(src + (int64_t)p * 4);
+      *(F4*)dst = v;
+    } else {
+      dst[0] = src ? src[p] : fill;
+    }
+  }
+};
+
+// models.support_to_scalar (models.py:645-666) of `rows` logit rows, one row per thread, in the
+// search kernels' canonical summation order (mzx_tree.h) -- Reanalyse's value decode
+// (replay_buffer.py:361-367).
+struct SupportToScalarOp {
+  const float* logits;
+  float* out;
+  int32_t rows, support_size;
+
+  MZX_HD size_t size() const { return (size_t)rows; }
+  MZX_HD void operator()(size_t i) const {
+    out[i] = support_to_scalar(logits + (int64_t)i * (2 * support_size + 1), support_size);
+  }
+};
+
+}  // namespace mzx

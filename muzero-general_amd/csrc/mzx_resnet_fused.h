@@ -946,6 +946,10 @@ inline RzLaunch rz_prepare(const mzx_net* net, const RzProgram& R, const float* 
   // networks): latencies of one wave (weight prefetch, epilogue, barriers) hide behind the other's MFMAs
   const int tiles = ((a.T * g.HW + 15) / 16) * ((net->cfg.channels + 15) / 16);
   L.eight = tiles >= 16 && net->rz_waves != 4;
+  if (rz_env_int("MZX_RZ_WLDS", 1) == 0 && wlds) {   // A/B knob: weights from L2 although they would fit in LDS
+    wlds = false;
+    L.lds = (size_t)4 * rz_lds_floats(g, R, a.T, false);
+  }
   const int force_w = rz_env_int("MZX_RZ_WAVES", 0);
   if (force_w == 4) L.eight = false;
   if (force_w == 8) L.eight = true;

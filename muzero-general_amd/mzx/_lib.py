@@ -59,6 +59,13 @@ class TreeDump(ctypes.Structure):
     ]
 
 
+class ObsLayout(ctypes.Structure):
+    _fields_ = [
+        ("channels", c_i32), ("height", c_i32), ("width", c_i32), ("stacked_observations", c_i32),
+        ("action_space_size", c_i32), ("num_games", c_i32), ("ring", c_i32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/mzx.h declares
 PROTOTYPES = {
     "mzx_abi_version": (ctypes.c_int, []),
@@ -95,6 +102,9 @@ PROTOTYPES = {
     "mzx_search_lockstep_apply": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mzx_search_finish": (ctypes.c_int, [c_vp, ctypes.POINTER(SearchIO), c_vp, c_vp]),
     "mzx_search_dump": (ctypes.c_int, [c_vp, ctypes.POINTER(TreeDump), c_vp, c_vp]),
+    "mzx_obs_stacked_floats": (c_i64, [ctypes.POINTER(ObsLayout)]),
+    "mzx_obs_stack": (ctypes.c_int, [ctypes.POINTER(ObsLayout), c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "mzx_support_to_scalar": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "mzx_rng_create": (ctypes.c_int, [c_i32, ctypes.POINTER(c_vp)]),
     "mzx_rng_destroy": (None, [c_vp]),
     "mzx_rng_seed": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp]),

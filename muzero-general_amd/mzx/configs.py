@@ -45,6 +45,7 @@ class HotPathConfig:
         self.training_steps = 10000
         self.self_play_delay = 0
         self.ratio = None
+        self.use_last_model_value = True   # every BASELINE game file but breakout (games/breakout.py:109)
         self.__dict__.update(kw)
 
     temperature_schedule = "fractions"
@@ -119,7 +120,7 @@ def breakout(**kw):
         reduced_channels_reward=4, reduced_channels_value=4, reduced_channels_policy=4,
         resnet_fc_reward_layers=[16], resnet_fc_value_layers=[16], resnet_fc_policy_layers=[16],
         encoding_size=10, fc_value_layers=[], fc_policy_layers=[], training_steps=int(1000e3),
-        temperature_schedule="breakout",
+        temperature_schedule="breakout", use_last_model_value=False,
     )
     base.update(kw)
     return HotPathConfig(**base)

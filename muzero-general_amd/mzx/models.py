@@ -34,8 +34,19 @@ def dict_to_cpu(dictionary):
     return cpu_dict
 
 
-def support_to_scalar(logits, support_size):
-    """models.py:645-666 (host/diagnostic use; the search decodes on the device)."""
+def support_to_scalar(logits, support_size, _backend=None):
+    """
+    models.py:645-666.  Device tensors are decoded by the library (``mzx_support_to_scalar``, the
+    search kernels' own decode); host tensors take the torch expression below (diagnostic use).
+    """
+    if logits.is_cuda or _backend is not None:
+        be = _backend if _backend is not None else _lib.default_backend()
+        x = logits.to(be.device, torch.float32).contiguous()
+        if x.dim() != 2 or x.shape[1] != 2 * support_size + 1:
+            raise ValueError(f"expected [rows, {2 * support_size + 1}] logits, got {tuple(x.shape)}")
+        out = be.empty((x.shape[0], 1), torch.float32)
+        be.lib.check(be.lib.mzx_support_to_scalar(be.ptr(x), x.shape[0], int(support_size), be.ptr(out), be.stream()))
+        return out
     probabilities = torch.softmax(logits, dim=1)
     support = torch.arange(-support_size, support_size + 1, device=logits.device).float().expand(probabilities.shape)
     x = torch.sum(support * probabilities, dim=1, keepdim=True)

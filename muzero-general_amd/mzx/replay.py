@@ -7,9 +7,19 @@ rewards (``compute_target_value``, :230-262): ~10 ms per 500-move game, i.e. ten
 of thousands of games, far more than playing them.  ``fill_initial_priorities`` computes the SAME numbers
 (same binary64 operations in the same order per position; the loop over the reward horizon is a vector
 operation over all positions) and stores them on the ``GameHistory``; ``save_game`` then takes its
-"priorities already present" branch (:35-37).  The stock buffer, trainer and reanalyse stay untouched.
+"priorities already present" branch (:35-37).  The stock buffer and trainer stay untouched.
+
+``Reanalyse`` (section 8f, second row) mirrors the reference worker of the same name
+(replay_buffer.py:306-373): same constructor and ``reanalyse(replay_buffer, shared_storage)`` loop, with the
+per-game work -- stacked observations of every position, one batched ``initial_inference``, value decode --
+on the device (``mzx.observations.stack_history`` + the network kernels + ``mzx_support_to_scalar``).
 """
+import time
+
 import numpy
+import torch
+
+from . import models, observations
 
 
 def n_step_values(game_history, config):
@@ -66,3 +76,55 @@ def fill_initial_priorities(game_history, config):
     game_history.priorities = numpy.array(priorities, dtype="float32")
     game_history.game_priority = numpy.max(game_history.priorities)
     return True
+
+
+def _remote(method, *args, **kwargs):
+    """Call an actor method (``.remote`` + ``ray.get``) or a plain method alike."""
+    if hasattr(method, "remote"):
+        import ray
+        return ray.get(method.remote(*args, **kwargs))
+    return method(*args, **kwargs)
+
+
+class Reanalyse:
+    """
+    replay_buffer.py:306-373 -- refreshes ``reanalysed_predicted_root_values`` of stored games with the
+    latest network.  ``reanalyse_game`` is the per-game step (new, reusable); ``reanalyse`` the worker loop.
+    """
+
+    def __init__(self, initial_checkpoint, config, _backend=None):
+        self.config = config
+        # Fix random generator seed (replay_buffer.py:318-319)
+        numpy.random.seed(self.config.seed)
+        torch.manual_seed(self.config.seed)
+        # the network lives on the GPU whatever config.reanalyse_on_gpu says: the engine has no CPU path
+        self.model = models.MuZeroNetwork(self.config, _backend=_backend)
+        self.model.set_weights(initial_checkpoint["weights"])
+        self.model.eval()
+        self.num_reanalysed_games = initial_checkpoint["num_reanalysed_games"]
+
+    def reanalyse_game(self, game_history):
+        """replay_buffer.py:343-367: float32 array [len(root_values)] of decoded root values under the current weights."""
+        n = len(game_history.root_values)
+        backend = self.model.backend
+        stacked = observations.stack_history(backend, self.config, game_history.observation_history,
+                                             game_history.action_history, count=n)
+        if n == 0:
+            return numpy.zeros((0,), numpy.float32)
+        value_logits = self.model.initial_inference(stacked)[0]
+        values = models.support_to_scalar(value_logits, self.config.support_size, _backend=backend)
+        return torch.squeeze(values).detach().cpu().numpy()
+
+    def reanalyse(self, replay_buffer, shared_storage):
+        get = lambda key: _remote(shared_storage.get_info, key)
+        while get("num_played_games") < 1:
+            time.sleep(0.1)
+        while get("training_step") < self.config.training_steps and not get("terminate"):
+            self.model.set_weights(get("weights"))
+            game_id, game_history, _ = _remote(replay_buffer.sample_game, force_uniform=True)
+            # Use the last model to provide a fresher, stable n-step value (See paper appendix Reanalyze)
+            if self.config.use_last_model_value:
+                game_history.reanalysed_predicted_root_values = self.reanalyse_game(game_history)
+            _remote(replay_buffer.update_game_history, game_id, game_history)
+            self.num_reanalysed_games += 1
+            _remote(shared_storage.set_info, "num_reanalysed_games", self.num_reanalysed_games)

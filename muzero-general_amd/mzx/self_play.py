@@ -34,6 +34,7 @@ import numpy
 import torch
 
 from . import _lib, _rng, models, replay
+from . import observations as observations_mod
 
 TAPE_WORDS = 64
 
@@ -316,7 +317,11 @@ class BatchedMCTS:
                     noise[i, : n_legal[i]] = rngs[i].dirichlet([cfg.root_dirichlet_alpha] * int(n_legal[i]))
                 states.append(rngs[i].get_state())
                 tape[i] = rngs[i].randint(0, 2 ** 32, size=TAPE_WORDS, dtype=numpy.uint32)
-        obs = numpy.ascontiguousarray(numpy.asarray(observations, dtype=numpy.float32).reshape(B, -1))
+        if isinstance(observations, torch.Tensor):   # already stacked on the device (mzx.observations.FrameStore)
+            assert observations.shape[0] == B
+            obs = observations.reshape(B, -1)
+        else:
+            obs = numpy.ascontiguousarray(numpy.asarray(observations, dtype=numpy.float32).reshape(B, -1))
         lib = self.backend.lib
         io, out, keep = self.make_io(B, obs, legal, numpy.asarray(to_play, numpy.int32), noise, tape)
         arena = self.arena(B)
@@ -479,6 +484,15 @@ class SelfPlay:
             observations[s] = observation
             if render:
                 self.games[s].render()
+        # stacked observations of a self-play shard are assembled on the device from a frame store
+        # (one upload of the new frames per move) instead of per-game numpy concatenations
+        store = None
+        if cfg.stacked_observations > 0 and opponent == "self":
+            store = observations_mod.FrameStore(cfg, len(self.games), self.model.backend)
+            frame = numpy.zeros((len(self.games),) + tuple(cfg.observation_shape), numpy.float32)
+            for s in slots:
+                frame[s] = numpy.asarray(observations[s])
+            store.push(frame, None)
         active = list(slots)
         while active:
             searching, stacked = [], []
@@ -489,7 +503,7 @@ class SelfPlay:
                     f"Observation should be 3 dimensionnal instead of {len(numpy.array(observation).shape)} dimensionnal. Got observation of shape: {numpy.array(observation).shape}"
                 assert numpy.array(observation).shape == cfg.observation_shape, \
                     f"Observation should match the observation_shape defined in MuZeroConfig. Expected {cfg.observation_shape} but got {numpy.array(observation).shape}."
-                st = gh.get_stacked_observations(-1, cfg.stacked_observations, A)
+                st = None if store is not None else gh.get_stacked_observations(-1, cfg.stacked_observations, A)
                 if opponent == "self" or muzero_player == self.games[s].to_play():
                     searching.append(s)
                     stacked.append(st)
@@ -499,7 +513,8 @@ class SelfPlay:
             if searching:
                 t0 = time.perf_counter()
                 result = self.engine.run(
-                    stacked, [self.games[s].legal_actions() for s in searching],
+                    stacked if store is None else store.stacked(searching),
+                    [self.games[s].legal_actions() for s in searching],
                     [self.games[s].to_play() for s in searching], True,
                     (self.bank, searching) if self.bank is not None else [self.rngs[s] for s in searching],
                 )
@@ -536,6 +551,12 @@ class SelfPlay:
                 observations[s] = observation
                 if not done and len(gh.action_history) <= cfg.max_moves:
                     still.append(s)
+            if store is not None and still:
+                moved = numpy.zeros(len(self.games), numpy.int32)
+                for s in active:
+                    frame[s] = numpy.asarray(observations[s])
+                    moved[s] = histories[s].action_history[-1]
+                store.push(frame, moved)
             active = still
         return [histories[s] for s in slots]
 
@@ -556,9 +577,13 @@ class SelfPlay:
         alive = numpy.ones(B, bool)
         length = numpy.zeros(B, numpy.int64)
         move = 0
+        store = None
+        if k > 0:   # frames stay in HBM; the stacked inputs are assembled there (csrc/mzx_obs.h)
+            store = observations_mod.FrameStore(cfg, B, self.model.backend)
+            store.push(obs, None)
         while alive.any() and move + 1 <= cfg.max_moves:      # len(action_history) <= max_moves, :129
             idx = numpy.nonzero(alive)[0]
-            stacked = self._stacked_batch(obs_hist, act_hist, k, A)[idx]
+            stacked = store.stacked(idx) if store is not None else obs_hist[-1][idx]
             legal = g.legal_actions()
             legal = legal[idx] if isinstance(legal, numpy.ndarray) else [legal[i] for i in idx]
             t0 = time.perf_counter()
@@ -584,6 +609,8 @@ class SelfPlay:
                     mask[r, acts] = True
             visits_hist.append(visits); value_hist.append(values); legal_hist.append(mask); alive_hist.append(alive.copy())
             obs_hist.append(numpy.asarray(obs)); act_hist.append(actions)
+            if store is not None:
+                store.push(obs_hist[-1], actions)
             rew_hist.append(numpy.asarray(reward)); tp_hist.append(numpy.asarray(g.to_play()).astype(numpy.int64))
             length[idx] += 1
             alive = alive & ~numpy.asarray(done, bool)

@@ -215,8 +215,88 @@ def make_net_fixture(name, game, weight_seed, batch, overrides=None, state_dict=
     print("net", name, "params", meta["n_float_params"])
 
 
+class _Remote:
+    """``actor.method.remote(...)`` of the ray shim: a plain call."""
+
+    def __init__(self, fn):
+        self.remote = fn
+
+
+def reference_reanalyse(cfg, weights, game_history):
+    """
+    Run the UNMODIFIED Reanalyse.reanalyse loop (replay_buffer.py:328-373) for exactly one game: stub
+    storage / buffer objects stand in for the ray actors, the loop ends after its first pass.
+    """
+    ref_shim.load()
+    import replay_buffer as ref_replay_buffer  # the reference module
+
+    class Storage:
+        def __init__(self):
+            self.passes = 0
+            self.info = {"num_played_games": 1, "terminate": False, "weights": weights}
+            self.get_info = _Remote(self._get)
+            self.set_info = _Remote(self._set)
+
+        def _get(self, key):
+            if key == "training_step":
+                self.passes += 1
+                return 0 if self.passes == 1 else cfg.training_steps
+            return self.info[key]
+
+        def _set(self, key, value=None):
+            self.info[key] = value
+
+    class Buffer:
+        def __init__(self):
+            self.updated = None
+            self.sample_game = _Remote(lambda force_uniform=False: (0, game_history, 1.0))
+            self.update_game_history = _Remote(self._update)
+
+        def _update(self, game_id, gh):
+            self.updated = gh
+
+    buffer = Buffer()
+    worker = ref_replay_buffer.Reanalyse({"weights": weights, "num_reanalysed_games": 0}, cfg)
+    worker.reanalyse(buffer, Storage())
+    return numpy.array(buffer.updated.reanalysed_predicted_root_values)
+
+
+def make_obs_fixture():
+    """GameHistory.get_stacked_observations (self_play.py:513-550) of the unmodified reference, every index."""
+    _, self_play = ref_shim.load()
+    cases = [
+        dict(shape=(3, 3, 3), dtype="int32", moves=6, k=2, A=9),      # tictactoe planes, HW % 4 != 0
+        dict(shape=(1, 1, 4), dtype="float32", moves=5, k=3, A=2),    # cartpole row
+        dict(shape=(3, 8, 8), dtype="float64", moves=4, k=7, A=4),    # k longer than the game
+        dict(shape=(2, 4, 6), dtype="float32", moves=9, k=1, A=5),
+        dict(shape=(3, 6, 7), dtype="float64", moves=3, k=0, A=7),    # no stacking
+    ]
+    data = {}
+    for c, case in enumerate(cases):
+        rs = numpy.random.RandomState(900 + c)
+        gh = self_play.GameHistory()
+        T = case["moves"]
+        for t in range(T + 1):
+            if case["dtype"] == "int32":
+                o = rs.randint(-1, 2, size=case["shape"]).astype("int32")
+            else:
+                o = rs.standard_normal(case["shape"]).astype(case["dtype"])
+            gh.observation_history.append(o)
+            gh.action_history.append(0 if t == 0 else int(rs.randint(0, case["A"])))
+        idx = list(range(T + 1)) + [-1, -2]
+        out = [torch.tensor(numpy.array(gh.get_stacked_observations(i, case["k"], case["A"]))).float().numpy()
+               for i in idx]
+        data[f"c{c}_history"] = numpy.array(gh.observation_history)
+        data[f"c{c}_actions"] = numpy.array(gh.action_history, numpy.int32)
+        data[f"c{c}_index"] = numpy.array(idx, numpy.int32)
+        data[f"c{c}_stacked"] = numpy.array(out)
+    data["meta"] = numpy.array(json.dumps(cases))
+    numpy.savez_compressed(os.path.join(OUT, "obs_stack.npz"), **data)
+    print("obs_stack cases", len(cases))
+
+
 def make_game_fixture(name, game, weight_seed, seed, overrides=None, synthetic_game=False,
-                      temperature=1.0):
+                      temperature=1.0, reanalyse=False):
     models, self_play = ref_shim.load()
     cfg = _config(game, **(overrides or {}))
     if synthetic_game:
@@ -237,6 +317,8 @@ def make_game_fixture(name, game, weight_seed, seed, overrides=None, synthetic_g
         root_values=numpy.array([float(v) for v in gh.root_values], numpy.float64),
         observation_history=numpy.array([numpy.array(o, dtype=numpy.float64) for o in gh.observation_history]),
     )
+    if reanalyse:  # the reference's Reanalyse worker on this very game (replay_buffer.py:328-373)
+        data["reanalysed_predicted_root_values"] = reference_reanalyse(cfg, weights, gh)
     meta = dict(game=game, weight_seed=weight_seed, seed=seed, overrides=overrides or {},
                 synthetic_game=synthetic_game, temperature=temperature)
     data["meta"] = numpy.array(json.dumps(meta))
@@ -281,6 +363,12 @@ def main():
     make_game_fixture("connect4", "connect4", 32, 6, overrides=dict(num_simulations=40))
     make_game_fixture("cartpole_synth", "cartpole", 33, 7, overrides=dict(max_moves=12),
                       synthetic_game=True)
+    # stacked observations (self_play.py:513-550 inside play_game) + the Reanalyse worker on the result
+    make_game_fixture("tictactoe_stacked", "tictactoe", 34, 8, overrides=dict(stacked_observations=2),
+                      reanalyse=True)
+    make_game_fixture("cartpole_synth_stacked", "cartpole", 35, 9,
+                      overrides=dict(max_moves=10, stacked_observations=3), synthetic_game=True, reanalyse=True)
+    make_obs_fixture()
 
 
 if __name__ == "__main__":

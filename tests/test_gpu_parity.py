@@ -100,7 +100,8 @@ def test_search_matches_reference(backend, name, mode, monkeypatch):
     common.test_search_matches_reference(backend, name)   # whole-search kernel (fully connected or residual)
 
 
-@pytest.mark.parametrize("name", ["tictactoe", "connect4", "cartpole_synth"])
+@pytest.mark.parametrize("name", ["tictactoe", "connect4", "cartpole_synth", "tictactoe_stacked",
+                                  "cartpole_synth_stacked"])
 def test_whole_game_matches_reference(backend, name):
     common.test_whole_game_matches_reference(backend, name)
 
@@ -445,3 +446,60 @@ def test_full_size_residual_configs(backend, name, B):
     print(f"{name}: visit-count match rate vs oracle {same}/{len(sample)}")
     # fp32 summation order differs between implementations; with 200 simulations a near-tie may flip on a tree
     assert same >= len(sample) - 2
+
+
+# ---- observation pipeline + Reanalyse: device twins of tests/test_observations.py
+
+import test_observations as obs_common  # noqa: E402
+
+
+def test_obs_stack_matches_reference_arrays(backend):
+    obs_common.test_stack_history_bit_exact(backend)
+
+
+@pytest.mark.parametrize("shape,k,A,G,moves", [((3, 3, 3), 2, 9, 5, 7), ((1, 1, 4), 3, 2, 3, 9), ((2, 4, 6), 4, 5, 4, 3),
+                                               ((3, 4, 4), 0, 3, 2, 4)])
+def test_frame_store_ring_bit_exact(backend, shape, k, A, G, moves):
+    obs_common.check_frame_store(backend, shape, k, A, G, moves)
+
+
+def test_frame_store_full_size_atari_shape(backend):
+    """games/atari.py geometry: 3x96x96 frames, 32 stacked -> 131 planes, 64 games; the ring wraps."""
+    obs_common.check_frame_store(backend, (3, 96, 96), 32, 4, 64, 35, probe={0, 31, 63})
+
+
+def test_obs_stack_rejects_bad_arguments(backend):
+    obs_common.test_obs_stack_rejects_bad_arguments(backend)
+
+
+def test_support_to_scalar_device(backend):
+    obs_common.test_support_to_scalar_matches_oracle(backend)
+
+
+@pytest.mark.parametrize("name", ["tictactoe_stacked", "cartpole_synth_stacked"])
+def test_reanalyse_matches_reference(backend, name):
+    obs_common.check_reanalyse(backend, name)
+
+
+def test_reanalyse_long_game_matches_oracle(backend):
+    """A 300-position connect4-shaped history in one batched initial_inference against the oracle network."""
+    cfg = configs.connect4(stacked_observations=1)
+    rs = numpy.random.RandomState(11)
+    gh = self_play.GameHistory()
+    T = 300
+    gh.observation_history = [rs.randint(-1, 2, size=cfg.observation_shape).astype("int32") for _ in range(T + 1)]
+    gh.action_history = [0] + [int(a) for a in rs.randint(0, len(cfg.action_space), size=T)]
+    gh.root_values = [0.0] * T
+    template = models.MuZeroNetwork(cfg).state_dict()
+    weights = synthetic.fill_state_dict(template, 5)
+    from mzx import replay
+    worker = replay.Reanalyse({"weights": weights, "num_reanalysed_games": 0}, cfg)
+    got = worker.reanalyse_game(gh)
+    net = net_oracle.make_oracle_network(cfg, weights)
+    A = len(cfg.action_space)
+    obs = numpy.array([mcts_oracle.stacked_observations(gh.observation_history, gh.action_history, i, 1, A) for i in range(T)])
+    with torch.no_grad():
+        want = torch.squeeze(net_oracle.support_to_scalar(net.initial_inference(torch.tensor(obs).float())[0],
+                                                          cfg.support_size)).numpy()
+    assert got.shape == want.shape == (T,)
+    assert numpy.allclose(got, want, atol=3 * TOL, rtol=3 * TOL), numpy.abs(got - want).max()

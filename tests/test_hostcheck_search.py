@@ -74,7 +74,8 @@ def load_game(name):
     return z, json.loads(str(z["meta"]))
 
 
-@pytest.mark.parametrize("name", ["tictactoe", "connect4", "cartpole_synth"])
+@pytest.mark.parametrize("name", ["tictactoe", "connect4", "cartpole_synth", "tictactoe_stacked",
+                                  "cartpole_synth_stacked"])
 def test_whole_game_matches_reference(backend, name):
     """SelfPlay.play_game: same GameHistory as the reference actor with the same seed."""
     z, meta = load_game(name)
