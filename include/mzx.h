@@ -183,6 +183,16 @@ typedef struct mzx_search_io {
  * num_simulations x {select, recurrent_inference, expand, backpropagate}. */
 int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_t arena_bytes, void* stream);
 
+/* MCTS.run(..., override_root_with=root) (self_play.py:275-277) for roots the caller expanded itself,
+ * as diagnose_model.py:57-74 does after a recurrent_inference: d_root_hidden [B][hidden_size],
+ * d_root_priors [B][A] (binary64 Node.prior of the root's children in slot order = order of
+ * io->d_legal_actions), d_root_reward [B] (Node.reward).  io->d_observation is not read and
+ * io->d_root_predicted_value not written (the reference reports None).  Exploration noise, the
+ * simulations and the outputs are those of mzx_search_run; always runs the per-operator path. */
+int mzx_search_run_from_roots(mzx_search* s, const mzx_search_io* io, const float* d_root_hidden,
+                              const double* d_root_priors, const double* d_root_reward, void* d_arena,
+                              int64_t arena_bytes, void* stream);
+
 /* Which implementation mzx_search_run uses, a set of flags:
  *   1  whole-search kernel: every simulation of the move in one launch.  mzx_search_fused_supported
  *      returns 1 for the LDS-resident fully connected kernel, 2 for the residual-network kernel

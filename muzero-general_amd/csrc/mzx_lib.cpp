@@ -309,6 +309,21 @@ int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_
   return search_run_generic(s, io, d_arena, (stream_t)stream);
 }
 
+int mzx_search_run_from_roots(mzx_search* s, const mzx_search_io* io, const float* d_root_hidden,
+                              const double* d_root_priors, const double* d_root_reward, void* d_arena,
+                              int64_t arena_bytes, void* stream) {
+  int rc = check_search_call(s, d_arena, arena_bytes, true);
+  if (rc) return rc;
+  if (!io || !io->d_legal_actions || !io->d_to_play || !io->d_tape || !io->d_visit_counts || !io->d_root_value ||
+      !io->d_info || !d_root_hidden || !d_root_priors || !d_root_reward) {
+    set_error("mzx_search_run_from_roots: missing buffer");
+    return MZX_ERR_INVALID;
+  }
+  RootOverride ov;
+  ov.hidden = d_root_hidden; ov.priors = d_root_priors; ov.reward = d_root_reward;
+  return search_run_generic(s, io, d_arena, (stream_t)stream, &ov);
+}
+
 int mzx_search_lockstep_begin(mzx_search* s, const mzx_search_io* io, const double* d_root_priors,
                               const double* d_root_reward, void* d_arena, int64_t arena_bytes, void* stream) {
   int rc = check_search_call(s, d_arena, arena_bytes, false);
@@ -391,6 +406,11 @@ static int obs_stack_launch(const mzx_obs_layout* L, const float* d_frames, cons
   op.time0 = time0; op.C = L->channels; op.hwv = L->height * L->width / VEC; op.k = L->stacked_observations;
   op.A = L->action_space_size; op.G = L->num_games; op.ring = L->ring; op.n_out = n_out;
   op.c_out = L->channels * (L->stacked_observations + 1) + L->stacked_observations;
+  op.pieces = (op.hwv + 64 * ObsStackOp<VEC>::UNROLL - 1) / (64 * ObsStackOp<VEC>::UNROLL);
+  if ((int64_t)n_out * op.c_out * op.pieces >= (int64_t)1 << 26) {   // 32-bit group index; split the call
+    set_error("obs_stack: %d samples x %d planes exceed one launch; stack in smaller batches", n_out, op.c_out);
+    return MZX_ERR_INVALID;
+  }
   MZX_TRY_LAUNCH(launch<256>(op, stream));
   return MZX_OK;
 }

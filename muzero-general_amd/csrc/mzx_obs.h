@@ -7,7 +7,7 @@
 // config.stacked_observations = 32 (games/atari.py:30) that is 131 planes of 96x96: 4.8 MB per
 // position, 36x the one new frame a move actually adds.  The host mirror therefore keeps the frames
 // of a shard in HBM (one upload of the NEW frame per move) and this operator assembles the stacked
-// inputs there: pure HBM-bound byte movement, one 16-byte load + store per thread.
+// inputs there: pure HBM-bound byte movement in 16-byte loads and stores.
 //
 // Frame store layout: frames[ring][G][C][H][W] fp32, actions[ring][G] int32; frame / action of game
 // g at history index t live in slot t % ring (ring >= k + 1 for self-play; ring = len(history) for
@@ -23,43 +23,58 @@
 
 namespace mzx {
 
+// Work split: one wavefront-sized group of 64 elements moves one 4 KB piece (UNROLL x 64 vectors) of
+// one output plane, so the (sample, plane) decode -- four 32-bit divisions -- is shared by UNROLL
+// 16-byte moves per thread and every load / store instruction of a wave covers 1 KB contiguous.
 template <int VEC>
 struct ObsStackOp {
+  static constexpr int UNROLL = 4;
   const float* frames;
   const int32_t* actions;
   const int32_t* game;   // nullable
   const int32_t* time;   // nullable
   float* out;
-  int32_t time0, C, hwv /* H*W / VEC */, k, A, G, ring, n_out, c_out;
+  int32_t time0, C, hwv /* H*W / VEC */, k, A, G, ring, n_out, c_out, pieces /* per plane */;
 
-  MZX_HD size_t size() const { return (size_t)n_out * c_out * hwv; }
+  MZX_HD size_t size() const { return (size_t)n_out * c_out * pieces * 64; }
   MZX_HD void operator()(size_t i) const {
-    const int p = (int)(i % (size_t)hwv);
-    const size_t plane = i / (size_t)hwv;
-    const int c = (int)(plane % (size_t)c_out), n = (int)(plane / (size_t)c_out);
+    const uint32_t lane = (uint32_t)i & 63u, grp = (uint32_t)(i >> 6);
+    const uint32_t plane = grp / (uint32_t)pieces, piece = grp % (uint32_t)pieces;
+    const int c = (int)(plane % (uint32_t)c_out), n = (int)(plane / (uint32_t)c_out);
     const int g = game ? game[n] : n % G;
     const int t = time ? time[n] : time0 + n / G;
     const int64_t plane_floats = (int64_t)hwv * VEC;
+    const int slot_t = t % ring;
     const float* src = nullptr;
     float fill = 0.f;
     if (c < C) {
-      src = frames + (((int64_t)(t % ring) * G + g) * C + c) * plane_floats;
+      src = frames + (((int64_t)slot_t * G + g) * C + c) * plane_floats;
     } else {
       const int j = (c - C) / (C + 1), r = (c - C) % (C + 1);
-      const int past = t - 1 - j;
-      if (past >= 0) {
-        if (r < C) src = frames + (((int64_t)(past % ring) * G + g) * C + r) * plane_floats;
-        else fill = (float)((double)actions[(int64_t)((past + 1) % ring) * G + g] / (double)A);
+      if (t - 1 - j >= 0) {                 // history index t - 1 - j; before the game: zeros
+        int slot = slot_t - 1 - j;          // its slot: (t - 1 - j) % ring without the division
+        if (slot < 0) slot += ring;         //   (j + 1 <= k < ring, or the ring holds the whole game)
+        if (r < C) {
+          src = frames + (((int64_t)slot * G + g) * C + r) * plane_floats;
+        } else {
+          int aslot = slot + 1;             // action_history[t - j]
+          if (aslot >= ring) aslot -= ring;
+          fill = (float)((double)actions[(int64_t)aslot * G + g] / (double)A);
+        }
       }
     }
-    float* dst = out + (int64_t)plane * plane_floats + (int64_t)p * VEC;
-    if (VEC == 4) {
-      struct alignas(16) F4 { float x, y, z, w; };
-      F4 v = {fill, fill, fill, fill};
-      if (src) v = *(const F4*)(src + (int64_t)p * 4);
-      *(F4*)dst = v;
-    } else {
-      dst[0] = src ? src[p] : fill;
+    float* dst = out + (int64_t)plane * plane_floats;
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint32_t p = piece * (64u * UNROLL) + (uint32_t)u * 64u + lane;
+      if (p >= (uint32_t)hwv) break;
+      if (VEC == 4) {
+        struct alignas(16) F4 { float x, y, z, w; };
+        F4 v = {fill, fill, fill, fill};
+        if (src) v = *(const F4*)(src + (int64_t)p * 4);
+        *(F4*)(dst + (int64_t)p * 4) = v;
+      } else {
+        dst[p] = src ? src[p] : fill;
+      }
     }
   }
 };

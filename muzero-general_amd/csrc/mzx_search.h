@@ -108,8 +108,17 @@ inline int search_finish(mzx_search* s, const mzx_search_io* io, void* d_arena, 
   return MZX_OK;
 }
 
+// Roots the caller expanded itself (MCTS.run(..., override_root_with=root), self_play.py:275-277):
+// prior per legal slot (binary64), reward and hidden state of each root replace initial_inference.
+struct RootOverride {
+  const float* hidden;    // [B][Hf]
+  const double* priors;   // [B][A] slot order
+  const double* reward;   // [B]
+};
+
 // Generic path: one kernel per operator (any network configuration).
-inline int search_run_generic(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream) {
+inline int search_run_generic(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream,
+                              const RootOverride* ov = nullptr) {
   const ArenaView v = arena_view(s, d_arena);
   mzx_net* net = s->net;
   const int B = s->p.num_trees;
@@ -125,19 +134,22 @@ inline int search_run_generic(mzx_search* s, const mzx_search_io* io, void* d_ar
   NetBuffers nb;
   nb.in = io->d_observation; nb.action = nullptr; nb.hidden = ix_init ? v.arena.hidden : v.dense_out;
   nb.value = v.value; nb.reward = v.reward; nb.policy = v.policy; nb.workspace = v.ws;
-  rc = run_network(net, false, nb, B, stream, ix_init ? &ix : nullptr);
-  if (rc) return rc;
+  if (!ov) {
+    rc = run_network(net, false, nb, B, stream, ix_init ? &ix : nullptr);
+    if (rc) return rc;
+  }
 
   RootInitOp ri;
-  ri.arena = v.arena; ri.p = v.p; ri.value_logits = v.value; ri.policy_logits = v.policy; ri.ext_priors = nullptr; ri.ext_root_reward = nullptr;
+  ri.arena = v.arena; ri.p = v.p; ri.value_logits = v.value; ri.policy_logits = v.policy;
+  ri.ext_priors = ov ? ov->priors : nullptr; ri.ext_root_reward = ov ? ov->reward : nullptr;
   ri.legal = io->d_legal_actions; ri.to_play = io->d_to_play; ri.noise = io->d_noise;
   ri.root_predicted_value = io->d_root_predicted_value;
   MZX_TRY_LAUNCH(launch<64>(ri, stream));
 
   HiddenMoveOp mv;
   mv.arena = v.arena; mv.num_trees = B; mv.num_nodes = s->p.num_nodes; mv.hidden_size = s->p.hidden_size;
-  if (!ix_init) {
-    mv.dense = v.dense_out; mv.node = nullptr; mv.to_arena = 1;
+  if (ov || !ix_init) {
+    mv.dense = ov ? const_cast<float*>(ov->hidden) : v.dense_out; mv.node = nullptr; mv.to_arena = 1;
     MZX_TRY_LAUNCH(launch<256>(mv, stream));
   }
 

@@ -40,7 +40,10 @@ TAPE_WORDS = 64
 
 
 class Node:
-    """self_play.py:433-476 -- read-only view of a searched node (built from the device tree)."""
+    """
+    self_play.py:433-476.  The search itself runs on the device; ``Node`` objects are how callers see a
+    searched tree (``BatchedMCTS.node_graph``) and how tooling hands a root in (``override_root_with``).
+    """
 
     def __init__(self, prior):
         self.visit_count = 0
@@ -58,6 +61,24 @@ class Node:
         if self.visit_count == 0:
             return 0
         return self.value_sum / self.visit_count
+
+    def expand(self, actions, to_play, reward, policy_logits, hidden_state):
+        """self_play.py:451-465 (host side: tooling such as diagnose_model.py:57-70 expands a root itself)."""
+        self.to_play = to_play
+        self.reward = reward
+        self.hidden_state = hidden_state
+        logits = policy_logits.detach().to("cpu", torch.float32)
+        policy_values = torch.softmax(torch.tensor([logits[0][a] for a in actions]), dim=0).tolist()
+        for action, p in zip(actions, policy_values):
+            self.children[action] = Node(p)
+
+    def add_exploration_noise(self, dirichlet_alpha, exploration_fraction):
+        """self_play.py:467-476"""
+        actions = list(self.children.keys())
+        noise = numpy.random.dirichlet([dirichlet_alpha] * len(actions))
+        frac = exploration_fraction
+        for a, n in zip(actions, noise):
+            self.children[a].prior = self.children[a].prior * (1 - frac) + n * frac
 
 
 class MinMaxStats:
@@ -271,7 +292,75 @@ class BatchedMCTS:
         keep = (t_obs, t_legal, t_tp, t_noise, t_tape)
         return io, out, keep
 
-    def run(self, observations, legal_actions, to_play, add_exploration_noise, rngs):
+    def run_from_roots(self, roots, to_play, add_exploration_noise, rngs):
+        """
+        MCTS.run(..., override_root_with=root) (self_play.py:275-277) for B roots the caller expanded itself
+        (``Node.expand`` after a ``recurrent_inference``, diagnose_model.py:57-74): the roots' hidden states,
+        child priors and rewards replace initial_inference.  Roots that already carry visits are not supported.
+        """
+        legal, priors, rewards, hidden = [], numpy.zeros((len(roots), self.A), numpy.float64), [], []
+        for i, root in enumerate(roots):
+            if not root.expanded() or root.hidden_state is None:
+                raise ValueError("override_root_with must be an expanded Node with a hidden_state")
+            if root.visit_count or any(c.visit_count or c.expanded() for c in root.children.values()):
+                raise NotImplementedError("override_root_with: only freshly expanded roots (no visits yet) are supported")
+            if root.to_play != to_play[i]:
+                raise NotImplementedError("override_root_with: root.to_play must equal the to_play argument")
+            acts = list(root.children.keys())
+            legal.append(acts)
+            priors[i, : len(acts)] = [root.children[a].prior for a in acts]
+            rewards.append(float(root.reward))
+            hidden.append(root.hidden_state.detach().reshape(1, -1))
+        override = dict(
+            hidden=torch.cat(hidden).to(self.backend.device, torch.float32).contiguous(),
+            priors=torch.as_tensor(priors).to(self.backend.device),
+            reward=torch.as_tensor(numpy.asarray(rewards, numpy.float64)).to(self.backend.device),
+        )
+        if override["hidden"].shape[1] != self.model.hidden_size:
+            raise ValueError("override_root_with: hidden_state does not match the network's encoded state")
+        return self.run(None, legal, to_play, add_exploration_noise, rngs, _override=override)
+
+    def node_graph(self, num_trees, i, root_actions):
+        """
+        Tree i of the last ``run`` as reference ``Node`` objects (self_play.py:433-476): children dicts keyed
+        by action, visit_count / value_sum / prior / reward / to_play / hidden_state ([1, *hidden_shape]
+        device tensor) per node -- what diagnose_model.py:145-192 walks.  Needs the per-operator engine
+        (mode 0), whose arena holds every node's hidden state in canonical order.
+        """
+        t = self.export_trees(num_trees)
+        off = self.arena_offsets(num_trees)
+        N, A, Hf = self.num_simulations + 1, self.A, self.model.hidden_size
+        hid = self.arena(num_trees)[off["hidden"]: off["hidden"] + num_trees * N * Hf * 4].view(torch.float32)
+        hid = hid.view(num_trees, N, Hf)[i].clone()
+        n_nodes = int(t["n_nodes"][i])
+        nodes = [None] * n_nodes
+
+        def build(n, prior):
+            node = Node(prior)
+            node.visit_count = int(t["visit"][i, n])
+            node.value_sum = float(t["value_sum"][i, n])
+            node.to_play = int(t["to_play"][i, n])
+            node.reward = float(t["reward"][i, n])
+            node.hidden_state = hid[n].view((1,) + tuple(self.model.hidden_shape))
+            nodes[n] = node
+            return node
+
+        root = build(0, 0)
+        order = [0]
+        while order:
+            n = order.pop()
+            actions = list(root_actions) if n == 0 else list(self.config.action_space)
+            for slot, a in enumerate(actions):
+                c = int(t["child"][i, n, slot])
+                prior = float(t["prior"][i, n, slot])
+                if c >= 0:
+                    nodes[n].children[a] = build(c, prior)
+                    order.append(c)
+                else:
+                    nodes[n].children[a] = Node(prior)
+        return root
+
+    def run(self, observations, legal_actions, to_play, add_exploration_noise, rngs, _override=None):
         """
         observations: B stacked observations; legal_actions: B lists; to_play: B ints;
         rngs: B numpy RandomState-like objects (dirichlet / randint / get_state / set_state), or a pair
@@ -317,7 +406,9 @@ class BatchedMCTS:
                     noise[i, : n_legal[i]] = rngs[i].dirichlet([cfg.root_dirichlet_alpha] * int(n_legal[i]))
                 states.append(rngs[i].get_state())
                 tape[i] = rngs[i].randint(0, 2 ** 32, size=TAPE_WORDS, dtype=numpy.uint32)
-        if isinstance(observations, torch.Tensor):   # already stacked on the device (mzx.observations.FrameStore)
+        if _override is not None:
+            obs = numpy.zeros((B, 1), numpy.float32)    # not read: the roots are given
+        elif isinstance(observations, torch.Tensor):   # already stacked on the device (mzx.observations.FrameStore)
             assert observations.shape[0] == B
             obs = observations.reshape(B, -1)
         else:
@@ -325,8 +416,14 @@ class BatchedMCTS:
         lib = self.backend.lib
         io, out, keep = self.make_io(B, obs, legal, numpy.asarray(to_play, numpy.int32), noise, tape)
         arena = self.arena(B)
-        lib.check(lib.mzx_search_run(self.handle(B), ctypes.byref(io), self.backend.ptr(arena), arena.numel(),
-                                     self.backend.stream()))
+        if _override is not None:
+            ptr = self.backend.ptr
+            lib.check(lib.mzx_search_run_from_roots(self.handle(B), ctypes.byref(io), ptr(_override["hidden"]),
+                                                    ptr(_override["priors"]), ptr(_override["reward"]), ptr(arena),
+                                                    arena.numel(), self.backend.stream()))
+        else:
+            lib.check(lib.mzx_search_run(self.handle(B), ctypes.byref(io), self.backend.ptr(arena), arena.numel(),
+                                         self.backend.stream()))
         visits = out["visits"].cpu().numpy()
         info = out["info"].cpu().numpy()
         result = SearchResult(visits, out["root_value"].cpu().numpy(), out["predicted"].cpu().numpy(), info,
@@ -351,19 +448,27 @@ class MCTS:
         self.config = config
 
     def run(self, model, observation, legal_actions, to_play, add_exploration_noise, override_root_with=None):
-        if override_root_with:
-            raise NotImplementedError("override_root_with (diagnose tooling) is not on the accelerated path yet")
+        # the single-root facade returns the whole searched tree as Node objects, like the reference; it uses
+        # the per-operator engine, whose arena keeps every node's hidden state
         engine = getattr(model, "_mcts_engine", None)
         if engine is None or engine.config is not self.config:
-            engine = BatchedMCTS(self.config, model, 1)
+            engine = BatchedMCTS(self.config, model, 1, mode=0)
             model._mcts_engine = engine
-        res = engine.run([observation], [list(legal_actions)], [to_play], add_exploration_noise,
-                         [numpy.random.mtrand._rand])
+        rng = [numpy.random.mtrand._rand]
+        if override_root_with:
+            res = engine.run_from_roots([override_root_with], [to_play], add_exploration_noise, rng)
+            searched = engine.node_graph(1, 0, res.legal_actions[0])
+            searched.hidden_state = override_root_with.hidden_state
+            override_root_with.__dict__.update(searched.__dict__)   # the reference searches the given object in place
+            root, predicted = override_root_with, None
+        else:
+            res = engine.run([observation], [list(legal_actions)], [to_play], add_exploration_noise, rng)
+            root, predicted = engine.node_graph(1, 0, res.legal_actions[0]), float(res.root_predicted_values[0])
         extra_info = {
             "max_tree_depth": int(res.max_tree_depth[0]),
-            "root_predicted_value": float(res.root_predicted_values[0]),
+            "root_predicted_value": predicted,
         }
-        return res.root(0), extra_info
+        return root, extra_info
 
 
 def _remote(method, *args):

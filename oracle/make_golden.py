@@ -14,7 +14,9 @@ through it, the HIP path:
                     (SURVEY.md section 8c') + min-max bounds + per-simulation trace.
   net_<name>.npz    initial_inference / recurrent_inference outputs of models.py
                     on seeded inputs and seeded weights (mzx.synthetic.fill_state_dict).
-  game_<game>.npz   whole GameHistory of SelfPlay.play_game.
+  game_<game>.npz   whole GameHistory of SelfPlay.play_game (+ the Reanalyse worker's values for *_stacked).
+  obs_stack.npz     GameHistory.get_stacked_observations, every index of seeded histories.
+  virtual_<game>.npz  searches from caller-expanded roots (override_root_with), diagnose_model.py:31-78.
 """
 import json
 import os
@@ -261,6 +263,63 @@ def reference_reanalyse(cfg, weights, game_history):
     return numpy.array(buffer.updated.reanalysed_predicted_root_values)
 
 
+def make_virtual_fixture(name, game, weight_seed, seed, horizon, overrides=None):
+    """
+    The loop of diagnose_model.py:31-78 (get_virtual_trajectory_from_obs) executed with the unmodified
+    reference classes: a search from an observation, then `horizon` searches from roots the caller expands
+    itself after a recurrent_inference (MCTS.run(..., override_root_with=root), self_play.py:275-277).
+    """
+    models, self_play = ref_shim.load()
+    cfg = _config(game, **(overrides or {}))
+    torch.manual_seed(0)
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), weight_seed))
+    net.eval()
+    A = len(cfg.action_space)
+    c_in = cfg.observation_shape[0] * (cfg.stacked_observations + 1) + cfg.stacked_observations
+    observation = synthetic.observations(1, (c_in,) + tuple(cfg.observation_shape[1:]), seed=77)[0]
+    numpy.random.seed(seed)
+    rows = []
+
+    def record(root, info, action, reward, value):
+        rows.append(dict(
+            action=-1 if action is None else int(action), reward=float(reward), prior_value=float(value),
+            visits=[root.children[a].visit_count if a in root.children else 0 for a in cfg.action_space],
+            priors=[float(root.children[a].prior) for a in cfg.action_space],
+            child_values=[float(root.children[a].value()) for a in cfg.action_space],
+            child_rewards=[float(root.children[a].reward) for a in cfg.action_space],
+            root_value=float(root.value()), root_visits=int(root.visit_count),
+            max_tree_depth=int(info["max_tree_depth"]),
+            predicted=float("nan") if info["root_predicted_value"] is None else float(info["root_predicted_value"]),
+        ))
+
+    to_play = 0
+    with torch.no_grad():
+        root, info = self_play.MCTS(cfg).run(net, observation, cfg.action_space, to_play, True)
+        record(root, info, None, float("nan"), float("nan"))
+        virtual_to_play = to_play
+        for _ in range(horizon):
+            action = self_play.SelfPlay.select_action(root, 0)
+            if virtual_to_play + 1 < len(cfg.players):
+                virtual_to_play = cfg.players[virtual_to_play + 1]
+            else:
+                virtual_to_play = cfg.players[0]
+            value, reward, policy_logits, hidden_state = net.recurrent_inference(
+                root.hidden_state, torch.tensor([[action]]))
+            value = models.support_to_scalar(value, cfg.support_size).item()
+            reward = models.support_to_scalar(reward, cfg.support_size).item()
+            root = self_play.Node(0)
+            root.expand(cfg.action_space, virtual_to_play, reward, policy_logits, hidden_state)
+            root, info = self_play.MCTS(cfg).run(net, None, cfg.action_space, virtual_to_play, True, root)
+            record(root, info, action, reward, value)
+    data = {k: numpy.array([r[k] for r in rows]) for k in rows[0]}
+    data["observation"] = observation
+    data["meta"] = numpy.array(json.dumps(dict(game=game, weight_seed=weight_seed, seed=seed, horizon=horizon,
+                                               overrides=overrides or {})))
+    numpy.savez_compressed(os.path.join(OUT, f"virtual_{name}.npz"), **data)
+    print("virtual", name, "steps", len(rows), "actions", data["action"].tolist())
+
+
 def make_obs_fixture():
     """GameHistory.get_stacked_observations (self_play.py:513-550) of the unmodified reference, every index."""
     _, self_play = ref_shim.load()
@@ -369,6 +428,9 @@ def main():
     make_game_fixture("cartpole_synth_stacked", "cartpole", 35, 9,
                       overrides=dict(max_moves=10, stacked_observations=3), synthetic_game=True, reanalyse=True)
     make_obs_fixture()
+    # searches from caller-expanded roots (override_root_with), the diagnose_model.py virtual trajectory
+    make_virtual_fixture("cartpole", "cartpole", 41, 3, 4)
+    make_virtual_fixture("tictactoe", "tictactoe", 42, 4, 3)
 
 
 if __name__ == "__main__":

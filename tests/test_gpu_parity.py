@@ -503,3 +503,17 @@ def test_reanalyse_long_game_matches_oracle(backend):
                                                           cfg.support_size)).numpy()
     assert got.shape == want.shape == (T,)
     assert numpy.allclose(got, want, atol=3 * TOL, rtol=3 * TOL), numpy.abs(got - want).max()
+
+
+# ---- reference-compat facade: Node graph + override_root_with on the device
+
+import test_virtual_trajectory as virtual_common  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["cartpole", "tictactoe"])
+def test_virtual_trajectory_matches_reference(backend, name):
+    virtual_common.check_virtual_trajectory(backend, name)
+
+
+def test_override_root_rejections(backend):
+    virtual_common.test_override_root_rejections(backend)
