@@ -62,7 +62,7 @@ typedef struct mzx_net_config {
   int32_t n_fc_value_layers, fc_value_layers[MZX_MAX_LAYERS];
   int32_t n_fc_policy_layers, fc_policy_layers[MZX_MAX_LAYERS];
   /* resnet (models.py:436-520) */
-  int32_t downsample;            /* 0 = False, 1 = "resnet" ("CNN" is not on the BASELINE path) */
+  int32_t downsample;            /* 0 = False, 1 = "resnet" (DownSample, models.py:233-275), 2 = "CNN" (DownsampleCNN, :278-297) */
   int32_t blocks, channels;
   int32_t reduced_channels_reward, reduced_channels_value, reduced_channels_policy;
   int32_t n_resnet_fc_reward_layers, resnet_fc_reward_layers[MZX_MAX_LAYERS];

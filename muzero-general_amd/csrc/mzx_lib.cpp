@@ -152,6 +152,7 @@ int64_t mzx_net_flops(const mzx_net* net, int32_t recurrent) {
   for (const OpDesc& d : (recurrent ? net->prog_recurrent : net->prog_initial)) {
     switch (d.kind) {
       case OP_CONV3: macs += (int64_t)d.cout * d.hout * d.wout * d.cin * 9; break;
+      case OP_CONVK: macs += (int64_t)d.cout * d.hout * d.wout * d.cin * d.ksize * d.ksize; break;
       case OP_CONV1: macs += (int64_t)d.cout * d.hin * d.cin; break;
       case OP_LINEAR: macs += (int64_t)d.out_features * d.w_stride; break;
       default: break;

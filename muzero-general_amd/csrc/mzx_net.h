@@ -23,7 +23,7 @@ namespace mzx {
 void set_error(const char* fmt, ...);
 
 enum BufId { BUF_IN = -1, BUF_HIDDEN = -2, BUF_VALUE = -3, BUF_REWARD = -4, BUF_POLICY = -5 };
-enum OpKind { OP_LINEAR, OP_CONV3, OP_POOL, OP_CONV1, OP_SCALE };
+enum OpKind { OP_LINEAR, OP_CONV3, OP_POOL, OP_CONV1, OP_SCALE, OP_CONVK, OP_MAXPOOL, OP_ADAPTIVE_POOL };
 
 struct TensorInfo {
   std::string name;
@@ -45,6 +45,7 @@ struct OpDesc {
   int32_t relu = 0, elu = 0, use_action = 0;
   int32_t in_features = 0, out_features = 0, w_stride = 0;
   int32_t groups_per_sample = 0, len = 0;  // OP_SCALE
+  int32_t ksize = 0, pad = 0;               // OP_CONVK
 };
 
 struct LayerSpec { int32_t n; const int32_t* sizes; };
@@ -206,6 +207,27 @@ class NetBuilder {
     note_act((int64_t)c * d.hout * d.wout);
     prog->push_back(d);
   }
+  // DownsampleCNN pieces (models.py:278-297)
+  void emit_convk(int in, int out, int64_t w, int64_t b, int cin, int cout, int hin, int win, int ksize, int stride,
+                  int pad) {
+    OpDesc d{};
+    d.kind = OP_CONVK;
+    d.in = in; d.out = out; d.res = -100;
+    d.w = w; d.b = b; d.cin = cin; d.cout = cout; d.hin = hin; d.win = win; d.ksize = ksize; d.stride = stride; d.pad = pad;
+    d.hout = (hin + 2 * pad - ksize) / stride + 1;
+    d.wout = (win + 2 * pad - ksize) / stride + 1;
+    d.relu = 1;
+    note_act((int64_t)cout * d.hout * d.wout);
+    prog->push_back(d);
+  }
+  void emit_window_pool(int kind, int in, int out, int c, int hin, int win, int hout, int wout) {
+    OpDesc d{};
+    d.kind = kind;
+    d.in = in; d.out = out; d.res = -100;
+    d.cin = d.cout = c; d.hin = hin; d.win = win; d.hout = hout; d.wout = wout;
+    note_act((int64_t)c * hout * wout);
+    prog->push_back(d);
+  }
   void emit_conv1(int in, int out, int64_t w, int64_t b, int cin, int cout, int hw) {
     OpDesc d{};
     d.kind = OP_CONV1;
@@ -271,7 +293,16 @@ inline bool NetBuilder::build_resnet() {
   // ---- declare tensors in state_dict order ----
   int64_t ds_conv1 = -1, ds_conv2 = -1;
   std::vector<Block> ds1, ds2, ds3;
-  if (c.downsample) {
+  // DownsampleCNN (models.py:278-297): features.0 / features.3 are the two biased convolutions
+  int64_t cnn_w1 = -1, cnn_b1 = -1, cnn_w2 = -1, cnn_b2 = -1;
+  const int cnn_mid = (cin + C) / 2, cnn_k = 2 * ((H + 15) / 16);
+  if (c.downsample == 2) {
+    cnn_w1 = add_tensor(R + ".downsample_net.features.0.weight", cnn_mid, cin, cnn_k, cnn_k);
+    cnn_b1 = add_tensor(R + ".downsample_net.features.0.bias", cnn_mid);
+    cnn_w2 = add_tensor(R + ".downsample_net.features.3.weight", C, cnn_mid, 5, 5);
+    cnn_b2 = add_tensor(R + ".downsample_net.features.3.bias", C);
+  }
+  if (c.downsample == 1) {
     ds_conv1 = add_tensor(R + ".downsample_net.conv1.weight", C / 2, cin, 3, 3);
     for (int i = 0; i < 2; ++i) ds1.push_back(declare_block(R + ".downsample_net.resblocks1." + std::to_string(i), C / 2));
     ds_conv2 = add_tensor(R + ".downsample_net.conv2.weight", C, C / 2, 3, 3);
@@ -286,7 +317,20 @@ inline bool NetBuilder::build_resnet() {
 
   // hidden-state geometry
   int h = H, w = W;
-  if (c.downsample) {
+  int cnn_h[4] = {0, 0, 0, 0}, cnn_w[4] = {0, 0, 0, 0};   // after conv1, pool1, conv2, pool2
+  if (c.downsample == 2) {
+    cnn_h[0] = (H + 4 - cnn_k) / 4 + 1; cnn_w[0] = (W + 4 - cnn_k) / 4 + 1;
+    if (H + 4 < cnn_k || W + 4 < cnn_k || cnn_h[0] < 3 || cnn_w[0] < 3) {
+      set_error("downsample=\"CNN\": observation %dx%d is too small for its %dx%d stride-4 convolution", H, W, cnn_k, cnn_k);
+      return false;
+    }
+    cnn_h[1] = (cnn_h[0] - 3) / 2 + 1; cnn_w[1] = (cnn_w[0] - 3) / 2 + 1;
+    cnn_h[2] = cnn_h[1]; cnn_w[2] = cnn_w[1];                                   // 5x5, padding 2
+    if (cnn_h[2] < 3 || cnn_w[2] < 3) { set_error("downsample=\"CNN\": observation %dx%d is too small for the second pooling", H, W); return false; }
+    cnn_h[3] = (cnn_h[2] - 3) / 2 + 1; cnn_w[3] = (cnn_w[2] - 3) / 2 + 1;
+    h = (H + 15) / 16; w = (W + 15) / 16;                                       // AdaptiveAvgPool2d target
+  }
+  if (c.downsample == 1) {
     h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;   // conv1 stride 2
     h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;   // conv2 stride 2
     h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;   // pooling1
@@ -334,7 +378,19 @@ inline bool NetBuilder::build_resnet() {
   // ---- initial_inference (models.py:522-553, :601-618) ----
   prog = &net->prog_initial;
   int cur = BUF_IN, ch = H, cw = W;
-  if (c.downsample) {  // DownSample.forward, models.py:264-275
+  if (c.downsample == 2) {  // DownsampleCNN.forward, models.py:293-296
+    int t = fresh({});
+    emit_convk(cur, t, cnn_w1, cnn_b1, cin, cnn_mid, H, W, cnn_k, 4, 2);
+    cur = t; t = fresh({cur});
+    emit_window_pool(OP_MAXPOOL, cur, t, cnn_mid, cnn_h[0], cnn_w[0], cnn_h[1], cnn_w[1]);
+    cur = t; t = fresh({cur});
+    emit_convk(cur, t, cnn_w2, cnn_b2, cnn_mid, C, cnn_h[1], cnn_w[1], 5, 1, 2);
+    cur = t; t = fresh({cur});
+    emit_window_pool(OP_MAXPOOL, cur, t, C, cnn_h[2], cnn_w[2], cnn_h[3], cnn_w[3]);
+    cur = t; t = fresh({cur});
+    emit_window_pool(OP_ADAPTIVE_POOL, cur, t, C, cnn_h[3], cnn_w[3], h, w);
+    cur = t;
+  } else if (c.downsample) {  // DownSample.forward, models.py:264-275
     int t = fresh({});
     emit_conv3(cur, t, -100, ds_conv1, nullptr, cin, C / 2, ch, cw, 2, 0, 0);
     cur = t; ch = (ch - 1) / 2 + 1; cw = (cw - 1) / 2 + 1;
@@ -383,8 +439,8 @@ inline bool NetBuilder::build() {
     if (c.observation_shape[i] < 1) { set_error("observation_shape must be 3 positive ints"); return false; }
   if (c.network == 0) return build_fc();
   if (c.network == 1) {
-    if (c.downsample != 0 && c.downsample != 1) {
-      set_error("downsample must be False or \"resnet\" on this path (\"CNN\" is out of scope, DESIGN.md)");
+    if (c.downsample < 0 || c.downsample > 2) {
+      set_error("downsample should be \"resnet\" or \"CNN\".");   // models.py:327
       return false;
     }
     if (c.blocks < 0 || c.channels < 1) { set_error("invalid blocks/channels"); return false; }
@@ -462,6 +518,26 @@ inline int run_program(const mzx_net* net, const std::vector<OpDesc>& prog, cons
         Conv1x1Op op;
         op.x = in; op.W = flat + d.w; op.bias = flat + d.b; op.y = out;
         op.batch = batch; op.cin = d.cin; op.cout = d.cout; op.hw = d.hin;
+        rc = launch<256>(op, stream);
+        break;
+      }
+      case OP_CONVK: {
+        ConvKxKOp op;
+        op.x = in; op.W = flat + d.w; op.bias = flat + d.b; op.y = out;
+        op.batch = batch; op.cin = d.cin; op.cout = d.cout; op.hin = d.hin; op.win = d.win; op.hout = d.hout;
+        op.wout = d.wout; op.ksize = d.ksize; op.stride = d.stride; op.pad = d.pad; op.relu = d.relu;
+        rc = launch<256>(op, stream);
+        break;
+      }
+      case OP_MAXPOOL: {
+        MaxPoolOp op;
+        op.x = in; op.y = out; op.planes = batch * d.cin; op.hin = d.hin; op.win = d.win; op.hout = d.hout; op.wout = d.wout;
+        rc = launch<256>(op, stream);
+        break;
+      }
+      case OP_ADAPTIVE_POOL: {
+        AdaptiveAvgPoolOp op;
+        op.x = in; op.y = out; op.planes = batch * d.cin; op.hin = d.hin; op.win = d.win; op.hout = d.hout; op.wout = d.wout;
         rc = launch<256>(op, stream);
         break;
       }

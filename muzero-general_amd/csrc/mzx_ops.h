@@ -113,6 +113,76 @@ struct AvgPoolOp {
   }
 };
 
+// Square convolution with bias and optional ReLU, NCHW fp32: torch.nn.Conv2d(cin, cout, K, stride, padding)
+// of DownsampleCNN.features (models.py:281-290: K = 2 * ceil(H / 16), stride 4, padding 2, then K = 5,
+// stride 1, padding 2).
+struct ConvKxKOp {
+  const float* x;
+  const float* W;     // [cout][cin][K][K]
+  const float* bias;  // [cout]
+  float* y;
+  int32_t batch, cin, cout, hin, win, hout, wout, ksize, stride, pad, relu;
+
+  MZX_HD size_t size() const { return (size_t)batch * cout * hout * wout; }
+  MZX_HD void operator()(size_t i) const {
+    const int ox = (int)(i % wout), oy = (int)((i / wout) % hout);
+    const int co = (int)((i / ((size_t)wout * hout)) % cout);
+    const int64_t b = (int64_t)(i / ((size_t)wout * hout * cout));
+    const float* xb = x + b * cin * hin * win;
+    const float* wc = W + (int64_t)co * cin * ksize * ksize;
+    float acc = 0.f;
+    for (int c = 0; c < cin; ++c) {
+      for (int ky = 0; ky < ksize; ++ky) {
+        const int iy = oy * stride + ky - pad;
+        if (iy < 0 || iy >= hin) continue;
+        for (int kx = 0; kx < ksize; ++kx) {
+          const int ix = ox * stride + kx - pad;
+          if (ix < 0 || ix >= win) continue;
+          acc = fmaf(xb[((int64_t)c * hin + iy) * win + ix], wc[(c * ksize + ky) * ksize + kx], acc);
+        }
+      }
+    }
+    acc += bias[co];
+    y[i] = relu ? fmaxf(acc, 0.f) : acc;
+  }
+};
+
+// torch.nn.MaxPool2d(kernel_size=3, stride=2): no padding, floor mode (models.py:286, :289).
+struct MaxPoolOp {
+  const float* x;
+  float* y;
+  int32_t planes, hin, win, hout, wout;
+
+  MZX_HD size_t size() const { return (size_t)planes * hout * wout; }
+  MZX_HD void operator()(size_t i) const {
+    const int ox = (int)(i % wout), oy = (int)((i / wout) % hout);
+    const float* xp = x + (int64_t)(i / ((size_t)wout * hout)) * hin * win;
+    float m = xp[(oy * 2) * win + ox * 2];
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) m = fmaxf(m, xp[(oy * 2 + ky) * win + ox * 2 + kx]);
+    y[i] = m;
+  }
+};
+
+// torch.nn.AdaptiveAvgPool2d((hout, wout)) (models.py:291): window [floor(o * in / out), ceil((o + 1) * in / out)).
+struct AdaptiveAvgPoolOp {
+  const float* x;
+  float* y;
+  int32_t planes, hin, win, hout, wout;
+
+  MZX_HD size_t size() const { return (size_t)planes * hout * wout; }
+  MZX_HD void operator()(size_t i) const {
+    const int ox = (int)(i % wout), oy = (int)((i / wout) % hout);
+    const float* xp = x + (int64_t)(i / ((size_t)wout * hout)) * hin * win;
+    const int y0 = (oy * hin) / hout, y1 = ((oy + 1) * hin + hout - 1) / hout;
+    const int x0 = (ox * win) / wout, x1 = ((ox + 1) * win + wout - 1) / wout;
+    float acc = 0.f;
+    for (int iy = y0; iy < y1; ++iy)
+      for (int ix = x0; ix < x1; ++ix) acc += xp[iy * win + ix];
+    y[i] = acc / (float)((y1 - y0) * (x1 - x0));
+  }
+};
+
 // 1x1 convolution with bias: y[b][r][p] = bias[r] + sum_c x[b][c][p] * W[r][c]
 struct Conv1x1Op {
   const float* x;

@@ -1180,7 +1180,8 @@ inline int run_network_prefix(const mzx_net* net, bool recurrent, int fused, int
   int64_t per = 0;
   switch (last.kind) {
     case OP_LINEAR: per = last.out_features; break;
-    case OP_CONV3: case OP_POOL: per = (int64_t)last.cout * last.hout * last.wout; break;
+    case OP_CONV3: case OP_POOL: case OP_CONVK: case OP_MAXPOOL: case OP_ADAPTIVE_POOL:
+      per = (int64_t)last.cout * last.hout * last.wout; break;
     case OP_CONV1: per = (int64_t)last.cout * last.hin; break;
     default: per = (int64_t)last.groups_per_sample * last.len; break;
   }

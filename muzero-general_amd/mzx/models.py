@@ -85,7 +85,7 @@ def net_config_from(config):
     elif config.downsample == "resnet":
         c.downsample = 1
     elif config.downsample == "CNN":
-        raise NotImplementedError('downsample="CNN" is outside the accelerated path (DESIGN.md, out of scope)')
+        c.downsample = 2
     else:
         raise NotImplementedError('downsample should be "resnet" or "CNN".')  # models.py:327
     c.blocks = int(config.blocks)

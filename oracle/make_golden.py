@@ -416,6 +416,11 @@ def main():
     make_net_fixture("resnet_tictactoe", "tictactoe", 23, 8)
     make_net_fixture("resnet_connect4", "connect4", 24, 4)
     make_net_fixture("resnet_breakout", "breakout", 25, 2)
+    # downsample="CNN" (DownsampleCNN, models.py:278-297): breakout geometry and a small non-square one
+    make_net_fixture("resnet_breakout_cnn", "breakout", 26, 2, overrides=dict(downsample="CNN"))
+    make_net_fixture("resnet_cnn_small", "breakout", 27, 3,
+                     overrides=dict(downsample="CNN", observation_shape=(2, 40, 56), stacked_observations=1,
+                                    channels=8, blocks=1))
 
     # ---- whole games -----------------------------------------------------------
     make_game_fixture("tictactoe", "tictactoe", 31, 5)

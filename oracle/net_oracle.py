@@ -129,12 +129,21 @@ class ResidualOracle:
         self.A = action_space_size
         self.F = 2 * support_size + 1
         self.downsample = downsample
-        if downsample not in (False, None, "resnet"):
-            raise NotImplementedError("oracle covers downsample in {False, 'resnet'}")
+        if downsample not in (False, None, "resnet", "CNN"):
+            raise NotImplementedError('downsample should be "resnet" or "CNN".')  # models.py:327
 
     def _downsample(self, x):
-        """DownSample.forward, models.py:264-275"""
         sd, p = self.sd, "representation_network.module.downsample_net"
+        if self.downsample == "CNN":
+            # DownsampleCNN, models.py:278-297: Conv2d(K = 2 * ceil(H / 16), stride 4, padding 2) + ReLU +
+            # MaxPool2d(3, 2) + Conv2d(5, padding 2) + ReLU + MaxPool2d(3, 2), AdaptiveAvgPool2d(ceil(H/16), ceil(W/16))
+            h_w = (math.ceil(x.shape[2] / 16), math.ceil(x.shape[3] / 16))
+            x = F.relu(F.conv2d(x, sd[p + ".features.0.weight"], sd[p + ".features.0.bias"], 4, 2))
+            x = F.max_pool2d(x, 3, 2)
+            x = F.relu(F.conv2d(x, sd[p + ".features.3.weight"], sd[p + ".features.3.bias"], 1, 2))
+            x = F.max_pool2d(x, 3, 2)
+            return F.adaptive_avg_pool2d(x, h_w)
+        # DownSample.forward, models.py:264-275
         x = F.conv2d(x, sd[p + ".conv1.weight"], None, 2, 1)
         x = _resblocks(sd, p + ".resblocks1", x)
         x = F.conv2d(x, sd[p + ".conv2.weight"], None, 2, 1)

@@ -46,7 +46,8 @@ def test_lockstep_tree_bit_exact(backend, name):
 
 @pytest.mark.parametrize("engine", ["fused", "per-operator"])
 @pytest.mark.parametrize("name", ["fc_cartpole", "fc_cartpole_pretrained", "fc_cartpole_stacked",
-                                  "resnet_tictactoe", "resnet_connect4", "resnet_breakout"])
+                                  "resnet_tictactoe", "resnet_connect4", "resnet_breakout", "resnet_breakout_cnn",
+                                  "resnet_cnn_small"])
 def test_network_heads_within_tolerance(backend, name, engine):
     z = numpy.load(os.path.join(GOLDEN, f"net_{name}.npz"))
     meta = json.loads(str(z["meta"]))

@@ -69,6 +69,27 @@ def test_search_matches_reference(backend, name):
         assert numpy.array_equal(ref.get_state()[1], rngs[c].get_state()[1])
 
 
+@pytest.mark.parametrize("name", ["fc_cartpole_stacked", "resnet_tictactoe", "resnet_breakout", "resnet_breakout_cnn",
+                                  "resnet_cnn_small"])
+def test_network_heads_within_tolerance(backend, name):
+    """The per-operator network programs (serial build) against models.py outputs, 1e-4."""
+    z = numpy.load(os.path.join(GOLDEN, f"net_{name}.npz"))
+    meta = json.loads(str(z["meta"]))
+    cfg = configs.BY_NAME[meta["game"]](**meta["overrides"])
+    net = build_model(backend, cfg, meta["weight_seed"])
+    assert [k for k, _, _ in meta["keys"]] == list(net.state_dict().keys())
+    o = net.initial_inference(torch.tensor(z["obs"]))
+    r1 = net.recurrent_inference(o[3], torch.tensor(z["act1"]))
+    for tag, res in (("init", o), ("rec1", r1)):
+        for key, t in zip(("value", "reward", "policy", "hidden"), res):
+            ref, got = z[f"{tag}_{key}"], t.cpu().numpy()
+            assert got.shape == ref.shape
+            if key == "reward" and tag == "init":
+                assert numpy.array_equal(got, ref)
+            else:
+                assert numpy.abs(got - ref).max() < 1e-4, (name, tag, key)
+
+
 def load_game(name):
     z = numpy.load(os.path.join(GOLDEN, f"game_{name}.npz"))
     return z, json.loads(str(z["meta"]))

@@ -105,7 +105,8 @@ def test_search_end_to_end_bit_exact(name):
 
 
 @pytest.mark.parametrize("name", ["fc_cartpole", "fc_cartpole_pretrained", "fc_cartpole_stacked",
-                                  "resnet_tictactoe", "resnet_connect4", "resnet_breakout"])
+                                  "resnet_tictactoe", "resnet_connect4", "resnet_breakout", "resnet_breakout_cnn",
+                                  "resnet_cnn_small"])
 def test_network_outputs(name):
     z, meta = load(f"net_{name}.npz")
     cfg = config_for(meta)
