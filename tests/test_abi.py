@@ -59,5 +59,6 @@ def test_no_silent_cpu_fallback():
 def test_config_errors_match_reference():
     with pytest.raises(NotImplementedError):
         models.net_config_from(configs.cartpole(network="transformer"))
-    with pytest.raises(NotImplementedError):
-        models.net_config_from(configs.breakout(downsample="CNN"))
+    assert models.net_config_from(configs.breakout(downsample="CNN")).downsample == 2
+    with pytest.raises(NotImplementedError):        # models.py:327
+        models.net_config_from(configs.breakout(downsample="pool"))
