@@ -518,3 +518,14 @@ def test_virtual_trajectory_matches_reference(backend, name):
 
 def test_override_root_rejections(backend):
     virtual_common.test_override_root_rejections(backend)
+
+
+# ---- randomised configurations (tests/test_random_configs.py) on the device, every engine
+
+import test_random_configs as random_common  # noqa: E402
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_config_matches_oracle_all_engines(backend, seed):
+    """Per-operator path (mode 0) vs the CPU oracle, and the whole-search kernels (mode 3) bit-identical to it."""
+    random_common.check_random_config(backend, seed, modes=(0, 3))

@@ -1,0 +1,94 @@
+"""
+Randomised configurations (the reference's MuZeroConfig space, not only the BASELINE files): network
+shapes, action-space sizes, player counts, support sizes, discounts, exploration constants, stacked
+observations and ragged legal-action sets drawn from a seed; the search of every tree is compared with
+the CPU oracle (reference algorithm + reference torch arithmetic) -- identical visit counts / depths,
+root values within tolerance.  CPU: the serial build of the C ABI; GPU twin (more seeds, every engine,
+bit-identical trees across engines): tests/test_gpu_parity.py.
+"""
+import numpy
+import pytest
+
+import hostcheck
+from mzx import configs, models, self_play, synthetic
+from oracle import mcts_oracle, net_oracle
+
+TOL = 1e-4
+
+
+def random_config(seed):
+    rs = numpy.random.RandomState(10_000 + seed)
+    pick = lambda xs: xs[rs.randint(len(xs))]
+    A = int(rs.randint(2, 10))
+    common = dict(
+        action_space=list(range(A)), players=list(range(pick([1, 2]))), num_simulations=int(rs.randint(3, 28)),
+        discount=pick([1.0, 0.997, 0.9]), root_dirichlet_alpha=pick([0.1, 0.25, 1.0, 2.5]),
+        root_exploration_fraction=pick([0.0, 0.25, 0.5]), pb_c_base=pick([19652, 50]), pb_c_init=pick([1.25, 0.5, 3.0]),
+        support_size=pick([1, 3, 10, 25]), stacked_observations=pick([0, 0, 1, 3]), max_moves=9,
+    )
+    if seed % 2 == 0:
+        layers = lambda: pick([[], [8], [16], [12, 6]])
+        cfg = configs.HotPathConfig(
+            network="fullyconnected", observation_shape=(int(rs.randint(1, 3)), 1, int(rs.randint(2, 9))),
+            encoding_size=int(rs.randint(3, 25)), fc_representation_layers=layers(), fc_dynamics_layers=layers(),
+            fc_reward_layers=layers(), fc_value_layers=layers(), fc_policy_layers=layers(), **common)
+    else:
+        layers = lambda: pick([[], [8], [6, 5]])
+        cfg = configs.HotPathConfig(
+            network="resnet", observation_shape=(int(rs.randint(1, 4)), int(rs.randint(3, 7)), int(rs.randint(3, 8))),
+            blocks=int(rs.randint(1, 3)), channels=pick([3, 8, 16, 20]), downsample=False,
+            reduced_channels_reward=int(rs.randint(1, 5)), reduced_channels_value=int(rs.randint(1, 5)),
+            reduced_channels_policy=int(rs.randint(1, 5)), resnet_fc_reward_layers=layers(),
+            resnet_fc_value_layers=layers(), resnet_fc_policy_layers=layers(), **common)
+    return cfg, rs
+
+
+def check_random_config(backend, seed, modes=(None,), B=6):
+    cfg, rs = random_config(seed)
+    A, P = len(cfg.action_space), len(cfg.players)
+    net = models.MuZeroNetwork(cfg, _backend=backend)
+    sd = synthetic.fill_state_dict(net.state_dict(), 300 + seed)
+    net.set_weights(sd)
+    obs = synthetic.observations(B, net.input_shape, seed=seed)
+    legal = [[int(rs.randint(0, A))] if i == 0 else sorted(rs.choice(A, size=rs.randint(1, A + 1), replace=False).tolist())
+             for i in range(B)]
+    to_play = [int(rs.randint(0, P)) for _ in range(B)]
+    noise = bool(seed % 3)
+    results = []
+    for mode in modes:
+        engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
+        res = engine.run(list(obs), legal, to_play, noise, [numpy.random.RandomState(7000 + 10 * seed + i) for i in range(B)])
+        results.append((res, engine.export_trees(B) if mode is not None and (mode & 2 or mode == 0) else None))
+    onet = net_oracle.make_oracle_network(cfg, sd)
+    res = results[0][0]
+    flips = 0
+    for i in range(B):
+        ev = net_oracle.NetworkEvaluator(onet, cfg.support_size)
+        tree = mcts_oracle.run_search(cfg, ev, obs[i], legal[i], to_play[i], noise, numpy.random.RandomState(7000 + 10 * seed + i))
+        want = tree.root_visit_counts(cfg.action_space)
+        if want != list(res.visit_counts[i]):
+            flips += 1       # an fp32 near-tie may flip a simulation on a rare tree; never more than one tree
+            continue
+        rv = tree.node_value(0)
+        # decoded values carry ~1e-4 RELATIVE error (inverse value transform, see test_hostcheck_search); the
+        # root value averages signed backed-up values, so the yardstick is the largest value in the tree
+        scale = max([1.0] + [abs(x) for x in (tree.minimum, tree.maximum) if numpy.isfinite(x)]
+                    + [abs(tree.node_value(n)) for n in range(len(tree.visit))])
+        assert abs(res.root_values[i] - rv) < 3 * TOL * scale, (seed, i)
+        assert int(res.max_tree_depth[i]) == tree.max_depth, (seed, i)
+    assert flips <= 1, (seed, flips)
+    # every engine of the device agrees bit for bit (same inline tree arithmetic, canonical fp32 order)
+    for other, trees in results[1:]:
+        assert numpy.array_equal(other.visit_counts, res.visit_counts), seed
+        assert numpy.array_equal(other.root_values.view(numpy.int64), res.root_values.view(numpy.int64)), seed
+        if trees is not None and results[0][1] is not None:
+            for key in ("visit", "value_sum", "prior", "child", "minmax"):
+                assert numpy.array_equal(trees[key].view(numpy.int64) if trees[key].dtype == numpy.float64 else trees[key],
+                                         results[0][1][key].view(numpy.int64) if trees[key].dtype == numpy.float64
+                                         else results[0][1][key]), (seed, key)
+    return cfg
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_config_matches_oracle(seed):
+    check_random_config(hostcheck.backend(), seed)
