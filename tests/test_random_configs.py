@@ -56,6 +56,10 @@ def check_random_config(backend, seed, modes=(None,), B=6):
     noise = bool(seed % 3)
     results = []
     for mode in modes:
+        if mode is not None and mode & 1:
+            probe = self_play.BatchedMCTS(cfg, net, B, mode=0)
+            if not backend.lib.mzx_search_fused_supported(probe.handle(B)):
+                continue     # shapes outside the whole-search kernels run the per-operator path only
         engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
         res = engine.run(list(obs), legal, to_play, noise, [numpy.random.RandomState(7000 + 10 * seed + i) for i in range(B)])
         results.append((res, engine.export_trees(B) if mode is not None and (mode & 2 or mode == 0) else None))
