@@ -129,6 +129,11 @@ int mzx_net_recurrent_inference(mzx_net* net, const float* d_hidden, const int32
  * staging, after the input load, after every operator, at the end) to d_out instead.
  * d_scratch: (hidden_size + 2 * (2 * support_size + 1) + action_space_size) * batch floats. */
 int mzx_net_num_operators(const mzx_net* net, int32_t recurrent);
+/* Schedule of the fused residual engine: slot_of_op[k] = slot (barrier interval) operator k of the program
+ * runs in, -1 for operators outside the fused part (down-sampling stem); operators sharing a slot have no
+ * data dependence and run concurrently on disjoint wave teams.  Returns the number of slots, 0 if the
+ * program is not fused.  `cap` = entries available in slot_of_op. */
+int mzx_net_fused_schedule(const mzx_net* net, int32_t recurrent, int32_t* slot_of_op, int32_t cap);
 int mzx_net_debug_prefix(mzx_net* net, int32_t recurrent, int32_t fused, int32_t n_ops, const float* d_input,
                          const int32_t* d_action, int32_t batch, float* d_out, int64_t out_floats,
                          float* d_scratch, int64_t scratch_floats, float* d_workspace, int64_t workspace_floats,

@@ -161,6 +161,20 @@ int64_t mzx_net_flops(const mzx_net* net, int32_t recurrent) {
   return 2 * macs;
 }
 
+int mzx_net_fused_schedule(const mzx_net* net, int32_t recurrent, int32_t* slot_of_op, int32_t cap) {
+  if (!net || !slot_of_op) return 0;
+  const RzProgram& R = recurrent ? net->rz.recurrent : net->rz.initial;
+  const int n = (int)(recurrent ? net->prog_recurrent.size() : net->prog_initial.size());
+  if (!net->rz.ok || !R.ok || cap < n) return 0;
+  for (int k = 0; k < n; ++k) slot_of_op[k] = -1;
+  for (int k = 0; k < R.n_ops; ++k) {
+    int slot = 0;
+    for (int q = 0; q < R.order[k]; ++q) slot += (int)((R.ops[q].sched >> 16) & 1u);
+    slot_of_op[R.first + k] = slot;
+  }
+  return R.n_slots;
+}
+
 int mzx_net_num_operators(const mzx_net* net, int32_t recurrent) {
   if (!net) return 0;
   return (int)(recurrent ? net->prog_recurrent.size() : net->prog_initial.size());

@@ -422,10 +422,12 @@ inline bool NetBuilder::build_resnet() {
     emit_conv3(BUF_IN, t, -100, dyn_conv, &dyn_bn, C + 1, C, h, w, 1, 1, 1);
     cur = t;
     for (const Block& b : dyn_blocks) cur = emit_block(b, cur, h, w);
+    // the reward head reads the UNSCALED state (models.py:574-599); the scaling is emitted first so that the
+    // reward chain, which nothing else waits for, can run beside the prediction trunk (rz_schedule)
+    emit_scale(cur, BUF_HIDDEN, C, h * w);
     const int r = fresh({cur});
     emit_conv1(cur, r, rw, rb, C, Rr, h * w);
     emit_mlp(rew, r, BUF_REWARD, {cur, r});
-    emit_scale(cur, BUF_HIDDEN, C, h * w);
     emit_prediction();
   }
   return true;

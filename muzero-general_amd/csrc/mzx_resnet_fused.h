@@ -147,6 +147,98 @@ inline int32_t rz_add_pack(RzPlan& P, size_t first_pack, int64_t w_base, int64_t
 }
 
 // Builds `R` from `prog`; returns false if the program cannot be fused.
+// Slots.  Operators of a program that neither read nor write a region another one writes are independent
+// (the heads after the trunk: reward / value / policy chains; the reward head beside the prediction trunk);
+// list scheduling in program order puts each operator into the earliest slot after everything it conflicts
+// with.  A slot costs one workgroup barrier and -- on the small networks, whose layers are latency-bound -- about
+// as much time as its longest operator, so fewer slots is fewer microseconds per simulation.  Only small GEMMs
+// share (at most three per slot); wide trunk convolutions and the scaling operator keep the whole workgroup.
+// Region offsets still hold slot indices / flat offsets here (rz_finish_program runs later), which is exactly
+// the identity the conflict test needs.
+inline void rz_schedule(RzProgram& R, int HW) {
+  const int n = R.n_ops;
+  const int Tn = std::max(1, std::min(16, (64 + HW / 2) / HW));   // nominal trees per workgroup for work estimates
+  struct Use { int kind[3], id[3], nr; int wkind, wid; };            // reads (in, res), write
+  std::vector<Use> use(n);
+  std::vector<int> tiles(n), work(n), slot(n, 0);
+  std::vector<bool> shareable(n);
+  for (int i = 0; i < n; ++i) {
+    const RzOp& o = R.ops[i];
+    Use& u = use[i];
+    u.nr = 0;
+    const bool in_spatial = !(o.kind == RZ_GEMM && o.rows == RZ_ROWS_TREE);
+    u.kind[u.nr] = in_spatial; u.id[u.nr] = o.in_off; ++u.nr;
+    if (o.res_off >= 0) { u.kind[u.nr] = 1; u.id[u.nr] = o.res_off; ++u.nr; }
+    u.wkind = (o.out_layout == RZ_OUT_PADDED); u.wid = o.out_off;
+    if (o.kind == RZ_GEMM) {
+      const int nt = (o.cout + 15) / 16;
+      tiles[i] = (o.rows == RZ_ROWS_POS ? (Tn * HW + 15) / 16 : 1) * nt;
+      work[i] = tiles[i] * (o.nchunks + 2);
+      shareable[i] = tiles[i] <= 6;
+    } else {
+      tiles[i] = 0; work[i] = 0; shareable[i] = false;
+    }
+  }
+  auto conflict = [&](int x, int y) {
+    for (int k = 0; k < use[x].nr; ++k) if (use[x].kind[k] == use[y].wkind && use[x].id[k] == use[y].wid) return true;
+    for (int k = 0; k < use[y].nr; ++k) if (use[y].kind[k] == use[x].wkind && use[y].id[k] == use[x].wid) return true;
+    return use[x].wkind == use[y].wkind && use[x].wid == use[y].wid;
+  };
+  std::vector<std::vector<int>> slots;
+  for (int i = 0; i < n; ++i) {
+    int earliest = 0;
+    for (int j = 0; j < i; ++j) if (conflict(i, j)) earliest = std::max(earliest, slot[j] + 1);
+    int s = (int)slots.size();
+    if (shareable[i]) {
+      for (int q = earliest; q < (int)slots.size(); ++q) {
+        bool ok = slots[q].size() < 3;
+        for (int j : slots[q]) ok = ok && shareable[j];
+        if (ok) { s = q; break; }
+      }
+    }
+    if (s == (int)slots.size()) slots.push_back({});
+    slots[s].push_back(i);
+    slot[i] = s;
+  }
+  // teams + table order
+  RzOp sorted[RZ_MAX_OPS];
+  int pos = 0;
+  for (std::vector<int>& members : slots) {
+    std::stable_sort(members.begin(), members.end(), [&](int x, int y) { return work[x] > work[y]; });
+    const int m = (int)members.size();
+    for (int k = 0; k < 2 && m > 1; ++k) {
+      const int nw = k ? 8 : 4;
+      int cnt[3] = {1, 1, 1};
+      for (int left = nw - m; left > 0; --left) {   // spare waves to the operator with the most work per wave
+        int best = -1;
+        for (int q = 0; q < m; ++q) {
+          const RzOp& o = R.ops[members[q]];
+          const int cap = (o.rows == RZ_ROWS_TREE) ? (o.cout + 15) / 16 : tiles[members[q]];
+          if (cnt[q] >= cap) continue;
+          if (best < 0 || work[members[q]] * cnt[best] > work[members[best]] * cnt[q]) best = q;
+        }
+        if (best < 0) break;
+        ++cnt[best];
+      }
+      int lo = 0;
+      for (int q = 0; q < m; ++q) {
+        RzOp& o = R.ops[members[q]];
+        o.team |= ((uint32_t)lo | ((uint32_t)cnt[q] << 8)) << (16 * k);
+        (k ? o.store_hidden : o.channels) = (65536 + cnt[q] - 1) / cnt[q];
+        lo += cnt[q];
+      }
+    }
+    for (int q = 0; q < m; ++q) {
+      R.order[members[q]] = pos;
+      sorted[pos] = R.ops[members[q]];
+      if (q == m - 1) sorted[pos].sched |= 1u << 16;
+      ++pos;
+    }
+  }
+  memcpy(R.ops, sorted, sizeof(RzOp) * n);
+  R.n_slots = (int32_t)slots.size();
+}
+
 inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog, RzPlan& P, RzProgram& R,
                              int64_t& cursor, int& max_c) {
   const int h = net->hh, w = net->hw, HW = h * w;
@@ -209,8 +301,18 @@ inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog
         const RzInst& t = inst[j];
         if (j != k && t.spatial && t.slot >= 0 && t.def < s.def && t.last >= s.def) busy[t.slot] = true;
       }
+      // among the free slots take the one whose previous tenant was read last the longest ago: a freshly
+      // vacated slot would chain this operator behind the vacating reader (a false dependence that keeps
+      // independent heads from sharing a barrier interval, rz_schedule)
       s.slot = -1;
-      for (int q = 0; q < 3; ++q) if (!busy[q]) { s.slot = q; break; }
+      int best_last = 0;
+      for (int q = 0; q < 3; ++q) {
+        if (busy[q]) continue;
+        int last_read = -1000;
+        for (size_t j = 0; j < k; ++j)
+          if (inst[j].spatial && inst[j].slot == q) last_read = std::max(last_read, inst[j].last);
+        if (s.slot < 0 || last_read < best_last) { s.slot = q; best_last = last_read; }
+      }
       if (s.slot < 0) return false;
     } else {
       s.tstride = rz_round16(s.size) + 8;   // whole 16-deep K chunks readable; 8 mod 16 spreads the rows over LDS slots
@@ -286,7 +388,7 @@ inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog
         const int nw = k ? 8 : 4;
         int lg = 0;
         while ((2 << lg) <= nw && (2 << lg) <= nt_total) ++lg;
-        o.lg_waves_n[k] = lg;
+        o.sched |= (uint32_t)lg << (8 * k);
       }
     }
     const int which = (d.out == BUF_VALUE) ? 0 : (d.out == BUF_REWARD) ? 1 : (d.out == BUF_POLICY) ? 2 : -1;
@@ -323,6 +425,7 @@ inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog
   }
   R.small_floats = (int32_t)(cursor - R.small_base);
   R.in_off = inst[ext].slot;
+  rz_schedule(R, HW);
   R.ok = 1;
   return true;
 }
@@ -650,14 +753,27 @@ template <bool WLDS, int NW>
 __device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const RzCtx& cx) {
   const int rows = (op.rows == RZ_ROWS_POS) ? cx.T * a.HW : cx.T;
   const int mt_total = (rows + 15) >> 4, nt_total = (op.cout + 15) >> 4;
-  // column tiles over the waves first (a power of two of them, precomputed), row tiles over the rest
-  const int lg_n = op.lg_waves_n[NW == 8 ? 1 : 0];
-  const int lg_m = (NW == 8 ? 3 : 2) - lg_n;
-  const int waves_n = 1 << lg_n, waves_m = 1 << lg_m;
-  const int wn = cx.wave & (waves_n - 1), wm = cx.wave >> lg_n;
+  // the waves running this operator: its team (operators sharing a slot), or the whole workgroup
+  const unsigned team = (NW == 8) ? (op.team >> 16) : (op.team & 0xFFFFu);
+  const int t_cnt = (int)(team >> 8);
+  int wn, wm, waves_n, waves_m;
+  unsigned rcp_m;   // ceil(2^16 / waves_m)
+  if (t_cnt == 0) {
+    // column tiles over the waves first (a power of two of them, precomputed), row tiles over the rest
+    const int lg_n = (int)((op.sched >> (NW == 8 ? 8 : 0)) & 0xFFu);
+    const int lg_m = (NW == 8 ? 3 : 2) - lg_n;
+    waves_n = 1 << lg_n; waves_m = 1 << lg_m;
+    wn = cx.wave & (waves_n - 1); wm = cx.wave >> lg_n;
+    rcp_m = 65536u >> lg_m;
+  } else {
+    const int tw = cx.wave - (int)(team & 0xFFu);
+    if ((unsigned)tw >= (unsigned)t_cnt) return;
+    if (op.rows == RZ_ROWS_TREE) { waves_n = t_cnt; waves_m = 1; wn = tw; wm = 0; rcp_m = 65536u; }   // one row tile
+    else { waves_n = 1; waves_m = t_cnt; wn = 0; wm = tw; rcp_m = (unsigned)(NW == 8 ? op.store_hidden : op.channels); }
+  }
   for (int nt = wn; nt < nt_total; nt += waves_n) {
     for (int mt0 = wm; mt0 < mt_total; mt0 += waves_m * 8) {
-      const int cnt = min(8, (mt_total - mt0 + waves_m - 1) >> lg_m);   // wave-uniform
+      const int cnt = min(8, (int)(((unsigned)(mt_total - mt0 + waves_m - 1) * rcp_m) >> 16));   // wave-uniform
       switch (cnt) {
         case 1: rz_gemm_tiles<1, WLDS>(op, a, cx, nt, mt0, waves_m); break;
         case 2: rz_gemm_tiles<2, WLDS>(op, a, cx, nt, mt0, waves_m); break;
@@ -814,19 +930,26 @@ rz_network_kernel(const RzArgs a) {
   rz_load_input<NW>(a, cx, b0, ntree, a.in_node, a.action, false);
   if (prof) stamps[2] = __builtin_readcyclecounter();
 
-  // ---- the layers
-  for (int o = 0; o < a.n_ops; ++o) {
+  // ---- the layers: slots of independent operators (rz_schedule), one barrier per slot
+  for (int o = 0; o < a.n_ops;) {
+    const int slot_first = o;
     RzCtx cxo = cx;
     unsigned long long* fine = stamps + (RZ_MAX_OPS + 4) + 8 * o;   // [8] per operator, LDS
     if (a.dump_op == -2 && blockIdx.x == 0) { cxo.fine = fine; if (tid == 0) fine[0] = __builtin_readcyclecounter(); }
-    const RzOp op = rz_fetch_op(cx.simg, o);   // from the LDS-resident program image
-    if (op.kind == RZ_GEMM) rz_gemm<WLDS, NW>(op, a, cxo);
-    else rz_scale<NW>(op, a, cx, b0, ntree, a.out_node, false);
+    bool last;
+    do {
+      const RzOp op = rz_fetch_op(cx.simg, o);   // from the LDS-resident program image
+      if (op.kind == RZ_GEMM) rz_gemm<WLDS, NW>(op, a, cxo);
+      else rz_scale<NW>(op, a, cx, b0, ntree, a.out_node, false);
+      last = ((op.sched >> 16) & 1u) != 0;
+      ++o;
+    } while (!last);
     if (cxo.fine && tid == 0) fine[5] = __builtin_readcyclecounter();
     __syncthreads();
     if (cxo.fine && tid == 0) fine[6] = __builtin_readcyclecounter();
-    if (prof) stamps[3 + o] = __builtin_readcyclecounter();
-    if (o == a.dump_op) {  // diagnostics: the output tensor of op `o`, dense per sample
+    if (prof) for (int k = slot_first; k < o; ++k) stamps[3 + k] = __builtin_readcyclecounter();
+    if (a.dump_op >= slot_first && a.dump_op < o) {  // diagnostics: the output tensor of one operator, dense per sample
+      const RzOp op = rz_fetch_op(cx.simg, a.dump_op);
       const float* src = reg + T * op.out_off;
       if (op.out_layout == RZ_OUT_PADDED) {
         const int C = (op.kind == RZ_GEMM) ? op.cout : op.channels;
@@ -1206,7 +1329,7 @@ inline int run_network_prefix(const mzx_net* net, bool recurrent, int fused, int
       if (out_floats < 2 * RZ_STAMP_WORDS) { set_error("profile buffer too small"); return MZX_ERR_WORKSPACE; }
       return rz_launch(net, R, in, nb, batch, nullptr, stream, -2, d_out);
     }
-    return rz_launch(net, R, in, nb, batch, nullptr, stream, n_ops - 1 - R.first, d_out);
+    return rz_launch(net, R, in, nb, batch, nullptr, stream, R.order[n_ops - 1 - R.first], d_out);
   }
 #else
   if (fused) { set_error("no fused engine in this build"); return MZX_ERR_INVALID; }

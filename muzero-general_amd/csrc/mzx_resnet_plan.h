@@ -37,10 +37,16 @@ struct RzOp {
   int32_t bias_off;      // bias, padded to whole column tiles
   int32_t asum_off;      // dynamics input convolution: border-aware tap sums of the action plane's weights [cout][H*W]
   int32_t act;           // RzAct
-  int32_t channels;      // RZ_SCALE: planes per tree
-  int32_t store_hidden;  // RZ_SCALE: also write the scaled state to the caller's hidden-state output
+  int32_t channels;      // RZ_SCALE: planes per tree.       RZ_GEMM with a team: ceil(2^16 / team waves), 4-wave kernels
+  int32_t store_hidden;  // RZ_SCALE: also write the scaled state to the caller's hidden-state output.
+                         //                                  RZ_GEMM with a team: the same reciprocal for 8-wave kernels
   uint32_t magic;        // ceil(2^20 / cchunks): chunk -> tap decode without a division
-  int32_t lg_waves_n[2]; // log2 of the waves the column tiles are spread over, for 4- and 8-wave workgroups
+  // Scheduling.  Operators without data dependences between them share a SLOT (one barrier per slot, not per
+  // operator): the slot's operators are consecutive in the table, each runs on its own TEAM of waves.
+  uint32_t sched;        // bits 0-7 / 8-15: log2 of the waves the column tiles are spread over when the whole
+                         // 4- / 8-wave workgroup runs the operator; bit 16: last operator of its slot
+  uint32_t team;         // bytes: first wave, wave count (4-wave kernels), first wave, wave count (8-wave kernels);
+                         // count 0 = the whole workgroup
 };
 static_assert(sizeof(RzOp) == 96, "RzOp is fetched as 24 scalar words");
 
@@ -72,7 +78,9 @@ struct RzProgram {
   int32_t first = 0;            // ops [0, first) of the operator program run as separate kernels (down-sampling stem)
   int32_t ext_buf = 0;          // logical buffer id feeding the fused part (BUF_IN or a stem temp)
   int32_t n_ops = 0;
-  RzOp ops[RZ_MAX_OPS];
+  RzOp ops[RZ_MAX_OPS];         // in SCHEDULE order (slots); order[k] = position of operator first + k of the program
+  int32_t order[RZ_MAX_OPS];
+  int32_t n_slots = 0;
   int32_t in_off = 0;           // region receiving the input tensor
   int32_t in_channels = 0;      // channels of the input tensor
   int32_t use_action = 0;       // 1: the first op adds the action plane's contribution (asum_off)
