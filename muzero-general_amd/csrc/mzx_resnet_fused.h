@@ -593,16 +593,16 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
   const unsigned magic = op.magic;
   const int pw9 = (op.taps == 9) ? a.PW * a.Cs : 0, one9 = (op.taps == 9) ? a.Cs : 0;
   const int last = op.nchunks - 1;
-  // With a single row tile the MFMAs of a chunk would form one dependent chain (40-cycle accumulator
-  // latency against a 32-cycle issue interval): even and odd chunks then accumulate into two tiles that are
-  // added at the end.
+  // With a single row tile consecutive MFMAs would form one dependent chain (40-cycle accumulator latency
+  // against a 32-cycle issue interval): K-steps then alternate between two accumulator tiles that are added
+  // at the end.
   f32x4 acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto compute = [&](const f32x4 (&av)[MT], const f32x4& bv, bool odd) {
+  auto compute = [&](const f32x4 (&av)[MT], const f32x4& bv, bool) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        if (MT == 1 && odd) acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][j], bv[j], acc_odd, 0, 0, 0);
+        if (MT == 1 && (j & 1)) acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][j], bv[j], acc_odd, 0, 0, 0);
         else acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][j], bv[j], acc[i], 0, 0, 0);
       }
   };

@@ -101,10 +101,13 @@ rz_search_kernel(const RzSearchArgs sa) {
     // ---- recurrent_inference on the T selected (parent state, action) pairs (models.py:620-623)
     rz_load_input<NW>(a, cx, b0, ntree, sel_parent, sel_action, true);
     RZS_PROF(2)
-    for (int o = 0; o < a.n_ops;) {   // slots of independent operators, one barrier per slot (rz_schedule)
+    // slots of independent operators, one barrier per slot (rz_schedule); descriptors come from the
+    // LDS-resident program image (measured faster than scalar loads from L2; fetching the next descriptor
+    // ahead of the current operator costs 4 %, profiles/r01_rz_slots_ab.txt)
+    for (int o = 0; o < a.n_ops;) {
       bool last;
       do {
-        const RzOp op = rz_fetch_op(cx.simg, o);   // from the LDS-resident program image (measured faster than scalar loads from L2)
+        const RzOp op = rz_fetch_op(cx.simg, o);
         if (op.kind == RZ_GEMM) { if (!RZ_DBG(a, 4)) rz_gemm<WLDS, NW>(op, a, cx); }
         else rz_scale<NW>(op, a, cx, b0, ntree, sel_leaf, true);
         last = ((op.sched >> 16) & 1u) != 0;

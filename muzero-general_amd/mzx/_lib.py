@@ -171,7 +171,7 @@ class Backend:
         return c_vp(0) if t is None else c_vp(t.data_ptr())
 
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmzx.so")
+LIB_PATH = os.environ.get("MZX_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmzx.so")   # MZX_LIB: A/B builds
 _default = None
 
 

@@ -78,7 +78,8 @@ def check_random_config(backend, seed, modes=(None,), B=6):
         # root value averages signed backed-up values, so the yardstick is the largest value in the tree
         scale = max([1.0] + [abs(x) for x in (tree.minimum, tree.maximum) if numpy.isfinite(x)]
                     + [abs(tree.node_value(n)) for n in range(len(tree.visit))])
-        assert abs(res.root_values[i] - rv) < 3 * TOL * scale, (seed, i)
+        # ... and a backed-up value is a discounted sum of up to depth + 1 decoded terms (rewards + leaf value)
+        assert abs(res.root_values[i] - rv) < TOL * scale * (tree.max_depth + 1), (seed, i)
         assert int(res.max_tree_depth[i]) == tree.max_depth, (seed, i)
     assert flips <= 1, (seed, flips)
     # every engine of the device agrees bit for bit (same inline tree arithmetic, canonical fp32 order)
