@@ -128,7 +128,11 @@ int mzx_net_set_weights(mzx_net* net, const float* d_flat, int64_t n_floats, flo
       MZX_TRY_LAUNCH(launch<256>(op, (stream_t)stream));
     }
     for (const RzProgram* R : {&net->rz.initial, &net->rz.recurrent})
-      if (R->ok) MZX_TRY_LAUNCH(copy_h2d(d_derived + R->small_base, R->ops, sizeof(RzOp) * R->n_ops, (stream_t)stream));
+      if (R->ok) {
+        MZX_TRY_LAUNCH(copy_h2d(d_derived + R->small_base, R->ops, sizeof(RzOp) * R->n_ops, (stream_t)stream));
+        MZX_TRY_LAUNCH(copy_h2d(d_derived + R->small_base + R->aoff_base, R->aoff.data(), sizeof(int32_t) * R->aoff.size(),
+                                (stream_t)stream));
+      }
   }
   return MZX_OK;
 }

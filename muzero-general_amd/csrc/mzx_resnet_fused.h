@@ -113,6 +113,16 @@ struct RzAsumOp {
 // host planner: operator program (mzx_net.h) -> fused program
 
 inline int rz_round4(int x) { return (x + 3) & ~3; }
+// ints of one A-fragment offset table: 3 leading pads, nchunks entries, 8 prefetch entries, rounded to 16 bytes
+MZX_HD inline int rz_aoff_ints(int nchunks) { return (3 + nchunks + 8 + 3) & ~3; }
+// entry of chunk c (clamped to the last chunk): K chunk -> (tap, 16-channel chunk) -> LDS float offset
+MZX_HD inline int rz_aoff_entry(int c, int nchunks, int taps, int cchunks, int PW, int Cs) {
+  const int cc = c < nchunks - 1 ? c : nchunks - 1;
+  if (taps != 9) return cc * 16;
+  const int tap = cc / cchunks, ch = cc - tap * cchunks;
+  const int ty = tap / 3, tx = tap - 3 * ty;
+  return (ty - 1) * PW * Cs + (tx - 1) * Cs + ch * 16;
+}
 inline int rz_round16(int x) { return (x + 15) & ~15; }
 
 inline bool rz_fusable(const OpDesc& d, int h, int w) {
@@ -381,8 +391,8 @@ inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog
     }
     if (o.kind == RZ_GEMM) {
       o.nchunks = o.taps * o.cchunks;
+      o.taps |= (int32_t)((((1u << 20) + (uint32_t)o.cchunks - 1) / (uint32_t)o.cchunks) << 8);
       o.wchunks = (o.nchunks + 1) & ~1;
-      o.magic = ((1u << 20) + (uint32_t)o.cchunks - 1) / (uint32_t)o.cchunks;
       const int nt_total = (o.cout + 15) / 16;
       for (int k = 0; k < 2; ++k) {   // column tiles over the waves first (a power of two of them)
         const int nw = k ? 8 : 4;
@@ -423,6 +433,15 @@ inline bool rz_build_program(const mzx_net* net, const std::vector<OpDesc>& prog
     cursor += rz_round4(d.cout * HW);
     P.asums.push_back(s);
   }
+  // A-fragment offset tables (values need the activation geometry: rz_finish_program)
+  R.aoff_base = (int32_t)(cursor - R.small_base);
+  for (int i = 0; i < R.n_ops; ++i) {
+    RzOp& o = R.ops[i];
+    if (o.kind != RZ_GEMM) continue;
+    o.aoff_off = (uint32_t)(cursor - R.small_base);
+    cursor += rz_aoff_ints(o.nchunks);
+  }
+  R.aoff.assign((size_t)(cursor - R.small_base) - R.aoff_base, 0);
   R.small_floats = (int32_t)(cursor - R.small_base);
   R.in_off = inst[ext].slot;
   rz_schedule(R, HW);
@@ -435,11 +454,13 @@ constexpr int RZ_STAMP_WORDS = (RZ_MAX_OPS + 4) + 8 * RZ_MAX_OPS;   // uint64 st
 inline int rz_scratch_floats(const RzGeometry& g, int T) { return rz_round4(2 * T * g.Cs + T) + 2 * RZ_STAMP_WORDS; }
 
 // LDS floats of a workgroup of T trees: row tables, scratch, regions, optionally the weight image
-inline int64_t rz_lds_floats(const RzGeometry& g, const RzProgram& R, int T, bool weights_in_lds) {
+// (`tables` = false: without the A-fragment offset tables at the end of the small image, which only the
+// 4-wave kernels read)
+inline int64_t rz_lds_floats(const RzGeometry& g, const RzProgram& R, int T, bool weights_in_lds, bool tables = true) {
   const int mpad = rz_round16(T * g.HW);
   const int64_t scratch = rz_scratch_floats(g, T);
-  return (int64_t)2 * mpad + scratch + R.small_floats + (int64_t)T * (3 * g.slot_ts + R.flat_floats) +
-         (weights_in_lds ? R.w_floats : 0);
+  return (int64_t)2 * mpad + scratch + (tables ? R.small_floats : R.aoff_base) +
+         (int64_t)T * (3 * g.slot_ts + R.flat_floats) + (weights_in_lds ? R.w_floats : 0);
 }
 
 inline int rz_max_trees(const RzGeometry& g, const RzProgram& R, bool weights_in_lds) {
@@ -459,6 +480,13 @@ inline void rz_finish_program(const RzGeometry& g, RzProgram& R) {
     if (in_spatial) { o.in_off *= g.slot_ts; o.in_tstride = g.slot_ts; } else { o.in_off += flat0; }
     if (o.out_layout == RZ_OUT_PADDED) { o.out_off *= g.slot_ts; o.out_tstride = g.slot_ts; } else { o.out_off += flat0; }
     if (o.res_off >= 0) o.res_off *= g.slot_ts;
+  }
+  for (int i = 0; i < R.n_ops; ++i) {
+    const RzOp& o = R.ops[i];
+    if (o.kind != RZ_GEMM) continue;
+    int32_t* tbl = R.aoff.data() + ((int32_t)o.aoff_off - R.aoff_base);
+    for (int k = 0; k < rz_aoff_ints(o.nchunks); ++k)
+      tbl[k] = rz_aoff_entry(k < 3 ? 0 : k - 3, o.nchunks, o.taps & 0xFF, o.cchunks, g.PW, g.Cs);
   }
   R.in_off *= g.slot_ts;
   for (int k = 0; k < 3; ++k) if (R.out_off[k] >= 0) R.out_off[k] += flat0;
@@ -494,7 +522,6 @@ inline void rz_plan(mzx_net* net) {
       sc.cchunks = rz_round16(d.cin) / 16;
       sc.nchunks = 9 * sc.cchunks;
       sc.wchunks = (sc.nchunks + 1) & ~1;
-      sc.magic = ((1u << 20) + (uint32_t)sc.cchunks - 1) / (uint32_t)sc.cchunks;
       sc.w_off = rz_add_pack(P, P.packs.size(), 0, d.w, 9, d.cin, d.cin, d.cout, cursor);
       P.stem.push_back(sc);
     }
@@ -565,7 +592,11 @@ __device__ __forceinline__ int rz_div(int x, int d, unsigned magic) {
 }
 
 // One group of MT row tiles x one column tile of a layer GEMM: K loop + epilogue.
-template <int MT, bool WLDS>
+// TBL: per-chunk A-fragment offsets come from the precomputed table (4-wave kernels: one wave per SIMD, the
+// ~20 scalar instructions of the tap decode per chunk are exposed).  The 8-wave kernels sit at the 256-register
+// limit of two waves per SIMD -- the 8 registers of the offset quads would spill -- and decode arithmetically;
+// their second wave hides the scalar work.
+template <int MT, bool WLDS, bool TBL>
 __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, const RzCtx& cx, int nt, int mt0,
                                               int mt_step) {
   const int lane = cx.lane, T = cx.T;
@@ -588,11 +619,10 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
     abase[i] = (pos_rows ? cx.rowaddr[m] : m * op.in_tstride) + 4 * (lane >> 4);
   }
   const f32x4* wp = (const f32x4*)((WLDS ? cx.wlds : a.weights) + op.w_off) + (size_t)nt * op.wchunks * 64 + lane;
-  // chunk c -> (tap, 16-channel chunk of the tap): tap = c / cchunks by a 20-bit reciprocal, exact for
-  // c < 4096 and cchunks < 256 (the planner checks both)
-  const unsigned magic = op.magic;
-  const int pw9 = (op.taps == 9) ? a.PW * a.Cs : 0, one9 = (op.taps == 9) ? a.Cs : 0;
-  const int last = op.nchunks - 1;
+  // chunk c -> LDS offset of its A fragment: a precomputed table (rz_aoff_entry) instead of ~20 scalar
+  // instructions of tap decode per chunk, which the small layers cannot hide behind four MFMAs
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const int* tbl = (const int*)cx.simg + op.aoff_off;
   // With a single row tile consecutive MFMAs would form one dependent chain (40-cycle accumulator latency
   // against a 32-cycle issue interval): K-steps then alternate between two accumulator tiles that are added
   // at the end.
@@ -608,14 +638,22 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
   };
   // software pipeline: A fragments (LDS) one chunk ahead, B fragments (L2 or LDS) two chunks ahead of the
   // 4 * MT MFMAs being issued; two chunks per iteration, ping-pong registers
-  auto load_a = [&](int c, f32x4 (&av)[MT]) {
-    c = c < last ? c : last;
-    const int tap = (op.taps == 9) ? (int)(((unsigned)c * magic) >> 20) : 0;
-    const int cc = c - tap * op.cchunks;
-    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;                 // tap / 3, tap % 3 for tap < 9
-    const int off = (ty - 1) * pw9 + (tx - 1) * one9 + cc * 16;
+  auto load_a = [&](int off, f32x4 (&av)[MT]) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) av[i] = *(const f32x4*)(in + abase[i] + off);
+  };
+  // arithmetic decode: chunk c -> (tap, 16-channel chunk of the tap), tap = c / cchunks by a 20-bit reciprocal
+  // (exact for c < 4096 and cchunks < 256, the planner checks both)
+  const unsigned magic = (unsigned)op.taps >> 8;
+  const bool nine = (op.taps & 0xFF) == 9;
+  const int pw9 = nine ? a.PW * a.Cs : 0, one9 = nine ? a.Cs : 0;
+  const int last = op.nchunks - 1;
+  auto decode = [&](int c) {
+    c = c < last ? c : last;
+    const int tap = nine ? (int)(((unsigned)c * magic) >> 20) : 0;
+    const int cc = c - tap * op.cchunks;
+    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;                 // tap / 3, tap % 3 for tap < 9
+    return (ty - 1) * pw9 + (tx - 1) * one9 + cc * 16;
   };
   // an odd chunk count is stored with one trailing zero chunk; prefetches beyond it re-read the last chunk
   const int wlast = op.wchunks - 1;
@@ -623,7 +661,6 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
   // Small tile counts (latency-bound layers of small networks): fetch everything the epilogue needs that
   // does not depend on the accumulators -- row addresses and the residual -- BEFORE the K loop, so that
   // these LDS round trips hide under the MFMAs instead of following them.
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
   constexpr bool EARLY = (MT <= 2);
   const int n = nt * 16 + (lane & 15);
   const int* rowo = cx.rowout ? cx.rowout : cx.rowaddr;
@@ -647,31 +684,36 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
   RZ_FINE(2)
   if (!RZ_DBG(a, 1)) {
   f32x4 a0[MT], a1[MT], b0, b1, b2, b3;
+  i32x4 ofs = i32x4{0, 0, 0, 0};
+  if (TBL) ofs = *(const i32x4*)(tbl + 4);       // chunks 1 .. 4
   load_b(0, b0);
   load_b(1, b1);
-  load_a(0, a0);
+  load_a(TBL ? tbl[3] : decode(0), a0);
   for (int c = 0; c < op.nchunks; c += 4) {   // four chunks per trip: no register copies in the rotation
+    i32x4 nxt = i32x4{0, 0, 0, 0};
+    if (TBL) nxt = *(const i32x4*)(tbl + 8 + c);   // chunks c + 5 .. c + 8, one trip ahead
     load_b(c + 2, b2);
     load_b(c + 3, b3);
-    load_a(c + 1, a1);
+    load_a(TBL ? ofs[0] : decode(c + 1), a1);
     __builtin_amdgcn_sched_barrier(0);
     compute(a0, b0, false);
     __builtin_amdgcn_sched_barrier(0);
-    load_a(c + 2, a0);
+    load_a(TBL ? ofs[1] : decode(c + 2), a0);
     __builtin_amdgcn_sched_barrier(0);
     compute(a1, b1, true);
     __builtin_amdgcn_sched_barrier(0);
     if (c + 2 >= op.nchunks) break;
     load_b(c + 4, b0);
     load_b(c + 5, b1);
-    load_a(c + 3, a1);
+    load_a(TBL ? ofs[2] : decode(c + 3), a1);
     __builtin_amdgcn_sched_barrier(0);
     compute(a0, b2, false);
     __builtin_amdgcn_sched_barrier(0);
-    load_a(c + 4, a0);
+    load_a(TBL ? ofs[3] : decode(c + 4), a0);
     __builtin_amdgcn_sched_barrier(0);
     compute(a1, b3, true);
     __builtin_amdgcn_sched_barrier(0);
+    if (TBL) ofs = nxt;
   }
   }
   if (MT == 1) acc[0] = acc[0] + acc_odd;
@@ -775,14 +817,14 @@ __device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const R
     for (int mt0 = wm; mt0 < mt_total; mt0 += waves_m * 8) {
       const int cnt = min(8, (int)(((unsigned)(mt_total - mt0 + waves_m - 1) * rcp_m) >> 16));   // wave-uniform
       switch (cnt) {
-        case 1: rz_gemm_tiles<1, WLDS>(op, a, cx, nt, mt0, waves_m); break;
-        case 2: rz_gemm_tiles<2, WLDS>(op, a, cx, nt, mt0, waves_m); break;
-        case 3: rz_gemm_tiles<3, WLDS>(op, a, cx, nt, mt0, waves_m); break;
-        case 4: rz_gemm_tiles<4, WLDS>(op, a, cx, nt, mt0, waves_m); break;
-        case 5: rz_gemm_tiles<5, WLDS>(op, a, cx, nt, mt0, waves_m); break;
-        case 6: rz_gemm_tiles<6, WLDS>(op, a, cx, nt, mt0, waves_m); break;
-        case 7: rz_gemm_tiles<7, WLDS>(op, a, cx, nt, mt0, waves_m); break;
-        default: rz_gemm_tiles<8, WLDS>(op, a, cx, nt, mt0, waves_m); break;
+        case 1: rz_gemm_tiles<1, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        case 2: rz_gemm_tiles<2, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        case 3: rz_gemm_tiles<3, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        case 4: rz_gemm_tiles<4, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        case 5: rz_gemm_tiles<5, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        case 6: rz_gemm_tiles<6, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        case 7: rz_gemm_tiles<7, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        default: rz_gemm_tiles<8, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
       }
     }
   }
@@ -1029,12 +1071,29 @@ inline RzLaunch rz_prepare(const mzx_net* net, const RzProgram& R, const float* 
   // between two smaller workgroups loses more M-tile efficiency and weight reuse than it hides.
   const int force_T = rz_env_int("MZX_RZ_TREES", 0);
   if (force_T > 0 && force_T < a.T) a.T = force_T;
+  // Two waves per SIMD (8-wave kernels) when the layer GEMMs have enough tiles to feed eight waves (big boards /
+  // wide networks): latencies of one wave (weight prefetch, epilogue, barriers) hide behind the other's MFMAs.
+  // Those kernels decode chunk offsets arithmetically and do not stage the offset tables, so the trees per
+  // workgroup are sized without them first.
+  const int force_w = rz_env_int("MZX_RZ_WAVES", 0);
+  bool tables = true;
   {
-    auto fits = [&](int T, bool w) {
-      return 4 * (rz_lds_floats(g, R, T, w) + extra_lds_floats_per_tree * T + extra_lds_floats) <= RZ_LDS_BUDGET;
+    auto fits = [&](int T, bool w, bool tb) {
+      return 4 * (rz_lds_floats(g, R, T, w, tb) + extra_lds_floats_per_tree * T + extra_lds_floats) <= RZ_LDS_BUDGET;
     };
-    while (a.T > 1 && !fits(a.T, false)) --a.T;
-    wlds = fits(a.T, true);
+    auto eight_for = [&](int T) {
+      const int tiles = ((T * g.HW + 15) / 16) * ((net->cfg.channels + 15) / 16);
+      return force_w == 8 || (force_w != 4 && tiles >= 16 && net->rz_waves != 4);
+    };
+    int T8 = a.T;
+    while (T8 > 1 && !fits(T8, false, false)) --T8;
+    L.eight = eight_for(T8);
+    if (L.eight) {
+      a.T = T8; tables = false;
+    } else {
+      while (a.T > 1 && !fits(a.T, false, true)) --a.T;
+    }
+    wlds = fits(a.T, true, tables);
   }
   a.n_ops = R.n_ops;
   a.batch = batch;
@@ -1051,7 +1110,7 @@ inline RzLaunch rz_prepare(const mzx_net* net, const RzProgram& R, const float* 
   a.dump_op = -1;
   a.dbg = rz_env_int("MZX_RZ_DBG", 0);
   a.w_floats = R.w_floats;
-  a.small_floats = R.small_floats;
+  a.small_floats = tables ? R.small_floats : R.aoff_base;
   a.in = in;
   a.in_node = ix ? ix->in_node : nullptr;
   a.out_node = ix ? ix->out_node : nullptr;
@@ -1062,20 +1121,13 @@ inline RzLaunch rz_prepare(const mzx_net* net, const RzProgram& R, const float* 
   a.weights = net->d_derived + R.w_base;
   a.small = net->d_derived + R.small_base;
   L.grid = (unsigned)((batch + a.T - 1) / a.T);
-  L.lds = (size_t)4 * rz_lds_floats(g, R, a.T, wlds);
+  L.lds = (size_t)4 * rz_lds_floats(g, R, a.T, wlds, tables);
   a.magic_hw = (uint32_t)((0x100000000ull + (uint64_t)g.HW - 1) / (uint64_t)g.HW);
   a.magic_w = (uint32_t)((0x100000000ull + (uint64_t)g.W - 1) / (uint64_t)g.W);
-  // two waves per SIMD when the layer GEMMs have enough tiles to feed eight waves (big boards / wide
-  // networks): latencies of one wave (weight prefetch, epilogue, barriers) hide behind the other's MFMAs
-  const int tiles = ((a.T * g.HW + 15) / 16) * ((net->cfg.channels + 15) / 16);
-  L.eight = tiles >= 16 && net->rz_waves != 4;
   if (rz_env_int("MZX_RZ_WLDS", 1) == 0 && wlds) {   // A/B knob: weights from L2 although they would fit in LDS
     wlds = false;
-    L.lds = (size_t)4 * rz_lds_floats(g, R, a.T, false);
+    L.lds = (size_t)4 * rz_lds_floats(g, R, a.T, false, tables);
   }
-  const int force_w = rz_env_int("MZX_RZ_WAVES", 0);
-  if (force_w == 4) L.eight = false;
-  if (force_w == 8) L.eight = true;
   L.wlds = wlds;
   return L;
 }
@@ -1118,8 +1170,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   int* rowaddr = (int*)rz_lds;
   int* rowtp = rowaddr + sa.mpad;
   int* rowout = rowtp + sa.mpad;
-  float* params = (float*)(rowout + sa.mpad);          // alpha[64], beta[64]
-  float* reg = params + 128;
+  float* params = (float*)(rowout + sa.mpad);          // alpha[64], beta[64], A-fragment offset table
+  const int aoff_ints = rz_aoff_ints(sa.op.nchunks);
+  float* reg = params + 128 + aoff_ints;
   const int in_floats = sa.PHin * sa.PWin * sa.Cs;
   const int out_floats = rows * sa.Cs;
   // ---- tables, parameters, input tile (+ halo), residual tile
@@ -1132,6 +1185,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   }
   if (tid < 128) params[tid] = (tid < 64) ? ((sa.alpha && tid < sa.cout) ? sa.alpha[tid] : 1.f)
                                           : ((sa.beta && tid - 64 < sa.cout) ? sa.beta[tid - 64] : 0.f);
+  for (int k = tid; k < aoff_ints; k += 256)
+    ((int*)params)[128 + k] = rz_aoff_entry(k < 3 ? 0 : k - 3, sa.op.nchunks, 9, sa.op.cchunks, sa.PWin, sa.Cs);
   {
     f32x4* z = (f32x4*)reg;
     for (int i = tid; i < (in_floats + 2 * out_floats) / 4; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1205,7 +1260,8 @@ inline int rz_stem_launch(const mzx_net* net, const RzStemConv& sc, const OpDesc
     sa.PHin = (sa.TH - 1) * d.stride + 3;
     sa.PWin = (sa.TW - 1) * d.stride + 3;
     sa.mpad = rz_round16(sa.TH * sa.TW);
-    const int64_t floats = 3 * (int64_t)sa.mpad + 128 + (int64_t)sa.PHin * sa.PWin * sa.Cs + 2 * (int64_t)sa.TH * sa.TW * sa.Cs;
+    const int64_t floats = 3 * (int64_t)sa.mpad + 128 + rz_aoff_ints(sc.nchunks) + (int64_t)sa.PHin * sa.PWin * sa.Cs +
+                           2 * (int64_t)sa.TH * sa.TW * sa.Cs;
     if (4 * floats <= RZ_LDS_BUDGET) break;
     if (sa.TH <= 1) return MZX_ERR_INVALID;
     sa.TH = (sa.TH + 1) / 2;
@@ -1213,11 +1269,12 @@ inline int rz_stem_launch(const mzx_net* net, const RzStemConv& sc, const OpDesc
   sa.tiles_x = (d.wout + sa.TW - 1) / sa.TW;
   const int tiles_y = (d.hout + sa.TH - 1) / sa.TH;
   RzOp& o = sa.op;
-  o.kind = RZ_GEMM; o.rows = RZ_ROWS_POS; o.taps = 9;
+  o.kind = RZ_GEMM; o.rows = RZ_ROWS_POS;
+  o.taps = 9 | (int32_t)((((1u << 20) + (uint32_t)sc.cchunks - 1) / (uint32_t)sc.cchunks) << 8);
   o.in_off = 0; o.in_tstride = 0;
   o.out_off = sa.PHin * sa.PWin * sa.Cs; o.out_tstride = 0; o.out_layout = RZ_OUT_PADDED;
   o.res_off = res ? o.out_off + sa.TH * sa.TW * sa.Cs : -1;
-  o.cchunks = sc.cchunks; o.cout = d.cout; o.nchunks = sc.nchunks; o.wchunks = sc.wchunks; o.magic = sc.magic;
+  o.cchunks = sc.cchunks; o.cout = d.cout; o.nchunks = sc.nchunks; o.wchunks = sc.wchunks; o.aoff_off = 128;
   o.w_off = 0;
   o.alpha_off = d.bn.channels ? 0 : -1; o.beta_off = d.bn.channels ? 64 : -1; o.bias_off = -1; o.asum_off = -1;
   o.act = d.relu ? RZ_ACT_RELU : RZ_ACT_NONE;
@@ -1225,7 +1282,7 @@ inline int rz_stem_launch(const mzx_net* net, const RzStemConv& sc, const OpDesc
   sa.weights = net->d_derived + sc.w_off;
   sa.alpha = d.bn.channels ? net->d_derived + d.bn.alpha : nullptr;
   sa.beta = d.bn.channels ? net->d_derived + d.bn.beta : nullptr;
-  const size_t lds = 4 * (size_t)(3 * sa.mpad + 128 + sa.PHin * sa.PWin * sa.Cs + 2 * sa.TH * sa.TW * sa.Cs);
+  const size_t lds = 4 * (size_t)(3 * sa.mpad + 128 + rz_aoff_ints(sc.nchunks) + sa.PHin * sa.PWin * sa.Cs + 2 * sa.TH * sa.TW * sa.Cs);
   hipLaunchKernelGGL(rz_stem_conv_kernel, dim3(sa.tiles_x * tiles_y, batch), dim3(256), lds, stream, sa);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("stem convolution launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }

@@ -25,7 +25,8 @@ struct RzOp {
   int32_t in_off, in_tstride;
   int32_t out_off, out_tstride, out_layout;   // RzOut
   int32_t res_off;       // residual input (padded layout), -1: none
-  int32_t taps;          // 9 (3x3, padding 1) or 1
+  int32_t taps;          // low byte: 9 (3x3, padding 1) or 1; upper bits: ceil(2^20 / cchunks), the reciprocal of the
+                         // arithmetic chunk -> tap decode (kernels that do not use the offset table)
   int32_t cchunks;       // 16-channel K chunks per tap (input channels padded to a multiple of 16)
   int32_t cout;
   int32_t nchunks;       // taps * cchunks
@@ -40,7 +41,10 @@ struct RzOp {
   int32_t channels;      // RZ_SCALE: planes per tree.       RZ_GEMM with a team: ceil(2^16 / team waves), 4-wave kernels
   int32_t store_hidden;  // RZ_SCALE: also write the scaled state to the caller's hidden-state output.
                          //                                  RZ_GEMM with a team: the same reciprocal for 8-wave kernels
-  uint32_t magic;        // ceil(2^20 / cchunks): chunk -> tap decode without a division
+  uint32_t aoff_off;     // A-fragment offset table of this GEMM inside the small image (ints): chunk c at [3 + c],
+                         // = (tap row - 1) * PW * Cs + (tap column - 1) * Cs + 16 * (channel chunk); the entries
+                         // after the last chunk repeat it (the software pipeline prefetches past the end), the
+                         // three leading pads put chunks 1..4 on a 16-byte boundary
   // Scheduling.  Operators without data dependences between them share a SLOT (one barrier per slot, not per
   // operator): the slot's operators are consecutive in the table, each runs on its own TEAM of waves.
   uint32_t sched;        // bits 0-7 / 8-15: log2 of the waves the column tiles are spread over when the whole
@@ -81,6 +85,8 @@ struct RzProgram {
   RzOp ops[RZ_MAX_OPS];         // in SCHEDULE order (slots); order[k] = position of operator first + k of the program
   int32_t order[RZ_MAX_OPS];
   int32_t n_slots = 0;
+  int32_t aoff_base = 0;        // A-fragment offset tables: start inside the small image, host copy (filled by
+  std::vector<int32_t> aoff;    // rz_finish_program once the activation geometry is known)
   int32_t in_off = 0;           // region receiving the input tensor
   int32_t in_channels = 0;      // channels of the input tensor
   int32_t use_action = 0;       // 1: the first op adds the action plane's contribution (asum_off)
@@ -108,7 +114,6 @@ struct RzStemConv {
   int32_t op_index;      // index in prog_initial
   int64_t w_off;         // derived-buffer offset of the packed weights
   int32_t cchunks, nchunks, wchunks;
-  uint32_t magic;
 };
 
 struct RzPlan {

@@ -43,11 +43,21 @@ def main():
         d = numpy.diff(stamps.astype(numpy.int64))
         print(f"{wl} {'recurrent' if recurrent else 'initial'} batch {batch}: {len(d)} intervals, total {d.sum()} cycles")
         print("  staging %d; input load %d; ops: %s" % (d[0], d[1], " ".join(str(int(v)) for v in d[2:])))
-        print("  intra-operator (wave 0): fetch+dispatch | row bases | K loop | epilogue | tail | barrier")
-        for o in range(len(d) - 3):
+        # operators sharing a slot (no data dependence, disjoint wave teams) carry one stamp set: that of the
+        # slot's first operator, which wave 0 runs
+        import ctypes
+        sched = (ctypes.c_int32 * n)()
+        n_slots = net.backend.lib.mzx_net_fused_schedule(net.handle, recurrent, sched, n)
+        members = {}
+        for k, sl in enumerate(sched):
+            if sl >= 0:
+                members.setdefault(sl, []).append(k)
+        print(f"  {n_slots} slots: " + " ".join("{" + ",".join(str(k) for k in members[sl]) + "}" for sl in sorted(members)))
+        print("  intra-slot (wave 0, first operator): fetch+dispatch | row bases | K loop | epilogue | other operators of the slot | barrier")
+        for o in range(48):
             f = fine[o]
-            if f[1] and f[4]:
-                print("   op %2d: %6d %6d %6d %6d %6d %6d" % (o, f[1] - f[0], f[2] - f[1], f[3] - f[2], f[4] - f[3], f[5] - f[4], f[6] - f[5]))
+            if f[1] and f[4] and f[6] > f[0]:
+                print("   table %2d: %6d %6d %6d %6d %6d %6d   = %6d" % (o, f[1] - f[0], f[2] - f[1], f[3] - f[2], f[4] - f[3], f[5] - f[4], f[6] - f[5], f[6] - f[0]))
 
 
 if __name__ == "__main__":
