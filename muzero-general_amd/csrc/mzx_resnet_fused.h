@@ -113,8 +113,8 @@ struct RzAsumOp {
 // host planner: operator program (mzx_net.h) -> fused program
 
 inline int rz_round4(int x) { return (x + 3) & ~3; }
-// ints of one A-fragment offset table: 3 leading pads, nchunks entries, 8 prefetch entries, rounded to 16 bytes
-MZX_HD inline int rz_aoff_ints(int nchunks) { return (3 + nchunks + 8 + 3) & ~3; }
+// ints of one A-fragment offset table: nchunks entries + 8 prefetch entries, rounded to 16 bytes
+MZX_HD inline int rz_aoff_ints(int nchunks) { return (nchunks + 8 + 3) & ~3; }
 // entry of chunk c (clamped to the last chunk): K chunk -> (tap, 16-channel chunk) -> LDS float offset
 MZX_HD inline int rz_aoff_entry(int c, int nchunks, int taps, int cchunks, int PW, int Cs) {
   const int cc = c < nchunks - 1 ? c : nchunks - 1;
@@ -486,7 +486,7 @@ inline void rz_finish_program(const RzGeometry& g, RzProgram& R) {
     if (o.kind != RZ_GEMM) continue;
     int32_t* tbl = R.aoff.data() + ((int32_t)o.aoff_off - R.aoff_base);
     for (int k = 0; k < rz_aoff_ints(o.nchunks); ++k)
-      tbl[k] = rz_aoff_entry(k < 3 ? 0 : k - 3, o.nchunks, o.taps & 0xFF, o.cchunks, g.PW, g.Cs);
+      tbl[k] = rz_aoff_entry(k, o.nchunks, o.taps & 0xFF, o.cchunks, g.PW, g.Cs);
   }
   R.in_off *= g.slot_ts;
   for (int k = 0; k < 3; ++k) if (R.out_off[k] >= 0) R.out_off[k] += flat0;
@@ -636,8 +636,6 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
         else acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][j], bv[j], acc[i], 0, 0, 0);
       }
   };
-  // software pipeline: A fragments (LDS) one chunk ahead, B fragments (L2 or LDS) two chunks ahead of the
-  // 4 * MT MFMAs being issued; two chunks per iteration, ping-pong registers
   auto load_a = [&](int off, f32x4 (&av)[MT]) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) av[i] = *(const f32x4*)(in + abase[i] + off);
@@ -683,37 +681,70 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
   }
   RZ_FINE(2)
   if (!RZ_DBG(a, 1)) {
-  f32x4 a0[MT], a1[MT], b0, b1, b2, b3;
-  i32x4 ofs = i32x4{0, 0, 0, 0};
-  if (TBL) ofs = *(const i32x4*)(tbl + 4);       // chunks 1 .. 4
-  load_b(0, b0);
-  load_b(1, b1);
-  load_a(TBL ? tbl[3] : decode(0), a0);
-  for (int c = 0; c < op.nchunks; c += 4) {   // four chunks per trip: no register copies in the rotation
-    i32x4 nxt = i32x4{0, 0, 0, 0};
-    if (TBL) nxt = *(const i32x4*)(tbl + 8 + c);   // chunks c + 5 .. c + 8, one trip ahead
-    load_b(c + 2, b2);
-    load_b(c + 3, b3);
-    load_a(TBL ? ofs[0] : decode(c + 1), a1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(a0, b0, false);
-    __builtin_amdgcn_sched_barrier(0);
-    load_a(TBL ? ofs[1] : decode(c + 2), a0);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(a1, b1, true);
-    __builtin_amdgcn_sched_barrier(0);
-    if (c + 2 >= op.nchunks) break;
-    load_b(c + 4, b0);
-    load_b(c + 5, b1);
-    load_a(TBL ? ofs[2] : decode(c + 3), a1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(a0, b2, false);
-    __builtin_amdgcn_sched_barrier(0);
-    load_a(TBL ? ofs[3] : decode(c + 4), a0);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(a1, b3, true);
-    __builtin_amdgcn_sched_barrier(0);
-    if (TBL) ofs = nxt;
+  if (TBL) {
+    // one wave per SIMD: nothing else hides the LDS round trip of a fragment, so four chunks are resident and
+    // every buffer is refilled (four chunks ahead) as soon as its MFMAs have issued
+    f32x4 A0[MT], A1[MT], A2[MT], A3[MT], B0, B1, B2, B3;
+    const int n = op.nchunks;
+    {
+      const i32x4 q = *(const i32x4*)tbl;          // chunks 0 .. 3
+      load_b(0, B0); load_a(q[0], A0);
+      load_b(1, B1); load_a(q[1], A1);
+      load_b(2, B2); load_a(q[2], A2);
+      load_b(3, B3); load_a(q[3], A3);
+    }
+    for (int c = 0; c < n; c += 4) {
+      const i32x4 q = *(const i32x4*)(tbl + c + 4);   // chunks c + 4 .. c + 7 (entries past the end repeat the last chunk)
+      __builtin_amdgcn_sched_barrier(0);
+      compute(A0, B0, false);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(c + 4, B0); load_a(q[0], A0);
+      if (c + 1 >= n) break;
+      __builtin_amdgcn_sched_barrier(0);
+      compute(A1, B1, false);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(c + 5, B1); load_a(q[1], A1);
+      if (c + 2 >= n) break;
+      __builtin_amdgcn_sched_barrier(0);
+      compute(A2, B2, false);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(c + 6, B2); load_a(q[2], A2);
+      if (c + 3 >= n) break;
+      __builtin_amdgcn_sched_barrier(0);
+      compute(A3, B3, false);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(c + 7, B3); load_a(q[3], A3);
+    }
+  } else {
+    // software pipeline: A fragments (LDS) one chunk ahead, B fragments (L2) two chunks ahead of the 4 * MT
+    // MFMAs being issued; ping-pong registers, four chunks per trip: no register copies in the rotation
+    f32x4 a0[MT], a1[MT], b0, b1, b2, b3;
+    load_b(0, b0);
+    load_b(1, b1);
+    load_a(decode(0), a0);
+    for (int c = 0; c < op.nchunks; c += 4) {
+      load_b(c + 2, b2);
+      load_b(c + 3, b3);
+      load_a(decode(c + 1), a1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(a0, b0, false);
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(decode(c + 2), a0);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(a1, b1, true);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 2 >= op.nchunks) break;
+      load_b(c + 4, b0);
+      load_b(c + 5, b1);
+      load_a(decode(c + 3), a1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(a0, b2, false);
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(decode(c + 4), a0);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(a1, b3, true);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   }
   if (MT == 1) acc[0] = acc[0] + acc_odd;
@@ -1186,7 +1217,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   if (tid < 128) params[tid] = (tid < 64) ? ((sa.alpha && tid < sa.cout) ? sa.alpha[tid] : 1.f)
                                           : ((sa.beta && tid - 64 < sa.cout) ? sa.beta[tid - 64] : 0.f);
   for (int k = tid; k < aoff_ints; k += 256)
-    ((int*)params)[128 + k] = rz_aoff_entry(k < 3 ? 0 : k - 3, sa.op.nchunks, 9, sa.op.cchunks, sa.PWin, sa.Cs);
+    ((int*)params)[128 + k] = rz_aoff_entry(k, sa.op.nchunks, 9, sa.op.cchunks, sa.PWin, sa.Cs);
   {
     f32x4* z = (f32x4*)reg;
     for (int i = tid; i < (in_floats + 2 * out_floats) / 4; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
