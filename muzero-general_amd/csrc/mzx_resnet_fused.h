@@ -822,7 +822,10 @@ __device__ __forceinline__ RzOp rz_fetch_op(const float* image, int o) {
   return ((const RzOp*)image)[o];
 }
 
-template <bool WLDS, int NW>
+// MM: the most row tiles one wave ever gets in this launch (host-checked).  Kernels for small activation
+// matrices are instantiated with MM = 3: without the code of the 4..8-tile variants the kernel is half the
+// size and the per-operator dispatch -- exposed on the latency-bound small networks -- is shorter.
+template <bool WLDS, int NW, int MM>
 __device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const RzCtx& cx) {
   const int rows = (op.rows == RZ_ROWS_POS) ? cx.T * a.HW : cx.T;
   const int mt_total = (rows + 15) >> 4, nt_total = (op.cout + 15) >> 4;
@@ -848,14 +851,14 @@ __device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const R
     for (int mt0 = wm; mt0 < mt_total; mt0 += waves_m * 8) {
       const int cnt = min(8, (int)(((unsigned)(mt_total - mt0 + waves_m - 1) * rcp_m) >> 16));   // wave-uniform
       switch (cnt) {
-        case 1: rz_gemm_tiles<1, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
-        case 2: rz_gemm_tiles<2, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
-        case 3: rz_gemm_tiles<3, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
-        case 4: rz_gemm_tiles<4, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
-        case 5: rz_gemm_tiles<5, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
-        case 6: rz_gemm_tiles<6, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
-        case 7: rz_gemm_tiles<7, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
-        default: rz_gemm_tiles<8, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        case 1: if constexpr (MM >= 1) rz_gemm_tiles<1, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        case 2: if constexpr (MM >= 2) rz_gemm_tiles<2, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        case 3: if constexpr (MM >= 3) rz_gemm_tiles<3, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        case 4: if constexpr (MM >= 4) rz_gemm_tiles<4, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        case 5: if constexpr (MM >= 5) rz_gemm_tiles<5, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        case 6: if constexpr (MM >= 6) rz_gemm_tiles<6, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        case 7: if constexpr (MM >= 7) rz_gemm_tiles<7, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
+        default: if constexpr (MM >= 8) rz_gemm_tiles<8, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
       }
     }
   }
@@ -983,7 +986,7 @@ __device__ __forceinline__ void rz_load_input(const RzArgs& a, const RzCtx& cx, 
   __syncthreads();
 }
 
-template <bool WLDS, int NW>
+template <bool WLDS, int NW, int MM>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 rz_network_kernel(const RzArgs a) {
   constexpr int NT = NW * 64;
@@ -1012,7 +1015,7 @@ rz_network_kernel(const RzArgs a) {
     bool last;
     do {
       const RzOp op = rz_fetch_op(cx.simg, o);   // from the LDS-resident program image
-      if (op.kind == RZ_GEMM) rz_gemm<WLDS, NW>(op, a, cxo);
+      if (op.kind == RZ_GEMM) rz_gemm<WLDS, NW, MM>(op, a, cxo);
       else rz_scale<NW>(op, a, cx, b0, ntree, a.out_node, false);
       last = ((op.sched >> 16) & 1u) != 0;
       ++o;
@@ -1065,22 +1068,22 @@ inline void rz_choose(const RzGeometry& g, const RzProgram& R, int batch, int& T
   wlds = 4 * rz_lds_floats(g, R, T, true) <= RZ_LDS_BUDGET;
 }
 
-template <bool WLDS, int NW>
+template <bool WLDS, int NW, int MM>
 inline int rz_launch_k(const RzArgs& a, unsigned grid, size_t lds_bytes, stream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)rz_network_kernel<WLDS, NW>,
+    hipError_t e = hipFuncSetAttribute((const void*)rz_network_kernel<WLDS, NW, MM>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((rz_network_kernel<WLDS, NW>), dim3(grid), dim3(NW * 64), lds_bytes, stream, a);
+  hipLaunchKernelGGL((rz_network_kernel<WLDS, NW, MM>), dim3(grid), dim3(NW * 64), lds_bytes, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("fused network launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
   return MZX_OK;
 }
 
-struct RzLaunch { RzArgs a; bool wlds; bool eight; unsigned grid; size_t lds; };
+struct RzLaunch { RzArgs a; bool wlds; bool eight; bool small; unsigned grid; size_t lds; };
 
 inline int rz_env_int(const char* name, int dflt) {
   const char* e = getenv(name);
@@ -1160,6 +1163,8 @@ inline RzLaunch rz_prepare(const mzx_net* net, const RzProgram& R, const float* 
     L.lds = (size_t)4 * rz_lds_floats(g, R, a.T, false, tables);
   }
   L.wlds = wlds;
+  // at most three row tiles in any layer GEMM: the kernels without the 4..8-tile code (4-wave kernels only)
+  L.small = !L.eight && (a.T * g.HW + 15) / 16 <= 3 && rz_env_int("MZX_RZ_SMALL", 1) != 0;
   return L;
 }
 
@@ -1170,8 +1175,9 @@ inline int rz_launch(const mzx_net* net, const RzProgram& R, const float* in, co
   RzLaunch L = rz_prepare(net, R, in, nb, batch, ix);
   L.a.dump_op = dump_op;
   L.a.dump = dump;
-  if (L.wlds) return L.eight ? rz_launch_k<true, 8>(L.a, L.grid, L.lds, stream) : rz_launch_k<true, 4>(L.a, L.grid, L.lds, stream);
-  return L.eight ? rz_launch_k<false, 8>(L.a, L.grid, L.lds, stream) : rz_launch_k<false, 4>(L.a, L.grid, L.lds, stream);
+  if (L.small) return L.wlds ? rz_launch_k<true, 4, 3>(L.a, L.grid, L.lds, stream) : rz_launch_k<false, 4, 3>(L.a, L.grid, L.lds, stream);
+  if (L.wlds) return L.eight ? rz_launch_k<true, 8, 8>(L.a, L.grid, L.lds, stream) : rz_launch_k<true, 4, 8>(L.a, L.grid, L.lds, stream);
+  return L.eight ? rz_launch_k<false, 8, 8>(L.a, L.grid, L.lds, stream) : rz_launch_k<false, 4, 8>(L.a, L.grid, L.lds, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -1254,7 +1260,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   RzCtx cx;
   cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.rowout = rowout; cx.scratch = params; cx.simg = params;
   cx.wlds = nullptr; cx.T = 1; cx.tid = tid; cx.lane = tid & 63; cx.wave = tid >> 6; cx.fine = nullptr;
-  rz_gemm<false, 4>(sa.op, a, cx);
+  rz_gemm<false, 4, 8>(sa.op, a, cx);
   __syncthreads();
   // ---- write back, coalesced along x
   {

@@ -46,7 +46,7 @@ __device__ __forceinline__ void load_state(const TreeRef& t, RowState& st) {
   st.root_n = t.meta(TM_ROOT_N); st.root_to_play = t.to_play(0);
 }
 
-template <bool WLDS, int NW, int AW>
+template <bool WLDS, int NW, int AW, int MM>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 rz_search_kernel(const RzSearchArgs sa) {
   constexpr int NT = NW * 64;
@@ -108,7 +108,7 @@ rz_search_kernel(const RzSearchArgs sa) {
       bool last;
       do {
         const RzOp op = rz_fetch_op(cx.simg, o);
-        if (op.kind == RZ_GEMM) { if (!RZ_DBG(a, 4)) rz_gemm<WLDS, NW>(op, a, cx); }
+        if (op.kind == RZ_GEMM) { if (!RZ_DBG(a, 4)) rz_gemm<WLDS, NW, MM>(op, a, cx); }
         else rz_scale<NW>(op, a, cx, b0, ntree, sel_leaf, true);
         last = ((op.sched >> 16) & 1u) != 0;
         ++o;
@@ -141,25 +141,25 @@ rz_search_kernel(const RzSearchArgs sa) {
   if (row_valid && sub == 0) store_state(t, st);
 }
 
-template <bool WLDS, int NW, int AW>
+template <bool WLDS, int NW, int AW, int MM>
 inline int rz_search_launch_k(const RzSearchArgs& sa, unsigned grid, size_t lds_bytes, stream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)rz_search_kernel<WLDS, NW, AW>,
+    hipError_t e = hipFuncSetAttribute((const void*)rz_search_kernel<WLDS, NW, AW, MM>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((rz_search_kernel<WLDS, NW, AW>), dim3(grid), dim3(NW * 64), lds_bytes, stream, sa);
+  hipLaunchKernelGGL((rz_search_kernel<WLDS, NW, AW, MM>), dim3(grid), dim3(NW * 64), lds_bytes, stream, sa);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("residual search kernel launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
   return MZX_OK;
 }
 
-template <bool WLDS, int NW>
+template <bool WLDS, int NW, int MM>
 inline int rz_search_launch_aw(const RzSearchArgs& sa, unsigned grid, size_t lds, stream_t stream) {
-  if (sa.p.num_actions <= 4) return rz_search_launch_k<WLDS, NW, 4>(sa, grid, lds, stream);
-  return rz_search_launch_k<WLDS, NW, 16>(sa, grid, lds, stream);
+  if (sa.p.num_actions <= 4) return rz_search_launch_k<WLDS, NW, 4, MM>(sa, grid, lds, stream);
+  return rz_search_launch_k<WLDS, NW, 16, MM>(sa, grid, lds, stream);
 }
 
 inline bool rz_search_supported(const mzx_search* s) {
@@ -221,8 +221,9 @@ inline int rz_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, 
     // mode flag 8: per-workgroup phase cycle counters in the (otherwise unused) network workspace region
     sa.prof = ((s->mode & 8) && s->ws_floats >= (int64_t)L.grid * 8) ? (uint32_t*)((char*)d_arena + s->off_ws) : nullptr;
     const size_t lds = L.lds + (size_t)4 * extra;
-    if (L.wlds) rc = L.eight ? rz_search_launch_aw<true, 8>(sa, L.grid, lds, stream) : rz_search_launch_aw<true, 4>(sa, L.grid, lds, stream);
-    else rc = L.eight ? rz_search_launch_aw<false, 8>(sa, L.grid, lds, stream) : rz_search_launch_aw<false, 4>(sa, L.grid, lds, stream);
+    if (L.small) rc = L.wlds ? rz_search_launch_aw<true, 4, 3>(sa, L.grid, lds, stream) : rz_search_launch_aw<false, 4, 3>(sa, L.grid, lds, stream);
+    else if (L.wlds) rc = L.eight ? rz_search_launch_aw<true, 8, 8>(sa, L.grid, lds, stream) : rz_search_launch_aw<true, 4, 8>(sa, L.grid, lds, stream);
+    else rc = L.eight ? rz_search_launch_aw<false, 8, 8>(sa, L.grid, lds, stream) : rz_search_launch_aw<false, 4, 8>(sa, L.grid, lds, stream);
     if (rc) return rc;
   }
   return search_finish(s, io, d_arena, stream);
