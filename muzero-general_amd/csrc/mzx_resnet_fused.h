@@ -872,19 +872,30 @@ __device__ __forceinline__ void rz_scale(const RzOp& op, const RzArgs& a, const 
   const int T = cx.T, C = op.channels;
   const float* in = cx.reg + T * op.in_off;
   float* out = cx.reg + T * op.out_off;
-  for (int t = 0; t < T; ++t) {
-    for (int c = cx.tid; c < C; c += NT) {
-      const float* pl = in + t * a.slot_ts + c;
-      float lo = pl[(a.PW + 1) * a.Cs], hi = lo;
-      for (int y = 0; y < a.H; ++y)
-        for (int x = 0; x < a.W; ++x) {
-          const float v = pl[((y + 1) * a.PW + x + 1) * a.Cs];
-          lo = fminf(lo, v); hi = fmaxf(hi, v);
-        }
-      float sc = hi - lo;
-      if (sc < 1e-5f) sc += 1e-5f;
-      cx.scratch[2 * (t * C + c)] = lo;
-      cx.scratch[2 * (t * C + c) + 1] = sc;
+  // plane minimum / maximum: one 16-lane row per (tree, channel) plane, lanes stride over the positions, then
+  // a four-step butterfly (min and max are exact in any order)
+  {
+    const int sub = cx.tid & 15, grp = cx.tid >> 4, planes = T * C;
+    for (int base = 0; base < planes; base += NT / 16) {   // uniform trip count: the shuffles need the whole wave
+      const int pr = base + grp;
+      const bool valid = pr < planes;
+      const int t = valid ? pr / C : 0, c = valid ? pr - t * C : 0;
+      float lo = MZX_INF, hi = -MZX_INF;
+      for (int p = sub; p < a.HW; p += 16) {
+        const float v = in[cx.rowaddr[t * a.HW + p] + c];
+        lo = fminf(lo, v); hi = fmaxf(hi, v);
+      }
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, m, 16));
+        hi = fmaxf(hi, __shfl_xor(hi, m, 16));
+      }
+      if (valid && sub == 0) {
+        float sc = hi - lo;
+        if (sc < 1e-5f) sc += 1e-5f;
+        cx.scratch[2 * pr] = lo;
+        cx.scratch[2 * pr + 1] = sc;
+      }
     }
   }
   __syncthreads();
