@@ -234,7 +234,6 @@ inline void rz_schedule(RzProgram& R, int HW) {
       for (int q = 0; q < m; ++q) {
         RzOp& o = R.ops[members[q]];
         o.team |= ((uint32_t)lo | ((uint32_t)cnt[q] << 8)) << (16 * k);
-        (k ? o.store_hidden : o.channels) = (65536 + cnt[q] - 1) / cnt[q];
         lo += cnt[q];
       }
     }
@@ -459,7 +458,7 @@ inline int rz_scratch_floats(const RzGeometry& g, int T) { return rz_round4(2 * 
 inline int64_t rz_lds_floats(const RzGeometry& g, const RzProgram& R, int T, bool weights_in_lds, bool tables = true) {
   const int mpad = rz_round16(T * g.HW);
   const int64_t scratch = rz_scratch_floats(g, T);
-  return (int64_t)2 * mpad + scratch + (tables ? R.small_floats : R.aoff_base) +
+  return (int64_t)2 * mpad + rz_round4(R.n_ops * 8) + scratch + (tables ? R.small_floats : R.aoff_base) +
          (int64_t)T * (3 * g.slot_ts + R.flat_floats) + (weights_in_lds ? R.w_floats : 0);
 }
 
@@ -579,6 +578,7 @@ struct RzCtx {
   const int* rowaddr;   // [mpad] activation address of row m = (tree, position): t * slot_ts + ((y+1) * PW + x + 1) * Cs
   const int* rowtp;     // [mpad] (t << 16) | position (0 for rows beyond T * HW)
   const int* rowout;    // output / residual address of row m (the stem kernel's tiles differ from rowaddr); null: rowaddr
+  const unsigned* work; // [n_ops][waves] work words (rz_work_word), built once per launch
   unsigned long long* fine;   // profiling: eight intra-operator clock stamps of wave 0 (null: off)
   float* scratch;       // [2 * T * Cs] min-max scratch, then actval[T] = action / |A| per tree
   const float* wlds;    // LDS copy of the weight image (WLDS kernels)
@@ -822,34 +822,55 @@ __device__ __forceinline__ RzOp rz_fetch_op(const float* image, int o) {
   return ((const RzOp*)image)[o];
 }
 
+// What one wave does for one operator, decided once per launch (rz_setup) instead of per operator and
+// simulation: the team / tile arithmetic and its branches were ~1 000 cycles of exposed scalar code per
+// operator on the small networks.  Bits 0-3 / 4-7: row tiles of the wave's first / second group (0 = none;
+// first 0 = the wave idles), 8-11 first column tile, 12-15 column tile step, 16-19 first row tile, 20-23 row
+// tile step.  Column tiles go to the waves first (a power of two of them), row tiles to the rest; an
+// operator that shares its slot runs on its team only (rz_schedule): per-tree GEMMs spread column tiles,
+// per-position GEMMs row tiles over the team.
+__device__ __forceinline__ unsigned rz_work_word(const RzOp& op, int T, int HW, int nw, int wave) {
+  if (op.kind != RZ_GEMM) return 0u;
+  const int rows = (op.rows == RZ_ROWS_POS) ? T * HW : T;
+  const int mt_total = (rows + 15) >> 4, nt_total = (op.cout + 15) >> 4;
+  const unsigned team = (nw == 8) ? (op.team >> 16) : (op.team & 0xFFFFu);
+  const int t_cnt = (int)(team >> 8);
+  int wn, wm, waves_n, waves_m;
+  if (t_cnt == 0) {
+    const int lg_n = (int)((op.sched >> (nw == 8 ? 8 : 0)) & 0xFFu);
+    waves_n = 1 << lg_n; waves_m = nw >> lg_n;
+    wn = wave & (waves_n - 1); wm = wave >> lg_n;
+  } else {
+    const int tw = wave - (int)(team & 0xFFu);
+    if (tw < 0 || tw >= t_cnt) return 0u;
+    if (op.rows == RZ_ROWS_TREE) { waves_n = t_cnt; waves_m = 1; wn = tw; wm = 0; }
+    else { waves_n = 1; waves_m = t_cnt; wn = 0; wm = tw; }
+  }
+  if (wn >= nt_total || wm >= mt_total) return 0u;
+  const int mine = (mt_total - wm + waves_m - 1) / waves_m;     // row tiles wm, wm + waves_m, ...
+  const int cnt0 = mine < 8 ? mine : 8, cnt1 = mine - cnt0 < 8 ? mine - cnt0 : 8;
+  return (unsigned)cnt0 | ((unsigned)cnt1 << 4) | ((unsigned)wn << 8) | ((unsigned)waves_n << 12) |
+         ((unsigned)wm << 16) | ((unsigned)waves_m << 20);
+}
+
 // MM: the most row tiles one wave ever gets in this launch (host-checked).  Kernels for small activation
 // matrices are instantiated with MM = 3: without the code of the 4..8-tile variants the kernel is half the
 // size and the per-operator dispatch -- exposed on the latency-bound small networks -- is shorter.
 template <bool WLDS, int NW, int MM>
-__device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const RzCtx& cx) {
-  const int rows = (op.rows == RZ_ROWS_POS) ? cx.T * a.HW : cx.T;
-  const int mt_total = (rows + 15) >> 4, nt_total = (op.cout + 15) >> 4;
-  // the waves running this operator: its team (operators sharing a slot), or the whole workgroup
-  const unsigned team = (NW == 8) ? (op.team >> 16) : (op.team & 0xFFFFu);
-  const int t_cnt = (int)(team >> 8);
-  int wn, wm, waves_n, waves_m;
-  unsigned rcp_m;   // ceil(2^16 / waves_m)
-  if (t_cnt == 0) {
-    // column tiles over the waves first (a power of two of them, precomputed), row tiles over the rest
-    const int lg_n = (int)((op.sched >> (NW == 8 ? 8 : 0)) & 0xFFu);
-    const int lg_m = (NW == 8 ? 3 : 2) - lg_n;
-    waves_n = 1 << lg_n; waves_m = 1 << lg_m;
-    wn = cx.wave & (waves_n - 1); wm = cx.wave >> lg_n;
-    rcp_m = 65536u >> lg_m;
-  } else {
-    const int tw = cx.wave - (int)(team & 0xFFu);
-    if ((unsigned)tw >= (unsigned)t_cnt) return;
-    if (op.rows == RZ_ROWS_TREE) { waves_n = t_cnt; waves_m = 1; wn = tw; wm = 0; rcp_m = 65536u; }   // one row tile
-    else { waves_n = 1; waves_m = t_cnt; wn = 0; wm = tw; rcp_m = (unsigned)(NW == 8 ? op.store_hidden : op.channels); }
-  }
+__device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const RzCtx& cx, unsigned w) {
+#ifdef MZX_RZ_EXPERIMENT
+  if (cx.fine && cx.tid == 0) cx.fine[7] = __builtin_readcyclecounter() + (unsigned long long)(op.kind & 0);   // after the descriptor fetch
+#endif
+  const int cnt0 = (int)(w & 15u);
+  if (cnt0 == 0) return;
+  const int cnt1 = (int)((w >> 4) & 15u), wn = (int)((w >> 8) & 15u), waves_n = (int)((w >> 12) & 15u);
+  const int wm = (int)((w >> 16) & 15u), waves_m = (int)((w >> 20) & 15u);
+  const int nt_total = (op.cout + 15) >> 4;
   for (int nt = wn; nt < nt_total; nt += waves_n) {
-    for (int mt0 = wm; mt0 < mt_total; mt0 += waves_m * 8) {
-      const int cnt = min(8, (int)(((unsigned)(mt_total - mt0 + waves_m - 1) * rcp_m) >> 16));   // wave-uniform
+    for (int g = 0; g < 2; ++g) {
+      const int cnt = g ? cnt1 : cnt0;   // wave-uniform
+      if (cnt == 0) break;
+      const int mt0 = wm + g * 8 * waves_m;
       switch (cnt) {
         case 1: if constexpr (MM >= 1) rz_gemm_tiles<1, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
         case 2: if constexpr (MM >= 2) rz_gemm_tiles<2, WLDS, NW == 4>(op, a, cx, nt, mt0, waves_m); break;
@@ -922,10 +943,12 @@ __device__ __forceinline__ RzCtx rz_carve(const RzArgs& a, float* lds) {
   RzCtx cx;
   int* rowaddr = (int*)lds;
   int* rowtp = rowaddr + a.mpad;
-  float* scratch = (float*)(rowtp + a.mpad);
+  unsigned* work = (unsigned*)(rowtp + a.mpad);
+  float* scratch = (float*)(work + ((a.n_ops * 8 + 3) & ~3));
   float* simg = scratch + a.scratch_floats;
   float* reg = simg + a.small_floats;
   cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.scratch = scratch; cx.simg = simg; cx.rowout = nullptr;
+  cx.work = work;
   cx.fine = nullptr;
   cx.wlds = reg + a.T * a.tree_floats;
   cx.T = a.T; cx.tid = threadIdx.x; cx.lane = threadIdx.x & 63; cx.wave = threadIdx.x >> 6;
@@ -953,6 +976,12 @@ __device__ __forceinline__ void rz_setup(const RzArgs& a, const RzCtx& cx) {
   {
     f32x4* z = (f32x4*)cx.reg;
     for (int i = tid; i < T * a.tree_floats / 4; i += NT) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // work words of every (operator, wave)
+  {
+    unsigned* work = (unsigned*)cx.work;
+    const RzOp* ops = (const RzOp*)a.small;
+    for (int i = tid; i < a.n_ops * NW; i += NT) work[i] = rz_work_word(ops[i / NW], T, a.HW, NW, i % NW);
   }
   int* rowaddr = (int*)cx.rowaddr;
   int* rowtp = (int*)cx.rowtp;
@@ -1025,8 +1054,9 @@ rz_network_kernel(const RzArgs a) {
     if (a.dump_op == -2 && blockIdx.x == 0) { cxo.fine = fine; if (tid == 0) fine[0] = __builtin_readcyclecounter(); }
     bool last;
     do {
+      const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)cx.work[o * NW + cx.wave]);
       const RzOp op = rz_fetch_op(cx.simg, o);   // from the LDS-resident program image
-      if (op.kind == RZ_GEMM) rz_gemm<WLDS, NW, MM>(op, a, cxo);
+      if (op.kind == RZ_GEMM) rz_gemm<WLDS, NW, MM>(op, a, cxo, w);
       else rz_scale<NW>(op, a, cx, b0, ntree, a.out_node, false);
       last = ((op.sched >> 16) & 1u) != 0;
       ++o;
@@ -1271,7 +1301,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   RzCtx cx;
   cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.rowout = rowout; cx.scratch = params; cx.simg = params;
   cx.wlds = nullptr; cx.T = 1; cx.tid = tid; cx.lane = tid & 63; cx.wave = tid >> 6; cx.fine = nullptr;
-  rz_gemm<false, 4, 8>(sa.op, a, cx);
+  cx.work = nullptr;
+  rz_gemm<false, 4, 8>(sa.op, a, cx, rz_work_word(sa.op, 1, rows, 4, tid >> 6));
   __syncthreads();
   // ---- write back, coalesced along x
   {

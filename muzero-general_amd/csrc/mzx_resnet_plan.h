@@ -38,9 +38,8 @@ struct RzOp {
   int32_t bias_off;      // bias, padded to whole column tiles
   int32_t asum_off;      // dynamics input convolution: border-aware tap sums of the action plane's weights [cout][H*W]
   int32_t act;           // RzAct
-  int32_t channels;      // RZ_SCALE: planes per tree.       RZ_GEMM with a team: ceil(2^16 / team waves), 4-wave kernels
-  int32_t store_hidden;  // RZ_SCALE: also write the scaled state to the caller's hidden-state output.
-                         //                                  RZ_GEMM with a team: the same reciprocal for 8-wave kernels
+  int32_t channels;      // RZ_SCALE: planes per tree
+  int32_t store_hidden;  // RZ_SCALE: also write the scaled state to the caller's hidden-state output
   uint32_t aoff_off;     // A-fragment offset table of this GEMM inside the small image (ints): chunk c at [3 + c],
                          // = (tap row - 1) * PW * Cs + (tap column - 1) * Cs + 16 * (channel chunk); the entries
                          // after the last chunk repeat it (the software pipeline prefetches past the end), the

@@ -107,8 +107,9 @@ rz_search_kernel(const RzSearchArgs sa) {
     for (int o = 0; o < a.n_ops;) {
       bool last;
       do {
+        const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)cx.work[o * NW + cx.wave]);
         const RzOp op = rz_fetch_op(cx.simg, o);
-        if (op.kind == RZ_GEMM) { if (!RZ_DBG(a, 4)) rz_gemm<WLDS, NW, MM>(op, a, cx); }
+        if (op.kind == RZ_GEMM) { if (!RZ_DBG(a, 4)) rz_gemm<WLDS, NW, MM>(op, a, cx, w); }
         else rz_scale<NW>(op, a, cx, b0, ntree, sel_leaf, true);
         last = ((op.sched >> 16) & 1u) != 0;
         ++o;

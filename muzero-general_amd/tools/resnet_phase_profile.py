@@ -53,11 +53,11 @@ def main():
             if sl >= 0:
                 members.setdefault(sl, []).append(k)
         print(f"  {n_slots} slots: " + " ".join("{" + ",".join(str(k) for k in members[sl]) + "}" for sl in sorted(members)))
-        print("  intra-slot (wave 0, first operator): fetch+dispatch | row bases | K loop | epilogue | other operators of the slot | barrier")
+        print("  intra-slot (wave 0, first operator): descriptor fetch | dispatch | row bases | K loop | epilogue | other operators of the slot | barrier")
         for o in range(48):
             f = fine[o]
             if f[1] and f[4] and f[6] > f[0]:
-                print("   table %2d: %6d %6d %6d %6d %6d %6d   = %6d" % (o, f[1] - f[0], f[2] - f[1], f[3] - f[2], f[4] - f[3], f[5] - f[4], f[6] - f[5], f[6] - f[0]))
+                print("   table %2d: %6d %6d %6d %6d %6d %6d %6d   = %6d" % (o, f[7] - f[0], f[1] - f[7], f[2] - f[1], f[3] - f[2], f[4] - f[3], f[5] - f[4], f[6] - f[5], f[6] - f[0]))
 
 
 if __name__ == "__main__":
