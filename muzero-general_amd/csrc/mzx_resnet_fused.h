@@ -549,6 +549,7 @@ struct RzArgs {
   int32_t n_ops, T, batch, num_actions;
   int32_t H, W, HW, PW, Cs, slot_ts, tree_floats, mpad, scratch_floats;
   uint32_t magic_hw, magic_w;     // ceil(2^32 / HW), ceil(2^32 / W): divisions by multiplication
+  uint32_t magic_pt;              // ceil(2^32 / (in_channels * HW))
   int32_t in_off, in_channels, use_action;
   int32_t out_off[3], out_ts[3], out_n[3];
   int32_t hidden_floats;          // C * H * W
@@ -1014,14 +1015,29 @@ __device__ __forceinline__ void rz_load_input(const RzArgs& a, const RzCtx& cx, 
   }
   float* dst = cx.reg + T * a.in_off;
   const int per_tree = a.in_channels * a.HW;
-  for (int t = 0; t < ntree; ++t) {
-    const int64_t s = b0 + t;
-    const int64_t node = in_node ? in_node[local ? t : s] : 0;
-    const float* src = a.in + (s * a.in_nodes + node) * per_tree;
-    for (int rem = tid; rem < per_tree; rem += NT) {
-      const int c = rz_div(rem, a.HW, a.magic_hw), p = rem - c * a.HW;
-      dst[cx.rowaddr[t * a.HW + p] + c] = src[rem];
+  // (tree, element) pairs are spread over the whole workgroup and every thread keeps four independent global
+  // loads in flight per trip: the states sit in L2 / HBM, so the gather costs one round trip per trip instead
+  // of one per tree
+  const int total = ntree * per_tree;
+  for (int i0 = tid; i0 < total; i0 += 4 * NT) {
+    float v[4];
+    int at[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * NT;
+      v[u] = 0.f; at[u] = -1;
+      if (i < total) {
+        const int t = rz_div(i, per_tree, a.magic_pt), rem = i - t * per_tree;
+        const int64_t s = b0 + t;
+        const int64_t node = in_node ? in_node[local ? t : s] : 0;
+        v[u] = a.in[(s * a.in_nodes + node) * per_tree + rem];
+        const int c = rz_div(rem, a.HW, a.magic_hw), p = rem - c * a.HW;
+        at[u] = cx.rowaddr[t * a.HW + p] + c;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (at[u] >= 0) dst[at[u]] = v[u];
   }
   __syncthreads();
 }
@@ -1199,6 +1215,10 @@ inline RzLaunch rz_prepare(const mzx_net* net, const RzProgram& R, const float* 
   L.lds = (size_t)4 * rz_lds_floats(g, R, a.T, wlds, tables);
   a.magic_hw = (uint32_t)((0x100000000ull + (uint64_t)g.HW - 1) / (uint64_t)g.HW);
   a.magic_w = (uint32_t)((0x100000000ull + (uint64_t)g.W - 1) / (uint64_t)g.W);
+  {
+    const uint64_t pt = (uint64_t)R.in_channels * (uint64_t)g.HW;
+    a.magic_pt = pt > 1 ? (uint32_t)((0x100000000ull + pt - 1) / pt) : 0u;
+  }
   if (rz_env_int("MZX_RZ_WLDS", 1) == 0 && wlds) {   // A/B knob: weights from L2 although they would fit in LDS
     wlds = false;
     L.lds = (size_t)4 * rz_lds_floats(g, R, a.T, false, tables);

@@ -34,6 +34,7 @@ struct RzSearchArgs {
   const uint32_t* tape;  // [num_trees][tape_words]
   int32_t num_sims, sim0;
   uint32_t* prof;        // nullable: [grid][8] cycles per phase, accumulated over the simulations (mode flag 8)
+  int32_t tree_lds;      // 1: the workgroup's trees are staged into LDS for the whole search (they fit)
 };
 
 // floats of LDS the search adds behind the network engine's image: selection hand-off, tables
@@ -75,6 +76,16 @@ rz_search_kernel(const RzSearchArgs sa) {
   TreeRef t;
   t.base = sa.trees + (size_t)tree * sa.L.tree_bytes;
   t.L = sa.L;
+  // Small searches: the trees of the workgroup live in LDS for the whole launch (the selection walk is a
+  // chain of dependent reads per level -- an LDS round trip instead of an L2 one), staged in and out once.
+  double* tree_lds = tables + ntab;
+  const int slab8 = (int)(sa.L.tree_bytes >> 3);      // tree_bytes is a multiple of 8
+  if (sa.tree_lds) {
+    const double* src = (const double*)(sa.trees + (size_t)b0 * sa.L.tree_bytes);
+    for (int i = tid; i < ntree * slab8; i += NT) tree_lds[i] = src[i];
+    t.base = (char*)(tree_lds + (size_t)(row_valid ? row : 0) * slab8);
+    __syncthreads();
+  }
   const uint32_t* tape = sa.tape + (size_t)tree * p.tape_words;
   RowState st;
   if (row_valid) load_state(t, st);
@@ -140,6 +151,11 @@ rz_search_kernel(const RzSearchArgs sa) {
 #undef RZS_PROF
   if (prof) for (int k = 0; k < 8; ++k) sa.prof[blockIdx.x * 8 + k] = pc[k];
   if (row_valid && sub == 0) store_state(t, st);
+  if (sa.tree_lds) {
+    __syncthreads();
+    double* dst = (double*)(sa.trees + (size_t)b0 * sa.L.tree_bytes);
+    for (int i = tid; i < ntree * slab8; i += NT) dst[i] = tree_lds[i];
+  }
 }
 
 template <bool WLDS, int NW, int AW, int MM>
@@ -211,6 +227,13 @@ inline int rz_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, 
     ir.in_nodes = s->p.num_nodes; ir.out_nodes = s->p.num_nodes;
     const int64_t extra = rz_search_extra_floats(s->p);
     RzLaunch L = rz_prepare(net, R, nr.in, nr, B, &ir, 0, extra);
+    // trees in LDS when that costs neither trees per workgroup nor the kernel shape (MZX_RZ_TREE_LDS=0: A/B knob)
+    const int64_t slab_floats = 2 * (int64_t)(s->L.tree_bytes >> 3);
+    bool tree_lds = false;
+    if (rz_env_int("MZX_RZ_TREE_LDS", 1) != 0) {
+      const RzLaunch L1 = rz_prepare(net, R, nr.in, nr, B, &ir, slab_floats, extra);
+      if (L1.a.T == L.a.T && L1.eight == L.eight && L1.small == L.small) { L = L1; tree_lds = true; }
+    }
     RzSearchArgs sa;
     sa.net = L.a;
     sa.p = v.p;
@@ -221,7 +244,8 @@ inline int rz_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, 
     sa.sim0 = 0;
     // mode flag 8: per-workgroup phase cycle counters in the (otherwise unused) network workspace region
     sa.prof = ((s->mode & 8) && s->ws_floats >= (int64_t)L.grid * 8) ? (uint32_t*)((char*)d_arena + s->off_ws) : nullptr;
-    const size_t lds = L.lds + (size_t)4 * extra;
+    sa.tree_lds = tree_lds ? 1 : 0;
+    const size_t lds = L.lds + (size_t)4 * (extra + (tree_lds ? slab_floats * L.a.T : 0));
     if (L.small) rc = L.wlds ? rz_search_launch_aw<true, 4, 3>(sa, L.grid, lds, stream) : rz_search_launch_aw<false, 4, 3>(sa, L.grid, lds, stream);
     else if (L.wlds) rc = L.eight ? rz_search_launch_aw<true, 8, 8>(sa, L.grid, lds, stream) : rz_search_launch_aw<true, 4, 8>(sa, L.grid, lds, stream);
     else rc = L.eight ? rz_search_launch_aw<false, 8, 8>(sa, L.grid, lds, stream) : rz_search_launch_aw<false, 4, 8>(sa, L.grid, lds, stream);
