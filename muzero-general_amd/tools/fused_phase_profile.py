@@ -62,7 +62,7 @@ def residual(args):
     raw = engine.arena(B)[off["workspace"]: off["workspace"] + 256 * 8 * 4].view(torch.int32).cpu().numpy().reshape(-1, 8)
     raw = raw[((raw[:, :6] > 0) & (raw[:, :6] < 2 ** 29)).all(1)]   # workgroups that wrote counters (the region is shared with the stem's workspace)
     S = cfg.num_simulations
-    names = ["select (lane-parallel, arena trees)", "barrier after select", "gather parent states -> LDS", "network layers",
+    names = ["select (lane-parallel)              ", "barrier after select", "gather parent states -> LDS", "network layers",
              "decode + expand + backpropagate", "barrier"]
     mean = raw[:, :6].mean(0)
     print(f"{args.workload}: {B} trees x {S} sims, {len(raw)} workgroups sampled, mean leaf depth {res.sum_depth.mean() / S:.2f}")
