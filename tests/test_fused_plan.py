@@ -41,6 +41,33 @@ def test_which_networks_are_fused(lib):
     lib.mzx_net_destroy(h)
 
 
+def test_schedule_puts_independent_operators_into_shared_slots(lib):
+    """
+    rz_schedule: the reward head runs beside the prediction trunk and the value / policy towers beside each
+    other wherever the layer GEMMs are small enough to share a workgroup (tic-tac-toe, breakout); connect4's wide
+    trunk convolutions keep the whole workgroup, only its heads pair up.  Every operator runs after everything it
+    reads: the slot index never decreases along a chain of the program.
+    """
+    want = {"tictactoe": ((12, 9), (15, 9)), "connect4": ((20, 17), (23, 20)), "breakout": ((35, 12), (19, 13))}
+    for name, per_program in want.items():
+        h = _create(lib, configs.BY_NAME[name]())
+        for recurrent, (n_ops, n_slots) in enumerate(per_program):
+            assert lib.mzx_net_num_operators(h, recurrent) == n_ops
+            slot = (ctypes.c_int32 * n_ops)()
+            assert lib.mzx_net_fused_schedule(h, recurrent, slot, n_ops) == n_slots, (name, recurrent)
+            fused = [s for s in slot if s >= 0]
+            assert fused[0] == 0 and max(fused) == n_slots - 1 and sorted(set(fused)) == list(range(n_slots))
+            first = list(slot).index(0)
+            assert all(s == -1 for s in slot[:first])            # the down-sampling stem precedes the fused part
+            assert all(slot[first + k] <= k for k in range(len(fused)))   # operators only move EARLIER than program order
+            assert max(fused.count(s) for s in set(fused)) <= 3
+        assert lib.mzx_net_fused_schedule(h, 0, slot, 1) == 0      # capacity too small
+        lib.mzx_net_destroy(h)
+    h = _create(lib, configs.cartpole())
+    assert lib.mzx_net_fused_schedule(h, 1, (ctypes.c_int32 * 16)(), 16) == 0   # fully connected: no fused programs
+    lib.mzx_net_destroy(h)
+
+
 def test_flops_match_survey(lib):
     # SURVEY.md section 8(d): 2 x MAC per simulation / per initial inference
     want = {"cartpole": (1312, 2752), "tictactoe": (187968, 231504), "connect4": (37372160, 40396160),
