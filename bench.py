@@ -16,6 +16,7 @@ once, outside the timed region, as the reference's weight pull self_play.py:37).
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   "roofline":     algorithmic tree bytes (SURVEY.md section 8d formula, with the measured mean
                   leaf depth) / HIP-event time of the search launch, vs the HBM peak
+  "observation_stacker": the path's HBM-bound kernel (mzx_obs_stack, atari geometry) against the HBM peak
   "cpu_baseline": the CPU oracle (oracle/*.py: the reference's per-node algorithm and its
                   batch-1 torch network, kind "port") timed on this box's host cores on a
                   bounded sample of the same workload.
@@ -108,6 +109,35 @@ def _state_dict_template(cfg):
         out[name.value.decode()] = torch.zeros(tuple(d for d in dims if d > 0))
     lib.mzx_net_destroy(h)
     return out
+
+
+def observation_stacker_leg(backend, games=64, stacked=32, iters=20):
+    """
+    The HBM-bound kernel beside the search: mzx_obs_stack at the games/atari.py
+    geometry (3x96x96 frames, 32 stacked observations -> 131 planes per sample).  Algorithmic bytes per
+    launch = every frame plane read once + every output plane written once; HIP events on the launch stream.
+    """
+    from mzx import configs, observations
+    cfg = configs.HotPathConfig(observation_shape=(3, 96, 96), stacked_observations=stacked, action_space=list(range(4)))
+    store = observations.FrameStore(cfg, games, backend)
+    rs = numpy.random.RandomState(0)
+    for t in range(stacked + 2):
+        store.push(rs.rand(games, 3, 96, 96).astype(numpy.float32), None if t == 0 else rs.randint(0, 4, size=games))
+    store.stacked()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(iters):
+        store.stacked()
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / iters
+    planes_in, planes_out = 3 * (stacked + 1), 3 * (stacked + 1) + stacked
+    nbytes = games * (planes_in + planes_out) * 96 * 96 * 4
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": "mzx_obs_stack (GameHistory.get_stacked_observations on the device)", "bound": "hbm",
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": nbytes, "launch_ms": ms, "games": games, "stacked_observations": stacked}
 
 
 def cpu_baseline(workload, seconds, cores):
@@ -327,6 +357,8 @@ def main():
         if world == 1 and args.selfplay_moves > 0:
             line["selfplay_end_to_end"] = selfplay_leg(cfg, net, B, args.selfplay_moves)
             line["selfplay_end_to_end_batched_game"] = selfplay_leg(cfg, net, B, args.selfplay_moves, batched=True)
+        if world == 1 and args.selfplay_moves > 0:
+            line["observation_stacker"] = observation_stacker_leg(net.backend)
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_cores)
         else:
