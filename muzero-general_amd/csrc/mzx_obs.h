@@ -68,10 +68,18 @@ struct ObsStackOp {
       const uint32_t p = piece * (64u * UNROLL) + (uint32_t)u * 64u + lane;
       if (p >= (uint32_t)hwv) break;
       if (VEC == 4) {
+#ifdef MZX_HOSTCHECK
         struct alignas(16) F4 { float x, y, z, w; };
         F4 v = {fill, fill, fill, fill};
         if (src) v = *(const F4*)(src + (int64_t)p * 4);
         *(F4*)(dst + (int64_t)p * 4) = v;
+#else
+        // streamed once in, once out: non-temporal 16-byte accesses keep the frames from displacing each other in L2
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        v4 v = {fill, fill, fill, fill};
+        if (src) v = __builtin_nontemporal_load((const v4*)(src + (int64_t)p * 4));
+        __builtin_nontemporal_store(v, (v4*)(dst + (int64_t)p * 4));
+#endif
       } else {
         dst[p] = src ? src[p] : fill;
       }
