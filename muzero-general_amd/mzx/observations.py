@@ -71,7 +71,8 @@ class FrameStore:
             raise ValueError(f"expected observations of shape {(self.G,) + self.shape}, got {obs.shape}")
         self.time += 1
         slot = self.time % self.ring
-        self.frames[slot].copy_(_frames_to_device(self.backend, obs))
+        # one conversion + upload straight into the slot (the reference's torch.tensor(obs).float())
+        self.frames[slot].copy_(torch.as_tensor(numpy.ascontiguousarray(obs)))
         if actions is None:
             self.actions[slot].zero_()
         else:
