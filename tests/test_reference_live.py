@@ -48,3 +48,90 @@ def test_game_doubles_equal_reference(game):
             (oa, ra, done), (ob, rb, db) = a.step(act), b.step(act)
             assert ra == rb and done == db
         assert numpy.array_equal(oa, ob)
+
+
+# ---- the "next" rows against the live reference classes, through the serial build of the C ABI
+
+def _random_history(ref_self_play, cfg, moves, seed):
+    rs = numpy.random.RandomState(seed)
+    gh = ref_self_play.GameHistory()
+    for t in range(moves + 1):
+        gh.observation_history.append(rs.standard_normal(cfg.observation_shape).astype("float32"))
+        gh.action_history.append(0 if t == 0 else int(rs.randint(0, len(cfg.action_space))))
+        gh.reward_history.append(0.0 if t == 0 else float(rs.randint(0, 2)))
+        gh.to_play_history.append(t % len(cfg.players))
+    gh.root_values = [float(v) for v in rs.standard_normal(moves)]
+    return gh
+
+
+@pytest.mark.parametrize("game,overrides,moves", [("tictactoe", dict(stacked_observations=3), 7),
+                                                  ("cartpole", dict(stacked_observations=2), 23),
+                                                  ("connect4", dict(), 11)])
+def test_reanalyse_equals_live_reference_worker(game, overrides, moves):
+    """mzx.replay.Reanalyse.reanalyse_game against replay_buffer.Reanalyse (unmodified) on a fresh random game."""
+    import torch
+    import hostcheck
+    from mzx import models, replay, synthetic
+    from oracle.make_golden import reference_reanalyse
+    ref_models, ref_self_play = ref_shim.load()
+    cfg = ref_shim.game_module(game).MuZeroConfig()
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    gh = _random_history(ref_self_play, cfg, moves, seed=moves)
+    torch.manual_seed(0)
+    weights = synthetic.fill_state_dict(ref_models.MuZeroNetwork(cfg).state_dict(), 77)
+    want = reference_reanalyse(cfg, weights, gh)
+    worker = replay.Reanalyse({"weights": weights, "num_reanalysed_games": 0}, cfg, _backend=hostcheck.backend())
+    got = worker.reanalyse_game(gh)                       # the reference's own GameHistory object drops in
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert numpy.allclose(got, want, atol=3e-4, rtol=3e-4), numpy.abs(got - want).max()
+
+
+def test_frame_store_equals_live_reference_history():
+    """FrameStore (ring of k + 1 device slots) against the reference GameHistory of every game of a shard."""
+    import torch
+    import hostcheck
+    from mzx import observations
+    _, ref_self_play = ref_shim.load()
+    cfg = configs.HotPathConfig(observation_shape=(2, 5, 4), stacked_observations=3, action_space=list(range(6)),
+                                players=[0])
+    G, moves = 5, 9
+    games = [_random_history(ref_self_play, cfg, moves, seed=100 + g) for g in range(G)]
+    store = observations.FrameStore(cfg, G, hostcheck.backend())
+    for t in range(moves + 1):
+        store.push(numpy.stack([g.observation_history[t] for g in games]),
+                   None if t == 0 else [g.action_history[t] for g in games])
+        got = store.stacked().cpu().numpy()
+        for i, g in enumerate(games):
+            part = ref_self_play.GameHistory()
+            part.observation_history = g.observation_history[: t + 1]
+            part.action_history = g.action_history[: t + 1]
+            want = torch.tensor(numpy.array(part.get_stacked_observations(-1, 3, 6))).float().numpy()
+            assert numpy.array_equal(got[i], want), (t, i)
+
+
+def test_cnn_stem_equals_live_reference_module():
+    """downsample="CNN" (models.py:278-297) on a fresh geometry: heads of both inferences within 1e-4."""
+    import torch
+    import hostcheck
+    from mzx import models, synthetic
+    ref_models, _ = ref_shim.load()
+    cfg = ref_shim.game_module("breakout").MuZeroConfig()
+    cfg.downsample, cfg.observation_shape, cfg.channels, cfg.blocks = "CNN", (3, 64, 48), 8, 1
+    torch.manual_seed(0)
+    ref = ref_models.MuZeroNetwork(cfg)
+    weights = synthetic.fill_state_dict(ref.state_dict(), 5)
+    ref.set_weights(weights)
+    ref.eval()
+    net = models.MuZeroNetwork(cfg, _backend=hostcheck.backend())
+    net.set_weights(weights)
+    obs = torch.tensor(synthetic.observations(2, net.input_shape, seed=4))
+    act = torch.tensor([[1], [3]])
+    with torch.no_grad():
+        want_i = ref.initial_inference(obs)
+        want_r = ref.recurrent_inference(want_i[3], act)
+    got_i = net.initial_inference(obs)
+    got_r = net.recurrent_inference(want_i[3], act)
+    for want, got in ((want_i, got_i), (want_r, got_r)):
+        for k in (0, 2, 3):
+            assert numpy.abs(got[k].cpu().numpy() - want[k].numpy()).max() < 1e-4
