@@ -32,6 +32,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "muzero-general_amd"))
 sys.path.insert(0, ROOT)
 
+# dmabuf IPC is the only mode the host driver supports: RCCL between the ranks of a node needs it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy  # noqa: E402
 import torch  # noqa: E402
 
