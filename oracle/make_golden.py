@@ -405,6 +405,21 @@ def main():
                       zero_keys=("prediction_policy_network.module.2.weight",
                                  "prediction_policy_network.module.2.bias"))
 
+    # non-default discount / exploration constants, two players: the sign flips and
+    # discounting of the back-propagation away from the game files' defaults
+    def subset2(c, cfg):
+        rs = numpy.random.RandomState(60 + c)
+        k = 1 if c == 0 else rs.randint(2, len(cfg.action_space) + 1)
+        return sorted(rs.choice(cfg.action_space, size=k, replace=False).tolist())
+
+    make_tree_fixture("tictactoe_custom", "tictactoe", 6, 15, subset2,
+                      overrides=dict(discount=0.9, pb_c_base=50, pb_c_init=3.0, root_exploration_fraction=0.5,
+                                     root_dirichlet_alpha=1.0, num_simulations=40),
+                      players_fn=lambda c, cfg: c % 2)
+    make_tree_fixture("cartpole_custom", "cartpole", 4, 16, full,
+                      overrides=dict(discount=0.8, pb_c_base=100, pb_c_init=0.5, root_exploration_fraction=0.0,
+                                     num_simulations=30))
+
     # ---- network outputs -------------------------------------------------------
     make_net_fixture("fc_cartpole", "cartpole", 21, 8)
     ckpt = torch.load(os.path.join(ref_shim.REFERENCE_ROOT, "results", "cartpole", "model.checkpoint"),

@@ -37,7 +37,8 @@ def test_native_library_is_loaded(backend):
         assert "libmzx.so" in f.read()
 
 
-@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties"])
+@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties", "tictactoe_custom",
+                                  "cartpole_custom"])
 def test_lockstep_tree_bit_exact(backend, name):
     got = lockstep.run_fixture(backend, name)
     if name == "cartpole_ties":
@@ -92,7 +93,8 @@ def test_network_heads_within_tolerance(backend, name, engine):
 
 
 @pytest.mark.parametrize("mode", ["generic", "fused"])
-@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties"])
+@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties", "tictactoe_custom",
+                                  "cartpole_custom"])
 def test_search_matches_reference(backend, name, mode, monkeypatch):
     if mode == "generic":
         orig = self_play.BatchedMCTS.__init__

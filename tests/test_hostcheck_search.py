@@ -34,7 +34,8 @@ def build_model(backend, cfg, weight_seed, zero_keys=()):
     return net
 
 
-@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties"])
+@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties", "tictactoe_custom",
+                                  "cartpole_custom"])
 def test_search_matches_reference(backend, name):
     z, meta, cfg = lockstep.load_fixture(name)
     cfg.num_simulations = meta["num_simulations"]

@@ -15,7 +15,8 @@ def backend():
     return hostcheck.backend()
 
 
-@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties"])
+@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties", "tictactoe_custom",
+                                  "cartpole_custom"])
 def test_lockstep_tree_bit_exact(backend, name):
     got = lockstep.run_fixture(backend, name)
     if name == "cartpole_ties":

@@ -69,7 +69,8 @@ def compare_tree(tree, z, c, cfg):
     assert tree.root_predicted_value == float(g("root_predicted_value"))
 
 
-@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties"])
+@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties", "tictactoe_custom",
+                                  "cartpole_custom"])
 def test_tree_lockstep_bit_exact(name):
     """Tree arithmetic alone: network outputs replayed from the reference run."""
     z, meta = load(f"tree_{name}.npz")
@@ -87,7 +88,8 @@ def test_tree_lockstep_bit_exact(name):
         assert total_ties >= sum(len(c["legal"]) > 1 for c in meta["cases"])
 
 
-@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties"])
+@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties", "tictactoe_custom",
+                                  "cartpole_custom"])
 def test_search_end_to_end_bit_exact(name):
     """Oracle network + oracle tree vs the reference's models.py + self_play.py."""
     z, meta = load(f"tree_{name}.npz")
