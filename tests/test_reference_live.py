@@ -135,3 +135,34 @@ def test_cnn_stem_equals_live_reference_module():
     for want, got in ((want_i, got_i), (want_r, got_r)):
         for k in (0, 2, 3):
             assert numpy.abs(got[k].cpu().numpy() - want[k].numpy()).max() < 1e-4
+
+
+@pytest.mark.parametrize("game,opponent,muzero_player,sims", [("tictactoe", "random", 0, 12), ("tictactoe", "expert", 1, 12),
+                                                              ("connect4", "expert", 0, 8), ("connect4", "random", 1, 8)])
+def test_play_game_against_opponents_equals_live_reference(game, opponent, muzero_player, sims):
+    """
+    test_mode games (self_play.py:139-162, :188-220): MuZero searches its own moves, the opponent's come from the
+    plugin's expert_agent / numpy.random.choice -- all draws from the process-global numpy stream, in the
+    reference's order.  Same seed => the same GameHistory (moves, rewards, None root values on opponent turns).
+    """
+    import torch
+    import hostcheck
+    from mzx import self_play, synthetic
+    ref_models, ref_self_play = ref_shim.load()
+    Game = ref_shim.game_module(game).Game
+    cfg = ref_shim.game_module(game).MuZeroConfig()
+    cfg.num_simulations = sims
+    torch.manual_seed(0)
+    weights = synthetic.fill_state_dict(ref_models.MuZeroNetwork(cfg).state_dict(), 91)
+    want = ref_self_play.SelfPlay({"weights": weights}, Game, cfg, 13).play_game(0, None, False, opponent, muzero_player)
+    got = self_play.SelfPlay({"weights": weights}, Game, cfg, 13, _backend=hostcheck.backend()).play_game(
+        0, None, False, opponent, muzero_player)
+    assert [int(a) for a in got.action_history] == [int(a) for a in want.action_history]
+    assert got.reward_history == want.reward_history and got.to_play_history == want.to_play_history
+    assert len(got.root_values) == len(want.root_values)
+    for a, b in zip(got.root_values, want.root_values):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert abs(a - b) < 3e-4 * max(1.0, abs(b))     # decoded values: ~1e-4 relative (inverse value transform)
+    assert any(v is None for v in want.root_values) and any(v is not None for v in want.root_values)
+    assert got.child_visits == want.child_visits
