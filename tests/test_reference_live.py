@@ -166,3 +166,85 @@ def test_play_game_against_opponents_equals_live_reference(game, opponent, muzer
             assert abs(a - b) < 3e-4 * max(1.0, abs(b))     # decoded values: ~1e-4 relative (inverse value transform)
     assert any(v is None for v in want.root_values) and any(v is not None for v in want.root_values)
     assert got.child_visits == want.child_visits
+
+
+class _Remote:
+    def __init__(self, fn):
+        self.remote = fn
+
+
+class _Storage:
+    """shared_storage stand-in (SharedStorage.get_info / set_info): the loop runs `passes` times."""
+
+    def __init__(self, weights, training_steps, passes):
+        self.info = {"terminate": False, "weights": weights, "num_played_steps": 0}
+        self.passes, self.training_steps, self.log = passes, training_steps, []
+        self.get_info = _Remote(self._get)
+        self.set_info = _Remote(self._set)
+
+    def _get(self, key):
+        if key == "training_step":
+            # the loop condition is the first read of every pass (self_play.py:32-34); later reads see the same step
+            return self.step
+        return self.info[key]
+
+    def _set(self, keys, values=None):
+        self.log.append((keys, values))
+
+    step = 0
+
+
+class _Buffer:
+    def __init__(self, storage, passes, training_steps):
+        self.games = []
+        self.save_game = _Remote(self._save)
+        self.storage, self.passes, self.training_steps = storage, passes, training_steps
+
+    def _save(self, game_history, shared_storage=None):
+        self.games.append(game_history)
+        if len(self.games) >= self.passes:
+            self.storage.step = self.training_steps      # ends the loop at the next condition check
+
+
+@pytest.mark.parametrize("test_mode", [False, True])
+def test_continuous_self_play_equals_live_reference(test_mode):
+    """The actor loop (self_play.py:31-108) with stand-in storage / buffer objects: same games, same reports."""
+    import torch
+    import hostcheck
+    from mzx import self_play, synthetic
+    ref_models, ref_self_play = ref_shim.load()
+    Game = ref_shim.game_module("tictactoe").Game
+    results = []
+    for module, extra in ((ref_self_play, {}), (self_play, {"_backend": hostcheck.backend()})):
+        cfg = ref_shim.game_module("tictactoe").MuZeroConfig()
+        cfg.num_simulations, cfg.training_steps, cfg.ratio, cfg.self_play_delay = 10, 1000, None, 0
+        torch.manual_seed(0)
+        weights = synthetic.fill_state_dict(ref_models.MuZeroNetwork(cfg).state_dict(), 17)
+        passes = 2
+        storage = _Storage(weights, cfg.training_steps, passes)
+        buffer = _Buffer(storage, passes, cfg.training_steps)
+        actor = module.SelfPlay({"weights": weights}, Game, cfg, 21, **extra)
+        if test_mode:
+            # test mode reports through set_info and saves nothing: end after `passes` reports
+            orig = storage._set
+
+            def counting(keys, values=None, orig=orig, storage=storage):
+                orig(keys, values)
+                if isinstance(keys, dict) and "episode_length" in keys:
+                    storage.reports = getattr(storage, "reports", 0) + 1
+                if getattr(storage, "reports", 0) >= passes and isinstance(keys, dict) and "opponent_reward" in keys:
+                    storage.step = cfg.training_steps
+            storage.set_info = _Remote(counting)
+        actor.continuous_self_play(storage, buffer, test_mode)
+        results.append((buffer.games, storage.log))
+    (ref_games, ref_log), (my_games, my_log) = results
+    assert len(ref_games) == len(my_games) == (0 if test_mode else 2)
+    for a, b in zip(ref_games, my_games):
+        assert [int(x) for x in a.action_history] == [int(x) for x in b.action_history]
+        assert a.reward_history == b.reward_history and a.child_visits == b.child_visits
+        assert numpy.allclose(a.root_values, b.root_values, atol=3e-4, rtol=3e-4)
+    assert len(ref_log) == len(my_log) == (4 if test_mode else 0)
+    for (ka, _), (kb, _) in zip(ref_log, my_log):
+        assert set(ka) == set(kb)
+        for key in ka:
+            assert numpy.allclose(ka[key], kb[key], atol=3e-4, rtol=3e-4), key
