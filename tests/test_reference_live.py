@@ -248,3 +248,43 @@ def test_continuous_self_play_equals_live_reference(test_mode):
         assert set(ka) == set(kb)
         for key in ka:
             assert numpy.allclose(ka[key], kb[key], atol=3e-4, rtol=3e-4), key
+
+
+@pytest.mark.parametrize("game", ["cartpole", "tictactoe"])
+def test_mcts_node_graph_equals_live_reference(game):
+    """MCTS(config).run: the returned Node graph (every node, not only the root) against the reference's."""
+    import torch
+    import hostcheck
+    from mzx import models, self_play, synthetic
+    ref_models, ref_self_play = ref_shim.load()
+    cfg = configs.BY_NAME[game](num_simulations=30)
+    torch.manual_seed(0)
+    ref = ref_models.MuZeroNetwork(cfg)
+    weights = synthetic.fill_state_dict(ref.state_dict(), 23)
+    ref.set_weights(weights)
+    ref.eval()
+    net = models.MuZeroNetwork(cfg, _backend=hostcheck.backend())
+    net.set_weights(weights)
+    obs = synthetic.observations(1, net.input_shape, seed=9)[0]
+    legal = list(cfg.action_space)[1:] if game == "tictactoe" else list(cfg.action_space)
+    numpy.random.seed(5)
+    with torch.no_grad():
+        want, want_info = ref_self_play.MCTS(cfg).run(ref, obs, legal, 0, True)
+    numpy.random.seed(5)
+    got, got_info = self_play.MCTS(cfg).run(net, obs, legal, 0, True)
+    assert got_info["max_tree_depth"] == want_info["max_tree_depth"]
+    assert abs(got_info["root_predicted_value"] - want_info["root_predicted_value"]) < 3e-4
+    nodes = 0
+    stack = [(want, got)]
+    while stack:
+        a, b = stack.pop()
+        nodes += 1
+        assert a.visit_count == b.visit_count and a.to_play == b.to_play and list(a.children) == list(b.children)
+        assert abs(a.value_sum - b.value_sum) < 3e-4 * max(1.0, abs(a.value_sum)) and abs(a.reward - b.reward) < 3e-4
+        if a.hidden_state is not None:
+            assert numpy.abs(a.hidden_state.numpy() - b.hidden_state.cpu().numpy()).max() < 1e-4
+        for action in a.children:
+            ca, cb = a.children[action], b.children[action]
+            assert abs(ca.prior - cb.prior) < 1e-5
+            stack.append((ca, cb))
+    assert nodes > cfg.num_simulations      # every expanded node and the unexpanded leaves under them
