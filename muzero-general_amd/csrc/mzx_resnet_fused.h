@@ -1257,6 +1257,7 @@ struct RzStemArgs {
   const float* beta;
   int32_t cin, cout, hin, win, hout, wout, stride;
   int32_t TH, TW, tiles_x, PWin, PHin, Cs, mpad;
+  uint32_t magic_pwin, magic_tw, magic_cells, magic_rows;   // ceil(2^32 / d): divisions by multiplication (rz_div)
 };
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) rz_stem_conv_kernel(const RzStemArgs sa) {
@@ -1272,7 +1273,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   const int aoff_ints = rz_aoff_ints(sa.op.nchunks);
   float* reg = params + 128 + aoff_ints;
   const int in_floats = sa.PHin * sa.PWin * sa.Cs;
-  const int out_floats = rows * sa.Cs;
   // ---- tables, parameters, input tile (+ halo), residual tile
   for (int m = tid; m < sa.mpad; m += 256) {
     const int ty = m / sa.TW, tx = m - ty * sa.TW;
@@ -1286,32 +1286,63 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   for (int k = tid; k < aoff_ints; k += 256)
     ((int*)params)[128 + k] = rz_aoff_entry(k, sa.op.nchunks, 9, sa.op.cchunks, sa.PWin, sa.Cs);
   {
+    // only the input tile needs zeros (halo cells outside the image, pad channels of the last K chunk); every
+    // output / residual element that is read back is written first
     f32x4* z = (f32x4*)reg;
-    for (int i = tid; i < (in_floats + 2 * out_floats) / 4; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < in_floats / 4; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
   {
-    // LDS cell (iy, ix) of the haloed tile = image pixel (ty0 * stride - 1 + iy, tx0 * stride - 1 + ix)
+    // LDS cell (iy, ix) of the haloed tile = image pixel (ty0 * stride - 1 + iy, tx0 * stride - 1 + ix).
+    // (channel, cell) pairs are spread over the workgroup with four global loads in flight per thread: the
+    // gather costs a few memory round trips, not one per channel and pass.
     const float* xb = sa.x + (size_t)b * sa.cin * sa.hin * sa.win;
     const int gy0 = ty0 * sa.stride - 1, gx0 = tx0 * sa.stride - 1;
-    const int cells = sa.PHin * sa.PWin;
-    for (int c = 0; c < sa.cin; ++c) {
-      const float* xc = xb + (size_t)c * sa.hin * sa.win;
-      for (int i = tid; i < cells; i += 256) {
-        const int iy = i / sa.PWin, ix = i - iy * sa.PWin;
-        const int gy = gy0 + iy, gx = gx0 + ix;
-        if (gy >= 0 && gy < sa.hin && gx >= 0 && gx < sa.win) reg[i * sa.Cs + c] = xc[gy * sa.win + gx];
-      }
-    }
-    if (sa.res) {
-      float* rr = reg + in_floats + out_floats;
-      const float* rb = sa.res + (size_t)b * sa.cout * sa.hout * sa.wout;
-      for (int c = 0; c < sa.cout; ++c)
-        for (int m = tid; m < rows; m += 256) {
-          const int ty = m / sa.TW, tx = m - ty * sa.TW;
-          const int oy = ty0 + ty, ox = tx0 + tx;
-          if (oy < sa.hout && ox < sa.wout) rr[m * sa.Cs + c] = rb[((size_t)c * sa.hout + oy) * sa.wout + ox];
+    const int cells = sa.PHin * sa.PWin, total = sa.cin * cells;
+    for (int i0 = tid; i0 < total; i0 += 4 * 256) {
+      float v[4];
+      int at[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + u * 256;
+        at[u] = -1; v[u] = 0.f;
+        if (idx < total) {
+          const int c = rz_div(idx, cells, sa.magic_cells), i = idx - c * cells;
+          const int iy = rz_div(i, sa.PWin, sa.magic_pwin), ix = i - iy * sa.PWin;
+          const int gy = gy0 + iy, gx = gx0 + ix;
+          if (gy >= 0 && gy < sa.hin && gx >= 0 && gx < sa.win) {
+            v[u] = xb[((size_t)c * sa.hin + gy) * sa.win + gx];
+            at[u] = i * sa.Cs + c;
+          }
         }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (at[u] >= 0) reg[at[u]] = v[u];
+    }
+    if (sa.res) {   // the residual tile lands in the OUTPUT region: the epilogue adds and overwrites it element by element
+      float* rr = reg + in_floats;
+      const float* rb = sa.res + (size_t)b * sa.cout * sa.hout * sa.wout;
+      const int rtotal = sa.cout * rows;
+      for (int i0 = tid; i0 < rtotal; i0 += 4 * 256) {
+        float v[4];
+        int at[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = i0 + u * 256;
+          at[u] = -1; v[u] = 0.f;
+          if (idx < rtotal) {
+            const int c = rz_div(idx, rows, sa.magic_rows), m = idx - c * rows;
+            const int ty = rz_div(m, sa.TW, sa.magic_tw), tx = m - ty * sa.TW;
+            const int oy = ty0 + ty, ox = tx0 + tx;
+            at[u] = m * sa.Cs + c;
+            if (oy < sa.hout && ox < sa.wout) v[u] = rb[((size_t)c * sa.hout + oy) * sa.wout + ox];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (at[u] >= 0) rr[at[u]] = v[u];
+      }
     }
   }
   __syncthreads();
@@ -1328,12 +1359,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   {
     const float* out = reg + in_floats;
     float* yb = sa.y + (size_t)b * sa.cout * sa.hout * sa.wout;
-    for (int c = 0; c < sa.cout; ++c)
-      for (int m = tid; m < rows; m += 256) {
-        const int ty = m / sa.TW, tx = m - ty * sa.TW;
-        const int oy = ty0 + ty, ox = tx0 + tx;
-        if (oy < sa.hout && ox < sa.wout) yb[((size_t)c * sa.hout + oy) * sa.wout + ox] = out[m * sa.Cs + c];
-      }
+    const int total = sa.cout * rows;
+    for (int idx = tid; idx < total; idx += 256) {
+      const int c = rz_div(idx, rows, sa.magic_rows), m = idx - c * rows;
+      const int ty = rz_div(m, sa.TW, sa.magic_tw), tx = m - ty * sa.TW;
+      const int oy = ty0 + ty, ox = tx0 + tx;
+      if (oy < sa.hout && ox < sa.wout) yb[((size_t)c * sa.hout + oy) * sa.wout + ox] = out[m * sa.Cs + c];
+    }
   }
 }
 
@@ -1360,7 +1392,7 @@ inline int rz_stem_launch(const mzx_net* net, const RzStemConv& sc, const OpDesc
     sa.PWin = (sa.TW - 1) * d.stride + 3;
     sa.mpad = rz_round16(sa.TH * sa.TW);
     const int64_t floats = 3 * (int64_t)sa.mpad + 128 + rz_aoff_ints(sc.nchunks) + (int64_t)sa.PHin * sa.PWin * sa.Cs +
-                           2 * (int64_t)sa.TH * sa.TW * sa.Cs;
+                           (int64_t)sa.TH * sa.TW * sa.Cs;
     if (4 * floats <= RZ_LDS_BUDGET) break;
     if (sa.TH <= 1) return MZX_ERR_INVALID;
     sa.TH = (sa.TH + 1) / 2;
@@ -1372,7 +1404,7 @@ inline int rz_stem_launch(const mzx_net* net, const RzStemConv& sc, const OpDesc
   o.taps = 9 | (int32_t)((((1u << 20) + (uint32_t)sc.cchunks - 1) / (uint32_t)sc.cchunks) << 8);
   o.in_off = 0; o.in_tstride = 0;
   o.out_off = sa.PHin * sa.PWin * sa.Cs; o.out_tstride = 0; o.out_layout = RZ_OUT_PADDED;
-  o.res_off = res ? o.out_off + sa.TH * sa.TW * sa.Cs : -1;
+  o.res_off = res ? o.out_off : -1;   // in place: the residual tile is loaded into the output region
   o.cchunks = sc.cchunks; o.cout = d.cout; o.nchunks = sc.nchunks; o.wchunks = sc.wchunks; o.aoff_off = 128;
   o.w_off = 0;
   o.alpha_off = d.bn.channels ? 0 : -1; o.beta_off = d.bn.channels ? 64 : -1; o.bias_off = -1; o.asum_off = -1;
@@ -1381,7 +1413,10 @@ inline int rz_stem_launch(const mzx_net* net, const RzStemConv& sc, const OpDesc
   sa.weights = net->d_derived + sc.w_off;
   sa.alpha = d.bn.channels ? net->d_derived + d.bn.alpha : nullptr;
   sa.beta = d.bn.channels ? net->d_derived + d.bn.beta : nullptr;
-  const size_t lds = 4 * (size_t)(3 * sa.mpad + 128 + rz_aoff_ints(sc.nchunks) + sa.PHin * sa.PWin * sa.Cs + 2 * sa.TH * sa.TW * sa.Cs);
+  const size_t lds = 4 * (size_t)(3 * sa.mpad + 128 + rz_aoff_ints(sc.nchunks) + sa.PHin * sa.PWin * sa.Cs + sa.TH * sa.TW * sa.Cs);
+  auto magic = [](int d) { return d > 1 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u; };
+  sa.magic_pwin = magic(sa.PWin); sa.magic_tw = magic(sa.TW);
+  sa.magic_cells = magic(sa.PHin * sa.PWin); sa.magic_rows = magic(sa.TH * sa.TW);
   hipLaunchKernelGGL(rz_stem_conv_kernel, dim3(sa.tiles_x * tiles_y, batch), dim3(256), lds, stream, sa);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("stem convolution launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
