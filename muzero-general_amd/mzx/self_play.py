@@ -633,9 +633,22 @@ class SelfPlay:
                 temps = [temperature if not temperature_threshold or len(histories[s].action_history) < temperature_threshold
                          else 0 for s in searching]
                 batch_actions = self._select_actions_bank(result, searching, temps)
+            # shard bookkeeping in bulk: with the stream bank the per-game Node objects are only needed for
+            # rendering; the child_visits rows (visit / total, 0 for illegal actions, self_play.py:496-511)
+            # and root values come from two array operations per move
+            fast_rows = None
+            if batch_actions is not None and not render:
+                vis = result.visit_counts
+                totals = vis.sum(1)
+                ratios = (vis / numpy.maximum(totals, 1)[:, None]).tolist()   # int / int true division, as Python's
+                fast_rows = (vis, totals, ratios)
             for s in active:
                 gh, game = histories[s], self.games[s]
-                if s in position:
+                root = None
+                if s in position and fast_rows is not None:
+                    k = position[s]
+                    action = batch_actions[k]
+                elif s in position:
                     root = result.root(position[s])
                     t = temperature if not temperature_threshold or len(gh.action_history) < temperature_threshold else 0
                     action = batch_actions[position[s]] if batch_actions is not None else self._select_action(root, t, self.rngs[s])
@@ -648,7 +661,18 @@ class SelfPlay:
                 if render:
                     print(f"Played action: {game.action_to_string(action)}")
                     game.render()
-                gh.store_search_statistics(root, cfg.action_space)
+                if s in position and fast_rows is not None:
+                    vis, totals, ratios = fast_rows
+                    k, legal_k = position[s], result.legal_actions[position[s]]
+                    total = int(totals[k])
+                    if len(legal_k) == A and total:
+                        gh.child_visits.append(ratios[k])
+                    else:
+                        legal_set = set(legal_k)
+                        gh.child_visits.append([int(vis[k][a]) / total if a in legal_set else 0 for a in cfg.action_space])
+                    gh.root_values.append(float(result.root_values[k]) if total else 0)
+                else:
+                    gh.store_search_statistics(root, cfg.action_space)
                 gh.action_history.append(action)
                 gh.observation_history.append(observation)
                 gh.reward_history.append(reward)
