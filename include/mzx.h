@@ -167,7 +167,10 @@ int mzx_search_create(const mzx_search_config* cfg, mzx_net* net /* nullable: lo
                       mzx_search** out);
 void mzx_search_destroy(mzx_search* s);
 /* Device memory the caller must provide as `d_arena` (trees + per-node hidden
- * states + per-simulation scratch + network workspace). */
+ * states + per-simulation scratch + network workspace).  The arena is scratch: its contents need
+ * NOT persist between calls (only mzx_search_dump / the lock-step calls read what the preceding
+ * call of the same handle left there); the pb_c / sqrt tables live in a small device buffer owned
+ * by the handle (allocated on the device current at mzx_search_create, freed by destroy). */
 int64_t mzx_search_arena_bytes(const mzx_search* s);
 
 /* Per-move inputs / outputs (all device pointers, all [num_trees] leading). */
@@ -212,7 +215,7 @@ int mzx_search_run_from_roots(mzx_search* s, const mzx_search_io* io, const floa
  * Default: 1 when supported, else 0. */
 int mzx_search_fused_supported(const mzx_search* s);
 int mzx_search_set_mode(mzx_search* s, int32_t mode);
-/* Byte offsets inside the arena (diagnostics): out[0..6] = tables, trees, hidden states,
+/* Byte offsets inside the arena (diagnostics): out[0..6] = (unused, 0), trees, hidden states,
  * network workspace, bytes per tree, workspace bytes, total bytes. */
 int mzx_search_arena_offsets(const mzx_search* s, int64_t out[8]);
 

@@ -841,7 +841,7 @@ inline int fused_fc_run(mzx_search* s, const mzx_search_io* io, void* d_arena, s
   int rc = ensure_tables(s, d_arena, stream);
   if (rc) return rc;
   P.args.flat = s->net->d_flat;
-  P.args.tables = (const double*)((char*)d_arena + s->off_tables);
+  P.args.tables = s->d_tables;
   P.args.io = *io;
   // the cycle-profile build parks its counters in the (otherwise unused) network workspace
   const bool profile = (s->mode & 8) != 0 &&

@@ -5,6 +5,7 @@
 // so that B trees spread over B/64 compute units instead of B/256.
 // tests/hostcheck: a serial loop (test infrastructure only).
 #pragma once
+#include <stdlib.h>
 #include <string.h>
 
 #include "mzx_platform.h"
@@ -28,6 +29,16 @@ inline int copy_h2d(void* dst, const void* src, size_t bytes, stream_t) {
 }
 
 inline int copy_d2d(void* dst, const void* src, size_t bytes, stream_t) {
+  memcpy(dst, src, bytes);
+  return 0;
+}
+
+inline int device_alloc(void** out, size_t bytes) {
+  *out = malloc(bytes);
+  return *out ? 0 : 1;
+}
+inline void device_free(void* p) { free(p); }
+inline int copy_h2d_blocking(void* dst, const void* src, size_t bytes) {
   memcpy(dst, src, bytes);
   return 0;
 }
@@ -59,6 +70,13 @@ inline int copy_h2d(void* dst, const void* src, size_t bytes, stream_t stream) {
 
 inline int copy_d2d(void* dst, const void* src, size_t bytes, stream_t stream) {
   return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+}
+
+// small library-owned device allocations (the search's pb_c / sqrt tables); every large buffer is the caller's
+inline int device_alloc(void** out, size_t bytes) { return (int)hipMalloc(out, bytes); }
+inline void device_free(void* p) { (void)hipFree(p); }
+inline int copy_h2d_blocking(void* dst, const void* src, size_t bytes) {
+  return (int)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
 }
 
 inline const char* runtime_error_string(int e) { return hipGetErrorString((hipError_t)e); }

@@ -274,6 +274,7 @@ int mzx_search_create(const mzx_search_config* cfg, mzx_net* net, mzx_search** o
   s->cfg.h_pb_c_table = nullptr;
   s->cfg.h_sqrt_table = nullptr;
   search_plan(s);
+  if (int rc = upload_tables(s)) { mzx_search_destroy(s); return rc; }
 #ifndef MZX_HOSTCHECK
   s->fused_ok = fused_fc_supported(s) ? 1 : (rz_search_supported(s) ? 2 : 0);
 #endif
@@ -282,7 +283,10 @@ int mzx_search_create(const mzx_search_config* cfg, mzx_net* net, mzx_search** o
   return MZX_OK;
 }
 
-void mzx_search_destroy(mzx_search* s) { delete s; }
+void mzx_search_destroy(mzx_search* s) {
+  if (s && s->d_tables) device_free(s->d_tables);
+  delete s;
+}
 
 int64_t mzx_search_arena_bytes(const mzx_search* s) { return s ? s->arena_bytes : 0; }
 

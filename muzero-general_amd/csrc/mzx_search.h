@@ -20,7 +20,9 @@ struct mzx_search {
   int64_t off_tables = 0, off_trees = 0, off_hidden = 0, off_dense_in = 0, off_dense_out = 0;
   int64_t off_value = 0, off_reward = 0, off_policy = 0, off_sel = 0, off_ws = 0, arena_bytes = 0;
   int64_t ws_floats = 0;
-  void* tables_arena = nullptr;  // arena whose table region is already filled
+  // pbc[N+1] then sqrt[N+1] on the device: owned by the handle (uploaded once at create), NOT carved from the
+  // caller's arena -- an arena may be cleared, freed or re-allocated at the same address between calls
+  double* d_tables = nullptr;
   int32_t mode = 0;
   int32_t fused_ok = 0;
 };
@@ -41,7 +43,7 @@ inline void search_plan(mzx_search* s) {
   p.tape_words = c.tape_words; p.discount = c.discount; p.exploration_fraction = c.root_exploration_fraction;
   p.pbc_table = nullptr; p.sqrt_table = nullptr;
   int64_t o = 0;
-  s->off_tables = o;    o += align256(int64_t(16) * (N + 1));
+  s->off_tables = o;    // (the tables live in a handle-owned buffer; no arena bytes)
   s->off_trees = o;     o += align256(s->L.tree_bytes * B);
   s->off_hidden = o;    o += align256(int64_t(4) * B * N * Hf);
   s->off_dense_in = o;  o += align256(int64_t(4) * B * Hf);
@@ -69,7 +71,7 @@ inline ArenaView arena_view(const mzx_search* s, void* d_arena) {
   v.arena.hidden = (float*)(base + s->off_hidden);
   v.arena.L = s->L;
   v.p = s->p;
-  v.p.pbc_table = (const double*)(base + s->off_tables);
+  v.p.pbc_table = s->d_tables;
   v.p.sqrt_table = v.p.pbc_table + (s->p.num_nodes + 1);
   v.dense_in = (float*)(base + s->off_dense_in);
   v.dense_out = (float*)(base + s->off_dense_out);
@@ -89,13 +91,18 @@ inline ArenaView arena_view(const mzx_search* s, void* d_arena) {
     if (_rc) { set_error("launch failed: %s", runtime_error_string(_rc)); return MZX_ERR_RUNTIME; } \
   } while (0)
 
-inline int ensure_tables(mzx_search* s, void* d_arena, stream_t stream) {
-  if (s->tables_arena == d_arena) return MZX_OK;
+// The handle's own device copy of the host tables (mzx_search_create); freed by mzx_search_destroy.
+inline int upload_tables(mzx_search* s) {
   const int n = s->p.num_nodes + 1;
-  char* base = (char*)d_arena + s->off_tables;
-  MZX_TRY_LAUNCH(copy_h2d(base, s->h_pbc.data(), sizeof(double) * n, stream));
-  MZX_TRY_LAUNCH(copy_h2d(base + sizeof(double) * n, s->h_sqrt.data(), sizeof(double) * n, stream));
-  s->tables_arena = d_arena;
+  void* d = nullptr;
+  MZX_TRY_LAUNCH(device_alloc(&d, sizeof(double) * 2 * n));
+  s->d_tables = (double*)d;
+  MZX_TRY_LAUNCH(copy_h2d_blocking(s->d_tables, s->h_pbc.data(), sizeof(double) * n));
+  MZX_TRY_LAUNCH(copy_h2d_blocking(s->d_tables + n, s->h_sqrt.data(), sizeof(double) * n));
+  return MZX_OK;
+}
+inline int ensure_tables(mzx_search* s, void*, stream_t) {
+  if (!s->d_tables) { set_error("search handle has no device tables"); return MZX_ERR_RUNTIME; }
   return MZX_OK;
 }
 

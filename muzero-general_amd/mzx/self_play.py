@@ -214,8 +214,9 @@ class BatchedMCTS:
         except Exception:
             pass
 
-    def handle(self, num_trees):
-        if num_trees not in self._handles:
+    def handle(self, num_trees, tape_words=TAPE_WORDS):
+        key = num_trees if tape_words == TAPE_WORDS else (num_trees, tape_words)
+        if key not in self._handles:
             lib = self.backend.lib
             c = _lib.SearchConfig()
             c.num_trees = num_trees
@@ -223,7 +224,7 @@ class BatchedMCTS:
             c.action_space_size = self.A
             c.num_players = len(self.config.players)
             c.support_size = self.config.support_size
-            c.tape_words = TAPE_WORDS
+            c.tape_words = tape_words
             c.discount = float(self.config.discount)
             c.root_exploration_fraction = float(self.config.root_exploration_fraction)
             c.h_pb_c_table = ctypes.cast(self._pbc, ctypes.POINTER(ctypes.c_double))
@@ -233,8 +234,8 @@ class BatchedMCTS:
             lib.check(lib.mzx_search_create(ctypes.byref(c), net, ctypes.byref(h)))
             if self._mode is not None:
                 lib.check(lib.mzx_search_set_mode(h, int(self._mode)))
-            self._handles[num_trees] = h
-        return self._handles[num_trees]
+            self._handles[key] = h
+        return self._handles[key]
 
     def arena(self, num_trees):
         need = self.backend.lib.mzx_search_arena_bytes(self.handle(num_trees))
@@ -360,6 +361,23 @@ class BatchedMCTS:
                     nodes[n].children[a] = Node(prior)
         return root
 
+    def _launch(self, B, obs, legal, to_play, noise, tape, tape_words, override):
+        """One mzx_search_run / mzx_search_run_from_roots over B roots; host copies of the outputs."""
+        lib = self.backend.lib
+        io, out, keep = self.make_io(B, obs, legal, to_play, noise, tape)
+        arena = self.arena(B)
+        handle = self.handle(B, tape_words)
+        if override is not None:
+            ptr = self.backend.ptr
+            lib.check(lib.mzx_search_run_from_roots(handle, ctypes.byref(io), ptr(override["hidden"]),
+                                                    ptr(override["priors"]), ptr(override["reward"]), ptr(arena),
+                                                    arena.numel(), self.backend.stream()))
+        else:
+            lib.check(lib.mzx_search_run(handle, ctypes.byref(io), self.backend.ptr(arena), arena.numel(),
+                                         self.backend.stream()))
+        return (out["visits"].cpu().numpy(), out["root_value"].cpu().numpy(), out["predicted"].cpu().numpy(),
+                out["info"].cpu().numpy())
+
     def run(self, observations, legal_actions, to_play, add_exploration_noise, rngs, _override=None):
         """
         observations: B stacked observations; legal_actions: B lists; to_play: B ints;
@@ -413,24 +431,35 @@ class BatchedMCTS:
             obs = observations.reshape(B, -1)
         else:
             obs = numpy.ascontiguousarray(numpy.asarray(observations, dtype=numpy.float32).reshape(B, -1))
-        lib = self.backend.lib
-        io, out, keep = self.make_io(B, obs, legal, numpy.asarray(to_play, numpy.int32), noise, tape)
-        arena = self.arena(B)
-        if _override is not None:
-            ptr = self.backend.ptr
-            lib.check(lib.mzx_search_run_from_roots(self.handle(B), ctypes.byref(io), ptr(_override["hidden"]),
-                                                    ptr(_override["priors"]), ptr(_override["reward"]), ptr(arena),
-                                                    arena.numel(), self.backend.stream()))
-        else:
-            lib.check(lib.mzx_search_run(self.handle(B), ctypes.byref(io), self.backend.ptr(arena), arena.numel(),
-                                         self.backend.stream()))
-        visits = out["visits"].cpu().numpy()
-        info = out["info"].cpu().numpy()
-        result = SearchResult(visits, out["root_value"].cpu().numpy(), out["predicted"].cpu().numpy(), info,
+        to_play = numpy.asarray(to_play, numpy.int32)
+        visits, root_values, predicted, info = self._launch(B, obs, legal, to_play, noise, tape, TAPE_WORDS, _override)
+        # A tree that exhausted its tie-break tape (a network with equal priors ties at every level) is searched
+        # again with a longer tape: same roots, same noise, the stream peeked further -- the reference never
+        # fails here (numpy.random.choice at self_play.py:371 simply keeps drawing).
+        words = TAPE_WORDS
+        while (info[:, 1] & 1).any():
+            words *= 8
+            if words > (1 << 22):
+                raise _lib.MzxError("tie-break tape: a search consumed more than 4M random words")
+            redo = numpy.nonzero(info[:, 1] & 1)[0]
+            if bank is not None:
+                _, long_tape = bank.root_draws(bank_idx[redo], cfg.root_dirichlet_alpha, n_legal[redo], A, words,
+                                               with_noise=False)
+            else:
+                long_tape = numpy.zeros((len(redo), words), numpy.uint32)
+                for k, i in enumerate(redo):
+                    rngs[i].set_state(states[i])
+                    long_tape[k] = rngs[i].randint(0, 2 ** 32, size=words, dtype=numpy.uint32)
+            ov = None if _override is None else {k: v[torch.as_tensor(redo, device=v.device)] for k, v in _override.items()}
+            sub_obs = obs[torch.as_tensor(redo, device=obs.device)] if isinstance(obs, torch.Tensor) else obs[redo]
+            v2, r2, p2, i2 = self._launch(len(redo), sub_obs, legal[redo], to_play[redo],
+                                          None if noise is None else noise[redo], long_tape, words, ov)
+            visits[redo], root_values[redo], predicted[redo], info[redo] = v2, r2, p2, i2
+        result = SearchResult(visits, root_values, predicted, info,
                               legal_actions if isinstance(legal_actions, numpy.ndarray) else [list(a) for a in legal_actions])
         if (info[:, 1] != 0).any():
             raise _lib.MzxError(f"search flagged trees {numpy.nonzero(info[:, 1])[0][:8]} (flags {set(info[:, 1])}): "
-                                "tie tape or node arena exhausted")
+                                "node arena exhausted")
         if bank is not None:
             bank.advance(bank_idx, info[:, 2])   # consume exactly what the device consumed
         else:
@@ -593,14 +622,14 @@ class SelfPlay:
         # (one upload of the new frames per move) instead of per-game numpy concatenations
         store = None
         if cfg.stacked_observations > 0 and opponent == "self":
-            store = observations_mod.FrameStore(cfg, len(self.games), self.model.backend)
+            store = self._frame_store(len(self.games))
             frame = numpy.zeros((len(self.games),) + tuple(cfg.observation_shape), numpy.float32)
             for s in slots:
                 frame[s] = numpy.asarray(observations[s])
             store.push(frame, None)
         active = list(slots)
         while active:
-            searching, stacked = [], []
+            searching, stacked, stacked_by_slot = [], [], {}
             for s in active:
                 observation, gh = observations[s], histories[s]
                 # self_play.py:132-137
@@ -613,7 +642,7 @@ class SelfPlay:
                     searching.append(s)
                     stacked.append(st)
                 else:
-                    stacked_for_opponent = st
+                    stacked_by_slot[s] = st      # what THIS game's opponent sees (self_play.py:161-165)
             result = None
             if searching:
                 t0 = time.perf_counter()
@@ -656,7 +685,7 @@ class SelfPlay:
                         print(f'Tree depth: {result.max_tree_depth[position[s]]}')
                         print(f"Root value for player {game.to_play()}: {root.value():.2f}")
                 else:
-                    action, root = self.select_opponent_action(opponent, stacked_for_opponent, game)
+                    action, root = self.select_opponent_action(opponent, stacked_by_slot[s], game)
                 observation, reward, done = game.step(action)
                 if render:
                     print(f"Played action: {game.action_to_string(action)}")
@@ -708,7 +737,7 @@ class SelfPlay:
         move = 0
         store = None
         if k > 0:   # frames stay in HBM; the stacked inputs are assembled there (csrc/mzx_obs.h)
-            store = observations_mod.FrameStore(cfg, B, self.model.backend)
+            store = self._frame_store(B)
             store.push(obs, None)
         while alive.any() and move + 1 <= cfg.max_moves:      # len(action_history) <= max_moves, :129
             idx = numpy.nonzero(alive)[0]
@@ -796,6 +825,15 @@ class SelfPlay:
                 pieces.append(numpy.zeros_like(current))
                 pieces.append(numpy.zeros(plane_shape, current.dtype))
         return numpy.concatenate(pieces, axis=1)
+
+    def _frame_store(self, num_games):
+        """The shard's device frame store: allocated once per actor, rewound for every game."""
+        store = getattr(self, "_store", None)
+        if store is None or store.G != num_games:
+            store = self._store = observations_mod.FrameStore(self.config, num_games, self.model.backend)
+        else:
+            store.reset()
+        return store
 
     def close_game(self):
         if self.batched_game is not None:

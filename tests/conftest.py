@@ -24,6 +24,17 @@ def pytest_collection_modifyitems(config, items):
         for item in items:
             if "reference" in item.keywords:
                 item.add_marker(skip)
+    # `pytest tests` on a box without a GPU (or without the built library): skip the gpu-marked tests
+    # instead of erroring out of every one of them (`-m gpu` on the GPU box is unaffected)
+    import torch
+
+    lib = os.path.join(ROOT, "muzero-general_amd", "mzx", "libmzx.so")
+    if not torch.cuda.is_available() or not os.path.isfile(lib):
+        why = "no GPU visible" if os.path.isfile(lib) else "libmzx.so not built"
+        skip_gpu = pytest.mark.skip(reason=f"gpu test: {why}")
+        for item in items:
+            if "gpu" in item.keywords:
+                item.add_marker(skip_gpu)
 
 
 @pytest.fixture(scope="session")

@@ -117,3 +117,67 @@ def test_whole_game_matches_reference(backend, name):
     assert numpy.allclose(numpy.array(gh.root_values, numpy.float64), z["root_values"], atol=1e-4, rtol=1e-4)
     for a, b in zip(gh.observation_history, z["observation_history"]):
         assert numpy.array_equal(numpy.array(a, dtype=numpy.float64), b)
+
+
+def _zero_weight_search(backend, rngs_kind, tape_words):
+    """
+    A network whose priors are all equal ties at EVERY selection level: the tape must grow, not
+    fail.  (Not compared with the oracle: with all-zero logits torch's softmax leaves a ~1e-8 residue in the
+    decoded value that min-max normalisation blows up to O(1) -- an ill-conditioned case by construction.)
+    """
+    cfg = configs.cartpole()
+    net = models.MuZeroNetwork(cfg, _backend=backend)
+    net.set_weights({k: torch.zeros_like(v) for k, v in net.state_dict().items()})
+    B = 3
+    obs = synthetic.observations(B, cfg.observation_shape, seed=3)
+    legal = [list(cfg.action_space)] * B
+    old = self_play.TAPE_WORDS
+    self_play.TAPE_WORDS = tape_words
+    try:
+        engine = self_play.BatchedMCTS(cfg, net, B)
+        if rngs_kind == "bank":
+            from mzx import _rng
+            bank = _rng.StreamBank(backend.lib, [900 + i for i in range(B)])
+            res = engine.run(list(obs), legal, [0] * B, True, (bank, numpy.arange(B)))
+            final = [bank.get_state(i) for i in range(B)]
+        else:
+            rngs = [numpy.random.RandomState(900 + i) for i in range(B)]
+            res = engine.run(list(obs), legal, [0] * B, True, rngs)
+            final = [r.get_state() for r in rngs]
+    finally:
+        self_play.TAPE_WORDS = old
+    return res, final
+
+
+@pytest.mark.parametrize("rngs_kind", ["bank", "randomstate"])
+def test_tie_tape_overflow_reruns_flagged_trees(backend, rngs_kind):
+    res, final = _zero_weight_search(backend, rngs_kind, 16)          # overflows: re-run with 128 words
+    want, want_final = _zero_weight_search(backend, rngs_kind, 4096)  # never overflows
+    assert (res.tape_used > 16).any() and (res.tape_used <= 16).sum() < len(res.tape_used)
+    assert numpy.array_equal(res.visit_counts, want.visit_counts)
+    assert numpy.array_equal(res.root_values, want.root_values)
+    assert numpy.array_equal(res.tape_used, want.tape_used) and (res.flags == 0).all()
+    cfg = configs.cartpole()
+    for i in range(len(final)):
+        assert final[i][2] == want_final[i][2] and numpy.array_equal(final[i][1], want_final[i][1])
+        # ... which is where the reference's global stream would be: Dirichlet draw, then one word per tie draw
+        ref = numpy.random.RandomState(900 + i)
+        ref.dirichlet([cfg.root_dirichlet_alpha] * len(cfg.action_space))
+        ref.randint(0, 2 ** 32, size=int(res.tape_used[i]), dtype=numpy.uint32)
+        assert ref.get_state()[2] == final[i][2] and numpy.array_equal(ref.get_state()[1], final[i][1])
+
+
+def test_arena_contents_need_not_persist(backend):
+    """the pb_c / sqrt tables must survive a cleared (or re-allocated) arena."""
+    cfg = configs.cartpole()
+    net = build_model(backend, cfg, 5)
+    B = 4
+    obs = synthetic.observations(B, cfg.observation_shape, seed=8)
+    engine = self_play.BatchedMCTS(cfg, net, B)
+    run = lambda: engine.run(list(obs), [list(cfg.action_space)] * B, [0] * B, True,
+                             [numpy.random.RandomState(40 + i) for i in range(B)])
+    first = run()
+    engine.arena(B).zero_()
+    second = run()
+    assert numpy.array_equal(first.visit_counts, second.visit_counts)
+    assert numpy.array_equal(first.root_values, second.root_values)
