@@ -1,30 +1,42 @@
 """
-bench.py -- BASELINE.json metric: MCTS simulations/s (whole job) and self-play steps/s.
+bench.py -- BASELINE.json metric: MCTS simulations/s (whole job) and self-play steps/s, CartPole & Connect4.
 
-    python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of synthetic input: B
-independent roots, each doing initial_inference + num_simulations x {select,
-recurrent_inference, expand, backpropagate} (one self-play move per tree,
-self_play.py:144-150).  Default workload = BASELINE config C2: CartPole
-FullyConnectedNetwork, 4096 trees x 50 simulations per GPU.  Inputs (stacked
-observations, legal actions, Dirichlet noise, tie tape, weights) are resident in
-HBM before the timed region; every rank owns an independent shard of trees (weak
-scaling, no data-path collective; RCCL only broadcasts the flat weight buffer
-once, outside the timed region, as the reference's weight pull self_play.py:37).
+N > 1 runs one rank per GPU over RCCL: either the driver launches this file under
+``python -m torch.distributed.run --nproc-per-node N ...`` or, when started as plain ``python bench.py --gpus N``,
+the script re-executes itself that way (the reference spawns its N self-play workers itself, muzero.py:156-203).
+
+One "step" = one pass of the hot path over one batch of synthetic input: B independent roots, each doing
+initial_inference + num_simulations x {select, recurrent_inference, expand, backpropagate} (one self-play move
+per tree, self_play.py:144-150).  Default workload = BASELINE config C2: CartPole FullyConnectedNetwork, 4096
+trees x 50 simulations per GPU; the same invocation also measures the Connect4 half of the metric (C4: Connect4
+ResNet, 1024 trees x 200 simulations per GPU, the configuration BASELINE.json shards over 8 GPUs) and reports it
+under ``workloads``.  Inputs (stacked observations, legal actions, Dirichlet noise, tie tape, weights) are
+resident in HBM before the timed region; every rank owns an independent shard of trees (weak scaling, no
+data-path collective; RCCL only broadcasts the flat weight buffer, outside the timed region, as the reference's
+weight pull self_play.py:37).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  "roofline":     algorithmic tree bytes (SURVEY.md section 8d formula, with the measured mean
-                  leaf depth) / HIP-event time of the search launch, vs the HBM peak
-  "observation_stacker": the path's HBM-bound kernel (mzx_obs_stack, atari geometry) against the HBM peak
-  "cpu_baseline": the CPU oracle (oracle/*.py: the reference's per-node algorithm and its
-                  batch-1 torch network, kind "port") timed on this box's host cores on a
-                  bounded sample of the same workload.
+  "roofline"      algorithmic tree bytes (SURVEY.md section 8d formula, with the measured mean leaf depth) /
+                  HIP-event time of the search launch, vs the HBM peak (residual networks: network FLOPs vs the
+                  dense FP32-input MFMA peak)
+  "workloads"     the other half of the metric (C4) measured in this invocation, same fields
+  "per_rank" / "single_gpu_reference"   N > 1: every rank's own rate, and rank 0 timed alone just before
+  "selfplay_end_to_end*"  self-play steps/s through the plugin surface (N = 1)
+  "observation_stacker"   the path's HBM-bound kernel (mzx_obs_stack, atari geometry) against the HBM peak
+  "cpu_baseline"  kind "reference": the UNMODIFIED reference MCTS(config).run + models.py (oracle/_ref, compiled
+                  from /root/reference by oracle/build_ref.py) on this box's host cores, bounded sample;
+                  "cpu_baseline_port": the CPU oracle (oracle/*.py) on the same sample.
+``--dry-run`` (CI only): gloo + the serial test double of the ABI on the CPU -- exercises the launch / sharding /
+broadcast / JSON plumbing without a GPU; its numbers are NOT measurements and the line says so.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -56,20 +68,127 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--also", default=None,
+                    help="comma list of further workloads measured in the same invocation and reported under "
+                         "'workloads' (default: c4 when the main workload is c2; 'none' = skip)")
+    ap.add_argument("--also-steps", type=int, default=3)
     ap.add_argument("--trees", type=int, default=None, help="trees per GPU (default: the workload's)")
     ap.add_argument("--mode", default="auto", choices=["auto", "generic", "fused"])
     ap.add_argument("--net-mode", default="fused", choices=["fused", "fused-4wave", "per-operator"],
                     help="residual networks: fused MFMA engine (default) or one kernel per operator")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall budget of each CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=None)
     ap.add_argument("--selfplay-moves", type=int, default=4,
                     help="moves of the end-to-end self-play leg (SelfPlay(num_games=B) on the synthetic game; 0 = skip)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CI plumbing check on the CPU (gloo + tests/hostcheck); not a measurement")
     return ap.parse_args()
 
 
-# ----------------------------------------------------------------------------- CPU baseline
-def _cpu_worker(args):
-    """One host core: the oracle's per-node MCTS with its batch-1 torch network (the reference's CPU algorithm)."""
+# ----------------------------------------------------------------------------- launch (N > 1)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` started by hand: become N ranks (one per GPU) and forward the exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MZX_BENCH_SELF_LAUNCHED="1")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+class Env:
+    """Rank / device plumbing; ``dry`` swaps RCCL + the GPU for gloo + the serial test double (CI only)."""
+
+    def __init__(self, args):
+        self.dry = bool(args.dry_run)
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = None
+        if self.dry:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import hostcheck  # test double of the ABI: plumbing check only
+            self.backend = hostcheck.backend()
+        else:
+            torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.dry:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+
+    def sync(self):
+        if not self.dry:
+            torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.world > 1:
+            torch.distributed.barrier()
+
+    def fence(self):
+        """barrier + device synchronize, as the contract brackets the timed region."""
+        self.sync()
+        self.barrier()
+        self.sync()
+
+    def all_max(self, x):
+        if self.world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if self.dry else "cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_gather(self, x):
+        if self.world == 1:
+            return [x]
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if self.dry else "cuda")
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        torch.distributed.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    def close(self):
+        if self.world > 1:
+            torch.distributed.destroy_process_group()
+
+
+class Stopwatch:
+    """HIP events on the launch stream (torch's current stream = the stream the ABI calls are given)."""
+
+    def __init__(self, env, n):
+        self.env = env
+        self.ev = None if env.dry else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                                        for _ in range(n)]
+        self.t = [[0.0, 0.0] for _ in range(n)]
+
+    def start(self, k):
+        if self.ev:
+            self.ev[k][0].record()
+        else:
+            self.t[k][0] = time.perf_counter()
+
+    def stop(self, k):
+        if self.ev:
+            self.ev[k][1].record()
+        else:
+            self.t[k][1] = time.perf_counter()
+
+    def mean_ms(self):
+        if self.ev:
+            return float(numpy.mean([a.elapsed_time(b) for a, b in self.ev]))
+        return float(numpy.mean([(b - a) * 1e3 for a, b in self.t]))
+
+
+# ----------------------------------------------------------------------------- CPU baselines
+def _cpu_worker_port(args):
+    """One host core: the oracle's per-node MCTS with its batch-1 torch network (restatement of the reference)."""
     workload, worker, seconds = args
     torch.set_num_threads(1)
     from mzx import configs, synthetic
@@ -77,8 +196,7 @@ def _cpu_worker(args):
 
     name, overrides, _, _ = WORKLOADS[workload]
     cfg = configs.BY_NAME[name](**overrides)
-    template = _state_dict_template(cfg)
-    sd = synthetic.fill_state_dict(template, 0)
+    sd = synthetic.fill_state_dict(_state_dict_template(cfg), 0)
     net = net_oracle.make_oracle_network(cfg, sd)
     c_in = cfg.observation_shape[0] * (cfg.stacked_observations + 1) + cfg.stacked_observations
     obs = synthetic.observations(64, (c_in,) + tuple(cfg.observation_shape[1:]), seed=123 + worker)
@@ -93,7 +211,31 @@ def _cpu_worker(args):
     return sims, searches, time.perf_counter() - t0
 
 
-_TEMPLATES = {}
+def _cpu_worker_reference(args):
+    """One host core: the UNMODIFIED reference -- self_play.MCTS(config).run on models.MuZeroNetwork (oracle/_ref)."""
+    workload, worker, seconds = args
+    torch.set_num_threads(1)
+    from mzx import configs, synthetic
+    from oracle import build_ref
+
+    ref_models, ref_self_play = build_ref.load()
+    name, overrides, _, _ = WORKLOADS[workload]
+    cfg = configs.BY_NAME[name](**overrides)
+    torch.manual_seed(0)
+    model = ref_models.MuZeroNetwork(cfg)
+    model.set_weights(synthetic.fill_state_dict(model.get_weights(), 0))   # the weights the GPU leg uses
+    model.eval()
+    c_in = cfg.observation_shape[0] * (cfg.stacked_observations + 1) + cfg.stacked_observations
+    obs = synthetic.observations(64, (c_in,) + tuple(cfg.observation_shape[1:]), seed=123 + worker)
+    legal = list(cfg.action_space)
+    sims, searches, t0 = 0, 0, time.perf_counter()
+    with torch.no_grad():
+        while time.perf_counter() - t0 < seconds:
+            numpy.random.seed(1000 + worker * 1000 + searches)
+            ref_self_play.MCTS(cfg).run(model, obs[searches % 64], legal, 0, True)
+            sims += cfg.num_simulations
+            searches += 1
+    return sims, searches, time.perf_counter() - t0
 
 
 def _state_dict_template(cfg):
@@ -114,6 +256,27 @@ def _state_dict_template(cfg):
     return out
 
 
+def cpu_baseline(workload, seconds, cores, kind):
+    import multiprocessing as mp
+
+    cores = cores or min(os.cpu_count() or 1, 64)
+    ctx = mp.get_context("spawn")
+    worker = _cpu_worker_reference if kind == "reference" else _cpu_worker_port
+    with ctx.Pool(cores) as pool:
+        res = pool.map(worker, [(workload, w, seconds) for w in range(cores)])
+    sims = sum(r[0] for r in res)
+    wall = max(r[2] for r in res)
+    what = ("unmodified reference self_play.MCTS(config).run + models.py (oracle/_ref bytecode of /root/reference)"
+            if kind == "reference" else "CPU oracle (oracle/mcts_oracle.py + net_oracle.py)")
+    return {
+        "value": sims / wall, "unit": "sims/s", "cores": cores, "kind": kind,
+        "sample": f"{sum(r[1] for r in res)} searches x {sims // max(1, sum(r[1] for r in res))} sims of the same "
+                  f"workload, {cores} processes x {seconds:.0f} s, torch.set_num_threads(1) each; {what}",
+        "per_core": res[0][0] / res[0][2],
+    }
+
+
+# ----------------------------------------------------------------------------- side legs (N = 1)
 def observation_stacker_leg(backend, games=64, stacked=32, iters=20):
     """
     The HBM-bound kernel beside the search: mzx_obs_stack at the games/atari.py
@@ -143,25 +306,6 @@ def observation_stacker_leg(backend, games=64, stacked=32, iters=20):
             "algorithmic_bytes_per_launch": nbytes, "launch_ms": ms, "games": games, "stacked_observations": stacked}
 
 
-def cpu_baseline(workload, seconds, cores):
-    import multiprocessing as mp
-
-    cores = cores or min(os.cpu_count() or 1, 64)
-    ctx = mp.get_context("spawn")
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(workload, w, seconds) for w in range(cores)])
-    sims = sum(r[0] for r in res)
-    wall = max(r[2] for r in res)
-    one = res[0][0] / res[0][2]
-    return {
-        "value": sims / wall, "unit": "sims/s", "cores": cores, "kind": "port",
-        "sample": f"{sum(r[1] for r in res)} searches x {sims // max(1, sum(r[1] for r in res))} sims of the same "
-                  f"workload, {cores} processes x {seconds:.0f} s, torch.set_num_threads(1) each",
-        "per_core": one,
-    }
-
-
-# ----------------------------------------------------------------------------- end-to-end self-play leg
 def selfplay_leg(cfg, net, B, moves, batched=False):
     """
     SelfPlay(num_games=B).play_games on the synthetic fixed-shape game (reference plugin surface): what a
@@ -176,12 +320,13 @@ def selfplay_leg(cfg, net, B, moves, batched=False):
     c.max_moves = moves
     make = synthetic.make_synthetic_batched_game if batched else synthetic.make_synthetic_game
     Game = make(c.observation_shape, len(c.action_space), len(c.players))
-    sp = self_play.SelfPlay({"weights": net.get_weights()}, Game, c, 0, num_games=B)
+    sp = self_play.SelfPlay({"weights": net.get_weights()}, Game, c, 0, num_games=B, _backend=net.backend)
     sp.play_games(1.0, None, False, "self", 0)          # warm-up (allocations, kernel attributes)
     sp.stats = {"searches": 0, "simulations": 0, "search_seconds": 0.0}
     t0 = time.perf_counter()
     histories = sp.play_games(1.0, None, False, "self", 0)
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     steps = sum(len(h.action_history) - 1 for h in histories)
     return {
@@ -193,35 +338,28 @@ def selfplay_leg(cfg, net, B, moves, batched=False):
     }
 
 
-# ----------------------------------------------------------------------------- GPU leg
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+# ----------------------------------------------------------------------------- the search workload
+def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_reference=False):
+    """
+    Times `steps` passes of the hot path of `workload` on every rank (contract bracket: barrier +
+    synchronize on both sides, MAX over ranks).  Returns (rank-0 result dict, cfg, net).
+    """
+    from mzx import configs, models, self_play, shared_storage, synthetic
 
-    from mzx import _lib, configs, models, self_play, shared_storage, synthetic
-
-    name, overrides, default_trees, description = WORKLOADS[args.workload]
+    name, overrides, default_trees, description = WORKLOADS[workload]
     cfg = configs.BY_NAME[name](**overrides)
-    B = args.trees or default_trees
+    B = trees or default_trees
     S, A = cfg.num_simulations, len(cfg.action_space)
+    rank, world = env.rank, env.world
 
-    net = models.MuZeroNetwork(cfg)
+    net = models.MuZeroNetwork(cfg, _backend=env.backend)
     # rank 0 holds the "trainer's" weights; every other rank starts from different ones and receives
     # them through the RCCL broadcast of the flat buffer (the reference's per-game weight pull)
     net.set_weights(synthetic.fill_state_dict(net.state_dict(), 0 if rank == 0 else 100 + rank))
+    env.fence()
     t_b0 = time.perf_counter()
     shared_storage.broadcast_weights(net, src=0)
-    torch.cuda.synchronize()
+    env.sync()
     broadcast_ms = (time.perf_counter() - t_b0) * 1e3
 
     if args.net_mode == "per-operator":
@@ -258,117 +396,166 @@ def main():
         io.d_visit_counts, io.d_root_value = be.ptr(sets[-1][1]["visits"]), be.ptr(sets[-1][1]["root_value"])
         io.d_root_predicted_value, io.d_info = be.ptr(sets[-1][1]["predicted"]), be.ptr(sets[-1][1]["info"])
     arena = engine.arena(B)
-    torch.cuda.synchronize()
+    env.sync()
 
     def step(k):
         io = sets[k % n_sets][0]
         lib.check(lib.mzx_search_run(handle, ctypes.byref(io), be.ptr(arena), arena.numel(), be.stream()))
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
+    def timed(n):
+        watch = Stopwatch(env, n)
+        t0 = time.perf_counter()
+        for k in range(n):
+            watch.start(k)
+            step(k)
+            watch.stop(k)
+        env.sync()
+        return time.perf_counter() - t0, watch
 
-    for k in range(args.warmup):
+    for k in range(warmup):
         step(k)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        step(k)
-        ev[k][1].record()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    launch_ms = float(numpy.mean([a.elapsed_time(b) for a, b in ev]))
+    solo = None
+    if solo_reference and world > 1:
+        # rank 0 alone, every other GPU idle: the N = 1 rate on this very box, for the weak-scaling ratio
+        env.fence()
+        if rank == 0:
+            solo_elapsed, _ = timed(steps)
+            solo = B * S * steps / solo_elapsed
+    env.fence()
+    own_elapsed, watch = timed(steps)
+    t_own_done = own_elapsed
+    env.barrier()
+    env.sync()
+    elapsed = env.all_max(t_own_done)
+    per_rank = [B * S * steps / t for t in env.all_gather(own_elapsed)]
+    launch_ms = watch.mean_ms()
 
     # sanity: the timed work is real (every tree ran S simulations, no flags)
-    for _, out, _ in sets[: min(n_sets, max(args.steps, args.warmup, 1))]:
+    for _, out, _ in sets[: min(n_sets, max(steps, warmup, 1))]:
         visits, info = out["visits"].cpu().numpy(), out["info"].cpu().numpy()
         assert (visits.sum(1) == S).all(), "a tree did not complete its simulations"
         assert (info[:, 1] == 0).all(), "search flagged an overflow"
     mean_leaf_depth = float(sets[0][1]["info"].cpu().numpy()[:, 3].mean() / S)
+    if rank != 0:
+        return None, cfg, net
 
-    if rank == 0:
-        sims_total = world * B * S * args.steps
-        value = sims_total / elapsed
-        Hf = net.hidden_size
-        L = mean_leaf_depth
-        bytes_per_sim = 28 * A * L + 29 * (L + 1) + (8 * A + 16) + 8 * Hf
-        achieved = bytes_per_sim * B * S / (launch_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        try:  # PMC-measured HBM bytes per launch of this kernel (collected by a separate rocprofv3 --pmc run)
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                key = "fused-lds" if fused else ("residual-whole-search" if fused_kind == 2 else "generic-per-op")
-                entry = json.load(f).get(f"{args.workload}:{key}")
-            if not fused and fused_kind != 2 and net_fused:
-                entry = None
-            if entry and B == default_trees:
-                traffic, traffic_src = entry["bytes"], entry["source"]
-        except (OSError, ValueError):
-            pass
-        kernel_name = ("fused-lds" if fused else
-                       "residual whole-search kernel (arena trees, fused MFMA network)" if fused_kind == 2 else
-                       "per-sim launches + fused-mfma network" if net_fused else "generic-per-op")
+    value = world * B * S * steps / elapsed
+    Hf, L = net.hidden_size, mean_leaf_depth
+    bytes_per_sim = 28 * A * L + 29 * (L + 1) + (8 * A + 16) + 8 * Hf
+    achieved = bytes_per_sim * B * S / (launch_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    try:  # PMC-measured HBM bytes per launch of this kernel (collected by a separate rocprofv3 --pmc run)
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            key = "fused-lds" if fused else ("residual-whole-search" if fused_kind == 2 else "generic-per-op")
+            entry = json.load(f).get(f"{workload}:{key}")
+        if not fused and fused_kind != 2 and net_fused:
+            entry = None
+        if entry and B == default_trees:
+            traffic, traffic_src = entry["bytes"], entry["source"]
+    except (OSError, ValueError):
+        pass
+    kernel_name = ("fused-lds" if fused else
+                   "residual whole-search kernel (arena trees, fused MFMA network)" if fused_kind == 2 else
+                   "per-sim launches + fused-mfma network" if net_fused else "generic-per-op")
+    roofline = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": bytes_per_sim * B * S,
+        "kernel": "mzx::fused_fc_search" if fused else "whole step (one kernel per operator)",
+        "launch_ms": launch_ms, "algorithmic_bytes_per_sim": bytes_per_sim,
+        "note": "tree bytes per simulation x B x S / HIP-event time of one search launch; trees live in "
+                "LDS in the fused kernel, so this is algorithmic traffic, not HBM traffic (DESIGN.md)",
+    }
+    if cfg.network == "resnet":  # dense contractions: FP32 MFMA roofline
+        f_init = int(lib.mzx_net_flops(net.handle, 0))
+        f_rec = int(lib.mzx_net_flops(net.handle, 1))
+        flops = B * (f_init + S * f_rec)
+        tf = flops / (launch_ms * 1e-3) / 1e12
         roofline = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": bytes_per_sim * B * S,
-            "kernel": "mzx::fused_fc_search" if fused else "whole step (one kernel per operator)",
-            "launch_ms": launch_ms, "algorithmic_bytes_per_sim": bytes_per_sim,
-            "note": "tree bytes per simulation x B x S / HIP-event time of one search launch; trees live in "
-                    "LDS in the fused kernel, so this is algorithmic traffic, not HBM traffic (DESIGN.md)",
+            "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "whole step: root kernels + mzx::rz_search_kernel (all simulations, one launch)" if fused_kind == 2
+                      else "whole step: select / rz_network_kernel (fused MFMA network) / expand+backprop per simulation"
+                      if net_fused else "whole step (one kernel per operator)",
+            "launch_ms": launch_ms, "flops_per_simulation": f_rec, "flops_initial_inference": f_init,
+            "flops_per_step": flops, "tree_bytes_per_sim": bytes_per_sim,
+            "note": "network FLOPs (2 x MAC of every conv / linear layer, as the reference's modules count) of one "
+                    "step / HIP-event time of the step, vs the dense FP32-input MFMA peak",
         }
-        if cfg.network == "resnet":  # dense contractions: FP32 MFMA roofline
-            f_init = int(lib.mzx_net_flops(net.handle, 0))
-            f_rec = int(lib.mzx_net_flops(net.handle, 1))
-            flops = B * (f_init + S * f_rec)
-            tf = flops / (launch_ms * 1e-3) / 1e12
-            roofline = {
-                "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "whole step: root kernels + mzx::rz_search_kernel (all simulations, one launch)" if fused_kind == 2
-                          else "whole step: select / rz_network_kernel (fused MFMA network) / expand+backprop per simulation"
-                          if net_fused else "whole step (one kernel per operator)",
-                "launch_ms": launch_ms, "flops_per_simulation": f_rec, "flops_initial_inference": f_init,
-                "flops_per_step": flops, "tree_bytes_per_sim": bytes_per_sim,
-                "note": "network FLOPs (2 x MAC of every conv / linear layer, as the reference's modules count) of one "
-                        "step / HIP-event time of the step, vs the dense FP32-input MFMA peak",
+    result = {
+        "metric": "mcts_simulations_per_sec", "value": value, "unit": "sims/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": description, "trees_per_gpu": B, "num_simulations": S, "action_space": A,
+            "network": cfg.network, "search_kernel": kernel_name,
+            "tree_statistics_dtype": "f64", "weights": "synthetic seed 0 (RCCL-broadcast flat buffer)",
+            "mean_leaf_depth": L,
+        },
+        "search_steps_per_sec": world * B * steps / elapsed,
+        "weight_broadcast_ms": broadcast_ms,
+        "collective_world_size": (torch.distributed.get_world_size() if world > 1 else 1),
+        "collective_backend": (torch.distributed.get_backend() if world > 1 else None),
+        "roofline": roofline,
+    }
+    if world > 1:
+        result["per_rank"] = {"sims_per_sec": per_rank, "min": min(per_rank), "max": max(per_rank)}
+        if solo is not None:
+            result["single_gpu_reference"] = {
+                "sims_per_sec": solo, "weak_scaling_efficiency": value / (world * solo),
+                "note": "rank 0 timed alone (other ranks idle at a barrier) on the same box, same steps; the driver "
+                        "computes the official efficiency from its own N = 1 run",
             }
-        line = {
-            "metric": "mcts_simulations_per_sec", "value": value, "unit": "sims/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": description, "trees_per_gpu": B, "num_simulations": S, "action_space": A,
-                "network": cfg.network, "search_kernel": kernel_name,
-                "tree_statistics_dtype": "f64", "weights": "synthetic seed 0 (RCCL-broadcast flat buffer)",
-                "mean_leaf_depth": L,
-            },
-            "search_steps_per_sec": world * B * args.steps / elapsed,
-            "weight_broadcast_ms": broadcast_ms,
-            "roofline": roofline,
-        }
-        if world == 1 and args.selfplay_moves > 0:
+    return result, cfg, net
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        relaunch_under_torchrun(args.gpus)
+    env = Env(args)
+    if args.gpus != env.world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env.world}")
+    also = args.also
+    if also is None:
+        also = "c4" if (args.workload == "c2" and not args.dry_run and args.trees is None) else "none"
+    also = [w for w in also.split(",") if w and w != "none"]
+
+    line, cfg, net = run_search_workload(env, args, args.workload, args.steps, args.warmup, args.trees,
+                                         solo_reference=True)
+    others = []
+    for w in also:
+        if w not in WORKLOADS:
+            raise SystemExit(f"unknown workload {w}")
+        r, _, n2 = run_search_workload(env, args, w, args.also_steps, 1)
+        del n2
+        if r is not None:
+            others.append(r)
+    if env.rank == 0:
+        if others:
+            line["workloads"] = others
+        if args.dry_run:
+            line["dry_run"] = True
+            line["data"] = "DRY RUN on the CPU test double (gloo): plumbing check, NOT a measurement"
+        B = args.trees or WORKLOADS[args.workload][2]
+        if env.world == 1 and args.selfplay_moves > 0:
             line["selfplay_end_to_end"] = selfplay_leg(cfg, net, B, args.selfplay_moves)
             line["selfplay_end_to_end_batched_game"] = selfplay_leg(cfg, net, B, args.selfplay_moves, batched=True)
-        if world == 1 and args.selfplay_moves > 0:
-            line["observation_stacker"] = observation_stacker_leg(net.backend)
-        if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_cores)
-        else:
-            line["cpu_baseline"] = None
+            if not args.dry_run:
+                line["observation_stacker"] = observation_stacker_leg(net.backend)
+        line["cpu_baseline"] = None
+        if env.world == 1 and args.cpu_seconds > 0 and not args.dry_run:
+            from oracle import build_ref
+            port = cpu_baseline(args.workload, min(args.cpu_seconds, 6.0), args.cpu_cores, "port")
+            if build_ref.available():
+                line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_cores, "reference")
+                line["cpu_baseline_port"] = port
+            else:   # oracle/_ref was not built (no /root/reference at build time): the restatement stands in
+                line["cpu_baseline"] = port
         print(json.dumps(line), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    env.barrier()
+    env.close()
 
 
 if __name__ == "__main__":

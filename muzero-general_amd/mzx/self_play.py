@@ -548,10 +548,21 @@ class SelfPlay:
 
     # ------------------------------------------------------------------ loops
     def continuous_self_play(self, shared_storage, replay_buffer, test_mode=False):
-        # self_play.py:31-108
-        get = lambda key: _remote(shared_storage.get_info, key)
+        """
+        self_play.py:31-108.  With a ``mzx.shared_storage.ShardedStorage`` (one self-play process per GPU under
+        torch.distributed) the per-game weight pull (:37) becomes the storage's collective ``refresh``: one
+        control all-reduce per iteration on every rank and -- when the trainer published new weights -- ONE
+        RCCL broadcast of the flat buffer; the loop condition is evaluated on the shared control values, so all
+        ranks leave the loop together.  This rank's games are seeded ``seed + i`` with ``seed`` =
+        ``shard_seeds(config.seed, num_games)[0]`` (muzero.py:185).
+        """
+        sharded = hasattr(shared_storage, "refresh")
+        get = (shared_storage.get_info if sharded else (lambda key: _remote(shared_storage.get_info, key)))
+        if sharded:
+            shared_storage.refresh(self.model)
         while get("training_step") < self.config.training_steps and not get("terminate"):
-            self.model.set_weights(get("weights"))
+            if not sharded:
+                self.model.set_weights(get("weights"))
             if not test_mode:
                 histories = self.play_games(
                     self.config.visit_softmax_temperature_fn(trained_steps=get("training_step")),
@@ -583,10 +594,14 @@ class SelfPlay:
                     })
             if not test_mode and self.config.self_play_delay:
                 time.sleep(self.config.self_play_delay)
+            if sharded:
+                shared_storage.refresh(self.model)     # played counts out, control + (new) weights in
             if not test_mode and self.config.ratio:
                 while (get("training_step") / max(1, get("num_played_steps")) < self.config.ratio
                        and get("training_step") < self.config.training_steps and not get("terminate")):
                     time.sleep(0.5)
+                    if sharded:
+                        shared_storage.refresh(self.model)
         self.close_game()
 
     def play_game(self, temperature, temperature_threshold, render, opponent, muzero_player):

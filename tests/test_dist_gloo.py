@@ -67,3 +67,124 @@ def test_weight_broadcast_and_sharding_world2(tmp_path):
     assert numpy.array_equal(r0["visits"], r1["visits"])     # ... and its derived BN terms were refreshed
     assert numpy.array_equal(r0["root_values"], r1["root_values"])
     assert r0["seeds"] == [0, 1, 2] and r1["seeds"] == [3, 4, 5]  # disjoint game shards (muzero.py:185)
+
+
+# ----------------------------------------------------------------------------- the actor loop, sharded
+class _ScriptedStorage:
+    """
+    Rank 0's real storage (duck type of shared_storage.py:7-40) playing the trainer: after the actors have
+    reported their first round of games it publishes NEW weights at a later training step, after the second
+    round it sets ``terminate``.
+    """
+
+    def __init__(self, weights_a, weights_b):
+        from mzx import shared_storage
+        self.inner = shared_storage.LocalStorage(training_step=0, terminate=False, weights=weights_a,
+                                                 num_played_games=0, num_played_steps=0)
+        self.weights_b = weights_b
+        self.reports = 0
+
+    def get_info(self, keys):
+        return self.inner.get_info(keys)
+
+    def set_info(self, keys, values=None):
+        self.inner.set_info(keys, values)
+        if isinstance(keys, dict) and keys.get("num_played_steps", 0) > 0:   # job-wide counts after a round
+            self.reports += 1
+            if self.reports == 1:
+                self.inner.set_info({"weights": self.weights_b, "training_step": 7})
+            elif self.reports == 2:
+                self.inner.set_info("terminate", True)
+
+
+class _ListBuffer:
+    """replay_buffer.py:33-65 reduced to what the actor loop touches: keep the game, report the counts."""
+
+    def __init__(self):
+        self.games, self.steps = [], 0
+
+    def save_game(self, game_history, shared_storage=None):
+        assert game_history.priorities is not None       # filled by the actor (vectorised initial PER priorities)
+        self.games.append(game_history)
+        self.steps += len(game_history.root_values)
+        if shared_storage:
+            shared_storage.set_info("num_played_games", len(self.games))
+            shared_storage.set_info("num_played_steps", self.steps)
+
+
+def _actor_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "muzero-general_amd"), ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import games_fixture
+    import hostcheck
+    from mzx import configs, models, self_play, shared_storage, synthetic
+
+    be = hostcheck.backend()
+    cfg = configs.tictactoe()
+    cfg.num_simulations = 8
+    cfg.training_steps = 100
+    cfg.ratio = None
+    cfg.self_play_delay = 0
+    cfg.PER, cfg.PER_alpha, cfg.td_steps = True, 0.5, 9      # games/tictactoe.py:87-96
+    G = 3
+    template = models.MuZeroNetwork(cfg, _backend=be).state_dict()
+    wa, wb = synthetic.fill_state_dict(template, 1), synthetic.fill_state_dict(template, 2)
+    seeds = shared_storage.shard_seeds(cfg.seed, G)
+    made = []
+
+    class Game(games_fixture.GAMES["tictactoe"]):
+        def __init__(self, seed=None):
+            made.append(seed)
+            super().__init__(seed)
+
+    # every rank starts from its OWN junk weights: what it plays with must come through the broadcast
+    start = synthetic.fill_state_dict(template, 50 + rank)
+    actor = self_play.SelfPlay({"weights": start}, Game, cfg, seeds[0], num_games=G, _backend=be)
+    storage = shared_storage.ShardedStorage(_ScriptedStorage(wa, wb) if rank == 0 else None, src=0)
+    buffer = _ListBuffer()
+    seen = []
+    play_games = actor.play_games
+
+    def recording_play_games(*a):
+        seen.append(actor.model.flat_weights().clone())      # the weights each round is played with
+        return play_games(*a)
+
+    actor.play_games = recording_play_games
+    actor.continuous_self_play(storage, buffer)
+    job_counts = storage.storage.inner.get_info(["num_played_games", "num_played_steps"]) if rank == 0 else None
+    torch.save(dict(seeds=made, rounds=len(seen), seen=seen, games=len(buffer.games), steps=buffer.steps,
+                    refreshes=storage.refreshes, broadcasts=storage.weight_broadcasts, job_counts=job_counts,
+                    control=storage.control,
+                    first_actions=[[int(a) for a in g.action_history] for g in buffer.games]),
+               os.path.join(out_dir, f"actor{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_continuous_self_play_two_ranks_with_midrun_weight_update(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_actor_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"actor{k}.pt", weights_only=False) for k in range(world)]
+    # disjoint game shards, seeded like the reference's workers (muzero.py:185)
+    assert r[0]["seeds"] == [0, 1, 2] and r[1]["seeds"] == [3, 4, 5]
+    # The trainer publishes after it has seen round 1's counts, i.e. during the refresh that follows round 1;
+    # the actors pick the new version up at the NEXT refresh (after round 2) and see `terminate` after round 3.
+    # Both ranks left the loop in the same iteration: three rounds of 3 games each
+    assert r[0]["rounds"] == r[1]["rounds"] == 3 and r[0]["games"] == r[1]["games"] == 9
+    assert r[0]["refreshes"] == r[1]["refreshes"] == 4
+    # rounds 1-2 with the trainer's first weights, round 3 with the update published mid-run -- on BOTH ranks,
+    # although only rank 0 can see the storage: one broadcast per published version, none in between
+    assert r[0]["broadcasts"] == r[1]["broadcasts"] == 2
+    for k in range(3):
+        assert torch.equal(r[0]["seen"][k], r[1]["seen"][k])
+    assert torch.equal(r[0]["seen"][0], r[0]["seen"][1]) and not torch.equal(r[0]["seen"][1], r[0]["seen"][2])
+    # the job-wide played counts reached the real storage (what the trainer's ratio throttle reads)
+    assert r[0]["job_counts"]["num_played_games"] == 18
+    assert r[0]["job_counts"]["num_played_steps"] == r[0]["steps"] + r[1]["steps"]
+    assert r[0]["control"] == r[1]["control"] and r[0]["control"]["terminate"] is True
+    # different seeds -> different games
+    assert r[0]["first_actions"] != r[1]["first_actions"]
