@@ -228,6 +228,8 @@ def _cpu_worker_reference(args):
     c_in = cfg.observation_shape[0] * (cfg.stacked_observations + 1) + cfg.stacked_observations
     obs = synthetic.observations(64, (c_in,) + tuple(cfg.observation_shape[1:]), seed=123 + worker)
     legal = list(cfg.action_space)
+    with torch.no_grad():   # one warm-up search, then the timed sample
+        ref_self_play.MCTS(cfg).run(model, obs[0], legal, 0, True)
     sims, searches, t0 = 0, 0, time.perf_counter()
     with torch.no_grad():
         while time.perf_counter() - t0 < seconds:
@@ -262,8 +264,19 @@ def cpu_baseline(workload, seconds, cores, kind):
     cores = cores or min(os.cpu_count() or 1, 64)
     ctx = mp.get_context("spawn")
     worker = _cpu_worker_reference if kind == "reference" else _cpu_worker_port
-    with ctx.Pool(cores) as pool:
-        res = pool.map(worker, [(workload, w, seconds) for w in range(cores)])
+    # CPU baseline: the workers must not see the GPU (the reference wraps its networks in
+    # torch.nn.DataParallel, models.py:98-126, which would route batch-1 inferences through cuda:0)
+    hidden = {k: os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")}
+    os.environ.update({"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+    try:
+        with ctx.Pool(cores) as pool:
+            res = pool.map(worker, [(workload, w, seconds) for w in range(cores)])
+    finally:
+        for k, v in hidden.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     sims = sum(r[0] for r in res)
     wall = max(r[2] for r in res)
     what = ("unmodified reference self_play.MCTS(config).run + models.py (oracle/_ref bytecode of /root/reference)"

@@ -53,6 +53,8 @@ class HotPathConfig:
     def visit_softmax_temperature_fn(self, trained_steps):
         if self.temperature_schedule == "constant":  # games/tictactoe.py:112-122, games/connect4.py:112-122
             return 1
+        if self.temperature_schedule == "lunarlander":  # games/lunarlander.py:117-125
+            return 0.35
         if self.temperature_schedule == "breakout":  # games/breakout.py:117-133
             if trained_steps < 500e3:
                 return 1.0
@@ -126,4 +128,23 @@ def breakout(**kw):
     return HotPathConfig(**base)
 
 
-BY_NAME = {"cartpole": cartpole, "tictactoe": tictactoe, "connect4": connect4, "breakout": breakout}
+def lunarlander(**kw):
+    """
+    games/lunarlander.py:17-115 -- the architecture of the shipped results/lunarlander/model.checkpoint
+    (SURVEY.md section 8c): fully connected, encoding 10, 64-wide hidden layers, 4 actions.
+    """
+    base = dict(
+        observation_shape=(1, 1, 8), action_space=list(range(4)), players=list(range(1)),
+        max_moves=700, num_simulations=50, discount=0.999, root_dirichlet_alpha=0.25,
+        network="fullyconnected", blocks=2, channels=16,
+        reduced_channels_reward=16, reduced_channels_value=16, reduced_channels_policy=16,
+        encoding_size=10, fc_representation_layers=[],
+        fc_dynamics_layers=[64], fc_reward_layers=[64], fc_value_layers=[64], fc_policy_layers=[64],
+        training_steps=200000, temperature_schedule="lunarlander",
+    )
+    base.update(kw)
+    return HotPathConfig(**base)
+
+
+BY_NAME = {"cartpole": cartpole, "tictactoe": tictactoe, "connect4": connect4, "breakout": breakout,
+           "lunarlander": lunarlander}

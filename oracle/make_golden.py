@@ -37,7 +37,7 @@ OUT = os.path.join(ROOT, "tests", "golden")
 
 
 def _config(game, **overrides):
-    cfg = ref_shim.game_module(game).MuZeroConfig()
+    cfg = ref_shim.muzero_config(game)
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg
@@ -152,10 +152,12 @@ def trace_search(models, self_play, cfg, net, observation, legal, to_play, rng_s
 
 
 def make_tree_fixture(name, game, n_cases, weight_seed, legal_fn, overrides=None, players_fn=None,
-                      zero_keys=()):
+                      zero_keys=(), state_dict=None):
     models, self_play = ref_shim.load()
     cfg = _config(game, **(overrides or {}))
     net = _reference_model(models, cfg, weight_seed)
+    if state_dict is not None:   # trained weights (a checkpoint the reference ships)
+        net.set_weights(state_dict)
     if zero_keys:  # e.g. zero policy head -> equal priors -> repeated argmax ties
         sd = net.state_dict()
         for k in zero_keys:
@@ -175,6 +177,9 @@ def make_tree_fixture(name, game, n_cases, weight_seed, legal_fn, overrides=None
             cases[f"c{c}_{k}"] = v
         cases[f"c{c}_obs"] = obs_all[c]
         meta["cases"].append(dict(legal=list(legal), to_play=int(to_play), rng_seed=rng_seed))
+    if state_dict is not None:  # ship the trained weights (small): flat, in state_dict key order
+        cases["flat_weights"] = numpy.concatenate(
+            [v.numpy().reshape(-1) for v in net.state_dict().values() if v.dtype.is_floating_point]).astype(numpy.float32)
     cases["meta"] = numpy.array(json.dumps(meta))
     numpy.savez_compressed(os.path.join(OUT, f"tree_{name}.npz"), **cases)
     print("tree", name, "cases", n_cases, "nodes", tr["visit"].shape[0])
@@ -425,6 +430,12 @@ def main():
     ckpt = torch.load(os.path.join(ref_shim.REFERENCE_ROOT, "results", "cartpole", "model.checkpoint"),
                       weights_only=False, map_location="cpu")
     make_net_fixture("fc_cartpole_pretrained", "cartpole", None, 8, state_dict=ckpt["weights"])
+    # the other shipped checkpoint: encoding 10, 64-wide hidden layers, 4 actions --
+    # the trained-weight case of the LDS-weight engine (the CartPole shape has a register specialisation)
+    ckpt_ll = torch.load(os.path.join(ref_shim.REFERENCE_ROOT, "results", "lunarlander", "model.checkpoint"),
+                         weights_only=False, map_location="cpu")
+    make_net_fixture("fc_lunarlander_pretrained", "lunarlander", None, 8, state_dict=ckpt_ll["weights"])
+    make_tree_fixture("lunarlander_pretrained", "lunarlander", 4, None, subset, state_dict=ckpt_ll["weights"])
     make_net_fixture("fc_cartpole_stacked", "cartpole", 22, 4,
                      overrides=dict(stacked_observations=3, fc_representation_layers=[12],
                                     fc_dynamics_layers=[16, 12], encoding_size=10))

@@ -47,7 +47,7 @@ class Tree:
     __slots__ = (
         "actions", "visit", "value_sum", "reward", "to_play", "hidden",
         "prior", "child", "parent", "parent_slot", "minimum", "maximum",
-        "trace", "max_depth", "root_predicted_value", "tie_draws",
+        "trace", "max_depth", "root_predicted_value", "tie_draws", "margins", "_sim_margin",
     )
 
     def __init__(self):
@@ -67,6 +67,11 @@ class Tree:
         self.max_depth = 0
         self.root_predicted_value = None
         self.tie_draws = 0     # number of select_child calls with more than one maximiser
+        # diagnostics (SURVEY.md section 8c'): per simulation, the smallest gap between the best and the
+        # second-best UCB score over the levels of its selection walk, as (gap, depth of that level) -- how
+        # close the simulation came to taking another branch under a perturbation of the network outputs
+        self.margins = []
+        self._sim_margin = (float("inf"), 0)
 
     def root_visit_counts(self, action_space):
         """Visit count per action of ``action_space`` (0 for non-children)."""
@@ -148,6 +153,10 @@ def _select_slot(tree, cfg, parent, rng):
     # score twice; evaluating once is bit-identical (pure function of the tree).
     scores = [ucb_score(tree, cfg, parent, s) for s in range(len(tree.actions[parent]))]
     best = max(scores)
+    if len(scores) > 1:
+        second = sorted(scores)[-2]
+        if best - second < tree._sim_margin[0]:
+            tree._sim_margin = (best - second, tree._sim_margin[1])
     ties = [s for s, v in enumerate(scores) if v == best]
     if len(ties) > 1:
         tree.tie_draws += 1
@@ -209,9 +218,13 @@ def run_search(cfg, evaluator, observation, legal_actions, to_play,
         node = root
         path = [node]
         depth = 0
+        tree._sim_margin = (float("inf"), 0)
         while True:
             depth += 1
+            before = tree._sim_margin[0]
             slot = _select_slot(tree, cfg, node, rng)
+            if tree._sim_margin[0] < before:
+                tree._sim_margin = (tree._sim_margin[0], depth)
             # players play turn by turn, self_play.py:331-334
             if virtual_to_play + 1 < len(cfg.players):
                 virtual_to_play = cfg.players[virtual_to_play + 1]
@@ -234,6 +247,7 @@ def run_search(cfg, evaluator, observation, legal_actions, to_play,
         _backpropagate(tree, cfg, path, value, virtual_to_play)
         tree.max_depth = max(tree.max_depth, depth)
         tree.trace.append((parent, int(action), depth))
+        tree.margins.append(tree._sim_margin)
     return tree
 
 

@@ -152,13 +152,17 @@ class ResidualOracle:
         x = _resblocks(sd, p + ".resblocks3", x)
         return F.avg_pool2d(x, 3, 2, 1)
 
-    def _representation(self, obs):
+    def representation_unscaled(self, obs):
+        """The encoded state BEFORE the per-plane min-max scaling (diagnostics: which planes are near-flat)."""
         sd, p = self.sd, "representation_network.module"
         if self.downsample:
             x = self._downsample(obs)
         else:
             x = F.relu(_bn(sd, p + ".bn", F.conv2d(obs, sd[p + ".conv.weight"], None, 1, 1)))
-        return _scale_planes(_resblocks(sd, p + ".resblocks", x))
+        return _resblocks(sd, p + ".resblocks", x)
+
+    def _representation(self, obs):
+        return _scale_planes(self.representation_unscaled(obs))
 
     def _prediction(self, s):
         sd, p = self.sd, "prediction_network.module"
@@ -174,14 +178,20 @@ class ResidualOracle:
         policy, value = self._prediction(s)
         return value, _zero_reward_logits(len(observation), self.F), policy, s
 
-    def recurrent_inference(self, encoded_state, action):
+    def dynamics_unscaled(self, encoded_state, action):
+        """The next state BEFORE the per-plane min-max scaling (what the reward head reads)."""
         sd, p = self.sd, "dynamics_network.module"
         b, _, h, w = encoded_state.shape
         # scalar action plane action/|A| (NOT one-hot), models.py:557-571
         plane = action[:, :, None, None] * torch.ones((b, 1, h, w)).float() / self.A
         x = torch.cat((encoded_state, plane), dim=1)
         x = F.relu(_bn(sd, p + ".bn", F.conv2d(x, sd[p + ".conv.weight"], None, 1, 1)))
-        state = _resblocks(sd, p + ".resblocks", x)
+        return _resblocks(sd, p + ".resblocks", x)
+
+    def recurrent_inference(self, encoded_state, action):
+        sd, p = self.sd, "dynamics_network.module"
+        b = encoded_state.shape[0]
+        state = self.dynamics_unscaled(encoded_state, action)
         r = F.conv2d(state, sd[p + ".conv1x1_reward.weight"], sd[p + ".conv1x1_reward.bias"])
         reward = _mlp(sd, p + ".fc.", r.reshape(b, -1))
         s = _scale_planes(state)

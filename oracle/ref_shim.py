@@ -46,3 +46,26 @@ def load():
 def game_module(name):
     load()
     return importlib.import_module("games." + name)
+
+
+def muzero_config(name):
+    """
+    ``games/<name>.py``'s MuZeroConfig().  Game files whose environment needs a package that is not installed
+    (lunarlander: Box2D) cannot be imported as modules; their UNMODIFIED ``MuZeroConfig`` class definition is
+    then taken from the file's syntax tree and executed on its own (it depends only on datetime / pathlib / torch).
+    """
+    try:
+        return game_module(name).MuZeroConfig()
+    except ImportError:
+        import ast
+        path = os.path.join(REFERENCE_ROOT, "games", name + ".py")
+        with open(path) as f:
+            tree = ast.parse(f.read(), filename=path)
+        keep = [n for n in tree.body
+                if (isinstance(n, ast.ClassDef) and n.name == "MuZeroConfig")
+                or (isinstance(n, (ast.Import, ast.ImportFrom)) and
+                    all(a.name.split(".")[0] in ("datetime", "pathlib", "os", "math", "numpy", "torch") for a in n.names)
+                    and getattr(n, "module", None) in (None, "datetime", "pathlib", "os", "math"))]
+        ns = {"__file__": path, "__name__": "games." + name}
+        exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+        return ns["MuZeroConfig"]()

@@ -25,6 +25,19 @@ def load_fixture(name):
     return z, meta, cfg
 
 
+def fixture_weights(z, template):
+    """Trained weights shipped inside a fixture (``flat_weights``: float tensors in state_dict key order), or None."""
+    if "flat_weights" not in z.files:
+        return None
+    sd, off = {}, 0
+    for k, t in template.items():
+        if t.dtype.is_floating_point:
+            sd[k] = torch.from_numpy(z["flat_weights"][off:off + t.numel()].reshape(tuple(t.shape)).copy())
+            off += t.numel()
+    assert off == z["flat_weights"].size
+    return sd
+
+
 def rng_inputs(cfg, cases, A, tape_words=self_play.TAPE_WORDS):
     """Per-case Dirichlet noise + raw-word tape exactly as the engine derives them from a RandomState."""
     B = len(cases)

@@ -17,9 +17,9 @@ ATTRS = ["observation_shape", "action_space", "players", "stacked_observations",
 
 
 @pytest.mark.reference
-@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "breakout"])
+@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "breakout", "lunarlander"])
 def test_restated_configs_equal_the_reference_game_files(name):
-    ref = ref_shim.game_module(name).MuZeroConfig()
+    ref = ref_shim.muzero_config(name)
     ours = configs.BY_NAME[name]()
     for a in ATTRS:
         want, got = getattr(ref, a), getattr(ours, a)

@@ -38,7 +38,7 @@ def test_native_library_is_loaded(backend):
 
 
 @pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties", "tictactoe_custom",
-                                  "cartpole_custom"])
+                                  "cartpole_custom", "lunarlander_pretrained"])
 def test_lockstep_tree_bit_exact(backend, name):
     got = lockstep.run_fixture(backend, name)
     if name == "cartpole_ties":
@@ -46,7 +46,7 @@ def test_lockstep_tree_bit_exact(backend, name):
 
 
 @pytest.mark.parametrize("engine", ["fused", "per-operator"])
-@pytest.mark.parametrize("name", ["fc_cartpole", "fc_cartpole_pretrained", "fc_cartpole_stacked",
+@pytest.mark.parametrize("name", ["fc_cartpole", "fc_cartpole_pretrained", "fc_lunarlander_pretrained", "fc_cartpole_stacked",
                                   "resnet_tictactoe", "resnet_connect4", "resnet_breakout", "resnet_breakout_cnn",
                                   "resnet_cnn_small"])
 def test_network_heads_within_tolerance(backend, name, engine):
@@ -94,7 +94,7 @@ def test_network_heads_within_tolerance(backend, name, engine):
 
 @pytest.mark.parametrize("mode", ["generic", "fused"])
 @pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties", "tictactoe_custom",
-                                  "cartpole_custom"])
+                                  "cartpole_custom", "lunarlander_pretrained"])
 def test_search_matches_reference(backend, name, mode, monkeypatch):
     if mode == "generic":
         orig = self_play.BatchedMCTS.__init__
@@ -118,6 +118,58 @@ def _tree_invariants(cfg, res, S):
     assert numpy.isfinite(res.root_values).all()
 
 
+def _device_trace(engine_factory, cfg, obs, legal, to_play, seeds):
+    """(parent, action) of every simulation of each tree, rebuilt from the exported canonical-order trees."""
+    B = len(legal)
+    engine = engine_factory(B)
+    engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(s) for s in seeds])
+    t = engine.export_trees(B)
+    traces = []
+    for i in range(B):
+        tr = []
+        for n in range(1, int(t["n_nodes"][i])):
+            par = int(t["parent"][i, n])
+            slot = int(numpy.nonzero(t["child"][i, par] == n)[0][0])
+            tr.append((par, legal[i][slot] if par == 0 else slot))
+        traces.append(tr)
+    return traces
+
+
+def _compare_sample_with_oracle(cfg, sd, res, obs, legal, to_play, seeds, sample, engine_factory, value_tol, label):
+    """
+    Tree-by-tree comparison of a sample against the CPU oracle (the reference's algorithm with its torch
+    network).  fp32 summation order differs between any two network implementations, so a simulation whose
+    best and second-best UCB scores are closer than that noise may take the other branch.  For every
+    mismatching tree this finds the FIRST diverging simulation, prints the oracle's UCB top-2 margin there
+    (SURVEY.md section 8c') and requires it to be tiny: a mismatch with a comfortable margin is a bug, not noise.
+    """
+    onet = net_oracle.make_oracle_network(cfg, sd)
+    mismatched, trees = [], {}
+    for i in sample:
+        ev = net_oracle.NetworkEvaluator(onet, cfg.support_size)
+        tree = mcts_oracle.run_search(cfg, ev, obs[i], legal[i], to_play[i], True, numpy.random.RandomState(seeds[i]))
+        if tree.root_visit_counts(cfg.action_space) == list(res.visit_counts[i]):
+            rv = tree.node_value(0)
+            assert abs(res.root_values[i] - rv) < value_tol * max(1.0, abs(rv)), (label, i)
+            assert res.max_tree_depth[i] == tree.max_depth, (label, i)
+        else:
+            mismatched.append(i)
+            trees[i] = tree
+    print(f"{label}: visit counts == oracle on {len(sample) - len(mismatched)}/{len(sample)} sampled trees")
+    if mismatched:
+        traces = _device_trace(engine_factory, cfg, [obs[i] for i in mismatched], [legal[i] for i in mismatched],
+                               [to_play[i] for i in mismatched], [seeds[i] for i in mismatched])
+        for i, got in zip(mismatched, traces):
+            want = [(p, a) for p, a, _ in trees[i].trace]
+            k = next((k for k in range(len(want)) if k >= len(got) or got[k] != want[k]), None)
+            assert k is not None, (label, i, "root visit counts differ but every simulation agrees")
+            gap, depth = trees[i].margins[k]
+            print(f"{label}: tree {i} diverges at simulation {k} (oracle {want[k]}, device {got[k] if k < len(got) else None}); "
+                  f"oracle UCB top-2 margin on that walk {gap:.3e} at depth {depth}")
+            assert gap < 2e-3, (label, i, k, gap, "divergence with a comfortable UCB margin: not fp32 noise")
+    return len(sample) - len(mismatched)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_full_size_c2_cartpole(backend, mode):
     """BASELINE config C2: CartPole-FC, 4096 trees x 50 simulations on one GPU."""
@@ -138,21 +190,14 @@ def test_full_size_c2_cartpole(backend, mode):
     res2 = engine.run(list(obs), legal, [0] * B, True, [numpy.random.RandomState(1000 + i) for i in range(B)])
     assert numpy.array_equal(res.visit_counts, res2.visit_counts)
     assert numpy.array_equal(res.root_values.view(numpy.int64), res2.root_values.view(numpy.int64))
-    # sampled trees against the CPU oracle (reference network arithmetic on the host)
-    onet = net_oracle.make_oracle_network(cfg, sd)
-    sample = list(range(0, B, 64))
-    same = 0
-    for i in sample:
-        ev = net_oracle.NetworkEvaluator(onet, cfg.support_size)
-        tree = mcts_oracle.run_search(cfg, ev, obs[i], legal[i], 0, True, numpy.random.RandomState(1000 + i))
-        same += int(tree.root_visit_counts(cfg.action_space) == list(res.visit_counts[i]))
-        rv = tree.node_value(0)
-        if tree.root_visit_counts(cfg.action_space) == list(res.visit_counts[i]):
-            assert abs(res.root_values[i] - rv) < TOL * max(1.0, abs(rv))
-    # fp32 network arithmetic is not bit-reproducible across implementations; a near-tie may flip
-    # one simulation on rare trees -- report the match rate, require it to be essentially all
-    print(f"visit-count match rate vs oracle: {same}/{len(sample)}")
-    assert same >= len(sample) - 1
+    # 256 sampled trees against the CPU oracle (reference network arithmetic on the host)
+    sample = list(range(0, B, 16))
+    seeds = [1000 + i for i in range(B)]
+    factory = lambda n: self_play.BatchedMCTS(cfg, net, n, mode=0 if mode == 0 else 3)
+    same = _compare_sample_with_oracle(cfg, sd, res, obs, legal, [0] * B, seeds, sample, factory, TOL, f"C2 mode {mode}")
+    # fp32 network arithmetic is not bit-reproducible across implementations; a near-tie may flip one
+    # simulation on rare trees (each such tree's margin is printed and bounded above)
+    assert same >= len(sample) - max(2, len(sample) // 50)
 
 
 @pytest.mark.parametrize("players", [1, 2])
@@ -262,10 +307,47 @@ def test_fused_resnet_operator_by_operator(backend, name):
         assert covered >= 10
 
 
+
+def _check_loose_samples_against_oracle(cfg, sd, net, obs, hidden_in, act, outs_fused, loose, label):
+    """
+    Samples on which the fused engine and the per-operator engine differ by more than the tight bound: compare
+    the FUSED outputs with the oracle (the reference's torch arithmetic) instead of waiving them.  Contract
+    (north_star): value / reward / policy logits within 1e-4.  Hidden states: within 1e-4 except on planes the
+    reference's own `scale < 1e-5 -> scale + 1e-5` guard (models.py:541-549) makes ill-conditioned -- a plane
+    whose pre-scaling range is below 1e-2 divides fp32 round-off (~1e-7) by that range.
+    """
+    if not len(loose):
+        return
+    onet = net_oracle.make_oracle_network(cfg, sd)
+    idx = torch.as_tensor(numpy.asarray(loose))
+    with torch.no_grad():
+        o = onet.initial_inference(obs[idx])
+        h_in = hidden_in.cpu()[idx]
+        a = act[idx].long().reshape(-1, 1)
+        r = onet.recurrent_inference(h_in, a)
+        pre = [onet.representation_unscaled(obs[idx]), onet.dynamics_unscaled(h_in, a)]
+    want = [t.numpy().reshape(len(loose), -1) for t in o + r]
+    for k, w in enumerate(want):
+        got = outs_fused[k][loose]
+        if k == 1:
+            assert numpy.array_equal(got, w)
+            continue
+        err = numpy.abs(got - w)
+        if k in (3, 7):      # hidden states: [n, C, H, W] flattened
+            C = pre[k // 4].shape[1]
+            rng = (pre[k // 4].flatten(2).max(2)[0] - pre[k // 4].flatten(2).min(2)[0]).numpy()   # [n, C]
+            plane_err = err.reshape(len(loose), C, -1).max(2)
+            bad = (plane_err >= TOL) & (rng >= 1e-2)
+            assert not bad.any(), (label, k, float(plane_err[bad].max()), float(rng[bad].min()))
+        else:
+            assert err.max() < TOL, (label, k, float(err.max()))
+
+
 @pytest.mark.parametrize("batch", [1, 37, 1024])
 @pytest.mark.parametrize("name", sorted(RESNET_CASES))
 def test_fused_resnet_matches_per_operator_engine(backend, name, batch):
     cfg, net = _resnet(name, seed=8)
+    sd = synthetic.fill_state_dict(net.state_dict(), 8)
     if name == "breakout" and batch > 64:
         batch = 64
     rs = numpy.random.RandomState(batch)
@@ -281,18 +363,20 @@ def test_fused_resnet_matches_per_operator_engine(backend, name, batch):
         r = net.recurrent_inference(hidden_in, act)
         outs[mode] = [t.cpu().numpy().reshape(batch, -1) for t in o + r]
     net.set_mode(1)
+    loose_rows = set()
     for k, (want, got) in enumerate(zip(outs[0], outs[1])):
         assert got.shape == want.shape
         if k == 1:
             assert numpy.array_equal(got, want)   # initial reward: -inf / 0 pattern
             continue
         # the per-plane min-max scaling divides by (max - min), or by 1e-5 for a flat plane
-        # (models.py:541-549): on such planes fp32 round-off of the two summation orders is amplified,
-        # so require the bulk of the samples tight and every sample loosely
+        # (models.py:541-549): on such planes fp32 round-off of the two summation orders is amplified.
+        # The bulk of the samples must agree tightly; the few that do not are compared with the ORACLE below
         err = numpy.abs(got - want).max(axis=1)
         tight = err < 5e-5 * (1.0 + numpy.abs(want).max())
-        loose = int((~tight).sum())
-        assert loose <= max(2, batch // 50) and err.max() < 2e-2, (name, batch, k, float(err.max()), loose)
+        assert int((~tight).sum()) <= max(2, batch // 50), (name, batch, k, float(err.max()))
+        loose_rows.update(numpy.nonzero(~tight)[0].tolist())
+    _check_loose_samples_against_oracle(cfg, sd, net, obs, hidden_in, act, outs[1], sorted(loose_rows), (name, batch))
 
 
 @pytest.mark.parametrize("name", ["tictactoe", "connect4"])
@@ -409,14 +493,15 @@ def test_zero_simulations(backend):
         assert (res.visit_counts == 0).all() and (res.root_values == 0).all() and (res.max_tree_depth == 0).all()
 
 
-@pytest.mark.parametrize("name,B", [("tictactoe", 1024), ("connect4", 1024)])
-def test_full_size_residual_configs(backend, name, B):
+@pytest.mark.parametrize("name,B,n_sample", [("tictactoe", 1024, 128), ("connect4", 1024, 64), ("breakout", 64, 32)])
+def test_full_size_residual_configs(backend, name, B, n_sample):
     """
-    BASELINE configs C3 (tic-tac-toe, 1024 trees x 25 simulations) and C4 (connect4, 1024 x 200) at full size
-    on the whole-search kernel: size-independent invariants, determinism, and a sample of trees against the
-    CPU oracle (the reference's algorithm with its torch network).
+    BASELINE configs C3 (tic-tac-toe, 1024 trees x 25 simulations), C4 (connect4, 1024 x 200) and C5 (breakout
+    96x96x3 with the resnet down-sampling stem, 64 trees per GPU x 50 simulations) at full size on the
+    whole-search kernel: size-independent invariants, determinism, and a sample of trees against the CPU
+    oracle (the reference's algorithm with its torch network).
     """
-    cfg = configs.BY_NAME[name]()
+    cfg = configs.BY_NAME[name](**({"num_simulations": 50} if name == "breakout" else {}))
     S = cfg.num_simulations
     net = models.MuZeroNetwork(cfg)
     sd = synthetic.fill_state_dict(net.state_dict(), 21)
@@ -427,28 +512,21 @@ def test_full_size_residual_configs(backend, name, B):
     rs = numpy.random.RandomState(8)
     A = len(cfg.action_space)
     legal = [sorted(rs.choice(A, size=rs.randint(2, A + 1), replace=False).tolist()) for _ in range(B)]
-    to_play = [int(i % 2) for i in range(B)]
-    res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(4000 + i) for i in range(B)])
+    to_play = [int(i % len(cfg.players)) for i in range(B)]
+    seeds = [4000 + i for i in range(B)]
+    res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(s) for s in seeds])
     _tree_invariants(cfg, res, S)
     for i in range(B):
         assert set(numpy.nonzero(res.visit_counts[i])[0]).issubset(set(legal[i]))
-    res2 = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(4000 + i) for i in range(B)])
+    res2 = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(s) for s in seeds])
     assert numpy.array_equal(res.visit_counts, res2.visit_counts)
     assert numpy.array_equal(res.root_values.view(numpy.int64), res2.root_values.view(numpy.int64))
-    onet = net_oracle.make_oracle_network(cfg, sd)
-    sample = list(range(0, B, 128))
-    same = 0
-    for i in sample:
-        ev = net_oracle.NetworkEvaluator(onet, cfg.support_size)
-        tree = mcts_oracle.run_search(cfg, ev, obs[i], legal[i], to_play[i], True, numpy.random.RandomState(4000 + i))
-        match = tree.root_visit_counts(cfg.action_space) == list(res.visit_counts[i])
-        same += int(match)
-        if match:
-            rv = tree.node_value(0)
-            assert abs(res.root_values[i] - rv) < 10 * TOL * max(1.0, abs(rv))
-    print(f"{name}: visit-count match rate vs oracle {same}/{len(sample)}")
+    sample = list(range(0, B, B // n_sample))
+    factory = lambda n: self_play.BatchedMCTS(cfg, net, n, mode=1)   # residual kernel: trees live in the arena
+    same = _compare_sample_with_oracle(cfg, sd, res, obs, legal, to_play, seeds, sample, factory, 10 * TOL, name)
     # fp32 summation order differs between implementations; with 200 simulations a near-tie may flip on a tree
-    assert same >= len(sample) - 2
+    # (every such tree's first divergence is printed with its UCB margin and bounded in the helper)
+    assert same >= len(sample) - max(2, len(sample) // 16)
 
 
 # ---- observation pipeline + Reanalyse: device twins of tests/test_observations.py
@@ -544,7 +622,8 @@ def test_random_residual_networks_fused_vs_per_operator(backend, seed, batch):
     cfg, _ = random_common.random_config(seed)
     assert cfg.network == "resnet"
     net = models.MuZeroNetwork(cfg)
-    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 400 + seed))
+    sd = synthetic.fill_state_dict(net.state_dict(), 400 + seed)
+    net.set_weights(sd)
     if not net.fused_supported():
         pytest.skip("shape outside the fused engine")
     rs = numpy.random.RandomState(batch + seed)
@@ -558,10 +637,13 @@ def test_random_residual_networks_fused_vs_per_operator(backend, seed, batch):
             hidden_in = o[3]
         r = net.recurrent_inference(hidden_in, act)
         outs[mode] = [t.cpu().numpy().reshape(batch, -1) for t in o + r]
+    loose_rows = set()
     for k, (want, got) in enumerate(zip(outs[0], outs[1])):
         if k == 1:
             assert numpy.array_equal(got, want)
             continue
         err = numpy.abs(got - want).max(axis=1)
         tight = err < 5e-5 * (1.0 + numpy.abs(want).max())
-        assert int((~tight).sum()) <= max(2, batch // 50) and err.max() < 2e-2, (seed, batch, k, float(err.max()))
+        assert int((~tight).sum()) <= max(2, batch // 50), (seed, batch, k, float(err.max()))
+        loose_rows.update(numpy.nonzero(~tight)[0].tolist())
+    _check_loose_samples_against_oracle(cfg, sd, net, obs, hidden_in, act, outs[1], sorted(loose_rows), (seed, batch))

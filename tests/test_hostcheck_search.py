@@ -17,7 +17,7 @@ from conftest import GOLDEN
 from mzx import configs, models, self_play, synthetic
 
 NET_FOR_GAME = {"cartpole": "net_fc_cartpole.npz", "tictactoe": "net_resnet_tictactoe.npz",
-                "connect4": "net_resnet_connect4.npz"}
+                "connect4": "net_resnet_connect4.npz", "lunarlander": "net_fc_lunarlander_pretrained.npz"}
 
 
 @pytest.fixture(scope="module")
@@ -25,9 +25,10 @@ def backend():
     return hostcheck.backend()
 
 
-def build_model(backend, cfg, weight_seed, zero_keys=()):
+def build_model(backend, cfg, weight_seed, zero_keys=(), fixture=None):
     net = models.MuZeroNetwork(cfg, _backend=backend)
-    sd = synthetic.fill_state_dict(net.state_dict(), weight_seed)
+    sd = fixture is not None and lockstep.fixture_weights(fixture, net.state_dict())
+    sd = sd or synthetic.fill_state_dict(net.state_dict(), weight_seed or 0)
     for k in zero_keys:
         sd[k] = torch.zeros_like(sd[k])
     net.set_weights(sd)
@@ -35,11 +36,11 @@ def build_model(backend, cfg, weight_seed, zero_keys=()):
 
 
 @pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties", "tictactoe_custom",
-                                  "cartpole_custom"])
+                                  "cartpole_custom", "lunarlander_pretrained"])
 def test_search_matches_reference(backend, name):
     z, meta, cfg = lockstep.load_fixture(name)
     cfg.num_simulations = meta["num_simulations"]
-    net = build_model(backend, cfg, meta["weight_seed"], meta.get("zero_keys", ()))
+    net = build_model(backend, cfg, meta["weight_seed"], meta.get("zero_keys", ()), fixture=z)
     cases = meta["cases"]
     B = len(cases)
     engine = self_play.BatchedMCTS(cfg, net, B)
@@ -70,14 +71,14 @@ def test_search_matches_reference(backend, name):
         assert numpy.array_equal(ref.get_state()[1], rngs[c].get_state()[1])
 
 
-@pytest.mark.parametrize("name", ["fc_cartpole_stacked", "resnet_tictactoe", "resnet_breakout", "resnet_breakout_cnn",
-                                  "resnet_cnn_small"])
+@pytest.mark.parametrize("name", ["fc_cartpole_stacked", "fc_lunarlander_pretrained", "resnet_tictactoe",
+                                  "resnet_breakout", "resnet_breakout_cnn", "resnet_cnn_small"])
 def test_network_heads_within_tolerance(backend, name):
     """The per-operator network programs (serial build) against models.py outputs, 1e-4."""
     z = numpy.load(os.path.join(GOLDEN, f"net_{name}.npz"))
     meta = json.loads(str(z["meta"]))
     cfg = configs.BY_NAME[meta["game"]](**meta["overrides"])
-    net = build_model(backend, cfg, meta["weight_seed"])
+    net = build_model(backend, cfg, meta["weight_seed"], fixture=z)
     assert [k for k, _, _ in meta["keys"]] == list(net.state_dict().keys())
     o = net.initial_inference(torch.tensor(z["obs"]))
     r1 = net.recurrent_inference(o[3], torch.tensor(z["act1"]))

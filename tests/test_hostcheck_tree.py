@@ -16,7 +16,7 @@ def backend():
 
 
 @pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties", "tictactoe_custom",
-                                  "cartpole_custom"])
+                                  "cartpole_custom", "lunarlander_pretrained"])
 def test_lockstep_tree_bit_exact(backend, name):
     got = lockstep.run_fixture(backend, name)
     if name == "cartpole_ties":

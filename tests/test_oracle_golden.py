@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from mzx import configs, synthetic
+import lockstep
 from oracle import mcts_oracle, net_oracle
 
 from conftest import GOLDEN
@@ -36,7 +37,7 @@ def state_dict_for(meta_net_name, weight_seed, zero_keys=()):
 
 
 NET_FOR_GAME = {"cartpole": "net_fc_cartpole.npz", "tictactoe": "net_resnet_tictactoe.npz",
-                "connect4": "net_resnet_connect4.npz"}
+                "connect4": "net_resnet_connect4.npz", "lunarlander": "net_fc_lunarlander_pretrained.npz"}
 
 
 def compare_tree(tree, z, c, cfg):
@@ -70,7 +71,7 @@ def compare_tree(tree, z, c, cfg):
 
 
 @pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties", "tictactoe_custom",
-                                  "cartpole_custom"])
+                                  "cartpole_custom", "lunarlander_pretrained"])
 def test_tree_lockstep_bit_exact(name):
     """Tree arithmetic alone: network outputs replayed from the reference run."""
     z, meta = load(f"tree_{name}.npz")
@@ -89,12 +90,13 @@ def test_tree_lockstep_bit_exact(name):
 
 
 @pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "cartpole_ties", "tictactoe_custom",
-                                  "cartpole_custom"])
+                                  "cartpole_custom", "lunarlander_pretrained"])
 def test_search_end_to_end_bit_exact(name):
     """Oracle network + oracle tree vs the reference's models.py + self_play.py."""
     z, meta = load(f"tree_{name}.npz")
     cfg = config_for(meta)
-    sd = state_dict_for(NET_FOR_GAME[meta["game"]], meta["weight_seed"], meta.get("zero_keys", ()))
+    sd = state_dict_for(NET_FOR_GAME[meta["game"]], meta["weight_seed"] or 0, meta.get("zero_keys", ()))
+    sd = lockstep.fixture_weights(z, sd) or sd      # trained weights shipped with the fixture
     net = net_oracle.make_oracle_network(cfg, sd)
     for c, case in enumerate(meta["cases"]):
         ev = net_oracle.NetworkEvaluator(net, cfg.support_size, record=True)
@@ -106,7 +108,7 @@ def test_search_end_to_end_bit_exact(name):
         assert numpy.array_equal(numpy.stack([e["value_logits"] for e in ev.log]), z[f"c{c}_value_logits"])
 
 
-@pytest.mark.parametrize("name", ["fc_cartpole", "fc_cartpole_pretrained", "fc_cartpole_stacked",
+@pytest.mark.parametrize("name", ["fc_cartpole", "fc_cartpole_pretrained", "fc_lunarlander_pretrained", "fc_cartpole_stacked",
                                   "resnet_tictactoe", "resnet_connect4", "resnet_breakout", "resnet_breakout_cnn",
                                   "resnet_cnn_small"])
 def test_network_outputs(name):
