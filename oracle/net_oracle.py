@@ -93,8 +93,9 @@ def _zero_reward_logits(n, full_support):
 class FullyConnectedOracle:
     """models.py:80-195 as pure functions of a state_dict."""
 
-    def __init__(self, state_dict, action_space_size, support_size):
-        self.sd = {k: v.float() for k, v in state_dict.items() if v.dtype.is_floating_point}
+    def __init__(self, state_dict, action_space_size, support_size, dtype=torch.float32):
+        self.dtype = dtype
+        self.sd = {k: v.to(dtype) for k, v in state_dict.items() if v.dtype.is_floating_point}
         self.A = action_space_size
         self.F = 2 * support_size + 1
 
@@ -111,7 +112,7 @@ class FullyConnectedOracle:
         return value, _zero_reward_logits(len(observation), self.F), policy, s
 
     def recurrent_inference(self, encoded_state, action):
-        onehot = torch.zeros(action.shape[0], self.A)
+        onehot = torch.zeros(action.shape[0], self.A, dtype=self.dtype)
         onehot.scatter_(1, action.long(), 1.0)
         x = torch.cat((encoded_state, onehot), dim=1)
         nxt = _mlp(self.sd, "dynamics_encoded_state_network.module.", x)
@@ -124,8 +125,9 @@ class FullyConnectedOracle:
 class ResidualOracle:
     """models.py:436-623 as pure functions of a state_dict."""
 
-    def __init__(self, state_dict, action_space_size, support_size, downsample):
-        self.sd = {k: v.float() for k, v in state_dict.items() if v.dtype.is_floating_point}
+    def __init__(self, state_dict, action_space_size, support_size, downsample, dtype=torch.float32):
+        self.dtype = dtype   # float32 = the reference's arithmetic; float64 = "exact" yardstick for conditioning checks
+        self.sd = {k: v.to(dtype) for k, v in state_dict.items() if v.dtype.is_floating_point}
         self.A = action_space_size
         self.F = 2 * support_size + 1
         self.downsample = downsample
@@ -184,7 +186,7 @@ class ResidualOracle:
         b, _, h, w = encoded_state.shape
         # scalar action plane action/|A| (NOT one-hot), models.py:557-571
         plane = action[:, :, None, None] * torch.ones((b, 1, h, w)).float() / self.A
-        x = torch.cat((encoded_state, plane), dim=1)
+        x = torch.cat((encoded_state, plane.to(self.dtype)), dim=1)
         x = F.relu(_bn(sd, p + ".bn", F.conv2d(x, sd[p + ".conv.weight"], None, 1, 1)))
         return _resblocks(sd, p + ".resblocks", x)
 
@@ -199,12 +201,12 @@ class ResidualOracle:
         return value, reward, policy, s
 
 
-def make_oracle_network(cfg, state_dict):
+def make_oracle_network(cfg, state_dict, dtype=torch.float32):
     """Counterpart of the factory models.py:7-41 for the two architectures."""
     if cfg.network == "fullyconnected":
-        return FullyConnectedOracle(state_dict, len(cfg.action_space), cfg.support_size)
+        return FullyConnectedOracle(state_dict, len(cfg.action_space), cfg.support_size, dtype)
     if cfg.network == "resnet":
-        return ResidualOracle(state_dict, len(cfg.action_space), cfg.support_size, cfg.downsample)
+        return ResidualOracle(state_dict, len(cfg.action_space), cfg.support_size, cfg.downsample, dtype)
     raise NotImplementedError('The network parameter should be "fullyconnected" or "resnet".')
 
 

@@ -138,36 +138,38 @@ def _device_trace(engine_factory, cfg, obs, legal, to_play, seeds):
 def _compare_sample_with_oracle(cfg, sd, res, obs, legal, to_play, seeds, sample, engine_factory, value_tol, label):
     """
     Tree-by-tree comparison of a sample against the CPU oracle (the reference's algorithm with its torch
-    network).  fp32 summation order differs between any two network implementations, so a simulation whose
-    best and second-best UCB scores are closer than that noise may take the other branch.  For every
-    mismatching tree this finds the FIRST diverging simulation, prints the oracle's UCB top-2 margin there
-    (SURVEY.md section 8c') and requires it to be tiny: a mismatch with a comfortable margin is a bug, not noise.
+    network), SIMULATION BY SIMULATION: the (parent, action) of every expansion, rebuilt from the exported
+    device trees, against the oracle's trace.  fp32 summation order differs between any two network
+    implementations, so a simulation whose best and second-best UCB scores are closer than that noise may take
+    the other branch.  For every tree that diverges this finds the FIRST diverging simulation, prints the
+    oracle's UCB top-2 margin on that walk (SURVEY.md section 8c') and requires it to be tiny: a divergence with a
+    comfortable margin is a bug, not noise.  Trees whose every simulation agrees must also agree on root
+    value (tolerance) and maximum depth.  Returns the number of trees identical in every simulation.
     """
     onet = net_oracle.make_oracle_network(cfg, sd)
-    mismatched, trees = [], {}
-    for i in sample:
+    traces = _device_trace(engine_factory, cfg, [obs[i] for i in sample], [legal[i] for i in sample],
+                           [to_play[i] for i in sample], [seeds[i] for i in sample])
+    identical = roots_equal = 0
+    for i, got in zip(sample, traces):
         ev = net_oracle.NetworkEvaluator(onet, cfg.support_size)
         tree = mcts_oracle.run_search(cfg, ev, obs[i], legal[i], to_play[i], True, numpy.random.RandomState(seeds[i]))
-        if tree.root_visit_counts(cfg.action_space) == list(res.visit_counts[i]):
+        want = [(p, a) for p, a, _ in tree.trace]
+        roots_equal += int(tree.root_visit_counts(cfg.action_space) == list(res.visit_counts[i]))
+        k = next((k for k in range(len(want)) if k >= len(got) or got[k] != want[k]), None)
+        if k is None:
+            identical += 1
+            assert tree.root_visit_counts(cfg.action_space) == list(res.visit_counts[i]), (label, i)
             rv = tree.node_value(0)
             assert abs(res.root_values[i] - rv) < value_tol * max(1.0, abs(rv)), (label, i)
             assert res.max_tree_depth[i] == tree.max_depth, (label, i)
-        else:
-            mismatched.append(i)
-            trees[i] = tree
-    print(f"{label}: visit counts == oracle on {len(sample) - len(mismatched)}/{len(sample)} sampled trees")
-    if mismatched:
-        traces = _device_trace(engine_factory, cfg, [obs[i] for i in mismatched], [legal[i] for i in mismatched],
-                               [to_play[i] for i in mismatched], [seeds[i] for i in mismatched])
-        for i, got in zip(mismatched, traces):
-            want = [(p, a) for p, a, _ in trees[i].trace]
-            k = next((k for k in range(len(want)) if k >= len(got) or got[k] != want[k]), None)
-            assert k is not None, (label, i, "root visit counts differ but every simulation agrees")
-            gap, depth = trees[i].margins[k]
-            print(f"{label}: tree {i} diverges at simulation {k} (oracle {want[k]}, device {got[k] if k < len(got) else None}); "
-                  f"oracle UCB top-2 margin on that walk {gap:.3e} at depth {depth}")
-            assert gap < 2e-3, (label, i, k, gap, "divergence with a comfortable UCB margin: not fp32 noise")
-    return len(sample) - len(mismatched)
+            continue
+        gap, depth = tree.margins[k]
+        print(f"{label}: tree {i} diverges at simulation {k} of {len(want)} (oracle {want[k]}, device "
+              f"{got[k] if k < len(got) else None}); oracle UCB top-2 margin on that walk {gap:.3e} at depth {depth}")
+        assert gap < 2e-3, (label, i, k, gap, "divergence with a comfortable UCB margin: not fp32 noise")
+    print(f"{label}: {identical}/{len(sample)} sampled trees identical to the oracle in EVERY simulation; "
+          f"root visit counts equal on {roots_equal}/{len(sample)}")
+    return identical
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -197,7 +199,7 @@ def test_full_size_c2_cartpole(backend, mode):
     same = _compare_sample_with_oracle(cfg, sd, res, obs, legal, [0] * B, seeds, sample, factory, TOL, f"C2 mode {mode}")
     # fp32 network arithmetic is not bit-reproducible across implementations; a near-tie may flip one
     # simulation on rare trees (each such tree's margin is printed and bounded above)
-    assert same >= len(sample) - max(2, len(sample) // 50)
+    assert same >= len(sample) - max(2, len(sample) // 25)
 
 
 @pytest.mark.parametrize("players", [1, 2])
@@ -311,36 +313,37 @@ def test_fused_resnet_operator_by_operator(backend, name):
 def _check_loose_samples_against_oracle(cfg, sd, net, obs, hidden_in, act, outs_fused, loose, label):
     """
     Samples on which the fused engine and the per-operator engine differ by more than the tight bound: compare
-    the FUSED outputs with the oracle (the reference's torch arithmetic) instead of waiving them.  Contract
-    (north_star): value / reward / policy logits within 1e-4.  Hidden states: within 1e-4 except on planes the
-    reference's own `scale < 1e-5 -> scale + 1e-5` guard (models.py:541-549) makes ill-conditioned -- a plane
-    whose pre-scaling range is below 1e-2 divides fp32 round-off (~1e-7) by that range.
+    the FUSED outputs with the oracle instead of waiving them.  These are samples with a near-flat plane in
+    front of the per-plane min-max scaling (models.py:541-549), where fp32 round-off is divided by the plane's
+    range: NO fp32 implementation reproduces the others there -- the reference's own torch arithmetic included.
+    So the yardstick is the oracle evaluated in binary64: on every output the fused engine's error against it
+    must stay within 1e-4 (north_star) or within a small multiple of the error the reference's fp32 arithmetic
+    itself makes on that very sample.  A genuine fused-engine defect shows up as an error the fp32 oracle does
+    not have.
     """
     if not len(loose):
         return
-    onet = net_oracle.make_oracle_network(cfg, sd)
+    o32 = net_oracle.make_oracle_network(cfg, sd)
+    o64 = net_oracle.make_oracle_network(cfg, sd, dtype=torch.float64)
     idx = torch.as_tensor(numpy.asarray(loose))
+    h_in = hidden_in.cpu()[idx]
+    a = act[idx].long().reshape(-1, 1)
     with torch.no_grad():
-        o = onet.initial_inference(obs[idx])
-        h_in = hidden_in.cpu()[idx]
-        a = act[idx].long().reshape(-1, 1)
-        r = onet.recurrent_inference(h_in, a)
-        pre = [onet.representation_unscaled(obs[idx]), onet.dynamics_unscaled(h_in, a)]
-    want = [t.numpy().reshape(len(loose), -1) for t in o + r]
-    for k, w in enumerate(want):
-        got = outs_fused[k][loose]
+        w32 = o32.initial_inference(obs[idx]) + o32.recurrent_inference(h_in, a)
+        w64 = o64.initial_inference(obs[idx].double()) + o64.recurrent_inference(h_in.double(), a)
+    for k in range(8):
+        got = outs_fused[k][loose].astype(numpy.float64)
+        ref64 = w64[k].numpy().reshape(len(loose), -1)
+        ref32 = w32[k].numpy().reshape(len(loose), -1).astype(numpy.float64)
         if k == 1:
-            assert numpy.array_equal(got, w)
+            assert numpy.array_equal(got, ref32)
             continue
-        err = numpy.abs(got - w)
-        if k in (3, 7):      # hidden states: [n, C, H, W] flattened
-            C = pre[k // 4].shape[1]
-            rng = (pre[k // 4].flatten(2).max(2)[0] - pre[k // 4].flatten(2).min(2)[0]).numpy()   # [n, C]
-            plane_err = err.reshape(len(loose), C, -1).max(2)
-            bad = (plane_err >= TOL) & (rng >= 1e-2)
-            assert not bad.any(), (label, k, float(plane_err[bad].max()), float(rng[bad].min()))
-        else:
-            assert err.max() < TOL, (label, k, float(err.max()))
+        err_fused = numpy.abs(got - ref64).max(axis=1)
+        err_ref32 = numpy.abs(ref32 - ref64).max(axis=1)
+        bad = err_fused > numpy.maximum(TOL, 8 * err_ref32)
+        print(f"{label}: output {k}: {len(loose)} loose samples, fused-vs-f64 {err_fused.max():.2e}, "
+              f"torch-fp32-vs-f64 {err_ref32.max():.2e}")
+        assert not bad.any(), (label, k, err_fused[bad].tolist(), err_ref32[bad].tolist())
 
 
 @pytest.mark.parametrize("batch", [1, 37, 1024])
@@ -524,9 +527,10 @@ def test_full_size_residual_configs(backend, name, B, n_sample):
     sample = list(range(0, B, B // n_sample))
     factory = lambda n: self_play.BatchedMCTS(cfg, net, n, mode=1)   # residual kernel: trees live in the arena
     same = _compare_sample_with_oracle(cfg, sd, res, obs, legal, to_play, seeds, sample, factory, 10 * TOL, name)
-    # fp32 summation order differs between implementations; with 200 simulations a near-tie may flip on a tree
-    # (every such tree's first divergence is printed with its UCB margin and bounded in the helper)
-    assert same >= len(sample) - max(2, len(sample) // 16)
+    # fp32 summation order differs between implementations; with 200 simulations of a 64-channel network a
+    # near-tie flips somewhere in a fair share of the trees.  Every divergence is printed with its UCB margin and
+    # bounded in the helper (the real gate); the share of trees identical in EVERY simulation is reported
+    assert same >= len(sample) // 2
 
 
 # ---- observation pipeline + Reanalyse: device twins of tests/test_observations.py
