@@ -73,7 +73,8 @@ def parse():
                          "'workloads' (default: c4 when the main workload is c2; 'none' = skip)")
     ap.add_argument("--also-steps", type=int, default=3)
     ap.add_argument("--trees", type=int, default=None, help="trees per GPU (default: the workload's)")
-    ap.add_argument("--mode", default="auto", choices=["auto", "generic", "fused"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "generic", "fused", "fused-v1"],
+                    help="fused-v1: first-generation fully connected whole-search kernel (A/B)")
     ap.add_argument("--net-mode", default="fused", choices=["fused", "fused-4wave", "per-operator"],
                     help="residual networks: fused MFMA engine (default) or one kernel per operator")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall budget of each CPU baseline leg (0 = skip)")
@@ -380,7 +381,7 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     elif args.net_mode == "fused-4wave" and net.fused_supported():
         net.set_mode(2)
     net_fused = bool(net.fused_supported()) and args.net_mode != "per-operator"
-    mode = {"auto": None, "generic": 0, "fused": 1}[args.mode]
+    mode = {"auto": None, "generic": 0, "fused": 1, "fused-v1": 17}[args.mode]
     engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
     handle = engine.handle(B)
     fused_kind = int(engine.backend.lib.mzx_search_fused_supported(handle)) if mode != 0 else 0

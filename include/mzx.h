@@ -212,6 +212,8 @@ int mzx_search_run_from_roots(mzx_search* s, const mzx_search_io* io, const floa
  *   8  cycle profile: phase cycle counters are left in the network-workspace region of the
  *      arena (mzx_search_arena_offsets): [tree][16] for the fully connected kernel (a
  *      separate profiling instantiation), [workgroup][8] for the residual kernel
+ *  16  (fully connected whole-search kernel) run the first-generation kernel (per-level UCB evaluation,
+ *      csrc/mzx_fused_fc.h) instead of the cached-prior-score kernel (csrc/mzx_fused_fc2.h): A/B measurements
  * Default: 1 when supported, else 0. */
 int mzx_search_fused_supported(const mzx_search* s);
 int mzx_search_set_mode(mzx_search* s, int32_t mode);

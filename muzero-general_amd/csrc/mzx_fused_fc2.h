@@ -1,0 +1,470 @@
+// mzx_fused_fc2.h -- second generation of the whole-search kernel for fully connected networks
+// (K5 of SURVEY.md section 8a): same contract as mzx_fused_fc.h -- initial_inference, root expansion and
+// num_simulations x {select, recurrent_inference, expand, backpropagate} in ONE launch, every tree resident
+// in LDS, bit-identical tree statistics to the generic path (mzx_tree.h) -- with the selection walk, which was
+// 46 % of a simulation, rebuilt around what actually changes between two visits of a node.
+//
+// Reference semantics: MCTS.run /root/reference/self_play.py:260-361, ucb_score :380-404,
+// backpropagate :406-430, MinMaxStats :553-570.
+//
+//   ucb_score(parent, child) = pb_c(N, n) * prior  +  [n > 0] normalize(reward + discount * (+-value))
+//
+//   * prior score  ps = (pbc[N] * (sqrt[N] / (n + 1))) * prior  depends on the parent's visit count N and the
+//     child's n only: it changes exactly for the slots of the nodes on the path just back-propagated.  It is
+//     CACHED per child slot and refreshed right after back-propagation by the lane that owns the path node
+//     (N is in its registers), A slots per lane.  The walk no longer evaluates it: no table look-ups chained
+//     behind the slot read, no division.
+//   * value score  normalize(q) = (q - min) / (max - min)  depends on the tree-wide MinMaxStats, which move in
+//     about every second simulation -- it cannot be cached, but its DIVISOR is the same for every node of a
+//     simulation.  hipcc expands a binary64 division into div_scale, rcp, two Newton steps on the reciprocal,
+//     then mul / fma / div_fmas / div_fixup on the numerator (AMDGPU LowerFDIV64); the first half depends on the
+//     divisor only and is hoisted out of the walk (`recip_refined`, once per simulation); per child remain
+//     mul, fma, fma, div_fixup -- the SAME instructions on the same operands, hence the same bits.  (div_scale
+//     is the identity unless an operand is denormal or the exponents differ by more than 2^9 orders of
+//     magnitude: tree statistics are sums of at most num_simulations fp32-origin values, so neither occurs.)
+//     The two divisions by small integers (sqrt[N] / (n + 1), value_sum / visit_count) use the same split with a
+//     per-integer reciprocal table filled at kernel start by the same instructions.
+//   * one LDS round trip per level: a child slot is ONE 32-byte record {prior score, q, visit count, child
+//     link, prior}; for two-action games the argmax needs no wave ballot (both scores are broadcast in the row).
+//   * the path of a walk is kept in an LDS array instead of "lane d remembers depth d", and back-propagation
+//     runs over 16-level chunks of it: searches deeper than 16 plies no longer fall back to a serial lane.
+//
+// Mapping, network engines (SmallNet / LdsNet) and the canonical fp32 reduction order are those of
+// mzx_fused_fc.h.  The trees are converted to the arena's TreeLayout on export (mode flag 2), so
+// mzx_search_dump and the bit-identity tests see the same data as with the generic path.
+#pragma once
+#include "mzx_fused_fc.h"
+
+namespace mzx {
+
+struct Fc2Args {
+  FusedFcArgs f;   // network description, search parameters, io, export pointers (f.L = arena TreeLayout)
+  int32_t off_slots, off_nodes, off_path, off_roota, off_hidden, off_scratch;  // byte offsets inside a tree's slab
+  int32_t tree_stride, lds_inv;                                               // lds_inv: reciprocal table (bytes)
+};
+
+#ifndef MZX_HOSTCHECK
+
+struct __attribute__((aligned(16))) Fc2Slot {   // one child slot of a node
+  double ps;       // cached prior score of the slot at the parent's current visit count
+  double q;        // reward + discount * (+-value()) of the child (written by back-propagation)
+  int32_t n;       // child's visit count
+  int32_t child;   // canonical node index or -1
+  double prior;
+};
+struct __attribute__((aligned(16))) Fc2Node {
+  double value_sum, reward;
+  int32_t visit, to_play, parent, parent_slot;
+};
+static_assert(sizeof(Fc2Slot) == 32 && sizeof(Fc2Node) == 32, "record size");
+
+// Divisor-only half of hipcc's binary64 division expansion: v_rcp_f64 + two Newton steps.
+__device__ __forceinline__ double recip_refined(double b) {
+  const double y0 = __builtin_amdgcn_rcp(b);
+  const double f0 = __builtin_fma(-b, y0, 1.0);
+  const double f1 = __builtin_fma(y0, f0, y0);
+  const double f2 = __builtin_fma(-b, f1, 1.0);
+  return __builtin_fma(f1, f2, f1);
+}
+// Numerator half: a / b given y = recip_refined(b).
+__device__ __forceinline__ double div_by(double a, double b, double y) {
+  const double m = a * y;
+  const double r = __builtin_fma(-b, m, a);
+  const double q = __builtin_fma(r, y, m);
+  return __builtin_amdgcn_div_fixup(q, b, a);
+}
+// prior_score of ucb_score (self_play.py:384-392), operation order of ucb_from (mzx_tree.h)
+__device__ __forceinline__ double prior_score(double pbcN, double sqN, int n, double inv_n1, double prior) {
+  const double pb_c = pbcN * div_by(sqN, (double)(n + 1), inv_n1);
+  return pb_c * prior;
+}
+
+template <int J>
+__device__ __forceinline__ void chain_step2(double r_eff, double disc, int ld, int sub, double& val, double& my_in) {
+  if (J <= ld) {  // row-uniform
+    const double rj = bcast_d<J>(r_eff);
+    if (sub == J) my_in = val;
+    val = rj + disc * val;
+  }
+  if constexpr (J > 1) chain_step2<J - 1>(r_eff, disc, ld, sub, val, my_in);
+}
+
+template <class Net, int AW, bool PROFILE>
+__global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int sub = tid & (FUSED_ROW - 1);
+  const int row = tid / FUSED_ROW;
+  const int row_in_wave = row & 3;
+  const int tree = blockIdx.x * a.f.trees_per_block + row;
+  const int A = a.f.p.num_actions, E = a.f.E, NN = a.f.p.num_nodes, P = a.f.p.num_players;
+  const double disc = a.f.p.discount;
+  uint32_t prof[FUSED_PROF_WORDS];
+  unsigned long long t_last = 0;
+  if (PROFILE) {
+    for (int k = 0; k < FUSED_PROF_WORDS; ++k) prof[k] = 0;
+    t_last = __builtin_readcyclecounter();
+  }
+
+  // ---- stage tables (+ weights): the only workgroup-wide barrier
+  Net net;
+  double* tables = (double*)(smem + a.f.lds_tables);
+  double* inv_y = (double*)(smem + a.lds_inv);   // [NN + 2]: refined reciprocal of the integer k >= 1
+  const int ntab = 2 * (NN + 1);
+  for (int i = tid; i < ntab; i += blockDim.x) tables[i] = a.f.tables[i];
+  for (int i = tid; i < NN + 2; i += blockDim.x) inv_y[i] = recip_refined((double)(i > 0 ? i : 1));
+  net.stage(a.f, smem, tid);
+  __syncthreads();
+  if (row >= a.f.trees_per_block || tree >= a.f.p.num_trees) return;  // whole rows exit together
+  net.setup(a.f, smem, sub);
+  const double* pbc = tables;
+  const double* sqt = tables + (NN + 1);
+
+  char* slab = smem + a.f.lds_trees + (size_t)row * a.tree_stride;
+  Fc2Slot* slots = (Fc2Slot*)(slab + a.off_slots);   // [NN][AW]
+  Fc2Node* nodes = (Fc2Node*)(slab + a.off_nodes);   // [NN]
+  int2* path = (int2*)(slab + a.off_path);           // [NN + 1]: {node at depth d, slot taken from its parent}
+  int32_t* roota = (int32_t*)(slab + a.off_roota);   // [AW]: action of root slot s
+  float* hidden = (float*)(slab + a.off_hidden);     // [NN][E]
+  float* scr = (float*)(slab + a.off_scratch);
+  const uint32_t* tape = (const uint32_t*)a.f.io.d_tape + (size_t)tree * a.f.p.tape_words;
+  const int tape_words = a.f.p.tape_words;
+
+  // per-tree scalars, row-uniform registers
+  double mn = MZX_INF, mx = -MZX_INF;
+  int32_t n_nodes = 1, tape_pos = 0, flags = 0, ties = 0, max_depth = 0, sum_depth = 0, root_n = 0, root_to_play = 0;
+  MZX_PROF(0)
+
+  // ---- initial_inference (models.py:172-190) + root expansion (self_play.py:286-314, :467-476)
+  {
+    NetOut o;
+    net.initial(a.f.io.d_observation + (size_t)tree * a.f.in_size, hidden, scr, sub, o);
+    const int32_t* lg = a.f.io.d_legal_actions + (size_t)tree * A;
+    const double* nz = a.f.io.d_noise ? a.f.io.d_noise + (size_t)tree * A : nullptr;
+    while (root_n < A && lg[root_n] >= 0) ++root_n;
+    if (sub < A) scr[sub] = o.policy;
+    wave_sync();
+    const bool in = sub < root_n;
+    const float l = in ? scr[lg[sub]] : -MZX_INF;   // logits gathered in the game's legal-action order
+    const float m = row_max(l);
+    const float e = in ? mzx_expf(l - m) : 0.f;
+    const float den = row_sum(e);
+    root_to_play = a.f.io.d_to_play[tree];
+    if (sub == 0) {
+      Fc2Node r;
+      r.value_sum = 0.0; r.reward = (double)support_inverse_transform(0.0f); r.visit = 0; r.to_play = root_to_play;
+      r.parent = -1; r.parent_slot = -1;
+      nodes[0] = r;
+      path[0] = make_int2(0, -1);
+      if (a.f.io.d_root_predicted_value) a.f.io.d_root_predicted_value[tree] = (double)o.value;
+    }
+    if (sub < AW) {
+      Fc2Slot s;
+      s.prior = in ? root_noisy_prior((double)(e / den), nz, sub, a.f.p.exploration_fraction) : 0.0;
+      s.q = 0.0; s.n = 0; s.child = -1;
+      s.ps = prior_score(pbc[0], sqt[0], 0, inv_y[1], s.prior);   // root visit count 0
+      slots[sub] = s;
+      roota[sub] = in ? lg[sub] : -1;
+    }
+    wave_sync();
+  }
+  MZX_PROF(1)
+
+  // ---- simulations (self_play.py:319-355)
+  const int num_sims = a.f.p.num_sims;
+  for (int sim = 0; sim < num_sims; ++sim) {
+    // ------------------------------------------------------------- select (self_play.py:325-334, :363-404)
+    const double dd = mx - mn;                 // MinMaxStats.normalize divisor, same for every node of this walk
+    const double yd = recip_refined(dd);       // (garbage while max <= min: results discarded like the reference's branch)
+    const bool norm_on = mx > mn;
+    int node = 0, depth = 0, slot = 0, vtp = root_to_play;
+    bool done = false;
+    for (;;) {
+      const int d1 = depth + 1;
+      const int nc = (node == 0) ? root_n : A;
+      const bool valid = sub < nc;
+      const Fc2Slot* rp = slots + (node * AW + (valid ? sub : 0));
+      const double ps = rp->ps, q = rp->q;
+      const int n = rp->n, c = rp->child;
+      const double nv = div_by(q - mn, dd, yd);
+      const double v = norm_on ? nv : q;
+      const double wv = ps + v;
+      const double u = (n > 0) ? wv : ps;
+      const double sc = valid ? u : -MZX_INF;
+      int sl, cw;
+      if constexpr (AW == 2) {
+        // two candidates: every lane sees both scores; no ballot
+        const double a0 = bcast_d<0>(sc), a1 = bcast_d<1>(sc);
+        sl = (a1 > a0) ? 1 : 0;
+        if (nc == 2 && a0 == a1 && !done) {  // numpy.random.choice([0, 1])
+          ++ties;
+          sl = tape_draw(tape, tape_words, tape_pos, flags, 2);
+        }
+        const int c0 = bcast_i<0>(c), c1 = bcast_i<1>(c);
+        cw = sl ? c1 : c0;
+      } else {
+        const double best = row_max_d<AW>(sc);
+        const unsigned bits = row_bits(__ballot(valid && sc == best), row_in_wave);
+        const int nbest = __popc(bits);
+        sl = nbest ? (__ffs(bits) - 1) : 0;
+        if (nbest > 1 && !done) {  // numpy.random.choice(ties): k-th maximiser in slot order
+          ++ties;
+          int k = tape_draw(tape, tape_words, tape_pos, flags, nbest);
+          unsigned b = bits;
+          for (; k > 0; --k) b &= b - 1;
+          sl = __ffs(b) - 1;
+        }
+        if constexpr (AW <= 4) cw = pick_i<AW>(c, sl);
+        else cw = perm_i(c, sl, row_in_wave);
+      }
+      const bool act = !done;
+      if (act && sub == 0) path[d1] = make_int2(cw, sl);   // the last level's entry is completed below
+      const int nvtp = (vtp + 1 < P) ? vtp + 1 : 0;        // players turn by turn, :331-334
+      depth = act ? d1 : depth;
+      slot = act ? sl : slot;
+      vtp = act ? nvtp : vtp;
+      node = (act && cw >= 0) ? cw : node;
+      done = done || (cw < 0);
+      if (__all(done)) break;
+    }
+    int leaf = n_nodes;
+    if (leaf >= NN) { flags |= TF_NODE_OVERFLOW; leaf = NN - 1; }
+    if (sub == 0) path[depth] = make_int2(leaf, slot);
+    const int parent = node;
+    const int ra = roota[slot < AW ? slot : 0];
+    const int action = (parent == 0) ? ra : slot;
+    MZX_PROF(2)
+
+    // ------------------------------------------------------------- recurrent_inference (models.py:192-195)
+    NetOut o;
+    net.recurrent(hidden + parent * E, action, hidden + leaf * E, scr, sub, o);
+    MZX_PROF(3)
+
+    // ------------------------------------------------------------- expand (self_play.py:451-465)
+    {
+      const bool in = sub < A;
+      const float m = row_max(in ? o.policy : -MZX_INF);
+      const float e = in ? mzx_expf(o.policy - m) : 0.f;
+      const float den = row_sum(e);
+      if (in) {
+        Fc2Slot s;
+        s.prior = (double)(e / den);
+        s.q = 0.0; s.n = 0; s.child = -1; s.ps = 0.0;   // ps: refreshed below, once the leaf has its first visit
+        slots[leaf * AW + sub] = s;
+      }
+    }
+    MZX_PROF(4)
+
+    // ------------------------------------------------------------- backpropagate (self_play.py:406-430)
+    n_nodes = leaf + 1;
+    if (depth > max_depth) max_depth = depth;
+    sum_depth += depth;
+    const double reward = (double)o.reward;
+    double val = (double)o.value;
+    int cmax = 0;
+    while (__any((depth >> 4) > cmax)) ++cmax;   // wave-uniform number of 16-level chunks - 1 (0 unless a path is > 15 deep)
+    wave_sync();
+    for (int c = cmax; c >= 0; --c) {
+      const int d = c * 16 + sub;
+      const int ld = depth - c * 16;             // row-uniform: depth of the leaf relative to this chunk
+      const bool active = d <= depth, is_leaf = d == depth;
+      int nd = 0, pslot = 0, par = 0;
+      if (active) {
+        const int2 pe = path[d];
+        nd = pe.x; pslot = pe.y;
+        if (d > 0) par = path[d - 1].x;
+      }
+      double rr = reward, vs = 0.0;
+      int vc = 0, tp = vtp;
+      if (active && !is_leaf) {
+        const Fc2Node* np = nodes + nd;
+        vs = np->value_sum; rr = np->reward; vc = np->visit;
+        if (P == 2) tp = np->to_play;
+      }
+      const bool same = (tp == vtp);
+      const double r_eff = (P == 1 || !same) ? rr : -rr;   // value = (+-reward) + discount * value
+      double my_in = val;
+      chain_step2<FUSED_ROW - 1>(r_eff, disc, ld, sub, val, my_in);
+      if (sub == 0) my_in = val;
+      if (c > 0 && ld >= 0) val = bcast_d<0>(r_eff) + disc * val;   // hand the value to the chunk above
+      const int vc2 = vc + 1;
+      const double vs2 = vs + ((P == 1 || same) ? my_in : -my_in);
+      double qv = 0.0;
+      if (active) {
+        const double mean = div_by(vs2, (double)vc2, inv_y[vc2]);
+        qv = rr + disc * ((P == 1) ? mean : -mean);
+        if (is_leaf) {
+          Fc2Node r;
+          r.value_sum = vs2; r.reward = reward; r.visit = vc2; r.to_play = vtp; r.parent = par; r.parent_slot = pslot;
+          nodes[nd] = r;
+          slots[par * AW + pslot].child = nd;
+        } else {
+          nodes[nd].value_sum = vs2;
+          nodes[nd].visit = vc2;
+        }
+        if (d > 0) {
+          Fc2Slot* ps = slots + (par * AW + pslot);
+          ps->q = qv;
+          ps->n = vc2;
+        }
+      }
+      // MinMaxStats.update over the path (pure min / max: order-free)
+      if (__any(active && qv > mx)) {
+        const double hi = row_max_d<16>(active ? qv : -MZX_INF);
+        if (hi > mx) mx = hi;
+      }
+      if (__any(active && qv < mn)) {
+        const double lo = row_min_d16(active ? qv : MZX_INF);
+        if (lo < mn) mn = lo;
+      }
+      wave_sync();
+      // prior scores of this node's child slots at its new visit count (see header)
+      if (active) {
+        const double pb = pbc[vc2], sv = sqt[vc2];
+        Fc2Slot* sp = slots + nd * AW;
+        for (int s = 0; s < A; ++s) {
+          const int ns = sp[s].n;
+          sp[s].ps = prior_score(pb, sv, ns, inv_y[ns + 1], sp[s].prior);
+        }
+      }
+    }
+    wave_sync();
+    MZX_PROF(5)
+  }
+
+  // ---- results (FinalizeOp)
+  if (sub == 0) {
+    for (int x = 0; x < A; ++x) a.f.io.d_visit_counts[(size_t)tree * A + x] = 0;
+    for (int s = 0; s < root_n; ++s) a.f.io.d_visit_counts[(size_t)tree * A + roota[s]] = slots[s].n;
+    const int vc = nodes[0].visit;
+    a.f.io.d_root_value[tree] = (vc == 0) ? 0.0 : nodes[0].value_sum / (double)vc;
+    a.f.io.d_info[tree * 4 + 0] = max_depth;
+    a.f.io.d_info[tree * 4 + 1] = flags;
+    a.f.io.d_info[tree * 4 + 2] = tape_pos;
+    a.f.io.d_info[tree * 4 + 3] = sum_depth;
+  }
+  if (a.f.export_trees) {  // parity / diagnose export: LDS records -> the arena's TreeLayout
+    TreeRef t;
+    t.base = a.f.export_trees + (size_t)tree * a.f.L.tree_bytes;
+    t.L = a.f.L;
+    for (int n = sub; n < n_nodes; n += FUSED_ROW) {
+      const Fc2Node r = nodes[n];
+      t.value_sum(n) = r.value_sum; t.reward(n) = r.reward; t.visit(n) = r.visit; t.to_play(n) = r.to_play;
+      t.parent(n) = r.parent; t.parent_slot(n) = r.parent_slot;
+      for (int s = 0; s < A; ++s) {
+        const Fc2Slot q = slots[n * AW + s];
+        t.prior(n, s) = q.prior; t.slot_q(n, s) = q.q; t.slot_visit(n, s) = q.n; t.child(n, s) = q.child;
+      }
+    }
+    if (sub == 0) {
+      for (int k = 0; k < TM_WORDS; ++k) t.meta(k) = 0;
+      t.mm_min() = mn; t.mm_max() = mx;
+      t.meta(TM_N_NODES) = n_nodes; t.meta(TM_TAPE_POS) = tape_pos; t.meta(TM_FLAGS) = flags;
+      t.meta(TM_TIE_DRAWS) = ties; t.meta(TM_MAX_DEPTH) = max_depth; t.meta(TM_SUM_DEPTH) = sum_depth;
+      t.meta(TM_ROOT_N) = root_n;
+      for (int s = 0; s < A; ++s) t.root_action(s) = roota[s];
+    }
+    float* hd = a.f.export_hidden + (size_t)tree * NN * E;
+    for (int i = sub; i < n_nodes * E; i += FUSED_ROW) hd[i] = hidden[i];
+  }
+  MZX_PROF(6)
+  if (PROFILE && sub == 0 && a.f.prof)
+    for (int k = 0; k < FUSED_PROF_WORDS; ++k) a.f.prof[(size_t)tree * FUSED_PROF_WORDS + k] = prof[k];
+}
+
+// ---------------------------------------------------------------------------
+// host side
+
+struct Fc2Plan {
+  Fc2Args args;
+  int lds_bytes = 0, ok = 0, small = 0, aw = 0;
+};
+
+inline Fc2Plan fc2_plan(const mzx_search* s, bool allow_small = true) {
+  Fc2Plan P;
+  const FusedPlan base = fused_plan(s, allow_small);   // network recovery + shape limits are shared
+  if (!base.ok) return P;
+  Fc2Args& a = P.args;
+  memset(&a, 0, sizeof(a));
+  a.f = base.args;
+  P.small = base.small;
+  const int A = s->p.num_actions, N = s->p.num_nodes, E = a.f.E;
+  const int AW = A <= 2 ? 2 : (A <= 4 ? 4 : 16);
+  P.aw = AW;
+  auto al16 = [](int64_t x) { return (x + 15) & ~int64_t(15); };
+  int64_t o = 0;
+  a.f.lds_tables = (int32_t)o;  o += al16(int64_t(16) * (N + 1));
+  a.lds_inv = (int32_t)o;       o += al16(int64_t(8) * (N + 2));
+  a.f.lds_weights = (int32_t)o; o += P.small ? 0 : al16(int64_t(4) * s->net->num_params);
+  a.f.lds_trees = (int32_t)o;
+  int64_t t = 0;
+  a.off_slots = (int32_t)t;   t += int64_t(32) * N * AW;
+  a.off_nodes = (int32_t)t;   t += int64_t(32) * N;
+  a.off_path = (int32_t)t;    t += al16(int64_t(8) * (N + 1));
+  a.off_roota = (int32_t)t;   t += al16(int64_t(4) * AW);
+  a.off_hidden = (int32_t)t;  t += al16(int64_t(4) * N * E);
+  a.off_scratch = (int32_t)t; t += int64_t(4) * (P.small ? 16 : FUSED_SCRATCH);
+  // the four rows of a wave touch the same offsets of four consecutive slabs in one instruction:
+  // keep the slab stride off the multiples of 256 bytes so that they land in different bank groups
+  t = al16(t);
+  if (t % 256 < 32 || t % 256 > 224) t += 64;
+  a.tree_stride = (int32_t)t;
+  int tpb = 16;
+  while (tpb >= 4 && o + int64_t(tpb) * a.tree_stride > FUSED_LDS_BUDGET) tpb /= 2;
+  if (tpb < 4) return P;
+  a.f.trees_per_block = tpb;
+  a.f.tree_stride = a.tree_stride;
+  P.lds_bytes = (int)(o + int64_t(tpb) * a.tree_stride);
+  P.ok = 1;
+  return P;
+}
+
+template <class Net, int AW, bool PROFILE>
+inline int fc2_launch(const Fc2Plan& P, unsigned grid, stream_t stream) {
+  static bool attr_set = false;  // one per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)fc2_search_kernel<Net, AW, PROFILE>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BUDGET);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((fc2_search_kernel<Net, AW, PROFILE>), dim3(grid), dim3(P.args.f.trees_per_block * FUSED_ROW),
+                     (size_t)P.lds_bytes, stream, P.args);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("fused kernel launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+  return MZX_OK;
+}
+
+template <class Net, bool PROFILE>
+inline int fc2_launch_aw(const Fc2Plan& P, unsigned grid, stream_t stream) {
+  if (P.aw == 2) return fc2_launch<Net, 2, PROFILE>(P, grid, stream);
+  if (P.aw == 4) return fc2_launch<Net, 4, PROFILE>(P, grid, stream);
+  return fc2_launch<Net, 16, PROFILE>(P, grid, stream);
+}
+
+// mode bits: 1 = fused, 2 = export trees to the arena, 4 = force LdsNet, 8 = cycle-profile build
+inline int fc2_run(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream) {
+  Fc2Plan P = fc2_plan(s, !(s->mode & 4));
+  if (!P.ok) { set_error("fused search kernel does not support this configuration"); return MZX_ERR_INVALID; }
+  int rc = ensure_tables(s, d_arena, stream);
+  if (rc) return rc;
+  P.args.f.flat = s->net->d_flat;
+  P.args.f.tables = s->d_tables;
+  P.args.f.io = *io;
+  const bool profile = (s->mode & 8) != 0 && s->ws_floats * 4 >= int64_t(s->p.num_trees) * FUSED_PROF_WORDS * 4;
+  if (s->mode & 2) {
+    P.args.f.export_trees = (char*)d_arena + s->off_trees;
+    P.args.f.export_hidden = (float*)((char*)d_arena + s->off_hidden);
+  }
+  if (profile) P.args.f.prof = (uint32_t*)((char*)d_arena + s->off_ws);
+  const int tpb = P.args.f.trees_per_block;
+  const unsigned grid = (unsigned)((s->p.num_trees + tpb - 1) / tpb);
+  if (P.small)   // SmallNetCartpole has A = 2
+    return profile ? fc2_launch<SmallNetCartpole, 2, true>(P, grid, stream)
+                   : fc2_launch<SmallNetCartpole, 2, false>(P, grid, stream);
+  return profile ? fc2_launch_aw<LdsNet, true>(P, grid, stream) : fc2_launch_aw<LdsNet, false>(P, grid, stream);
+}
+
+#endif  // !MZX_HOSTCHECK
+
+}  // namespace mzx

@@ -13,6 +13,7 @@
 #include "mzx_search.h"
 #ifndef MZX_HOSTCHECK
 #include "mzx_fused_fc.h"
+#include "mzx_fused_fc2.h"
 #include "mzx_resnet_search.h"
 #endif
 
@@ -276,7 +277,7 @@ int mzx_search_create(const mzx_search_config* cfg, mzx_net* net, mzx_search** o
   search_plan(s);
   if (int rc = upload_tables(s)) { mzx_search_destroy(s); return rc; }
 #ifndef MZX_HOSTCHECK
-  s->fused_ok = fused_fc_supported(s) ? 1 : (rz_search_supported(s) ? 2 : 0);
+  s->fused_ok = fc2_plan(s).ok ? 1 : (rz_search_supported(s) ? 2 : 0);
 #endif
   s->mode = s->fused_ok ? 1 : 0;
   *out = s;
@@ -301,7 +302,10 @@ int mzx_search_arena_offsets(const mzx_search* s, int64_t out[8]) {
 
 int mzx_search_set_mode(mzx_search* s, int32_t mode) {
   if (!s) { set_error("null search handle"); return MZX_ERR_INVALID; }
-  if (mode < 0 || mode > 15) { set_error("mode is a 4-bit flag set"); return MZX_ERR_INVALID; }
+  if (mode < 0 || mode > 31) { set_error("mode is a 5-bit flag set"); return MZX_ERR_INVALID; }
+#ifndef MZX_HOSTCHECK
+  if ((mode & 16) && !(s->fused_ok == 1 && fused_fc_supported(s))) { set_error("flag 16 selects the first-generation fully connected kernel"); return MZX_ERR_INVALID; }
+#endif
   if ((mode & 1) && !s->fused_ok) { set_error("fused search kernel does not support this configuration"); return MZX_ERR_INVALID; }
   s->mode = mode;
   return MZX_OK;
@@ -326,7 +330,8 @@ int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_
     return MZX_ERR_INVALID;
   }
 #ifndef MZX_HOSTCHECK
-  if ((s->mode & 1) && s->fused_ok == 1) return fused_fc_run(s, io, d_arena, (stream_t)stream);
+  if ((s->mode & 1) && s->fused_ok == 1)
+    return (s->mode & 16) ? fused_fc_run(s, io, d_arena, (stream_t)stream) : fc2_run(s, io, d_arena, (stream_t)stream);
   if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) return rz_search_run(s, io, d_arena, (stream_t)stream);
 #endif
   return search_run_generic(s, io, d_arena, (stream_t)stream);
@@ -528,11 +533,7 @@ int mzx_rng_root_draws(mzx_rng* r, const int32_t* idx, int32_t count, double alp
         for (int j = 0; j < n; ++j) out[j] = out[j] * invacc;
         for (int j = n; j < action_space_size; ++j) out[j] = 0.0;
       }
-      if (tape_words > 0) {  // peek: the next raw words, generator state restored afterwards
-        Mt19937 copy = m;
-        uint32_t* t = tape + (size_t)k * tape_words;
-        for (int j = 0; j < tape_words; ++j) t[j] = copy.next32();
-      }
+      if (tape_words > 0) m.peek(tape_words, tape + (size_t)k * tape_words);   // generator state untouched
     }
   });
   return MZX_OK;

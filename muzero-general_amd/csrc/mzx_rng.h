@@ -70,6 +70,24 @@ struct Mt19937 {
     y ^= (y >> 18);
     return y;
   }
+  static inline uint32_t temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+  }
+  // The next `n` raw words WITHOUT advancing the stream (the device draws the tie breaks of a search
+  // from them; the host then advances by what was consumed).  No copy of the 2.5 KB state unless the
+  // window crosses a regeneration of the key array.
+  void peek(int n, uint32_t* out) const {
+    if (pos + n <= 624) {
+      for (int j = 0; j < n; ++j) out[j] = temper(key[pos + j]);
+      return;
+    }
+    Mt19937 copy = *this;
+    for (int j = 0; j < n; ++j) out[j] = copy.next32();
+  }
   inline double next_double() {
     const int32_t a = (int32_t)(next32() >> 5), b = (int32_t)(next32() >> 6);
     return (a * 67108864.0 + b) / 9007199254740992.0;

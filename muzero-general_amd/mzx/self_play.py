@@ -361,10 +361,64 @@ class BatchedMCTS:
                     nodes[n].children[a] = Node(prior)
         return root
 
+    def _staging(self, B, tape_words, obs_floats, with_noise):
+        """
+        Persistent I/O of one (B, tape) geometry: ONE pinned host block + ONE device block for a move's inputs
+        (observations | noise | legal | to_play | tape; 8-byte fields first) and one of each for its outputs
+        (root value | predicted root value | visit counts | info) -- a move costs one upload, one launch, one
+        download and one stream synchronisation instead of five uploads and four blocking downloads.
+        """
+        key = ("staging", B, tape_words, obs_floats, bool(with_noise))
+        st = self._buffers.get(key)
+        if st is not None:
+            return st
+        A, be = self.A, self.backend
+        on_gpu = be.device.type == "cuda"
+
+        def carve(fields):
+            off, table = 0, {}
+            for name, dtype, count in fields:
+                nbytes = numpy.dtype(dtype).itemsize * count
+                table[name] = (off, dtype, count)
+                off += (nbytes + 15) & ~15
+            return table, max(off, 16)
+
+        fin, n_in = carve([("noise", numpy.float64, B * A if with_noise else 0), ("obs", numpy.float32, B * obs_floats),
+                           ("legal", numpy.int32, B * A), ("to_play", numpy.int32, B), ("tape", numpy.uint32, B * tape_words)])
+        fout, n_out = carve([("root_value", numpy.float64, B), ("predicted", numpy.float64, B),
+                             ("visits", numpy.int32, B * A), ("info", numpy.int32, B * 4)])
+        h_in = torch.empty(n_in, dtype=torch.uint8, pin_memory=on_gpu)
+        h_out = torch.empty(n_out, dtype=torch.uint8, pin_memory=on_gpu)
+        d_in = be.empty((n_in,), torch.uint8) if on_gpu else h_in
+        d_out = be.zeros((n_out,), torch.uint8) if on_gpu else h_out
+        views = lambda block, table: {k: block.numpy()[o:o + numpy.dtype(dt).itemsize * c].view(dt)
+                                      for k, (o, dt, c) in table.items()}
+        st = dict(h_in=h_in, h_out=h_out, d_in=d_in, d_out=d_out, vin=views(h_in, fin), vout=views(h_out, fout),
+                  pin={k: d_in.data_ptr() + o for k, (o, _, _) in fin.items()},
+                  pout={k: d_out.data_ptr() + o for k, (o, _, _) in fout.items()}, on_gpu=on_gpu)
+        self._buffers[key] = st
+        return st
+
     def _launch(self, B, obs, legal, to_play, noise, tape, tape_words, override):
         """One mzx_search_run / mzx_search_run_from_roots over B roots; host copies of the outputs."""
-        lib = self.backend.lib
-        io, out, keep = self.make_io(B, obs, legal, to_play, noise, tape)
+        lib, A = self.backend.lib, self.A
+        obs_dev = obs if isinstance(obs, torch.Tensor) else None      # already stacked on the device (FrameStore)
+        obs_floats = 0 if obs_dev is not None else int(obs.size // B)
+        st = self._staging(B, tape_words, obs_floats, noise is not None)
+        vin = st["vin"]
+        if obs_dev is None:
+            vin["obs"][:] = obs.reshape(-1)
+        if noise is not None:
+            vin["noise"][:] = noise.reshape(-1)
+        vin["legal"][:] = legal.reshape(-1)
+        vin["to_play"][:] = to_play
+        vin["tape"][:] = tape.reshape(-1).view(numpy.uint32)
+        if st["on_gpu"]:
+            st["d_in"].copy_(st["h_in"], non_blocking=True)
+        c_vp, pin, pout = ctypes.c_void_p, st["pin"], st["pout"]
+        io = _lib.SearchIO(c_vp(obs_dev.data_ptr()) if obs_dev is not None else c_vp(pin["obs"]), c_vp(pin["legal"]),
+                           c_vp(pin["to_play"]), c_vp(pin["noise"]) if noise is not None else c_vp(0), c_vp(pin["tape"]),
+                           c_vp(pout["visits"]), c_vp(pout["root_value"]), c_vp(pout["predicted"]), c_vp(pout["info"]))
         arena = self.arena(B)
         handle = self.handle(B, tape_words)
         if override is not None:
@@ -375,8 +429,12 @@ class BatchedMCTS:
         else:
             lib.check(lib.mzx_search_run(handle, ctypes.byref(io), self.backend.ptr(arena), arena.numel(),
                                          self.backend.stream()))
-        return (out["visits"].cpu().numpy(), out["root_value"].cpu().numpy(), out["predicted"].cpu().numpy(),
-                out["info"].cpu().numpy())
+        if st["on_gpu"]:
+            st["h_out"].copy_(st["d_out"], non_blocking=True)
+            torch.cuda.current_stream(self.backend.device).synchronize()
+        vout = st["vout"]
+        return (vout["visits"].reshape(B, A).copy(), vout["root_value"].copy(), vout["predicted"].copy(),
+                vout["info"].reshape(B, 4).copy())
 
     def run(self, observations, legal_actions, to_play, add_exploration_noise, rngs, _override=None):
         """

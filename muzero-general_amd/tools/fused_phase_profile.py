@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trees", type=int, default=4096)
     ap.add_argument("--lds", action="store_true", help="force the LDS-weight engine")
+    ap.add_argument("--v1", action="store_true", help="first-generation fully connected kernel (mode flag 16)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     args = ap.parse_args()
     if args.workload != "c2":
@@ -29,7 +30,7 @@ def main():
     B = args.trees
     net = models.MuZeroNetwork(cfg)
     net.set_weights(synthetic.fill_state_dict(net.state_dict(), 0))
-    engine = self_play.BatchedMCTS(cfg, net, B, mode=1 | 8 | (4 if args.lds else 0))
+    engine = self_play.BatchedMCTS(cfg, net, B, mode=1 | 8 | (4 if args.lds else 0) | (16 if args.v1 else 0))
     obs = synthetic.observations(B, cfg.observation_shape, seed=123)
     res = engine.run(list(obs), [list(cfg.action_space)] * B, [0] * B, True,
                      [numpy.random.RandomState(1000 + i) for i in range(B)])
@@ -38,7 +39,7 @@ def main():
     raw = engine.arena(B)[off["workspace"]: off["workspace"] + B * 16 * 4].view(torch.int32).cpu().numpy().reshape(B, 16)
     S = cfg.num_simulations
     total = raw[:, : len(PHASES)].sum(1).mean()
-    print(f"trees {B}  sims {S}  mean leaf depth {res.sum_depth.mean() / S:.2f}  engine {'LdsNet' if args.lds else 'auto'}")
+    print(f"trees {B}  sims {S}  mean leaf depth {res.sum_depth.mean() / S:.2f}  engine {'LdsNet' if args.lds else 'auto'}{' (v1 kernel)' if args.v1 else ''}")
     for k, name in enumerate(PHASES):
         c = raw[:, k].mean()
         per = c / S if k in (2, 3, 4, 5) else c
