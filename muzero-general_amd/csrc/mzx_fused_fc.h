@@ -187,8 +187,8 @@ __device__ __forceinline__ float row_decode2(float l0, float l1, int F, int supp
   if (v1) dl += e1;
   const float den = row_sum(dl);
   float num = 0.f;
-  if (v0) num += (float)(sub - support) * (e0 / den);
-  if (v1) num += (float)(sub + 16 - support) * (e1 / den);
+  if (v0) num += (float)(sub - support) * mzx_div(e0, den);
+  if (v1) num += (float)(sub + 16 - support) * mzx_div(e1, den);
   return support_inverse_transform(row_sum(num));
 }
 
@@ -401,7 +401,7 @@ struct LdsNet {
     for (int k = 1; k < E; ++k) { lo = fminf(lo, x[k]); hi = fmaxf(hi, x[k]); }
     float sc = hi - lo;
     if (sc < 1e-5f) sc += 1e-5f;
-    for (int j = sub; j < E; j += FUSED_ROW) y[j] = (x[j] - lo) / sc;
+    for (int j = sub; j < E; j += FUSED_ROW) y[j] = mzx_div(x[j] - lo, sc);
     wave_sync();
   }
   __device__ __forceinline__ float decode(const float* lg, int sub) const {
@@ -413,7 +413,7 @@ struct LdsNet {
     for (int i = sub; i < F; i += FUSED_ROW) den += mzx_expf(lg[i] - m);
     den = row_sum(den);
     float num = 0.f;
-    for (int i = sub; i < F; i += FUSED_ROW) num += (float)(i - S) * (mzx_expf(lg[i] - m) / den);
+    for (int i = sub; i < F; i += FUSED_ROW) num += (float)(i - S) * mzx_div(mzx_expf(lg[i] - m), den);
     return support_inverse_transform(row_sum(num));
   }
   __device__ __forceinline__ void heads(const float* h, float* scr, int sub, NetOut& o) const {
@@ -565,7 +565,7 @@ struct SmallNet {
     const float lo = row_min(in ? s : MZX_INF), hi = row_max(in ? s : -MZX_INF);
     float sc = hi - lo;
     if (sc < 1e-5f) sc += 1e-5f;
-    return (s - lo) / sc;
+    return mzx_div(s - lo, sc);
   }
   // prediction heads from the scaled state (lane k holds element k)
   __device__ __forceinline__ void heads(float hn, int sub, NetOut& o) const {
@@ -607,11 +607,17 @@ struct SmallNet {
 // ---------------------------------------------------------------------------
 // the kernel
 
+// Phase stamps of the profiling instantiations: outstanding LDS / memory operations are drained and the
+// compiler may not move code across the stamp, so a phase is charged with its own latency (the profiling
+// build is a few per cent slower than the product build for that reason).
 #define MZX_PROF(k)                                             \
   if (PROFILE) {                                                \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
     const unsigned long long _t = __builtin_readcyclecounter(); \
     prof[k] += (uint32_t)(_t - t_last);                         \
     t_last = _t;                                                \
+    __builtin_amdgcn_sched_barrier(0);                          \
   }
 
 // AW = lanes that can hold a child slot in this instantiation: 2, 4 (DPP hand-off of the
@@ -676,7 +682,7 @@ __global__ void __launch_bounds__(256) fused_fc_search_kernel(const FusedFcArgs 
       tree_init_root_record(t, p, lg, st.root_to_play, (double)support_inverse_transform(0.0f));
       if (a.io.d_root_predicted_value) a.io.d_root_predicted_value[tree] = (double)o.value;
     }
-    if (sub < A) tree_init_slot(t, 0, sub, in ? root_noisy_prior((double)(e / den), nz, sub, p.exploration_fraction) : 0.0);
+    if (sub < A) tree_init_slot(t, 0, sub, in ? root_noisy_prior((double)mzx_div(e, den), nz, sub, p.exploration_fraction) : 0.0);
     st.mn = MZX_INF; st.mx = -MZX_INF;
     st.n_nodes = 1; st.tape_pos = 0; st.flags = 0; st.ties = 0; st.max_depth = 0; st.sum_depth = 0; st.root_n = nroot;
     wave_sync();
@@ -695,7 +701,7 @@ __global__ void __launch_bounds__(256) fused_fc_search_kernel(const FusedFcArgs 
     const float m = row_max(in ? o.policy : -MZX_INF);
     const float e = in ? mzx_expf(o.policy - m) : 0.f;
     const float den = row_sum(e);
-    if (in) tree_init_slot(t, sel.c.leaf, sub, (double)(e / den));
+    if (in) tree_init_slot(t, sel.c.leaf, sub, (double)mzx_div(e, den));
     MZX_PROF(4)
     row_backprop(t, p, sel, sub, row_in_wave, (double)o.value, (double)o.reward, st);
     wave_sync();

@@ -39,7 +39,7 @@ namespace mzx {
 
 struct Fc2Args {
   FusedFcArgs f;   // network description, search parameters, io, export pointers (f.L = arena TreeLayout)
-  int32_t off_slots, off_nodes, off_path, off_roota, off_hidden, off_scratch;  // byte offsets inside a tree's slab
+  int32_t off_slots, off_nodes, off_path, off_roota, off_mm, off_hidden, off_scratch;  // byte offsets inside a tree's slab
   int32_t tree_stride, lds_inv;                                               // lds_inv: reciprocal table (bytes)
 };
 
@@ -77,6 +77,33 @@ __device__ __forceinline__ double div_by(double a, double b, double y) {
 __device__ __forceinline__ double prior_score(double pbcN, double sqN, int n, double inv_n1, double prior) {
   const double pb_c = pbcN * div_by(sqN, (double)(n + 1), inv_n1);
   return pb_c * prior;
+}
+
+// Butterflies over the first W lanes of a row (the other lanes hold the neutral element): the canonical
+// order xor 1, xor 2, half-mirror, mirror cut after log2(W) steps -- the skipped steps would add zeros / compare
+// with the neutral element, so the result has the same bits as the 16-lane form.
+template <int W>
+__device__ __forceinline__ float row_sum_w(float v) {
+  v = v + dpp_f<DPP_XOR1>(v);
+  if constexpr (W > 2) v = v + dpp_f<DPP_XOR2>(v);
+  if constexpr (W > 4) v = v + dpp_f<DPP_HALF_MIRROR>(v);
+  if constexpr (W > 8) v = v + dpp_f<DPP_MIRROR>(v);
+  return v;
+}
+template <int W>
+__device__ __forceinline__ float row_max_w(float v) {
+  v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+  if constexpr (W > 2) v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+  if constexpr (W > 4) v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+  if constexpr (W > 8) v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
+  return v;
+}
+constexpr int DPP_ROW_SHL1 = 0x101;   // lane i reads lane i + 1 of its row (lane 15: keeps `old`)
+__device__ __forceinline__ int shl1_i(int v, int old) {
+  return __builtin_amdgcn_update_dpp(old, v, DPP_ROW_SHL1, 0xF, 0xF, false);
+}
+__device__ __forceinline__ double shl1_d(double v, double old) {
+  return __hiloint2double(shl1_i(__double2hiint(v), __double2hiint(old)), shl1_i(__double2loint(v), __double2loint(old)));
 }
 
 template <int J>
@@ -119,19 +146,22 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
   net.setup(a.f, smem, sub);
   const double* pbc = tables;
   const double* sqt = tables + (NN + 1);
+  // prior-score factor of a freshly expanded leaf's slots: the leaf has ONE visit after its own
+  // back-propagation and its children none -- pb_c(N = 1, n = 0)
+  const double pb_leaf = pbc[1] * div_by(sqt[1], 1.0, inv_y[1]);
 
   char* slab = smem + a.f.lds_trees + (size_t)row * a.tree_stride;
   Fc2Slot* slots = (Fc2Slot*)(slab + a.off_slots);   // [NN][AW]
   Fc2Node* nodes = (Fc2Node*)(slab + a.off_nodes);   // [NN]
   int2* path = (int2*)(slab + a.off_path);           // [NN + 1]: {node at depth d, slot taken from its parent}
   int32_t* roota = (int32_t*)(slab + a.off_roota);   // [AW]: action of root slot s
+  double* mm = (double*)(slab + a.off_mm);           // MinMaxStats {minimum, maximum}: updated by LDS min / max
   float* hidden = (float*)(slab + a.off_hidden);     // [NN][E]
   float* scr = (float*)(slab + a.off_scratch);
   const uint32_t* tape = (const uint32_t*)a.f.io.d_tape + (size_t)tree * a.f.p.tape_words;
   const int tape_words = a.f.p.tape_words;
 
   // per-tree scalars, row-uniform registers
-  double mn = MZX_INF, mx = -MZX_INF;
   int32_t n_nodes = 1, tape_pos = 0, flags = 0, ties = 0, max_depth = 0, sum_depth = 0, root_n = 0, root_to_play = 0;
   MZX_PROF(0)
 
@@ -146,9 +176,9 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
     wave_sync();
     const bool in = sub < root_n;
     const float l = in ? scr[lg[sub]] : -MZX_INF;   // logits gathered in the game's legal-action order
-    const float m = row_max(l);
+    const float m = row_max_w<AW>(l);
     const float e = in ? mzx_expf(l - m) : 0.f;
-    const float den = row_sum(e);
+    const float den = row_sum_w<AW>(e);
     root_to_play = a.f.io.d_to_play[tree];
     if (sub == 0) {
       Fc2Node r;
@@ -156,13 +186,14 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
       r.parent = -1; r.parent_slot = -1;
       nodes[0] = r;
       path[0] = make_int2(0, -1);
+      mm[0] = MZX_INF; mm[1] = -MZX_INF;      // MinMaxStats (self_play.py:558-560)
       if (a.f.io.d_root_predicted_value) a.f.io.d_root_predicted_value[tree] = (double)o.value;
     }
     if (sub < AW) {
       Fc2Slot s;
-      s.prior = in ? root_noisy_prior((double)(e / den), nz, sub, a.f.p.exploration_fraction) : 0.0;
+      s.prior = in ? root_noisy_prior((double)mzx_div(e, den), nz, sub, a.f.p.exploration_fraction) : 0.0;
       s.q = 0.0; s.n = 0; s.child = -1;
-      s.ps = prior_score(pbc[0], sqt[0], 0, inv_y[1], s.prior);   // root visit count 0
+      s.ps = in ? prior_score(pbc[0], sqt[0], 0, inv_y[1], s.prior) : -MZX_INF;   // root visit count 0
       slots[sub] = s;
       roota[sub] = in ? lg[sub] : -1;
     }
@@ -174,29 +205,30 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
   const int num_sims = a.f.p.num_sims;
   for (int sim = 0; sim < num_sims; ++sim) {
     // ------------------------------------------------------------- select (self_play.py:325-334, :363-404)
+    const double2 mmv = *(const double2*)mm;   // MinMaxStats after the previous back-propagation
+    const double mn = mmv.x, mx = mmv.y;
     const double dd = mx - mn;                 // MinMaxStats.normalize divisor, same for every node of this walk
     const double yd = recip_refined(dd);       // (garbage while max <= min: results discarded like the reference's branch)
     const bool norm_on = mx > mn;
-    int node = 0, depth = 0, slot = 0, vtp = root_to_play;
+    // Slots that do not exist (root slots beyond the legal actions, padding up to AW) carry a prior score of
+    // -inf and n = 0, so their score is -inf without a validity test in the walk.  A row that has reached its
+    // leaf keeps executing with its state frozen (one straight-line body per level for the whole wave).
+    int node = 0, depth = 0, slot = 0;
     bool done = false;
     for (;;) {
-      const int d1 = depth + 1;
-      const int nc = (node == 0) ? root_n : A;
-      const bool valid = sub < nc;
-      const Fc2Slot* rp = slots + (node * AW + (valid ? sub : 0));
+      const Fc2Slot* rp = slots + (node * AW + (sub & (AW - 1)));
       const double ps = rp->ps, q = rp->q;
       const int n = rp->n, c = rp->child;
       const double nv = div_by(q - mn, dd, yd);
       const double v = norm_on ? nv : q;
       const double wv = ps + v;
-      const double u = (n > 0) ? wv : ps;
-      const double sc = valid ? u : -MZX_INF;
+      const double sc = (n > 0) ? wv : ps;
       int sl, cw;
       if constexpr (AW == 2) {
         // two candidates: every lane sees both scores; no ballot
         const double a0 = bcast_d<0>(sc), a1 = bcast_d<1>(sc);
         sl = (a1 > a0) ? 1 : 0;
-        if (nc == 2 && a0 == a1 && !done) {  // numpy.random.choice([0, 1])
+        if (__builtin_expect(a0 == a1 && !done, 0)) {  // numpy.random.choice([0, 1]): first walk of a search, rare later
           ++ties;
           sl = tape_draw(tape, tape_words, tape_pos, flags, 2);
         }
@@ -204,10 +236,10 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
         cw = sl ? c1 : c0;
       } else {
         const double best = row_max_d<AW>(sc);
-        const unsigned bits = row_bits(__ballot(valid && sc == best), row_in_wave);
+        const unsigned bits = row_bits(__ballot(sc == best), row_in_wave) & ((1u << AW) - 1u);
         const int nbest = __popc(bits);
         sl = nbest ? (__ffs(bits) - 1) : 0;
-        if (nbest > 1 && !done) {  // numpy.random.choice(ties): k-th maximiser in slot order
+        if (__builtin_expect(nbest > 1 && !done, 0)) {  // numpy.random.choice(ties): k-th maximiser in slot order
           ++ties;
           int k = tape_draw(tape, tape_words, tape_pos, flags, nbest);
           unsigned b = bits;
@@ -218,21 +250,64 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
         else cw = perm_i(c, sl, row_in_wave);
       }
       const bool act = !done;
-      if (act && sub == 0) path[d1] = make_int2(cw, sl);   // the last level's entry is completed below
-      const int nvtp = (vtp + 1 < P) ? vtp + 1 : 0;        // players turn by turn, :331-334
-      depth = act ? d1 : depth;
+      // entry of the level just decided; a finished row rewrites the entry beyond its leaf (never read)
+      if (sub == 0) path[depth + 1] = make_int2(cw, sl);
+      depth += act ? 1 : 0;
       slot = act ? sl : slot;
-      vtp = act ? nvtp : vtp;
       node = (act && cw >= 0) ? cw : node;
       done = done || (cw < 0);
       if (__all(done)) break;
     }
+    // players play turn by turn (self_play.py:331-334): the leaf's player follows from the depth
+    const int vtp = (P == 1) ? 0 : ((root_to_play + depth) & 1);
     int leaf = n_nodes;
     if (leaf >= NN) { flags |= TF_NODE_OVERFLOW; leaf = NN - 1; }
     if (sub == 0) path[depth] = make_int2(leaf, slot);
     const int parent = node;
     const int ra = roota[slot < AW ? slot : 0];
     const int action = (parent == 0) ? ra : slot;
+    int cmax = 0;
+    while (__any((depth >> 4) > cmax)) ++cmax;   // wave-uniform number of 16-level chunks - 1 (0 unless a path is > 15 deep)
+    wave_sync();
+
+    // Everything back-propagation needs from the tree is independent of the network: fetched NOW, so that the
+    // LDS latency hides behind recurrent_inference.  Lane j of a chunk owns the path node at depth 16 c + j.
+    struct PathLane {
+      int nd, pslot, par, vc, tp;
+      double vs, rr, inv_vc2, inv_vc3, pb, sv;
+      int sn[AW <= 4 ? AW : 1];
+      double sprior[AW <= 4 ? AW : 1], sinv[AW <= 4 ? AW : 1];
+    };
+    auto load_lane = [&](int c) {
+      PathLane L;
+      const int d = c * 16 + sub;
+      const bool active = d <= depth, is_leaf = d == depth;
+      L.nd = 0; L.pslot = 0; L.par = 0; L.vc = 0; L.tp = vtp; L.vs = 0.0; L.rr = 0.0;
+      if (active) {
+        const int2 pe = path[d];
+        L.nd = pe.x; L.pslot = pe.y;
+        if (d > 0) L.par = path[d - 1].x;
+      }
+      if (active && !is_leaf) {
+        const Fc2Node* np = nodes + L.nd;
+        L.vs = np->value_sum; L.rr = np->reward; L.vc = np->visit;
+        if (P == 2) L.tp = np->to_play;
+      }
+      L.inv_vc2 = inv_y[L.vc + 1];        // reciprocal of this node's visit count after the update
+      L.inv_vc3 = inv_y[L.vc + 2];        // ... and of (that + 1): what its PARENT's prior score divides by
+      L.pb = pbc[L.vc + 1]; L.sv = sqt[L.vc + 1];
+      if constexpr (AW <= 4) {
+#pragma unroll
+        for (int s = 0; s < AW; ++s) {
+          L.sn[s] = 0; L.sprior[s] = 0.0;
+          if (active && !is_leaf && s < A) { L.sn[s] = slots[L.nd * AW + s].n; L.sprior[s] = slots[L.nd * AW + s].prior; }
+        }
+#pragma unroll
+        for (int s = 0; s < AW; ++s) L.sinv[s] = inv_y[L.sn[s] + 1];
+      }
+      return L;
+    };
+    PathLane L = load_lane(cmax);
     MZX_PROF(2)
 
     // ------------------------------------------------------------- recurrent_inference (models.py:192-195)
@@ -243,13 +318,14 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
     // ------------------------------------------------------------- expand (self_play.py:451-465)
     {
       const bool in = sub < A;
-      const float m = row_max(in ? o.policy : -MZX_INF);
+      const float m = row_max_w<AW>(in ? o.policy : -MZX_INF);
       const float e = in ? mzx_expf(o.policy - m) : 0.f;
-      const float den = row_sum(e);
-      if (in) {
+      const float den = row_sum_w<AW>(e);
+      if (sub < AW) {
         Fc2Slot s;
-        s.prior = (double)(e / den);
-        s.q = 0.0; s.n = 0; s.child = -1; s.ps = 0.0;   // ps: refreshed below, once the leaf has its first visit
+        s.prior = in ? (double)mzx_div(e, den) : 0.0;
+        s.q = 0.0; s.n = 0; s.child = -1;
+        s.ps = in ? pb_leaf * s.prior : -MZX_INF;   // prior score once the leaf has its first visit (N = 1, n = 0)
         slots[leaf * AW + sub] = s;
       }
     }
@@ -261,70 +337,71 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
     sum_depth += depth;
     const double reward = (double)o.reward;
     double val = (double)o.value;
-    int cmax = 0;
-    while (__any((depth >> 4) > cmax)) ++cmax;   // wave-uniform number of 16-level chunks - 1 (0 unless a path is > 15 deep)
-    wave_sync();
+    int carry_vc2 = 0, carry_pslot = -1;       // lane 0 of the chunk below (deeper), for lane 15 of this one
+    double carry_inv = 0.0;
     for (int c = cmax; c >= 0; --c) {
+      if (c != cmax) { wave_sync(); L = load_lane(c); }
       const int d = c * 16 + sub;
       const int ld = depth - c * 16;             // row-uniform: depth of the leaf relative to this chunk
       const bool active = d <= depth, is_leaf = d == depth;
-      int nd = 0, pslot = 0, par = 0;
-      if (active) {
-        const int2 pe = path[d];
-        nd = pe.x; pslot = pe.y;
-        if (d > 0) par = path[d - 1].x;
-      }
-      double rr = reward, vs = 0.0;
-      int vc = 0, tp = vtp;
-      if (active && !is_leaf) {
-        const Fc2Node* np = nodes + nd;
-        vs = np->value_sum; rr = np->reward; vc = np->visit;
-        if (P == 2) tp = np->to_play;
-      }
-      const bool same = (tp == vtp);
+      const double rr = is_leaf ? reward : L.rr;
+      const bool same = (L.tp == vtp);
       const double r_eff = (P == 1 || !same) ? rr : -rr;   // value = (+-reward) + discount * value
       double my_in = val;
       chain_step2<FUSED_ROW - 1>(r_eff, disc, ld, sub, val, my_in);
       if (sub == 0) my_in = val;
       if (c > 0 && ld >= 0) val = bcast_d<0>(r_eff) + disc * val;   // hand the value to the chunk above
-      const int vc2 = vc + 1;
-      const double vs2 = vs + ((P == 1 || same) ? my_in : -my_in);
+      const int vc2 = L.vc + 1;
+      const double vs2 = L.vs + ((P == 1 || same) ? my_in : -my_in);
       double qv = 0.0;
       if (active) {
-        const double mean = div_by(vs2, (double)vc2, inv_y[vc2]);
+        const double mean = div_by(vs2, (double)vc2, L.inv_vc2);
         qv = rr + disc * ((P == 1) ? mean : -mean);
         if (is_leaf) {
           Fc2Node r;
-          r.value_sum = vs2; r.reward = reward; r.visit = vc2; r.to_play = vtp; r.parent = par; r.parent_slot = pslot;
-          nodes[nd] = r;
-          slots[par * AW + pslot].child = nd;
+          r.value_sum = vs2; r.reward = reward; r.visit = vc2; r.to_play = vtp; r.parent = L.par; r.parent_slot = L.pslot;
+          nodes[L.nd] = r;
+          slots[L.par * AW + L.pslot].child = L.nd;
         } else {
-          nodes[nd].value_sum = vs2;
-          nodes[nd].visit = vc2;
+          nodes[L.nd].value_sum = vs2;
+          nodes[L.nd].visit = vc2;
         }
         if (d > 0) {
-          Fc2Slot* ps = slots + (par * AW + pslot);
+          Fc2Slot* ps = slots + (L.par * AW + L.pslot);
           ps->q = qv;
           ps->n = vc2;
         }
+        // MinMaxStats.update (self_play.py:562-564): pure min / max over the path nodes, order-free
+        __hip_atomic_fetch_min(&mm[0], qv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(&mm[1], qv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      // MinMaxStats.update over the path (pure min / max: order-free)
-      if (__any(active && qv > mx)) {
-        const double hi = row_max_d<16>(active ? qv : -MZX_INF);
-        if (hi > mx) mx = hi;
-      }
-      if (__any(active && qv < mn)) {
-        const double lo = row_min_d16(active ? qv : MZX_INF);
-        if (lo < mn) mn = lo;
-      }
-      wave_sync();
-      // prior scores of this node's child slots at its new visit count (see header)
-      if (active) {
-        const double pb = pbc[vc2], sv = sqt[vc2];
-        Fc2Slot* sp = slots + nd * AW;
-        for (int s = 0; s < A; ++s) {
-          const int ns = sp[s].n;
-          sp[s].ps = prior_score(pb, sv, ns, inv_y[ns + 1], sp[s].prior);
+      // prior scores of this node's child slots at its new visit count N = vc2 (see header).  The slot on the
+      // path just received the child's new visit count: taken from the lane above instead of LDS.
+      if constexpr (AW <= 4) {
+        const int ch_vc2 = shl1_i(vc2, carry_vc2), ch_slot = shl1_i(L.pslot, carry_pslot);
+        const double ch_inv = shl1_d(L.inv_vc3, carry_inv);
+        if (active && !is_leaf) {
+          const int nslots = (L.nd == 0) ? root_n : A;
+#pragma unroll
+          for (int s = 0; s < AW; ++s) {
+            if (s < nslots) {
+              const bool on_path = (s == ch_slot);
+              const int ns = on_path ? ch_vc2 : L.sn[s];
+              const double iv = on_path ? ch_inv : L.sinv[s];
+              slots[L.nd * AW + s].ps = prior_score(L.pb, L.sv, ns, iv, L.sprior[s]);
+            }
+          }
+        }
+        carry_vc2 = bcast_i<0>(vc2); carry_pslot = bcast_i<0>(L.pslot); carry_inv = bcast_d<0>(L.inv_vc3);
+      } else {
+        wave_sync();
+        if (active && !is_leaf) {
+          Fc2Slot* sp = slots + L.nd * AW;
+          const int nslots = (L.nd == 0) ? root_n : A;
+          for (int s = 0; s < nslots; ++s) {
+            const int ns = sp[s].n;
+            sp[s].ps = prior_score(L.pb, L.sv, ns, inv_y[ns + 1], sp[s].prior);
+          }
         }
       }
     }
@@ -358,7 +435,7 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
     }
     if (sub == 0) {
       for (int k = 0; k < TM_WORDS; ++k) t.meta(k) = 0;
-      t.mm_min() = mn; t.mm_max() = mx;
+      t.mm_min() = mm[0]; t.mm_max() = mm[1];
       t.meta(TM_N_NODES) = n_nodes; t.meta(TM_TAPE_POS) = tape_pos; t.meta(TM_FLAGS) = flags;
       t.meta(TM_TIE_DRAWS) = ties; t.meta(TM_MAX_DEPTH) = max_depth; t.meta(TM_SUM_DEPTH) = sum_depth;
       t.meta(TM_ROOT_N) = root_n;
@@ -402,6 +479,7 @@ inline Fc2Plan fc2_plan(const mzx_search* s, bool allow_small = true) {
   a.off_nodes = (int32_t)t;   t += int64_t(32) * N;
   a.off_path = (int32_t)t;    t += al16(int64_t(8) * (N + 1));
   a.off_roota = (int32_t)t;   t += al16(int64_t(4) * AW);
+  a.off_mm = (int32_t)t;      t += 16;
   a.off_hidden = (int32_t)t;  t += al16(int64_t(4) * N * E);
   a.off_scratch = (int32_t)t; t += int64_t(4) * (P.small ? 16 : FUSED_SCRATCH);
   // the four rows of a wave touch the same offsets of four consecutive slabs in one instruction:

@@ -218,7 +218,7 @@ struct MinMaxScaleOp {
     for (int k = 1; k < len; ++k) { lo = fminf(lo, xg[k]); hi = fmaxf(hi, xg[k]); }
     float scale = hi - lo;
     if (scale < 1e-5f) scale += 1e-5f;
-    y[i] = (x[i] - lo) / scale;
+    y[i] = mzx_div(x[i] - lo, scale);
   }
 };
 
@@ -282,7 +282,7 @@ struct RootInitOp {
       while (nroot < A && lg[nroot] >= 0) ++nroot;
       const SoftmaxStats st = softmax_stats(nroot, [&](int s) { return pl[lg[s]]; });
       tree_init_root(t, p, lg, to_play[b], r0,
-                     [&](int s) { return (double)(mzx_expf(pl[lg[s]] - st.m) / st.den); }, nz);
+                     [&](int s) { return (double)mzx_div(mzx_expf(pl[lg[s]] - st.m), st.den); }, nz);
       if (root_predicted_value)
         root_predicted_value[b] = (double)support_to_scalar(value_logits + (int64_t)b * (2 * p.support_size + 1),
                                                             p.support_size);
@@ -335,7 +335,7 @@ struct ExpandBackpropOp {
       const double v = (double)support_to_scalar(value_logits + (int64_t)b * F, p.support_size);
       const double r = (double)support_to_scalar(reward_logits + (int64_t)b * F, p.support_size);
       const SoftmaxStats st = softmax_stats(A, [&](int s) { return pl[s]; });
-      tree_expand_backprop(t, p, v, r, [&](int s) { return (double)(mzx_expf(pl[s] - st.m) / st.den); });
+      tree_expand_backprop(t, p, v, r, [&](int s) { return (double)mzx_div(mzx_expf(pl[s] - st.m), st.den); });
     }
   }
 };

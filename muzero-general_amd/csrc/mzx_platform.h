@@ -26,7 +26,26 @@
 
 namespace mzx {
 
-MZX_HD inline float mzx_expf(float x) { return expf(x); }
+// e^x for the network's activations and soft-maxes (every call site has x <= 0 or small).  Device:
+// v_exp_f32(x * log2 e) -- two instructions instead of libm's fifteen; relative error <= ~|x| * 2^-24
+// (1e-6 at x = -16), far inside the 1e-4 contract on the heads.  The generic operators and the
+// whole-search kernels share it, so they stay bit-identical to each other on the device.
+MZX_HD inline float mzx_expf(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+#else
+  return expf(x);
+#endif
+}
+// a / b where one ulp does not matter (soft-max normalisation, min-max scaling): device v_rcp_f32 + multiply
+// instead of the ten-instruction IEEE expansion.  NOT used by support_inverse_transform (cancellation).
+MZX_HD inline float mzx_div(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return a * __builtin_amdgcn_rcpf(b);
+#else
+  return a / b;
+#endif
+}
 MZX_HD inline float mzx_expm1f(float x) { return expm1f(x); }
 // torch.nn.ELU(alpha=1): x > 0 ? x : exp(x) - 1   (models.py:635).  exp(x) - 1 rather than
 // expm1(x): a third of the instructions on gfx950, absolute error <= 2^-24 (the tolerance

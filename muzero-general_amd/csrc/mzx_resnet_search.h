@@ -141,7 +141,7 @@ rz_search_kernel(const RzSearchArgs sa) {
       const float m = row_max(in ? lg : -MZX_INF);
       const float e = in ? mzx_expf(lg - m) : 0.f;
       const float den = row_sum(e);
-      if (in) tree_init_slot(t, sel.c.leaf, sub, (double)(e / den));
+      if (in) tree_init_slot(t, sel.c.leaf, sub, (double)mzx_div(e, den));
       row_backprop(t, p, sel, sub, row_in_wave, (double)value, (double)reward, st);
     }
     RZS_PROF(4)

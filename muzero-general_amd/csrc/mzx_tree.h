@@ -396,7 +396,7 @@ MZX_HD inline float support_to_scalar(const float* logits, int support_size) {
   float lane[16];
   for (int j = 0; j < 16; ++j) {
     float acc = 0.f;
-    for (int i = j; i < F; i += 16) acc += (float)(i - support_size) * (mzx_expf(logits[i] - st.m) / st.den);
+    for (int i = j; i < F; i += 16) acc += (float)(i - support_size) * mzx_div(mzx_expf(logits[i] - st.m), st.den);
     lane[j] = acc;
   }
   return support_inverse_transform(butterfly16_sum(lane));
