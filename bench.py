@@ -79,8 +79,9 @@ def parse():
                     help="residual networks: fused MFMA engine (default) or one kernel per operator")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall budget of each CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=None)
-    ap.add_argument("--selfplay-moves", type=int, default=4,
-                    help="moves of the end-to-end self-play leg (SelfPlay(num_games=B) on the synthetic game; 0 = skip)")
+    ap.add_argument("--selfplay-moves", type=int, default=16,
+                    help="moves per game of the end-to-end self-play legs (SelfPlay(num_games=B) on the synthetic game; "
+                         "0 = skip); the games of the path's configurations run for hundreds of moves (cartpole: 500)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CI plumbing check on the CPU (gloo + tests/hostcheck); not a measurement")
     return ap.parse_args()
@@ -342,10 +343,17 @@ def selfplay_leg(cfg, net, B, moves, batched=False):
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    t1 = time.perf_counter()
     steps = sum(len(h.action_history) - 1 for h in histories)
+    for h in histories:       # batched protocol: per-game records are views until touched; time touching ALL of them
+        if hasattr(h, "materialize"):
+            h.materialize()
+    materialize = time.perf_counter() - t1
     return {
         "steps_per_sec": steps / wall, "sims_per_sec": steps * c.num_simulations / wall, "games": B, "moves_per_game": moves,
         "wall_s": wall, "search_share": sp.stats["search_seconds"] / wall,
+        "materialize_all_histories_s": materialize if batched else 0.0,
+        "steps_per_sec_with_all_histories_as_lists": steps / (wall + (materialize if batched else 0.0)),
         "game_protocol": "batched (one object steps the shard)" if batched else "reference plugin surface (B Game objects)",
         "note": "one host process: plugin game stepping + host bookkeeping + batched search "
                 "(search_share = fraction of the wall spent inside BatchedMCTS.run incl. uploads/downloads)",

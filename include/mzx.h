@@ -302,6 +302,13 @@ int mzx_rng_advance(mzx_rng* r, const int32_t* idx, int32_t count, const int32_t
 int mzx_rng_random_sample(mzx_rng* r, const int32_t* idx, int32_t count, double* out);
 /* One RandomState.randint(0, n[k]) per stream (numpy.random.choice(list of n) draws exactly that). */
 int mzx_rng_randint(mzx_rng* r, const int32_t* idx, int32_t count, const int32_t* n, int32_t* out);
+/* numpy.random.choice(actions, p=dist / sum(dist)) of SelfPlay.select_action (self_play.py:236-243) for `count`
+ * streams at once: weights [count][row_stride] binary64 (the caller's visit_counts ** (1 / temperature), first
+ * n[k] entries of a row are used), out[k] = the chosen POSITION in 0..n[k]-1.  Same arithmetic as the Python
+ * statement + numpy's legacy choice: left-to-right sum, division, cumulative sum, division by its last
+ * element, one random_sample(), right bisection. */
+int mzx_rng_choice_weighted(mzx_rng* r, const int32_t* idx, int32_t count, const double* weights,
+                            int32_t row_stride, const int32_t* n, int32_t* out);
 
 #ifdef __cplusplus
 }

@@ -569,4 +569,28 @@ int mzx_rng_randint(mzx_rng* r, const int32_t* idx, int32_t count, const int32_t
   return MZX_OK;
 }
 
+int mzx_rng_choice_weighted(mzx_rng* r, const int32_t* idx, int32_t count, const double* weights,
+                            int32_t row_stride, const int32_t* n, int32_t* out) {
+  int rc = rng_check(r, idx, count);
+  if (rc) return rc;
+  if (count > 0 && (!weights || !n || !out)) { set_error("mzx_rng_choice_weighted: null"); return MZX_ERR_INVALID; }
+  for (int32_t k = 0; k < count; ++k)
+    if (n[k] < 1 || n[k] > row_stride || n[k] > 4096) { set_error("choice: row %d has %d candidates (stride %d)", k, n[k], row_stride); return MZX_ERR_INVALID; }
+  for (int32_t k = 0; k < count; ++k) {
+    const double* w = weights + (size_t)k * row_stride;
+    const int m = n[k];
+    double total = 0.0;                       // Python's sum(dist): 0 + d0 + d1 + ...
+    for (int j = 0; j < m; ++j) total = total + w[j];
+    double cdf[4096];
+    double acc = 0.0;                         // ndarray.cumsum of p = dist / total
+    for (int j = 0; j < m; ++j) { acc = acc + w[j] / total; cdf[j] = acc; }
+    const double last = cdf[m - 1];
+    const double u = r->streams[idx[k]].next_double();
+    int pos = 0;                              // searchsorted(u, side="right") on cdf / cdf[-1]
+    for (int j = 0; j < m; ++j) pos += (cdf[j] / last <= u) ? 1 : 0;
+    out[k] = pos;
+  }
+  return MZX_OK;
+}
+
 }  // extern "C"

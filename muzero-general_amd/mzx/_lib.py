@@ -117,6 +117,7 @@ PROTOTYPES = {
     "mzx_rng_advance": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp]),
     "mzx_rng_random_sample": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp]),
     "mzx_rng_randint": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "mzx_rng_choice_weighted": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp]),
 }
 
 

@@ -70,6 +70,16 @@ class StreamBank:
         self.lib.check(self.lib.mzx_rng_randint(self.handle, _ptr(idx), int(idx.size), _ptr(n), _ptr(out)))
         return out
 
+    def choice_weighted(self, idx, weights, n):
+        """numpy.random.choice(range(n[k]), p=weights[k] / sum(weights[k])) per stream: positions, int32 [k]."""
+        idx = self._idx(idx)
+        w = numpy.ascontiguousarray(weights, dtype=numpy.float64)
+        n = numpy.ascontiguousarray(n, dtype=numpy.int32)
+        out = numpy.empty(idx.size, numpy.int32)
+        self.lib.check(self.lib.mzx_rng_choice_weighted(self.handle, _ptr(idx), int(idx.size), _ptr(w), int(w.shape[1]),
+                                                        _ptr(n), _ptr(out)))
+        return out
+
     def get_state(self, i):
         """The tuple ``RandomState.get_state()`` returns."""
         key = numpy.empty(624, numpy.uint32)

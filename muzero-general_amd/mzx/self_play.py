@@ -142,6 +142,76 @@ class GameHistory:
         return numpy.concatenate(pieces)
 
 
+class ShardGameHistory(GameHistory):
+    """
+    The GameHistory of one game of a shard played through the batched protocol.  The shard records a move as a
+    handful of arrays over all games; this object is a VIEW of game ``i`` in them whose list-typed fields
+    (``observation_history`` ... ``root_values``, self_play.py:482-489) are created on first access and are
+    ordinary lists from then on -- field-identical to the eager record (tests/test_selfplay_shard.py).  A
+    consumer pays only for the fields it touches (the replay buffer: ``root_values`` on save, the rest for
+    sampled games); pickling (Ray object store) materialises everything.
+    """
+    _LAZY = ("observation_history", "action_history", "reward_history", "to_play_history", "child_visits", "root_values")
+
+    def __init__(self, source, i, n):
+        self.__dict__["_view"] = (source, i, n)
+        self.reanalysed_predicted_root_values = None
+        self.priorities = None
+        self.game_priority = None
+
+    def __getattr__(self, name):          # reached only while the field has not been materialised
+        if name in ShardGameHistory._LAZY:
+            source, i, n = self.__dict__["_view"]
+            value = source.field(name, i, n)
+            self.__dict__[name] = value
+            return value
+        raise AttributeError(name)
+
+    def materialize(self):
+        for name in ShardGameHistory._LAZY:
+            getattr(self, name)
+        return self
+
+    def __getstate__(self):
+        state = dict(self.materialize().__dict__)
+        state.pop("_view", None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+
+class _ShardRecord:
+    """Game-major arrays of one finished shard (what ShardGameHistory objects view)."""
+
+    def __init__(self, A, obs, acts, rews, tps, vis=None, vals=None, totals=None, ratios=None, simple=None, legal_mask=None):
+        self.A, self.obs, self.acts, self.rews, self.tps = A, obs, acts, rews, tps
+        self.vis, self.vals, self.totals, self.ratios, self.simple, self.legal_mask = vis, vals, totals, ratios, simple, legal_mask
+
+    def field(self, name, i, n):
+        if name == "observation_history":
+            return list(self.obs[i, : n + 1])
+        if name == "action_history":
+            return self.acts[i, : n + 1].tolist()
+        if name == "reward_history":
+            return self.rews[i, : n + 1].tolist()
+        if name == "to_play_history":
+            return self.tps[i, : n + 1].tolist()
+        if n == 0:
+            return []
+        if self.simple[i]:      # every row "all actions legal, root visited": two array slices
+            return (self.ratios if name == "child_visits" else self.vals)[i, :n].tolist()
+        out = []                 # illegal actions get 0, an unvisited root reports value 0 (self_play.py:496-511)
+        for t in range(n):
+            total = int(self.totals[i, t])
+            if name == "child_visits":
+                ok = (lambda a: True) if self.legal_mask is None else (lambda a: self.legal_mask[i, t, a])
+                out.append([int(self.vis[i, t, a]) / total if ok(a) else 0 for a in range(self.A)])
+            else:
+                out.append(float(self.vals[i, t]) if total else 0)
+        return out
+
+
 class SearchResult:
     """Per-root outputs of one batched search (host numpy arrays)."""
 
@@ -154,6 +224,7 @@ class SearchResult:
         self.tape_used = info[:, 2]
         self.sum_depth = info[:, 3]
         self.legal_actions = legal_actions
+        self.shared_legal = None     # set when every root has the same legal-action list (list protocol)
 
     def root(self, i):
         """A ``Node`` whose children carry the visit counts of root i (self_play.py:222-245, :496-511)."""
@@ -463,7 +534,18 @@ class BatchedMCTS:
             assert (legal < A).all() and ((legal >= 0) == (numpy.arange(A)[None, :] < n_legal[:, None])).all(), \
                 "Legal actions should be a subset of the action space (padded with -1 at the end)."
             legal_actions = legal
-        for i, acts in enumerate(legal_actions if not isinstance(legal_actions, numpy.ndarray) else ()):
+        if not isinstance(legal_actions, numpy.ndarray) and B > 1 and legal_actions.count(legal_actions[0]) == B:
+            # every game offers the same list (the common case): validate it once (self_play.py:296-301)
+            acts = legal_actions[0]
+            assert acts, f"Legal actions should not be an empty array. Got {acts}."
+            assert set(acts).issubset(action_set), "Legal actions should be a subset of the action space."
+            assert len(set(acts)) == len(acts), "Legal actions must not repeat."
+            legal[:, : len(acts)] = acts
+            n_legal[:] = len(acts)
+            shared = [list(acts)] * B
+        else:
+            shared = None
+        for i, acts in enumerate(legal_actions if not isinstance(legal_actions, numpy.ndarray) and shared is None else ()):
             # self_play.py:296-301
             assert acts, f"Legal actions should not be an empty array. Got {acts}."
             assert set(acts).issubset(action_set), "Legal actions should be a subset of the action space."
@@ -514,7 +596,10 @@ class BatchedMCTS:
                                           None if noise is None else noise[redo], long_tape, words, ov)
             visits[redo], root_values[redo], predicted[redo], info[redo] = v2, r2, p2, i2
         result = SearchResult(visits, root_values, predicted, info,
-                              legal_actions if isinstance(legal_actions, numpy.ndarray) else [list(a) for a in legal_actions])
+                              legal_actions if isinstance(legal_actions, numpy.ndarray) else
+                              (shared if shared is not None else [list(a) for a in legal_actions]))
+        if shared is not None:
+            result.shared_legal = shared[0]
         if (info[:, 1] != 0).any():
             raise _lib.MzxError(f"search flagged trees {numpy.nonzero(info[:, 1])[0][:8]} (flags {set(info[:, 1])}): "
                                 "node arena exhausted")
@@ -672,8 +757,105 @@ class SelfPlay:
             if opponent != "self" or render:
                 raise NotImplementedError("the batched game protocol covers self-play without rendering")
             return self._play_batched(temperature, temperature_threshold)
+        if self.bank is not None and opponent == "self" and not render:
+            return self._play_shard(temperature, temperature_threshold)
         return self._play(list(range(self.num_games)), temperature, temperature_threshold, render, opponent,
                           muzero_player)
+
+    def _check_observation(self, observation):
+        # self_play.py:132-137 (same messages); ndarray observations of the right shape take the fast exit
+        shape = self.config.observation_shape
+        if getattr(observation, "shape", None) == shape:
+            return
+        got = numpy.array(observation).shape
+        assert len(got) == 3, \
+            f"Observation should be 3 dimensionnal instead of {len(got)} dimensionnal. Got observation of shape: {got}"
+        assert got == shape, \
+            f"Observation should match the observation_shape defined in MuZeroConfig. Expected {shape} but got {got}."
+
+    def _play_shard(self, temperature, temperature_threshold):
+        """
+        play_game (self_play.py:110-183) for all games of the shard through the REFERENCE plugin surface (B
+        unmodified ``Game`` objects): self-play, no rendering, native stream bank.  Everything that is not a call
+        into a plugin object or an append to one of its GameHistory lists is done once per move for the whole
+        shard: observations land in one persistent float32 batch as they are produced, legal-action lists are
+        validated once per distinct list, actions / child_visits rows / root values come from array operations.
+        Game by game the result equals the single-game actor's (tests/test_selfplay_shard.py).
+        """
+        cfg, games = self.config, self.games
+        A, G = len(cfg.action_space), len(self.games)
+        shape = tuple(cfg.observation_shape)
+        cfg_shape_is_tuple = cfg.observation_shape if isinstance(cfg.observation_shape, tuple) else shape
+        batch = getattr(self, "_obs_batch", None)
+        if batch is None or batch.shape != (G,) + shape:
+            batch = self._obs_batch = numpy.empty((G,) + shape, numpy.float32)
+        histories = []
+        for s, game in enumerate(games):
+            gh = GameHistory()
+            observation = game.reset()
+            gh.action_history.append(0)
+            gh.observation_history.append(observation)
+            gh.reward_history.append(0)
+            gh.to_play_history.append(game.to_play())
+            self._check_observation(observation)
+            batch[s] = observation
+            histories.append(gh)
+        store = None
+        if cfg.stacked_observations > 0:
+            store = self._frame_store(G)
+            store.push(batch, None)
+        max_moves = cfg.max_moves
+        active = list(range(G))
+        moved = numpy.zeros(G, numpy.int32)
+        while active:
+            everyone = len(active) == G
+            legal = [games[s].legal_actions() for s in active]
+            to_play = [games[s].to_play() for s in active]
+            if store is not None:
+                stacked = store.stacked(None if everyone else active)
+            else:
+                stacked = batch if everyone else batch[active]
+            t0 = time.perf_counter()
+            result = self.engine.run(stacked, legal, to_play, True, (self.bank, active))
+            self.stats["search_seconds"] += time.perf_counter() - t0
+            self.stats["searches"] += len(active)
+            self.stats["simulations"] += len(active) * self.engine.num_simulations
+            if temperature_threshold:
+                temps = [temperature if len(histories[s].action_history) < temperature_threshold else 0 for s in active]
+            else:
+                temps = temperature
+            actions = self._select_actions_bank(result, active, temps)
+            vis = result.visit_counts
+            totals = vis.sum(1)
+            rows = (vis / numpy.maximum(totals, 1)[:, None]).tolist()     # int / int true division, as Python's
+            values = result.root_values.tolist()
+            plain = bool((totals > 0).all()) and all(len(l) == A for l in result.legal_actions)
+            still = []
+            for j, s in enumerate(active):
+                game, gh, action = games[s], histories[s], actions[j]
+                observation, reward, done = game.step(action)
+                if plain:
+                    gh.child_visits.append(rows[j])
+                    gh.root_values.append(values[j])
+                else:      # illegal actions get 0, an unvisited root reports value 0 (self_play.py:496-511, :446-449)
+                    total, legal_set = int(totals[j]), set(result.legal_actions[j])
+                    gh.child_visits.append([int(vis[j][a]) / total if a in legal_set else 0 for a in cfg.action_space])
+                    gh.root_values.append(values[j] if total else 0)
+                gh.action_history.append(action)
+                gh.observation_history.append(observation)
+                gh.reward_history.append(reward)
+                gh.to_play_history.append(game.to_play())
+                if getattr(observation, "shape", None) != cfg_shape_is_tuple:
+                    self._check_observation(observation)
+                batch[s] = observation
+                if not done and len(gh.action_history) <= max_moves:
+                    still.append(s)
+            if store is not None and still:
+                for s in active:
+                    moved[s] = histories[s].action_history[-1]
+                store.push(batch, moved)
+            active = still
+        return histories
 
     def _play(self, slots, temperature, temperature_threshold, render, opponent, muzero_player):
         cfg = self.config
@@ -796,6 +978,7 @@ class SelfPlay:
         play_game (self_play.py:110-183) for a shard behind the batched plugin protocol: per move ONE game
         call, ONE search, ONE action draw for all running games; the per-game GameHistory objects
         (field-identical to the per-object path, tests/test_selfplay_shard.py) are materialised at the end.
+        While every game of the shard is still running (the common case) no index gathers / scatters happen.
         """
         cfg, g, B = self.config, self.batched_game, self.num_games
         A, k = len(cfg.action_space), int(cfg.stacked_observations)
@@ -804,80 +987,88 @@ class SelfPlay:
             f"Observation should match the observation_shape defined in MuZeroConfig. Expected {(B,) + tuple(cfg.observation_shape)} but got {obs.shape}."
         obs_hist, act_hist, rew_hist = [obs], [numpy.zeros(B, numpy.int64)], [numpy.zeros(B, numpy.int64)]
         tp_hist = [numpy.asarray(g.to_play()).astype(numpy.int64)]
-        visits_hist, value_hist, legal_hist, alive_hist = [], [], [], []
+        visits_hist, value_hist, legal_hist = [], [], []
         alive = numpy.ones(B, bool)
+        n_alive = B
         length = numpy.zeros(B, numpy.int64)
+        everyone_idx = numpy.arange(B)
         move = 0
         store = None
         if k > 0:   # frames stay in HBM; the stacked inputs are assembled there (csrc/mzx_obs.h)
             store = self._frame_store(B)
             store.push(obs, None)
-        while alive.any() and move + 1 <= cfg.max_moves:      # len(action_history) <= max_moves, :129
-            idx = numpy.nonzero(alive)[0]
-            stacked = store.stacked(idx) if store is not None else obs_hist[-1][idx]
+        while n_alive and move + 1 <= cfg.max_moves:      # len(action_history) <= max_moves, :129
+            everyone = n_alive == B
+            idx = everyone_idx if everyone else numpy.nonzero(alive)[0]
+            if store is not None:
+                stacked = store.stacked(None if everyone else idx)
+            else:
+                stacked = obs_hist[-1] if everyone else obs_hist[-1][idx]
             legal = g.legal_actions()
-            legal = legal[idx] if isinstance(legal, numpy.ndarray) else [legal[i] for i in idx]
+            if not everyone:
+                legal = legal[idx] if isinstance(legal, numpy.ndarray) else [legal[i] for i in idx]
+            to_play = tp_hist[-1] if everyone else tp_hist[-1][idx]
             t0 = time.perf_counter()
-            result = self.engine.run(stacked, legal, tp_hist[-1][idx], True, (self.bank, idx))
+            result = self.engine.run(stacked, legal, to_play, True, (self.bank, idx))
             self.stats["search_seconds"] += time.perf_counter() - t0
             self.stats["searches"] += len(idx)
             self.stats["simulations"] += len(idx) * self.engine.num_simulations
             t = temperature if not temperature_threshold or move + 1 < temperature_threshold else 0
-            chosen = self._select_actions_bank(result, idx, [t] * len(idx))
-            actions = numpy.zeros(B, numpy.int64)
-            actions[idx] = chosen
-            obs, reward, done = g.step(actions, alive.copy())
-            visits = numpy.zeros((B, A), numpy.int32)
-            visits[idx] = result.visit_counts
-            values = numpy.zeros(B, numpy.float64)
-            values[idx] = result.root_values
-            mask = numpy.zeros((B, A), bool)
-            if isinstance(legal, numpy.ndarray):
-                rows = numpy.repeat(idx, (legal >= 0).sum(1))
-                mask[rows, legal[legal >= 0]] = True
+            chosen = self._select_actions_bank(result, idx, t)
+            if everyone:
+                actions = numpy.asarray(chosen, numpy.int64)
+                visits, values = result.visit_counts, result.root_values
             else:
-                for r, acts in zip(idx, legal):
-                    mask[r, acts] = True
-            visits_hist.append(visits); value_hist.append(values); legal_hist.append(mask); alive_hist.append(alive.copy())
+                actions = numpy.zeros(B, numpy.int64)
+                actions[idx] = chosen
+                visits = numpy.zeros((B, A), numpy.int32)
+                visits[idx] = result.visit_counts
+                values = numpy.zeros(B, numpy.float64)
+                values[idx] = result.root_values
+            obs, reward, done = g.step(actions, alive if everyone else alive.copy())
+            if isinstance(legal, numpy.ndarray) and (legal >= 0).all():
+                mask = None                                  # every action legal for every searched game
+            else:
+                mask = numpy.zeros((B, A), bool)
+                if isinstance(legal, numpy.ndarray):
+                    rows = numpy.repeat(idx, (legal >= 0).sum(1))
+                    mask[rows, legal[legal >= 0]] = True
+                else:
+                    for r, acts in zip(idx, legal):
+                        mask[r, acts] = True
+            visits_hist.append(visits); value_hist.append(values); legal_hist.append(mask)
             obs_hist.append(numpy.asarray(obs)); act_hist.append(actions)
             if store is not None:
                 store.push(obs_hist[-1], actions)
             rew_hist.append(numpy.asarray(reward)); tp_hist.append(numpy.asarray(g.to_play()).astype(numpy.int64))
-            length[idx] += 1
-            alive = alive & ~numpy.asarray(done, bool)
+            if everyone:
+                length += 1
+            else:
+                length[idx] += 1
+            done = numpy.asarray(done, bool)
+            if done.any():
+                alive = alive & ~done
+                n_alive = int(alive.sum())
             move += 1
-        # ---- per-game records (self_play.py:479-511): stack once, slice per game
+        # ---- per-game records (self_play.py:479-511): transpose once to game-major, slice per game
         n_moves = len(visits_hist)
-        acts = numpy.stack(act_hist)                      # [n_moves + 1][B]
-        rews = numpy.stack(rew_hist)
-        tps = numpy.stack(tp_hist)
+        by_game = lambda seq: numpy.ascontiguousarray(numpy.swapaxes(numpy.stack(seq), 0, 1))
+        acts, rews, tps, obs_all = by_game(act_hist), by_game(rew_hist), by_game(tp_hist), by_game(obs_hist)
+        record = _ShardRecord(A, obs_all, acts, rews, tps)
         if n_moves:
-            vis = numpy.stack(visits_hist)                # [n_moves][B][A]
-            vals = numpy.stack(value_hist)
-            legal_mask = numpy.stack(legal_hist)
+            vis = by_game(visits_hist)                    # [B][n_moves][A]
+            vals = by_game(value_hist)
             totals = vis.sum(2)
             # visit_count / total: true division of small integers == Python's int / int
             ratios = vis / numpy.maximum(totals, 1)[:, :, None]
-            all_legal = legal_mask.all(2)
-        histories = []
-        for i in range(B):
-            n = int(length[i])
-            gh = GameHistory()
-            gh.observation_history = [obs_hist[t][i] for t in range(n + 1)]
-            gh.action_history = acts[: n + 1, i].tolist()
-            gh.reward_history = rews[: n + 1, i].tolist()
-            gh.to_play_history = tps[: n + 1, i].tolist()
-            if n:
-                if all_legal[:n, i].all() and (totals[:n, i] > 0).all():
-                    gh.child_visits = ratios[:n, i].tolist()
-                    gh.root_values = vals[:n, i].tolist()
-                else:
-                    for t in range(n):
-                        total = int(totals[t, i])
-                        gh.child_visits.append([int(vis[t, i, a]) / total if legal_mask[t, i, a] else 0 for a in range(A)])
-                        gh.root_values.append(float(vals[t, i]) if total else 0)
-            histories.append(gh)
-        return histories
+            played = numpy.arange(n_moves)[None, :] < length[:, None]
+            plain = (totals > 0) | ~played
+            legal_mask = None
+            if any(m is not None for m in legal_hist):
+                legal_mask = by_game([numpy.ones((B, A), bool) if m is None else m for m in legal_hist])
+                plain &= legal_mask.all(2)
+            record = _ShardRecord(A, obs_all, acts, rews, tps, vis, vals, totals, ratios, plain.all(1), legal_mask)
+        return [ShardGameHistory(record, i, n) for i, n in enumerate(length.tolist())]
 
     @staticmethod
     def _stacked_batch(obs_hist, act_hist, k, A):
@@ -950,12 +1141,16 @@ class SelfPlay:
             legal_arr = result.legal_actions
             n[:] = (legal_arr >= 0).sum(1)
             counts = numpy.where(legal_arr >= 0, numpy.take_along_axis(result.visit_counts, numpy.maximum(legal_arr, 0), 1), 0).astype(numpy.int32)
+        elif result.shared_legal is not None:          # one list for every game: gather its columns once
+            shared = numpy.asarray(result.shared_legal, numpy.int64)
+            n[:] = shared.size
+            counts[:, : shared.size] = result.visit_counts[:, shared]
         else:
             for r, legal in enumerate(result.legal_actions):
                 n[r] = len(legal)
                 counts[r, : n[r]] = result.visit_counts[r][legal]
         actions = numpy.zeros(k, numpy.int64)
-        temps = numpy.asarray(temps, dtype=numpy.float64)
+        temps = numpy.full(k, float(temps)) if numpy.isscalar(temps) else numpy.asarray(temps, dtype=numpy.float64)
         greedy = numpy.nonzero(temps == 0)[0]
         if greedy.size:
             masked = numpy.where(numpy.arange(A)[None, :] < n[greedy, None], counts[greedy], -1)
@@ -964,24 +1159,16 @@ class SelfPlay:
         if uniform.size:
             actions[uniform] = self.bank.randint([searching[r] for r in uniform], n[uniform])
         rest = numpy.nonzero((temps != 0) & ~numpy.isinf(temps))[0]
-        for t in numpy.unique(temps[rest]):
-            rows = rest[temps[rest] == t]
-            dist = counts[rows] ** (1 / float(t))                    # int32 ** float -> float64 pow, elementwise
-            total = numpy.zeros(len(rows))
-            for j in range(A):                                       # Python's sum(): left to right
-                total = total + dist[:, j]
-            dist = dist / total[:, None]
-            cdf = numpy.empty_like(dist)
-            acc = numpy.zeros(len(rows))
-            for j in range(A):                                       # ndarray.cumsum: left to right
-                acc = acc + dist[:, j]
-                cdf[:, j] = acc
-            cdf = cdf / cdf[numpy.arange(len(rows)), n[rows] - 1][:, None]
-            u = self.bank.random_sample([searching[r] for r in rows])
-            inside = numpy.arange(A)[None, :] < n[rows, None]
-            actions[rows] = ((cdf <= u[:, None]) & inside).sum(axis=1)   # searchsorted(u, side="right")
+        for t in (numpy.unique(temps[rest]) if rest.size else ()):
+            rows = rest if rest.size == k else rest[temps[rest] == t]
+            dist = counts[rows] ** (1 / float(t))                    # int32 ** float -> float64 pow, elementwise (numpy's own)
+            # sum / normalise / cumulative sum / bisection + the one random_sample() per game: native, one call
+            stream = searching if rows.size == k else [searching[r] for r in rows]
+            actions[rows] = self.bank.choice_weighted(stream, dist, n[rows])
         if isinstance(result.legal_actions, numpy.ndarray):
             return result.legal_actions[numpy.arange(k), actions].astype(numpy.int64)
+        if result.shared_legal is not None:
+            return [result.shared_legal[a] for a in actions.tolist()]
         return [result.legal_actions[r][int(actions[r])] for r in range(k)]
 
     @staticmethod

@@ -64,6 +64,18 @@ def _hash_u32(x):
     return x
 
 
+def _hash_u32_int(x):
+    """``_hash_u32`` on one Python int (same 32-bit mix, no numpy): the per-object game's step is on the
+    per-move path of the plugin-surface benchmark, where a numpy call on a 4-element array costs 20x the work."""
+    x &= 0xFFFFFFFF
+    x = ((x ^ 61) ^ (x >> 16)) & 0xFFFFFFFF
+    x = (x * 9) & 0xFFFFFFFF
+    x = x ^ (x >> 4)
+    x = (x * 0x27D4EB2D) & 0xFFFFFFFF
+    x = x ^ (x >> 15)
+    return x
+
+
 def make_synthetic_game(observation_shape, num_actions, num_players=1):
     """
     Build a ``Game`` class with the reference plugin surface
@@ -85,18 +97,22 @@ def make_synthetic_game(observation_shape, num_actions, num_players=1):
             self.key = self.seed & 0xFFFFFFFF
 
         def _observation(self):
+            if size <= 16:   # small vectors: plain integer arithmetic (identical values; x / 2**32 is exact)
+                key = self.key
+                return numpy.array([_hash_u32_int(k * 2654435761 + key) / 4294967296.0 for k in range(size)],
+                                   dtype=numpy.float32).reshape(shape)
             h = _hash_u32(lane * numpy.uint64(2654435761) + numpy.uint64(self.key))
             return (h.astype(numpy.float64) / 4294967296.0).astype(numpy.float32).reshape(shape)
 
         def reset(self):
             self.t = 0
             self.player = 0
-            self.key = int(_hash_u32(self.seed * 7919 + 17))
+            self.key = _hash_u32_int(self.seed * 7919 + 17)
             return self._observation()
 
         def step(self, action):
             self.t += 1
-            self.key = int(_hash_u32(self.key * 31 + int(action) * 131 + self.t))
+            self.key = _hash_u32_int(self.key * 31 + int(action) * 131 + self.t)
             self.player = (self.player + 1) % num_players
             reward = int(self.key & 1)
             return self._observation(), reward, False

@@ -66,3 +66,31 @@ def test_batched_game_protocol_equals_per_object_games(backend, temperature, thr
             assert numpy.array_equal(x, y)
         for i in range(len(want.root_values) + 1):
             assert numpy.array_equal(got.get_stacked_observations(i, stacked, actions), want.get_stacked_observations(i, stacked, actions))
+
+
+def test_lazy_shard_histories_behave_like_game_history(backend):
+    """ShardGameHistory (batched protocol): fields appear as plain lists on first touch; pickling, the
+    replay hand-off and mutation work as on an eager GameHistory."""
+    import pickle
+
+    from mzx import replay
+
+    cfg = configs.cartpole(num_simulations=8, max_moves=5, PER=True, PER_alpha=0.5, td_steps=3)
+    Batched = synthetic.make_synthetic_batched_game(cfg.observation_shape, 2, 1)
+    Game = synthetic.make_synthetic_game(cfg.observation_shape, 2, 1)
+    template = models.MuZeroNetwork(cfg, _backend=backend).state_dict()
+    weights = synthetic.fill_state_dict(template, 9)
+    lazy = self_play.SelfPlay({"weights": weights}, Batched, cfg, 3, num_games=4, _backend=backend).play_games(1.0, None, False, "self", 0)
+    eager = self_play.SelfPlay({"weights": weights}, Game, cfg, 3, num_games=4, _backend=backend).play_games(1.0, None, False, "self", 0)
+    assert all(isinstance(h, self_play.GameHistory) for h in lazy)
+    assert "child_visits" not in lazy[0].__dict__            # nothing materialised yet
+    for a, b in zip(lazy, eager):
+        assert replay.fill_initial_priorities(a, cfg) and replay.fill_initial_priorities(b, cfg)
+        assert numpy.array_equal(a.priorities, b.priorities) and a.game_priority == b.game_priority
+        assert "observation_history" not in a.__dict__        # the hand-off only touched what it needs
+        c = pickle.loads(pickle.dumps(a))
+        for name in self_play.ShardGameHistory._LAZY[1:]:
+            assert getattr(c, name) == getattr(b, name), name
+        assert all(numpy.array_equal(x, y) for x, y in zip(c.observation_history, b.observation_history))
+        a.root_values.append(1.5)                              # a real list from now on
+        assert a.root_values[-1] == 1.5 and len(a.root_values) == len(b.root_values) + 1
