@@ -36,7 +36,9 @@ import torch
 from . import _lib, _rng, models, replay
 from . import observations as observations_mod
 
-TAPE_WORDS = 64
+# raw MT19937 words per tree handed to a search for its tie draws: a search normally consumes ONE (the all-zero
+# scores of its first walk); a tree that needs more is searched again with a longer tape (BatchedMCTS.run)
+TAPE_WORDS = 16
 
 
 class Node:

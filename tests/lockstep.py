@@ -38,7 +38,10 @@ def fixture_weights(z, template):
     return sd
 
 
-def rng_inputs(cfg, cases, A, tape_words=self_play.TAPE_WORDS):
+LOCKSTEP_TAPE_WORDS = 64   # the lock-step entry points have no overflow re-run: give every case a long tape
+
+
+def rng_inputs(cfg, cases, A, tape_words=LOCKSTEP_TAPE_WORDS):
     """Per-case Dirichlet noise + raw-word tape exactly as the engine derives them from a RandomState."""
     B = len(cases)
     legal = numpy.full((B, A), -1, numpy.int32)
@@ -64,7 +67,7 @@ class Lockstep:
         self._sqrt = (ctypes.c_double * n)(*[math.sqrt(k) for k in range(n)])
         c = _lib.SearchConfig()
         c.num_trees, c.num_simulations, c.action_space_size = B, S, self.A
-        c.num_players, c.support_size, c.tape_words = len(cfg.players), cfg.support_size, self_play.TAPE_WORDS
+        c.num_players, c.support_size, c.tape_words = len(cfg.players), cfg.support_size, LOCKSTEP_TAPE_WORDS
         c.discount, c.root_exploration_fraction = float(cfg.discount), float(cfg.root_exploration_fraction)
         c.h_pb_c_table = ctypes.cast(self._pbc, ctypes.POINTER(ctypes.c_double))
         c.h_sqrt_table = ctypes.cast(self._sqrt, ctypes.POINTER(ctypes.c_double))
