@@ -47,6 +47,108 @@ __device__ __forceinline__ void load_state(const TreeRef& t, RowState& st) {
   st.root_n = t.meta(TM_ROOT_N); st.root_to_play = t.to_play(0);
 }
 
+
+// ---------------------------------------------------------------------------
+// Wide action spaces (more than one 16-lane row of child slots: gomoku 121, atari 18, ...).  Lane l scores
+// the slots l, l + 16, l + 32, ... of the node (self_play.py:363-404, same binary64 operations as ucb_from);
+// the arg-max is the row butterfly over the lanes' own maxima, the maximisers are counted per 16-slot chunk
+// with one wave ballot each so that numpy.random.choice(ties) picks the k-th one in SLOT order, and the
+// winner's link / visit count are re-read from the tree (one broadcast load) instead of permuted.
+constexpr int WIDE_MAX_CHUNKS = 16;   // up to 256 actions
+
+__device__ __forceinline__ RowSel row_select_wide(const TreeRef& t, const SearchParams& p, const uint32_t* tape, int sub,
+                                                  int row_in_wave, int sim, RowState& st) {
+  RowSel r;
+  int node = 0, depth = 0, slot = 0;
+  int vtp = st.root_to_play;
+  int N = sim;  // every finished simulation visited the root once
+  r.my_node = 0; r.my_parent = -1; r.my_pslot = -1;
+  bool done = false;
+  for (;;) {
+    const int d1 = depth + 1;
+    const int nc = (node == 0) ? st.root_n : p.num_actions;
+    const int nch = (nc + FUSED_ROW - 1) / FUSED_ROW;
+    const double pbc = p.pbc_table[N], sq = p.sqrt_table[N];
+    double sc[WIDE_MAX_CHUNKS];
+    double mine = -MZX_INF;
+#pragma unroll
+    for (int ch = 0; ch < WIDE_MAX_CHUNKS; ++ch) {
+      sc[ch] = -MZX_INF;
+      if (ch < nch) {   // wave-uniform per row set; rows of a wave may differ (root vs inner node): plain select
+        const int s = ch * FUSED_ROW + sub;
+        const bool valid = s < nc;
+        const int ss = valid ? s : 0;
+        const double u = ucb_from(pbc, sq, t.slot_visit(node, ss), t.prior(node, ss), t.slot_q(node, ss), st.mn, st.mx);
+        sc[ch] = valid ? u : -MZX_INF;
+        mine = (sc[ch] > mine) ? sc[ch] : mine;
+      }
+    }
+    const double best = row_max_d<16>(mine);
+    // maximisers, chunk by chunk in slot order
+    int nbest = 0, sl = 0;
+    unsigned bits[WIDE_MAX_CHUNKS];
+#pragma unroll
+    for (int ch = 0; ch < WIDE_MAX_CHUNKS; ++ch) {
+      bits[ch] = row_bits(__ballot(sc[ch] == best && ch * FUSED_ROW + sub < nc), row_in_wave);
+      if (nbest == 0 && bits[ch]) sl = ch * FUSED_ROW + (__ffs(bits[ch]) - 1);
+      nbest += __popc(bits[ch]);
+    }
+    if (nbest > 1 && !done) {  // numpy.random.choice(ties): k-th maximiser in slot order
+      ++st.ties;
+      int k = tape_draw(tape, p.tape_words, st.tape_pos, st.flags, nbest);
+#pragma unroll
+      for (int ch = 0; ch < WIDE_MAX_CHUNKS; ++ch) {
+        const int cnt = __popc(bits[ch]);
+        if (k >= 0 && k < cnt) {
+          unsigned b = bits[ch];
+          for (int q = k; q > 0; --q) b &= b - 1;
+          sl = ch * FUSED_ROW + (__ffs(b) - 1);
+          k = -1;
+        } else if (k >= cnt) {
+          k -= cnt;
+        }
+      }
+    }
+    const int cw = t.child(node, sl);
+    const int n_w = t.slot_visit(node, sl);
+    const bool act = !done;
+    const bool mine_lane = act && sub == d1;
+    r.my_parent = mine_lane ? node : r.my_parent;
+    r.my_pslot = mine_lane ? sl : r.my_pslot;
+    r.my_node = mine_lane ? cw : r.my_node;
+    const int nvtp = (vtp + 1 < p.num_players) ? vtp + 1 : 0;  // players turn by turn, :331-334
+    depth = act ? d1 : depth;
+    slot = act ? sl : slot;
+    vtp = act ? nvtp : vtp;
+    const bool go = act && cw >= 0;
+    N = go ? n_w : N;
+    node = go ? cw : node;
+    done = done || (cw < 0);
+    if (__all(done)) break;
+  }
+  int leaf = st.n_nodes;
+  if (leaf >= p.num_nodes) { st.flags |= TF_NODE_OVERFLOW; leaf = p.num_nodes - 1; }
+  if (sub == depth) r.my_node = leaf;
+  r.c.parent = node; r.c.slot = slot; r.c.leaf = leaf; r.c.depth = depth; r.c.to_play = vtp;
+  r.action = (node == 0) ? t.root_action(slot) : slot;
+  return r;
+}
+
+// support_to_scalar (models.py:645-666) of F logits readable by every lane, canonical lane order (mzx_tree.h):
+// element i belongs to lane i % 16, accumulated in increasing i; any F.
+__device__ __forceinline__ float row_decode_wide(const float* lg, int F, int support, int sub) {
+  float m = -MZX_INF;
+  for (int i = sub; i < F; i += FUSED_ROW) m = fmaxf(m, lg[i]);
+  m = row_max(m);
+  float dl = 0.f;
+  for (int i = sub; i < F; i += FUSED_ROW) dl += mzx_expf(lg[i] - m);
+  const float den = row_sum(dl);
+  float num = 0.f;
+  for (int i = sub; i < F; i += FUSED_ROW) num += (float)(i - support) * mzx_div(mzx_expf(lg[i] - m), den);
+  return support_inverse_transform(row_sum(num));
+}
+
+// AW: lanes that can hold a child slot (4, 16), or 0 = wide (several slots per lane, any support size)
 template <bool WLDS, int NW, int AW, int MM>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 rz_search_kernel(const RzSearchArgs sa) {
@@ -102,7 +204,8 @@ rz_search_kernel(const RzSearchArgs sa) {
     // ---- selection (self_play.py:325-334)
     RowSel sel;
     if (row_valid) {
-      sel = row_select<AW>(t, p, tape, sub, row_in_wave, sa.sim0 + sim, st);
+      if constexpr (AW == 0) sel = row_select_wide(t, p, tape, sub, row_in_wave, sa.sim0 + sim, st);
+      else sel = row_select<AW>(t, p, tape, sub, row_in_wave, sa.sim0 + sim, st);
       if (sub == 0) { sel_parent[row] = sel.c.parent; sel_action[row] = sel.action; sel_leaf[row] = sel.c.leaf; }
     }
     RZS_PROF(0)
@@ -134,14 +237,28 @@ rz_search_kernel(const RzSearchArgs sa) {
       const float* vl = cx.reg + T * a.out_off[0] + row * a.out_ts[0];
       const float* rl = cx.reg + T * a.out_off[1] + row * a.out_ts[1];
       const float* pl = cx.reg + T * a.out_off[2] + row * a.out_ts[2];
-      const float value = row_decode2(sub < F ? vl[sub] : 0.f, sub + 16 < F ? vl[sub + 16] : 0.f, F, p.support_size, sub);
-      const float reward = row_decode2(sub < F ? rl[sub] : 0.f, sub + 16 < F ? rl[sub + 16] : 0.f, F, p.support_size, sub);
-      const bool in = sub < A;
-      const float lg = in ? pl[sub] : 0.f;
-      const float m = row_max(in ? lg : -MZX_INF);
-      const float e = in ? mzx_expf(lg - m) : 0.f;
-      const float den = row_sum(e);
-      if (in) tree_init_slot(t, sel.c.leaf, sub, (double)mzx_div(e, den));
+      float value, reward;
+      if constexpr (AW == 0) {
+        value = row_decode_wide(vl, F, p.support_size, sub);
+        reward = row_decode_wide(rl, F, p.support_size, sub);
+        // priors = fp32 softmax over the full action space (self_play.py:460-462), canonical lane order
+        float m = -MZX_INF;
+        for (int i = sub; i < A; i += FUSED_ROW) m = fmaxf(m, pl[i]);
+        m = row_max(m);
+        float dl = 0.f;
+        for (int i = sub; i < A; i += FUSED_ROW) dl += mzx_expf(pl[i] - m);
+        const float den = row_sum(dl);
+        for (int i = sub; i < A; i += FUSED_ROW) tree_init_slot(t, sel.c.leaf, i, (double)mzx_div(mzx_expf(pl[i] - m), den));
+      } else {
+        value = row_decode2(sub < F ? vl[sub] : 0.f, sub + 16 < F ? vl[sub + 16] : 0.f, F, p.support_size, sub);
+        reward = row_decode2(sub < F ? rl[sub] : 0.f, sub + 16 < F ? rl[sub + 16] : 0.f, F, p.support_size, sub);
+        const bool in = sub < A;
+        const float lg = in ? pl[sub] : 0.f;
+        const float m = row_max(in ? lg : -MZX_INF);
+        const float e = in ? mzx_expf(lg - m) : 0.f;
+        const float den = row_sum(e);
+        if (in) tree_init_slot(t, sel.c.leaf, sub, (double)mzx_div(e, den));
+      }
       row_backprop(t, p, sel, sub, row_in_wave, (double)value, (double)reward, st);
     }
     RZS_PROF(4)
@@ -169,12 +286,18 @@ inline int rz_search_launch_k(const RzSearchArgs& sa, unsigned grid, size_t lds_
   }
   hipLaunchKernelGGL((rz_search_kernel<WLDS, NW, AW, MM>), dim3(grid), dim3(NW * 64), lds_bytes, stream, sa);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { set_error("residual search kernel launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+  if (e != hipSuccess) {
+    set_error("residual search kernel launch failed: %s (grid %u, %d threads, %zu bytes of LDS, %d trees per workgroup, "
+              "weights in LDS %d, action lanes %d)", hipGetErrorString(e), grid, NW * 64, lds_bytes, sa.net.T, (int)WLDS, AW);
+    return MZX_ERR_RUNTIME;
+  }
   return MZX_OK;
 }
 
 template <bool WLDS, int NW, int MM>
 inline int rz_search_launch_aw(const RzSearchArgs& sa, unsigned grid, size_t lds, stream_t stream) {
+  const bool wide = sa.p.num_actions > FUSED_ROW || 2 * sa.p.support_size + 1 > 2 * FUSED_ROW;
+  if (wide) return rz_search_launch_k<WLDS, NW, 0, MM>(sa, grid, lds, stream);
   if (sa.p.num_actions <= 4) return rz_search_launch_k<WLDS, NW, 4, MM>(sa, grid, lds, stream);
   return rz_search_launch_k<WLDS, NW, 16, MM>(sa, grid, lds, stream);
 }
@@ -182,7 +305,7 @@ inline int rz_search_launch_aw(const RzSearchArgs& sa, unsigned grid, size_t lds
 inline bool rz_search_supported(const mzx_search* s) {
   const mzx_net* net = s->net;
   if (!net || !net->rz.ok || !net->rz.recurrent.ok) return false;
-  if (s->p.num_actions > FUSED_ROW || 2 * s->p.support_size + 1 > 2 * FUSED_ROW) return false;
+  if (s->p.num_actions > WIDE_MAX_CHUNKS * FUSED_ROW) return false;
   const RzProgram& R = net->rz.recurrent;
   // at least one tree per workgroup must fit beside the search's own LDS
   return 4 * (rz_lds_floats(net->rz.g, R, 1, false) + rz_search_extra_floats(s->p)) <= RZ_LDS_BUDGET;
@@ -232,7 +355,8 @@ inline int rz_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, 
     bool tree_lds = false;
     if (rz_env_int("MZX_RZ_TREE_LDS", 1) != 0) {
       const RzLaunch L1 = rz_prepare(net, R, nr.in, nr, B, &ir, slab_floats, extra);
-      if (L1.a.T == L.a.T && L1.eight == L.eight && L1.small == L.small) { L = L1; tree_lds = true; }
+      const bool fits = (int64_t)L1.lds + 4 * (extra + slab_floats * L1.a.T) <= RZ_LDS_BUDGET;   // (one tree per workgroup is not re-checked by rz_prepare)
+      if (fits && L1.a.T == L.a.T && L1.eight == L.eight && L1.small == L.small) { L = L1; tree_lds = true; }
     }
     RzSearchArgs sa;
     sa.net = L.a;

@@ -275,6 +275,15 @@ RESNET_CASES = {
         resnet_fc_reward_layers=[7, 9], resnet_fc_value_layers=[], resnet_fc_policy_layers=[33]),
     "wide": lambda: configs.connect4(channels=40, blocks=1, observation_shape=(3, 5, 5), action_space=list(range(25)),
                                      resnet_fc_policy_layers=[48, 20]),
+    # games/gomoku.py:22-23 geometry (11 x 11 board, 121 actions, two players) with a network small enough for
+    # the fused engine: several child slots per lane in the whole-search kernel
+    "gomoku": lambda: configs.connect4(observation_shape=(3, 11, 11), action_space=list(range(121)), channels=16, blocks=2,
+                                       reduced_channels_reward=2, reduced_channels_value=2, reduced_channels_policy=4,
+                                       resnet_fc_reward_layers=[32], resnet_fc_value_layers=[32],
+                                       resnet_fc_policy_layers=[32], num_simulations=60, root_dirichlet_alpha=0.3),
+    # games/atari.py:58-59 style heads: 18 actions and a support wider than two 16-lane rows (F = 41)
+    "widesupport": lambda: configs.tictactoe(observation_shape=(3, 6, 6), action_space=list(range(18)), support_size=20,
+                                             channels=8, players=list(range(1))),
 }
 
 
@@ -408,7 +417,8 @@ def test_search_with_fused_resnet_matches_per_operator_search(backend, name):
     assert numpy.abs(res[0].root_values - res[1].root_values).max() < 1e-3
 
 
-@pytest.mark.parametrize("name,B", [("tictactoe", 70), ("connect4", 19), ("odd", 33), ("breakout", 9)])
+@pytest.mark.parametrize("name,B", [("tictactoe", 70), ("connect4", 19), ("odd", 33), ("breakout", 9), ("wide", 21),
+                                    ("gomoku", 13), ("widesupport", 37)])
 def test_residual_whole_search_kernel_bit_identical_to_generic(backend, name, B):
     """
     Every simulation in one launch (mzx_resnet_search.h: lane-parallel tree walks on arena-resident trees +
@@ -440,6 +450,33 @@ def test_residual_whole_search_kernel_bit_identical_to_generic(backend, name, B)
         if a.dtype == numpy.float64:
             a, b = a.view(numpy.int64), b.view(numpy.int64)
         assert numpy.array_equal(a, b), (name, k)
+
+
+def test_gomoku_shaped_search_matches_oracle(backend):
+    """121 actions (several child slots per lane), two players, ragged legal sets: whole-search kernel vs the CPU oracle."""
+    cfg = RESNET_CASES["gomoku"]()
+    cfg.pb_c_init = 2.5     # weight on the priors: bushier trees than the one deep chain a random network digs
+    B, S = 24, cfg.num_simulations
+    net = models.MuZeroNetwork(cfg)
+    sd = synthetic.fill_state_dict(net.state_dict(), 33)
+    net.set_weights(sd)
+    engine = self_play.BatchedMCTS(cfg, net, B)
+    assert backend.lib.mzx_search_fused_supported(engine.handle(B)) == 2
+    obs = synthetic.observations(B, net.input_shape, seed=5)
+    rs = numpy.random.RandomState(4)
+    A = len(cfg.action_space)
+    legal = [sorted(rs.choice(A, size=rs.randint(2, A + 1), replace=False).tolist()) for _ in range(B)]
+    to_play = [int(i % 2) for i in range(B)]
+    seeds = [600 + i for i in range(B)]
+    res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(s) for s in seeds])
+    _tree_invariants(cfg, res, S)
+    for i in range(B):
+        assert set(numpy.nonzero(res.visit_counts[i])[0]).issubset(set(legal[i]))
+    factory = lambda n: self_play.BatchedMCTS(cfg, net, n, mode=1)
+    # root values: a path of d plies is d recurrent inferences of a random (expanding) network deep, so fp32
+    # round-off of two network implementations grows with it -- 5e-3 relative here, the visit counts are the gate
+    same = _compare_sample_with_oracle(cfg, sd, res, obs, legal, to_play, seeds, list(range(B)), factory, 50 * TOL, "gomoku-shaped")
+    assert same >= B - 4
 
 
 # ----------------------------------------------------------------------------- edge cases of the whole-search kernels
