@@ -495,6 +495,79 @@ __device__ __forceinline__ void dot16x2_bcast(float x, const float (&u)[16], con
   rv = b;
 }
 
+
+// ---- interleaved chains ------------------------------------------------------------------------------------
+// Several neurons' fmac chains issued round-robin in ONE asm statement: consecutive instructions belong to
+// different accumulators, so none waits for its predecessor (a lone chain issues one dependent fmac every ~8
+// cycles on a SIMD that holds a single wave).  Per chain the k order -- and hence every bit -- is unchanged.
+// (An asm statement takes at most 30 operands: four K steps of five chains per statement.)
+#define MZX_FD_X(ACC, X, W, K) "v_fmac_f32_dpp " ACC ", " X ", " W " row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+
+// first layers of the three towers that follow the dynamics state: r1 <- s ; p1, v1 <- hn  (8 inputs each)
+__device__ __forceinline__ void dot8x3_bcast(float xs, float xh, const float (&wr)[8], const float (&wp)[8],
+                                             const float (&wv)[8], float& r, float& p, float& v) {
+  float a = 0.f, b = 0.f, c = 0.f;
+#define MZX_STEP3(K, J) MZX_FD_X("%[a]", "%[xs]", "%[r" #J "]", K) MZX_FD_X("%[b]", "%[xh]", "%[p" #J "]", K) MZX_FD_X("%[c]", "%[xh]", "%[v" #J "]", K)
+  asm("s_nop 1\n\t" MZX_STEP3(0, 0) MZX_STEP3(1, 1) MZX_STEP3(2, 2) MZX_STEP3(3, 3)
+      : [a] "+v"(a), [b] "+v"(b), [c] "+v"(c)
+      : [xs] "v"(xs), [xh] "v"(xh), [r0] "v"(wr[0]), [r1] "v"(wr[1]), [r2] "v"(wr[2]), [r3] "v"(wr[3]),
+        [p0] "v"(wp[0]), [p1] "v"(wp[1]), [p2] "v"(wp[2]), [p3] "v"(wp[3]),
+        [v0] "v"(wv[0]), [v1] "v"(wv[1]), [v2] "v"(wv[2]), [v3] "v"(wv[3]));
+  asm("s_nop 1\n\t" MZX_STEP3(4, 0) MZX_STEP3(5, 1) MZX_STEP3(6, 2) MZX_STEP3(7, 3)
+      : [a] "+v"(a), [b] "+v"(b), [c] "+v"(c)
+      : [xs] "v"(xs), [xh] "v"(xh), [r0] "v"(wr[4]), [r1] "v"(wr[5]), [r2] "v"(wr[6]), [r3] "v"(wr[7]),
+        [p0] "v"(wp[4]), [p1] "v"(wp[5]), [p2] "v"(wp[6]), [p3] "v"(wp[7]),
+        [v0] "v"(wv[4]), [v1] "v"(wv[5]), [v2] "v"(wv[6]), [v3] "v"(wv[7]));
+#undef MZX_STEP3
+  r = a; p = b; v = c;
+}
+
+// output layers of the three towers: (ra, rb) <- r1 ; pl <- p1 ; (va, vb) <- v1  (16 inputs each)
+__device__ __forceinline__ void dot16x5_bcast(float xr, float xp, float xv, const float (&ra)[16], const float (&rb)[16],
+                                              const float (&pw)[16], const float (&va)[16], const float (&vb)[16],
+                                              float& o_ra, float& o_rb, float& o_p, float& o_va, float& o_vb) {
+  float a = 0.f, b = 0.f, c = 0.f, d = 0.f, e = 0.f;
+#define MZX_STEP5(K, J)                                                                                             \
+  MZX_FD_X("%[a]", "%[xr]", "%[s" #J "]", K) MZX_FD_X("%[b]", "%[xr]", "%[t" #J "]", K) MZX_FD_X("%[c]", "%[xp]", "%[u" #J "]", K) \
+  MZX_FD_X("%[d]", "%[xv]", "%[w" #J "]", K) MZX_FD_X("%[e]", "%[xv]", "%[z" #J "]", K)
+#define MZX_BLOCK5(K0, K1, K2, K3, B)                                                                              \
+  asm("s_nop 1\n\t" MZX_STEP5(K0, 0) MZX_STEP5(K1, 1) MZX_STEP5(K2, 2) MZX_STEP5(K3, 3)                             \
+      : [a] "+v"(a), [b] "+v"(b), [c] "+v"(c), [d] "+v"(d), [e] "+v"(e)                                             \
+      : [xr] "v"(xr), [xp] "v"(xp), [xv] "v"(xv),                                                                    \
+        [s0] "v"(ra[B]), [s1] "v"(ra[B + 1]), [s2] "v"(ra[B + 2]), [s3] "v"(ra[B + 3]),                               \
+        [t0] "v"(rb[B]), [t1] "v"(rb[B + 1]), [t2] "v"(rb[B + 2]), [t3] "v"(rb[B + 3]),                               \
+        [u0] "v"(pw[B]), [u1] "v"(pw[B + 1]), [u2] "v"(pw[B + 2]), [u3] "v"(pw[B + 3]),                               \
+        [w0] "v"(va[B]), [w1] "v"(va[B + 1]), [w2] "v"(va[B + 2]), [w3] "v"(va[B + 3]),                               \
+        [z0] "v"(vb[B]), [z1] "v"(vb[B + 1]), [z2] "v"(vb[B + 2]), [z3] "v"(vb[B + 3]))
+  MZX_BLOCK5(0, 1, 2, 3, 0);
+  MZX_BLOCK5(4, 5, 6, 7, 4);
+  MZX_BLOCK5(8, 9, 10, 11, 8);
+  MZX_BLOCK5(12, 13, 14, 15, 12);
+#undef MZX_BLOCK5
+#undef MZX_STEP5
+  o_ra = a; o_rb = b; o_p = c; o_va = d; o_vb = e;
+}
+
+// two support_to_scalar decodes (value and reward heads) in one straight-line body: the two dependency chains
+// -- max butterfly, exp, sum butterfly, expectation, sum butterfly, inverse transform -- interleave.
+__device__ __forceinline__ void row_decode2x2(float a0, float a1, float b0, float b1, int F, int support, int sub,
+                                              float& out_a, float& out_b) {
+  const bool v0 = sub < F, v1 = sub + 16 < F;
+  const float ma = row_max(fmaxf(v0 ? a0 : -MZX_INF, v1 ? a1 : -MZX_INF));
+  const float mb = row_max(fmaxf(v0 ? b0 : -MZX_INF, v1 ? b1 : -MZX_INF));
+  const float ea0 = v0 ? mzx_expf(a0 - ma) : 0.f, ea1 = v1 ? mzx_expf(a1 - ma) : 0.f;
+  const float eb0 = v0 ? mzx_expf(b0 - mb) : 0.f, eb1 = v1 ? mzx_expf(b1 - mb) : 0.f;
+  float da = 0.f, db = 0.f;      // canonical lane partial: 0 + e[sub] + e[sub + 16]
+  da += ea0; db += eb0;
+  if (v1) { da += ea1; db += eb1; }
+  const float dena = row_sum(da), denb = row_sum(db);
+  float na = 0.f, nb = 0.f;
+  if (v0) { na += (float)(sub - support) * mzx_div(ea0, dena); nb += (float)(sub - support) * mzx_div(eb0, denb); }
+  if (v1) { na += (float)(sub + 16 - support) * mzx_div(ea1, dena); nb += (float)(sub + 16 - support) * mzx_div(eb1, denb); }
+  out_a = support_inverse_transform(row_sum(na));
+  out_b = support_inverse_transform(row_sum(nb));
+}
+
 template <int K, int I = 0>
 __device__ __forceinline__ float fma_bcast(float x, const float (&w)[K], float acc) {
   if constexpr (I < K) {
@@ -594,6 +667,19 @@ struct SmallNet {
     for (int x = 1; x < A; ++x) col = (action == x) ? w_d1[E + x] : col;
     const float d1 = mzx_elu((acc + col) + b_d1);
     const float s = dot_bcast<HD>(d1, w_d2) + b_d2;                // next state, unscaled (lane k < E)
+    if constexpr (E == 8 && HR == 16 && HP == 16 && HV == 16) {
+      // the three towers behind the dynamics state side by side (see dot8x3_bcast): same values, bit for bit
+      const float hn = scale(s, sub);
+      if (sub < E) h_out[sub] = hn;
+      float r1, p1, v1;
+      dot8x3_bcast(s, hn, w_r1, w_p1, w_v1, r1, p1, v1);          // the reward head reads the UNscaled state
+      r1 = mzx_elu(r1 + b_r1); p1 = mzx_elu(p1 + b_p1); v1 = mzx_elu(v1 + b_v1);
+      float ra, rb, pl, va, vb;
+      dot16x5_bcast(r1, p1, v1, w_r2a, w_r2b, w_p2, w_v2a, w_v2b, ra, rb, pl, va, vb);
+      o.policy = pl + b_p2;
+      row_decode2x2(va + b_v2a, vb + b_v2b, ra + b_r2a, rb + b_r2b, F, support, sub, o.value, o.reward);
+      return;
+    }
     const float r1 = mzx_elu(dot_bcast<E>(s, w_r1) + b_r1);         // reward head reads the UNscaled state
     float ra, rb;
     dot2_bcast<HR>(r1, w_r2a, w_r2b, ra, rb);

@@ -106,14 +106,42 @@ __device__ __forceinline__ double shl1_d(double v, double old) {
   return __hiloint2double(shl1_i(__double2hiint(v), __double2hiint(old)), shl1_i(__double2loint(v), __double2loint(old)));
 }
 
+// One step of the value recurrence  value = (+-reward) + discount * value  (self_play.py:417 / :424-427) at path
+// lane J: the lane notes the value arriving at its node, every lane advances the row-uniform value.  Rows whose
+// leaf is above lane J (J > ld) keep theirs -- a select, no exec-mask branch.
 template <int J>
 __device__ __forceinline__ void chain_step2(double r_eff, double disc, int ld, int sub, double& val, double& my_in) {
-  if (J <= ld) {  // row-uniform
-    const double rj = bcast_d<J>(r_eff);
-    if (sub == J) my_in = val;
-    val = rj + disc * val;
+  const double rj = bcast_d<J>(r_eff);
+  const double nv = rj + disc * val;
+  my_in = (sub == J) ? val : my_in;
+  val = (J <= ld) ? nv : val;
+}
+// Steps 15 .. 1 in groups guarded by the deepest row of the wave (wmax, wave-uniform: plain scalar branches, no
+// exec masking); a step above a row's own leaf is a no-op by its select, so a group may run a step too many.
+__device__ __forceinline__ void value_chain(double r_eff, double disc, int ld, int sub, int wmax, double& val, double& my_in) {
+  if (wmax >= 13) {
+    chain_step2<15>(r_eff, disc, ld, sub, val, my_in);
+    chain_step2<14>(r_eff, disc, ld, sub, val, my_in);
+    chain_step2<13>(r_eff, disc, ld, sub, val, my_in);
   }
-  if constexpr (J > 1) chain_step2<J - 1>(r_eff, disc, ld, sub, val, my_in);
+  if (wmax >= 9) {
+    chain_step2<12>(r_eff, disc, ld, sub, val, my_in);
+    chain_step2<11>(r_eff, disc, ld, sub, val, my_in);
+    chain_step2<10>(r_eff, disc, ld, sub, val, my_in);
+    chain_step2<9>(r_eff, disc, ld, sub, val, my_in);
+  }
+  if (wmax >= 7) {
+    chain_step2<8>(r_eff, disc, ld, sub, val, my_in);
+    chain_step2<7>(r_eff, disc, ld, sub, val, my_in);
+  }
+  if (wmax >= 5) {
+    chain_step2<6>(r_eff, disc, ld, sub, val, my_in);
+    chain_step2<5>(r_eff, disc, ld, sub, val, my_in);
+  }
+  if (wmax >= 4) chain_step2<4>(r_eff, disc, ld, sub, val, my_in);
+  if (wmax >= 3) chain_step2<3>(r_eff, disc, ld, sub, val, my_in);
+  if (wmax >= 2) chain_step2<2>(r_eff, disc, ld, sub, val, my_in);
+  if (wmax >= 1) chain_step2<1>(r_eff, disc, ld, sub, val, my_in);
 }
 
 template <class Net, int AW, bool PROFILE>
@@ -214,8 +242,10 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
     // -inf and n = 0, so their score is -inf without a validity test in the walk.  A row that has reached its
     // leaf keeps executing with its state frozen (one straight-line body per level for the whole wave).
     int node = 0, depth = 0, slot = 0;
+    int levels = 0;                  // walk iterations = depth of the deepest leaf in this wave (scalar)
     bool done = false;
     for (;;) {
+      ++levels;
       const Fc2Slot* rp = slots + (node * AW + (sub & (AW - 1)));
       const double ps = rp->ps, q = rp->q;
       const int n = rp->n, c = rp->child;
@@ -260,18 +290,18 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
     }
     // players play turn by turn (self_play.py:331-334): the leaf's player follows from the depth
     const int vtp = (P == 1) ? 0 : ((root_to_play + depth) & 1);
+    MZX_PROF(2)
     int leaf = n_nodes;
     if (leaf >= NN) { flags |= TF_NODE_OVERFLOW; leaf = NN - 1; }
     if (sub == 0) path[depth] = make_int2(leaf, slot);
     const int parent = node;
     const int ra = roota[slot < AW ? slot : 0];
     const int action = (parent == 0) ? ra : slot;
-    int cmax = 0;
-    while (__any((depth >> 4) > cmax)) ++cmax;   // wave-uniform number of 16-level chunks - 1 (0 unless a path is > 15 deep)
+    const int cmax = levels >> 4;    // wave-uniform number of 16-level chunks - 1 (0 unless a path is > 15 deep)
     wave_sync();
 
-    // Everything back-propagation needs from the tree is independent of the network: fetched NOW, so that the
-    // LDS latency hides behind recurrent_inference.  Lane j of a chunk owns the path node at depth 16 c + j.
+    // Everything back-propagation needs from the tree is independent of the network: complete before it, so that
+    // the LDS latency hides behind recurrent_inference.  Lane j of a chunk owns the path node at depth 16 c + j.
     struct PathLane {
       int nd, pslot, par, vc, tp;
       double vs, rr, inv_vc2, inv_vc3, pb, sv;
@@ -308,7 +338,7 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
       return L;
     };
     PathLane L = load_lane(cmax);
-    MZX_PROF(2)
+    MZX_PROF(7)
 
     // ------------------------------------------------------------- recurrent_inference (models.py:192-195)
     NetOut o;
@@ -348,9 +378,11 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
       const bool same = (L.tp == vtp);
       const double r_eff = (P == 1 || !same) ? rr : -rr;   // value = (+-reward) + discount * value
       double my_in = val;
-      chain_step2<FUSED_ROW - 1>(r_eff, disc, ld, sub, val, my_in);
+      const int wm = levels - c * 16;             // deepest leaf of the wave relative to this chunk (wave-uniform)
+      value_chain(r_eff, disc, ld, sub, wm > 15 ? 15 : (wm < 0 ? 0 : wm), val, my_in);
       if (sub == 0) my_in = val;
       if (c > 0 && ld >= 0) val = bcast_d<0>(r_eff) + disc * val;   // hand the value to the chunk above
+      MZX_PROF(8)
       const int vc2 = L.vc + 1;
       const double vs2 = L.vs + ((P == 1 || same) ? my_in : -my_in);
       double qv = 0.0;

@@ -14,7 +14,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mzx import configs, models, self_play, synthetic  # noqa: E402
 
-PHASES = ["setup/stage", "initial+root", "select", "recurrent net", "priors+expand", "attach+backprop", "finalize"]
+PHASES = ["setup/stage", "initial+root", "select", "recurrent net", "priors+expand", "attach+backprop", "finalize",
+          "path prefetch (v2)", "value chain (v2)"]
 
 
 def main():
@@ -42,8 +43,8 @@ def main():
     print(f"trees {B}  sims {S}  mean leaf depth {res.sum_depth.mean() / S:.2f}  engine {'LdsNet' if args.lds else 'auto'}{' (v1 kernel)' if args.v1 else ''}")
     for k, name in enumerate(PHASES):
         c = raw[:, k].mean()
-        per = c / S if k in (2, 3, 4, 5) else c
-        print(f"  {name:18s} {c:12.0f} cycles/tree  ({100 * c / total:5.1f}%)" + (f"   {per:8.0f} per simulation" if k in (2, 3, 4, 5) else ""))
+        per = c / S if k in (2, 3, 4, 5, 7, 8) else c
+        print(f"  {name:18s} {c:12.0f} cycles/tree  ({100 * c / total:5.1f}%)" + (f"   {per:8.0f} per simulation" if k in (2, 3, 4, 5, 7, 8) else ""))
     print(f"  total              {total:12.0f} cycles/tree  = {total / 2.4e3:.1f} us at 2.4 GHz")
 
 
