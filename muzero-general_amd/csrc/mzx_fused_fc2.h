@@ -516,8 +516,11 @@ inline Fc2Plan fc2_plan(const mzx_search* s, bool allow_small = true) {
   a.off_scratch = (int32_t)t; t += int64_t(4) * (P.small ? 16 : FUSED_SCRATCH);
   // the four rows of a wave touch the same offsets of four consecutive slabs in one instruction:
   // keep the slab stride off the multiples of 256 bytes so that they land in different bank groups
+  // (bank = (address / 4) mod 64): a stride of 64 (mod 256) bytes puts the rows' records into four different
+  // bank groups; with 0 or 128 (mod 256) two rows collide on every access (measured: 43 % of the LDS cycles
+  // were bank conflicts at a stride of 128 mod 256, profiles/r02_rocprof_fc2_c2.txt)
   t = al16(t);
-  if (t % 256 < 32 || t % 256 > 224) t += 64;
+  t += (64 - t % 256 + 256) % 256;
   a.tree_stride = (int32_t)t;
   int tpb = 16;
   while (tpb >= 4 && o + int64_t(tpb) * a.tree_stride > FUSED_LDS_BUDGET) tpb /= 2;

@@ -94,3 +94,33 @@ def test_lazy_shard_histories_behave_like_game_history(backend):
         assert all(numpy.array_equal(x, y) for x, y in zip(c.observation_history, b.observation_history))
         a.root_values.append(1.5)                              # a real list from now on
         assert a.root_values[-1] == 1.5 and len(a.root_values) == len(b.root_values) + 1
+
+
+@pytest.mark.parametrize("temperature,threshold", [(1.0, None), (0.5, 3)])
+def test_shard_of_board_games_with_ragged_legal_sets(backend, temperature, threshold):
+    """
+    Tic-tac-toe through the plugin surface: legal-action lists shrink and differ between the games of a shard,
+    games end at different moves -- the shard path must still equal independent single-game actors.
+    """
+    import games_fixture
+
+    cfg = configs.tictactoe(num_simulations=10, temperature_threshold=threshold)
+    Game = games_fixture.GAMES["tictactoe"]
+    template = models.MuZeroNetwork(cfg, _backend=backend).state_dict()
+    weights = synthetic.fill_state_dict(template, 21)
+    B, seed = 6, 70
+    shard = self_play.SelfPlay({"weights": weights}, Game, cfg, seed, num_games=B, _backend=backend)
+    histories = shard.play_games(temperature, cfg.temperature_threshold, False, "self", 0)
+    lengths = set()
+    for i in range(B):
+        single = self_play.SelfPlay({"weights": weights}, Game, cfg, seed + i, _backend=backend)
+        want = single.play_game(temperature, cfg.temperature_threshold, False, "self", 0)
+        got = histories[i]
+        assert [int(a) for a in got.action_history] == [int(a) for a in want.action_history], i
+        assert got.reward_history == want.reward_history and got.to_play_history == want.to_play_history
+        assert got.child_visits == want.child_visits
+        assert numpy.array_equal(numpy.array(got.root_values).view(numpy.int64), numpy.array(want.root_values).view(numpy.int64))
+        for a, b in zip(got.observation_history, want.observation_history):
+            assert numpy.array_equal(numpy.array(a), numpy.array(b))
+        lengths.add(len(got.action_history))
+    assert len(lengths) > 1, "the games of the shard should end at different moves for this test to mean anything"
