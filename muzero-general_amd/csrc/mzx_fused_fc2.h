@@ -518,7 +518,7 @@ inline Fc2Plan fc2_plan(const mzx_search* s, bool allow_small = true) {
   // keep the slab stride off the multiples of 256 bytes so that they land in different bank groups
   // (bank = (address / 4) mod 64): a stride of 64 (mod 256) bytes puts the rows' records into four different
   // bank groups; with 0 or 128 (mod 256) two rows collide on every access (measured: 43 % of the LDS cycles
-  // were bank conflicts at a stride of 128 mod 256, profiles/r02_rocprof_fc2_c2.txt)
+  // were bank conflicts at a stride of 128 mod 256, profiles/r02_rocprof_fc2_c2_v1.txt)
   t = al16(t);
   t += (64 - t % 256 + 256) % 256;
   a.tree_stride = (int32_t)t;
