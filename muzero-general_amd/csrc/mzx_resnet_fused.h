@@ -1260,7 +1260,11 @@ struct RzStemArgs {
   uint32_t magic_pwin, magic_tw, magic_cells, magic_rows;   // ceil(2^32 / d): divisions by multiplication (rz_div)
 };
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) rz_stem_conv_kernel(const RzStemArgs sa) {
+// Occupancy: the kernel is a chain of memory phases (tile gather, residual gather, write-back) around one GEMM
+// phase, separated by workgroup barriers -- alone on a CU it exposes every one of those latencies (measured
+// ~21 us per 16 x 16 tile at 48 x 48 x 8, 89 % of a breakout Reanalyse pass).  Registers are capped so that two or
+// three workgroups share a CU (their LDS tiles are sized for it, rz_stem_launch) and overlap each other's phases.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) rz_stem_conv_kernel(const RzStemArgs sa) {
   extern __shared__ __attribute__((aligned(16))) float rz_lds[];
   const int tid = threadIdx.x;
   const int tile = blockIdx.x, b = blockIdx.y;
@@ -1353,7 +1357,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   cx.reg = reg; cx.rowaddr = rowaddr; cx.rowtp = rowtp; cx.rowout = rowout; cx.scratch = params; cx.simg = params;
   cx.wlds = nullptr; cx.T = 1; cx.tid = tid; cx.lane = tid & 63; cx.wave = tid >> 6; cx.fine = nullptr;
   cx.work = nullptr;
-  rz_gemm<false, 4, 8>(sa.op, a, cx, rz_work_word(sa.op, 1, rows, 4, tid >> 6));
+  rz_gemm<false, 4, 4>(sa.op, a, cx, rz_work_word(sa.op, 1, rows, 4, tid >> 6));   // at most 256 rows = 4 row tiles per wave
   __syncthreads();
   // ---- write back, coalesced along x
   {
@@ -1383,7 +1387,10 @@ inline int rz_stem_launch(const mzx_net* net, const RzStemConv& sc, const OpDesc
   RzStemArgs sa;
   memset(&sa, 0, sizeof(sa));
   sa.cin = d.cin; sa.cout = d.cout; sa.hin = d.hin; sa.win = d.win; sa.hout = d.hout; sa.wout = d.wout; sa.stride = d.stride;
-  sa.Cs = rz_round16(std::max(d.cin, d.cout)) + 8;
+  // floats per position: whole 16-channel K chunks + 4.  A row stride of 16 c + 4 words keeps the 16-byte reads of
+  // 16 consecutive rows on distinct banks (20 k mod 64, k = 0..15, are 16 disjoint 4-word ranges) at 5/6 of the
+  // LDS of the engine's 16 c + 8 layout: three workgroups per CU fit at the 8- and 16-channel stages
+  sa.Cs = rz_round16(std::max(d.cin, d.cout)) + 4;
   // output tile: up to 256 positions (16 MFMA row tiles over 4 waves), halo'ed input tile beside it in LDS
   sa.TW = std::min(16, d.wout);
   sa.TH = std::min(256 / sa.TW, d.hout);

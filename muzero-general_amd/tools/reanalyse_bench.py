@@ -4,7 +4,9 @@ stacking of every position, ONE batched initial_inference, value decode, downloa
 
     python muzero-general_amd/tools/reanalyse_bench.py [--repeat 5]
 
-One JSON line per configuration: positions/s and the initial_inference FLOP rate it corresponds to.
+One JSON line per configuration: positions/s and the initial_inference FLOP rate it corresponds to (wall clock of
+the whole step incl. the upload of the frames), and the FLOP rate of the batched initial_inference alone on
+observations already resident in HBM (HIP events).
 """
 import argparse
 import json
@@ -43,8 +45,20 @@ def main():
             values = worker.reanalyse_game(gh)
         dt = (time.perf_counter() - t0) / args.repeat
         flops = worker.model.backend.lib.mzx_net_flops(worker.model.handle, 0)
+        # the batched initial_inference alone, observations already stacked in HBM (no upload / download): HIP events
+        obs = torch.rand((T,) + tuple(worker.model.input_shape), device=worker.model.backend.device)
+        worker.model.initial_inference(obs)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(args.repeat):
+            worker.model.initial_inference(obs)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / args.repeat
         print(json.dumps({"config": name, "overrides": kw, "positions": T, "ms_per_game": round(dt * 1e3, 3),
                           "positions_per_s": round(T / dt, 1), "initial_inference_TFLOPs": round(T * flops / dt / 1e12, 3),
+                          "device_resident_ms": round(ms, 3),
+                          "device_resident_initial_inference_TFLOPs": round(T * flops / (ms * 1e-3) / 1e12, 3),
                           "finite": bool(numpy.isfinite(values).all())}))
 
 
