@@ -366,9 +366,27 @@ struct LdsNet {
   const float* W;
   const FusedFcArgs* a;
 
+  // Weights go to LDS TRANSPOSED, [K][O] per layer at the flat buffer's own offsets: lane o of a row then reads
+  // element k of ITS neuron at k * O + o -- consecutive lanes, consecutive words.  In the state_dict's [O][K]
+  // order the 16 lanes of a row are K words apart: for K = 64 (games/lunarlander.py:69-74) all of them hit one
+  // bank and every weight read is a 16-way conflict.
+  __device__ __forceinline__ void stage_mlp(const FusedMlp& m, const float* flat, float* w, int tid) {
+    for (int l = 0; l < m.n; ++l) {
+      const int K = m.sizes[l], O = m.sizes[l + 1], base = m.w[l];
+      for (int i = tid; i < O * K; i += blockDim.x) {
+        const int o = i / K, k = i - o * K;
+        w[base + k * O + o] = flat[base + i];
+      }
+      for (int i = tid; i < O; i += blockDim.x) w[m.b[l] + i] = flat[m.b[l] + i];
+    }
+  }
   __device__ __forceinline__ void stage(const FusedFcArgs& args, char* smem, int tid) {
     float* w = (float*)(smem + args.lds_weights);
-    for (int i = tid; i < args.n_params; i += blockDim.x) w[i] = args.flat[i];
+    stage_mlp(args.rep, args.flat, w, tid);
+    stage_mlp(args.dyn, args.flat, w, tid);
+    stage_mlp(args.rew, args.flat, w, tid);
+    stage_mlp(args.pol, args.flat, w, tid);
+    stage_mlp(args.val, args.flat, w, tid);
   }
   __device__ __forceinline__ void setup(const FusedFcArgs& args, char* smem, int) {
     W = (const float*)(smem + args.lds_weights);
@@ -385,10 +403,16 @@ struct LdsNet {
       const bool last = (l == m.n - 1);
       float* y = last ? out : ((l & 1) ? tmp1 : tmp0);
       for (int o = sub; o < O; o += FUSED_ROW) {
-        const float* wr = W + m.w[l] + o * K;
+        const float* wr = W + m.w[l] + o;      // transposed: element k of neuron o at k * O
         float acc = 0.f;
-        for (int k = 0; k < Kx; ++k) acc = fmaf(x[k], wr[k], acc);
-        if (l == 0 && onehot) acc += wr[Kx + action];
+        int k = 0;
+        for (; k + 4 <= Kx; k += 4) {          // four independent loads each of x and w in flight, one fmaf chain
+          const float x0 = x[k], x1 = x[k + 1], x2 = x[k + 2], x3 = x[k + 3];
+          const float w0 = wr[k * O], w1 = wr[(k + 1) * O], w2 = wr[(k + 2) * O], w3 = wr[(k + 3) * O];
+          acc = fmaf(x0, w0, acc); acc = fmaf(x1, w1, acc); acc = fmaf(x2, w2, acc); acc = fmaf(x3, w3, acc);
+        }
+        for (; k < Kx; ++k) acc = fmaf(x[k], wr[k * O], acc);
+        if (l == 0 && onehot) acc += wr[(Kx + action) * O];
         acc += W[m.b[l] + o];
         y[o] = last ? acc : mzx_elu(acc);
       }
