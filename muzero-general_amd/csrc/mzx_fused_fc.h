@@ -393,8 +393,53 @@ struct LdsNet {
     a = &args;
   }
 
+  // One Linear layer for the neurons o0, o0 + 16, ..., o0 + 16 (G - 1) of this lane (G = 1, 2 or 4 by the layer's
+  // width): the input value x[k] is loaded once and feeds G independent fmaf chains, so wide layers (the 64-wide
+  // hidden layers of games/lunarlander.py) cost a quarter of the x loads and their chains overlap.  Per neuron
+  // the k order -- the sequential fmaf chain of LinearOp (mzx_ops.h) -- is unchanged.  Reads of neurons beyond O
+  // stay inside LDS and their results are discarded.
+  template <int G>
+  __device__ __forceinline__ void layer(const float* wl, const float* bl, const float* x, float* y, int K, int Kx, int O,
+                                        int sub, int action, bool onehot, bool last) const {
+    for (int o0 = sub; o0 < O; o0 += G * FUSED_ROW) {
+      const float* wr = wl + o0;      // transposed: element k of neuron o at k * O + o
+      float acc[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) acc[j] = 0.f;
+      int k = 0;
+      constexpr int U = (G == 1) ? 8 : 4;   // k values per trip: U x loads + U * G w loads in flight
+      for (; k + U <= Kx; k += U) {
+        float xv[U], wv[U][G];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          xv[u] = x[k + u];
+#pragma unroll
+          for (int j = 0; j < G; ++j) wv[u][j] = wr[(k + u) * O + j * FUSED_ROW];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int j = 0; j < G; ++j) acc[j] = fmaf(xv[u], wv[u][j], acc[j]);
+      }
+      for (; k < Kx; ++k) {
+        const float xk = x[k];
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[j] = fmaf(xk, wr[k * O + j * FUSED_ROW], acc[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int o = o0 + j * FUSED_ROW;
+        if (o < O) {
+          float v = acc[j];
+          if (onehot) v += wr[(Kx + action) * O + j * FUSED_ROW];
+          v += bl[o];
+          y[o] = last ? v : mzx_elu(v);
+        }
+      }
+    }
+  }
+
   // One MLP (models.py:630-642): x = K0 floats readable by every lane; result in `out`.
-  // Same per-neuron operation order as LinearOp (mzx_ops.h).
   __device__ __forceinline__ void mlp(const FusedMlp& m, const float* x, float* tmp0, float* tmp1, float* out, int sub,
                                       int action, int onehot) const {
     for (int l = 0; l < m.n; ++l) {
@@ -402,20 +447,12 @@ struct LdsNet {
       const int Kx = (l == 0) ? K - onehot : K;
       const bool last = (l == m.n - 1);
       float* y = last ? out : ((l & 1) ? tmp1 : tmp0);
-      for (int o = sub; o < O; o += FUSED_ROW) {
-        const float* wr = W + m.w[l] + o;      // transposed: element k of neuron o at k * O
-        float acc = 0.f;
-        int k = 0;
-        for (; k + 4 <= Kx; k += 4) {          // four independent loads each of x and w in flight, one fmaf chain
-          const float x0 = x[k], x1 = x[k + 1], x2 = x[k + 2], x3 = x[k + 3];
-          const float w0 = wr[k * O], w1 = wr[(k + 1) * O], w2 = wr[(k + 2) * O], w3 = wr[(k + 3) * O];
-          acc = fmaf(x0, w0, acc); acc = fmaf(x1, w1, acc); acc = fmaf(x2, w2, acc); acc = fmaf(x3, w3, acc);
-        }
-        for (; k < Kx; ++k) acc = fmaf(x[k], wr[k * O], acc);
-        if (l == 0 && onehot) acc += wr[(Kx + action) * O];
-        acc += W[m.b[l] + o];
-        y[o] = last ? acc : mzx_elu(acc);
-      }
+      const float* wl = W + m.w[l];
+      const float* bl = W + m.b[l];
+      const bool oh = (l == 0 && onehot);
+      if (O > 2 * FUSED_ROW) layer<4>(wl, bl, x, y, K, Kx, O, sub, action, oh, last);
+      else if (O > FUSED_ROW) layer<2>(wl, bl, x, y, K, Kx, O, sub, action, oh, last);
+      else layer<1>(wl, bl, x, y, K, Kx, O, sub, action, oh, last);
       wave_sync();
       x = y;
     }

@@ -23,11 +23,12 @@ def main():
     ap.add_argument("--trees", type=int, default=4096)
     ap.add_argument("--lds", action="store_true", help="force the LDS-weight engine")
     ap.add_argument("--v1", action="store_true", help="first-generation fully connected kernel (mode flag 16)")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "lunarlander"],
+                    help="lunarlander: games/lunarlander.py shape (encoding 10, 64-wide hidden layers, 4 actions) on the LDS-weight engine")
     args = ap.parse_args()
-    if args.workload != "c2":
+    if args.workload not in ("c2", "lunarlander"):
         return residual(args)
-    cfg = configs.cartpole()
+    cfg = configs.cartpole() if args.workload == "c2" else configs.lunarlander()
     B = args.trees
     net = models.MuZeroNetwork(cfg)
     net.set_weights(synthetic.fill_state_dict(net.state_dict(), 0))
