@@ -390,6 +390,35 @@ def make_game_fixture(name, game, weight_seed, seed, overrides=None, synthetic_g
     print("game", name, "moves", len(gh.action_history) - 1)
 
 
+def make_replay_batch_fixture():
+    """
+    ReplayBuffer.get_batch of the UNMODIFIED reference (replay_buffer.py:70-138) on seeded games: sampled
+    (game, position) pairs, targets, PER weights, stacked observations -- what mzx.replay.ReplayBuffer must
+    reproduce element for element (tests/test_replay_batch.py builds the same games from the same seeds).
+    """
+    ref_shim.load()
+    import replay_buffer as ref_rb
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    import test_replay_batch as t
+
+    cases, data = [], {}
+    for c, (per, players, stacked) in enumerate(t.CASES):
+        config = t.config_for(per, players, stacked)
+        case = dict(per=per, players=players, stacked=stacked, games_seed=40 + c, n_games=8, rounds=3, seed0=500 + 10 * c)
+        rb = ref_rb.ReplayBuffer({"num_played_games": 0, "num_played_steps": 0}, {}, config)
+        for gh in t.make_games(case["games_seed"], case["n_games"], players):
+            rb.save_game(gh)
+        for r in range(case["rounds"]):
+            numpy.random.seed(case["seed0"] + r)
+            for k, v in t.as_arrays(rb.get_batch()).items():
+                if v is not None:
+                    data[f"c{c}_r{r}_{k}"] = v
+        cases.append(case)
+    data["meta"] = numpy.array(json.dumps(dict(cases=cases)))
+    numpy.savez_compressed(os.path.join(OUT, "replay_batch.npz"), **data)
+    print("replay batch cases", len(cases))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     full = lambda c, cfg: list(cfg.action_space)
@@ -462,6 +491,7 @@ def main():
     # searches from caller-expanded roots (override_root_with), the diagnose_model.py virtual trajectory
     make_virtual_fixture("cartpole", "cartpole", 41, 3, 4)
     make_virtual_fixture("tictactoe", "tictactoe", 42, 4, 3)
+    make_replay_batch_fixture()
 
 
 if __name__ == "__main__":
