@@ -55,12 +55,18 @@ def test_bench_single_rank_dry_run_with_second_workload():
 
 def test_cpu_baseline_workers_reference_and_port():
     sys.path.insert(0, ROOT)
+    import torch
+
     import bench
     from oracle import build_ref
 
-    sims, searches, wall = bench._cpu_worker_port(("c2", 0, 0.5))
-    assert searches >= 1 and sims == 50 * searches and wall > 0
-    if not build_ref.available():
-        pytest.skip("oracle/_ref not built (no /root/reference at build time)")
-    sims, searches, wall = bench._cpu_worker_reference(("c2", 0, 0.5))
-    assert searches >= 1 and sims == 50 * searches and wall > 0
+    threads = torch.get_num_threads()     # the workers pin torch to one thread (one process per core in the bench):
+    try:                                  # restore it, ATen's convolutions are not bit-reproducible across thread counts
+        sims, searches, wall = bench._cpu_worker_port(("c2", 0, 0.5))
+        assert searches >= 1 and sims == 50 * searches and wall > 0
+        if not build_ref.available():
+            pytest.skip("oracle/_ref not built (no /root/reference at build time)")
+        sims, searches, wall = bench._cpu_worker_reference(("c2", 0, 0.5))
+        assert searches >= 1 and sims == 50 * searches and wall > 0
+    finally:
+        torch.set_num_threads(threads)
