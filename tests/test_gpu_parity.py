@@ -150,6 +150,18 @@ def _compare_sample_with_oracle(cfg, sd, res, obs, legal, to_play, seeds, sample
     traces = _device_trace(engine_factory, cfg, [obs[i] for i in sample], [legal[i] for i in sample],
                            [to_play[i] for i in sample], [seeds[i] for i in sample])
     identical = roots_equal = 0
+    # batch-1 inferences of small convolutions: one torch thread is an order of magnitude faster than a 64-core
+    # box's default pool (325 s -> tens of seconds for the connect4 sample)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        return _compare_loop(cfg, res, obs, legal, to_play, seeds, sample, traces, onet, value_tol, label)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _compare_loop(cfg, res, obs, legal, to_play, seeds, sample, traces, onet, value_tol, label):
+    identical = roots_equal = 0
     for i, got in zip(sample, traces):
         ev = net_oracle.NetworkEvaluator(onet, cfg.support_size)
         tree = mcts_oracle.run_search(cfg, ev, obs[i], legal[i], to_play[i], True, numpy.random.RandomState(seeds[i]))
