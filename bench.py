@@ -79,7 +79,7 @@ def parse():
                     help="residual networks: fused MFMA engine (default) or one kernel per operator")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall budget of each CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=None)
-    ap.add_argument("--selfplay-moves", type=int, default=16,
+    ap.add_argument("--selfplay-moves", type=int, default=32,
                     help="moves per game of the end-to-end self-play legs (SelfPlay(num_games=B) on the synthetic game; "
                          "0 = skip); the games of the path's configurations run for hundreds of moves (cartpole: 500)")
     ap.add_argument("--dry-run", action="store_true",

@@ -521,7 +521,7 @@ int mzx_rng_root_draws(mzx_rng* r, const int32_t* idx, int32_t count, double alp
   if (noise)
     for (int32_t k = 0; k < count; ++k)
       if (n_legal[k] < 1 || n_legal[k] > action_space_size) { set_error("n_legal[%d] = %d out of range", k, n_legal[k]); return MZX_ERR_INVALID; }
-  rng_parallel(count, n_threads, [=](int lo, int hi) {
+  rng_parallel(r, count, n_threads, [=](int lo, int hi) {
     for (int k = lo; k < hi; ++k) {
       Mt19937& m = r->streams[idx[k]];
       if (noise) {  // RandomState.dirichlet([alpha] * n): gammas, then multiplication by 1 / sum

@@ -24,6 +24,10 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -156,24 +160,87 @@ struct Mt19937 {
 
 }  // namespace mzx
 
+namespace mzx {
+
+// A few persistent worker threads: the per-move draws of a shard (4 096 Dirichlet samples, ~2 us each) are worth
+// spreading over cores, but creating and joining std::threads on every move costs more than the draws themselves
+// (~30 us per thread).  Workers sleep on a condition variable between moves.
+class RngPool {
+ public:
+  explicit RngPool(int n) : stop_(false), generation_(0), pending_(0) {
+    for (int t = 0; t < n; ++t) workers_.emplace_back([this, t]() { loop(t); });
+  }
+  ~RngPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+      ++generation_;
+    }
+    cv_.notify_all();
+    for (std::thread& th : workers_) th.join();
+  }
+  int size() const { return (int)workers_.size(); }
+  // fn(lo, hi) over [0, count) split into size() + 1 pieces (the caller's thread takes one)
+  void run(int count, const std::function<void(int, int)>& fn) {
+    const int parts = size() + 1, per = (count + parts - 1) / parts;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn; count_ = count; per_ = per; pending_ = size();
+      ++generation_;
+    }
+    cv_.notify_all();
+    const int lo = size() * per;
+    if (lo < count) fn(lo, count);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this]() { return pending_ == 0; });
+  }
+
+ private:
+  void loop(int t) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int, int)>* fn;
+      int lo, hi;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&]() { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) return;
+        fn = fn_;
+        lo = t * per_; hi = lo + per_ < count_ ? lo + per_ : count_;
+      }
+      if (lo < hi) (*fn)(lo, hi);
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (--pending_ == 0) done_.notify_one();
+      }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  bool stop_;
+  uint64_t generation_;
+  int pending_, count_ = 0, per_ = 0;
+  const std::function<void(int, int)>* fn_ = nullptr;
+};
+
+}  // namespace mzx
+
 struct mzx_rng {
   std::vector<mzx::Mt19937> streams;
+  std::unique_ptr<mzx::RngPool> pool;   // created on the first large parallel call
 };
 
 namespace mzx {
 
 template <class Fn>
-inline void rng_parallel(int count, int n_threads, Fn fn) {
+inline void rng_parallel(mzx_rng* r, int count, int n_threads, Fn fn) {
   if (n_threads <= 1 || count < 256) { fn(0, count); return; }
   if (n_threads > 64) n_threads = 64;
-  std::vector<std::thread> pool;
-  const int per = (count + n_threads - 1) / n_threads;
-  for (int t = 0; t < n_threads; ++t) {
-    const int lo = t * per, hi = lo + per < count ? lo + per : count;
-    if (lo >= hi) break;
-    pool.emplace_back([=]() { fn(lo, hi); });
-  }
-  for (std::thread& th : pool) th.join();
+  if (!r->pool || r->pool->size() != n_threads - 1) r->pool.reset(new RngPool(n_threads - 1));
+  const std::function<void(int, int)> f = fn;
+  r->pool->run(count, f);
 }
 
 }  // namespace mzx

@@ -26,7 +26,7 @@ class StreamBank:
         self.handle = ctypes.c_void_p()
         lib.check(lib.mzx_rng_create(self.n, ctypes.byref(self.handle)))
         lib.check(lib.mzx_rng_seed(self.handle, 0, self.n, _ptr(seeds)))
-        self.threads = max(1, min(32, (os.cpu_count() or 1) // 2))
+        self.threads = max(1, min(16, (os.cpu_count() or 1) // 2))     # persistent native workers (csrc/mzx_rng.h)
 
     def __del__(self):
         try:

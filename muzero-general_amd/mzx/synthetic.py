@@ -88,6 +88,7 @@ def make_synthetic_game(observation_shape, num_actions, num_players=1):
     shape = tuple(observation_shape)
     size = int(numpy.prod(shape))
     lane = numpy.arange(size, dtype=numpy.uint64)
+    legal = list(range(num_actions))
 
     class SyntheticGame:
         def __init__(self, seed=None):
@@ -121,7 +122,7 @@ def make_synthetic_game(observation_shape, num_actions, num_players=1):
             return self.player
 
         def legal_actions(self):
-            return list(range(num_actions))
+            return legal           # every action is always legal: one shared list (callers must not mutate it)
 
         def render(self):
             print(f"SyntheticGame t={self.t} key={self.key:08x}")
