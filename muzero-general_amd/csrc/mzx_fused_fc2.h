@@ -144,6 +144,233 @@ __device__ __forceinline__ void value_chain(double r_eff, double disc, int ld, i
   if (wmax >= 1) chain_step2<1>(r_eff, disc, ld, sub, val, my_in);
 }
 
+
+// ---------------------------------------------------------------------------
+// The tree side of one simulation as row-collective functions over LDS records (one 16-lane row per tree): used by
+// the fully connected kernel below and by the residual whole-search kernel (mzx_resnet_search.h) when its trees
+// are LDS-resident.
+
+struct Fc2Tree {              // LDS views of one tree + the workgroup's tables
+  Fc2Slot* slots;             // [NN][AW]
+  Fc2Node* nodes;             // [NN]
+  int2* path;                 // [NN + 1]: {node at depth d, slot taken from its parent}
+  int32_t* roota;             // [AW]: action of root slot s
+  double* mm;                 // MinMaxStats {minimum, maximum}: updated by LDS min / max
+  const double *pbc, *sqt, *inv_y;
+  double pb_leaf, disc;       // pb_c(N = 1, n = 0): prior-score factor of a fresh leaf's slots
+  int A, NN, P;
+};
+struct Fc2Row { int32_t n_nodes, tape_pos, flags, ties, max_depth, sum_depth, root_n, root_to_play; };
+struct Fc2Walk { int parent, slot, leaf, depth, levels, vtp, action; };
+
+// Selection walk (self_play.py:325-334, :363-404).  Slots that do not exist (root slots beyond the legal actions,
+// padding up to AW) carry a prior score of -inf and n = 0, so their score is -inf without a validity test.  A row
+// that has reached its leaf keeps executing with its state frozen (one straight-line body per level per wave).
+template <int AW>
+__device__ __forceinline__ Fc2Walk fc2_walk(const Fc2Tree& T, Fc2Row& st, const uint32_t* tape, int tape_words, int sub,
+                                            int row_in_wave) {
+  const double2 mmv = *(const double2*)T.mm;   // MinMaxStats after the previous back-propagation
+  const double mn = mmv.x, mx = mmv.y;
+  const double dd = mx - mn;                 // MinMaxStats.normalize divisor, same for every node of this walk
+  const double yd = recip_refined(dd);       // (garbage while max <= min: results discarded like the reference's branch)
+  const bool norm_on = mx > mn;
+  int node = 0, depth = 0, slot = 0;
+  int levels = 0;                  // walk iterations = depth of the deepest leaf in this wave (scalar)
+  bool done = false;
+  for (;;) {
+    ++levels;
+    const Fc2Slot* rp = T.slots + (node * AW + (sub & (AW - 1)));
+    const double ps = rp->ps, q = rp->q;
+    const int n = rp->n, c = rp->child;
+    const double nv = div_by(q - mn, dd, yd);
+    const double v = norm_on ? nv : q;
+    const double wv = ps + v;
+    const double sc = (n > 0) ? wv : ps;
+    int sl, cw;
+    if constexpr (AW == 2) {
+      // two candidates: every lane sees both scores; no ballot
+      const double a0 = bcast_d<0>(sc), a1 = bcast_d<1>(sc);
+      sl = (a1 > a0) ? 1 : 0;
+      if (__builtin_expect(a0 == a1 && !done, 0)) {  // numpy.random.choice([0, 1]): first walk of a search, rare later
+        ++st.ties;
+        sl = tape_draw(tape, tape_words, st.tape_pos, st.flags, 2);
+      }
+      const int c0 = bcast_i<0>(c), c1 = bcast_i<1>(c);
+      cw = sl ? c1 : c0;
+    } else {
+      const double best = row_max_d<AW>(sc);
+      const unsigned bits = row_bits(__ballot(sc == best), row_in_wave) & ((1u << AW) - 1u);
+      const int nbest = __popc(bits);
+      sl = nbest ? (__ffs(bits) - 1) : 0;
+      if (__builtin_expect(nbest > 1 && !done, 0)) {  // numpy.random.choice(ties): k-th maximiser in slot order
+        ++st.ties;
+        int k = tape_draw(tape, tape_words, st.tape_pos, st.flags, nbest);
+        unsigned b = bits;
+        for (; k > 0; --k) b &= b - 1;
+        sl = __ffs(b) - 1;
+      }
+      if constexpr (AW <= 4) cw = pick_i<AW>(c, sl);
+      else cw = perm_i(c, sl, row_in_wave);
+    }
+    const bool act = !done;
+    // entry of the level just decided; a finished row rewrites the entry beyond its leaf (never read)
+    if (sub == 0) T.path[depth + 1] = make_int2(cw, sl);
+    depth += act ? 1 : 0;
+    slot = act ? sl : slot;
+    node = (act && cw >= 0) ? cw : node;
+    done = done || (cw < 0);
+    if (__all(done)) break;
+  }
+  Fc2Walk w;
+  // players play turn by turn (self_play.py:331-334): the leaf's player follows from the depth
+  w.vtp = (T.P == 1) ? 0 : ((st.root_to_play + depth) & 1);
+  int leaf = st.n_nodes;
+  if (leaf >= T.NN) { st.flags |= TF_NODE_OVERFLOW; leaf = T.NN - 1; }
+  if (sub == 0) T.path[depth] = make_int2(leaf, slot);
+  const int ra = T.roota[slot < AW ? slot : 0];
+  w.parent = node; w.slot = slot; w.leaf = leaf; w.depth = depth; w.levels = levels;
+  w.action = (node == 0) ? ra : slot;
+  return w;
+}
+
+// What back-propagation needs about the path node a lane owns (lane j of chunk c <-> depth 16 c + j).
+template <int AW>
+struct Fc2Lane {
+  int nd, pslot, par, vc, tp;
+  double vs, rr, inv_vc2, inv_vc3, pb, sv;
+  int sn[AW <= 4 ? AW : 1];
+  double sprior[AW <= 4 ? AW : 1], sinv[AW <= 4 ? AW : 1];
+};
+
+// Everything back-propagation needs from the tree is independent of the network: fetched BEFORE it, so that the
+// LDS latency hides behind recurrent_inference.  (Call after a wave_sync following fc2_walk.)
+template <int AW>
+__device__ __forceinline__ Fc2Lane<AW> fc2_load_lane(const Fc2Tree& T, const Fc2Walk& w, int c, int sub) {
+  Fc2Lane<AW> L;
+  const int d = c * 16 + sub;
+  const bool active = d <= w.depth, is_leaf = d == w.depth;
+  L.nd = 0; L.pslot = 0; L.par = 0; L.vc = 0; L.tp = w.vtp; L.vs = 0.0; L.rr = 0.0;
+  if (active) {
+    const int2 pe = T.path[d];
+    L.nd = pe.x; L.pslot = pe.y;
+    if (d > 0) L.par = T.path[d - 1].x;
+  }
+  if (active && !is_leaf) {
+    const Fc2Node* np = T.nodes + L.nd;
+    L.vs = np->value_sum; L.rr = np->reward; L.vc = np->visit;
+    if (T.P == 2) L.tp = np->to_play;
+  }
+  L.inv_vc2 = T.inv_y[L.vc + 1];        // reciprocal of this node's visit count after the update
+  L.inv_vc3 = T.inv_y[L.vc + 2];        // ... and of (that + 1): what its PARENT's prior score divides by
+  L.pb = T.pbc[L.vc + 1]; L.sv = T.sqt[L.vc + 1];
+  if constexpr (AW <= 4) {
+#pragma unroll
+    for (int s = 0; s < AW; ++s) {
+      L.sn[s] = 0; L.sprior[s] = 0.0;
+      if (active && !is_leaf && s < T.A) { L.sn[s] = T.slots[L.nd * AW + s].n; L.sprior[s] = T.slots[L.nd * AW + s].prior; }
+    }
+#pragma unroll
+    for (int s = 0; s < AW; ++s) L.sinv[s] = T.inv_y[L.sn[s] + 1];
+  }
+  return L;
+}
+
+// Node.expand (self_play.py:451-465): child slot `sub` of the new leaf (lanes < AW; `in`: the slot exists).
+template <int AW>
+__device__ __forceinline__ void fc2_expand(const Fc2Tree& T, int leaf, int sub, bool in, double prior) {
+  if (sub < AW) {
+    Fc2Slot s;
+    s.prior = in ? prior : 0.0;
+    s.q = 0.0; s.n = 0; s.child = -1;
+    s.ps = in ? T.pb_leaf * s.prior : -MZX_INF;   // prior score once the leaf has its first visit (N = 1, n = 0)
+    T.slots[leaf * AW + sub] = s;
+  }
+}
+
+// MCTS.backpropagate (self_play.py:406-430) + refresh of the cached prior scores along the path.  `L` = the
+// lane's operands of chunk w.levels >> 4 (fc2_load_lane before the network).
+template <int AW>
+__device__ __forceinline__ void fc2_backprop(const Fc2Tree& T, Fc2Row& st, const Fc2Walk& w, Fc2Lane<AW> L, int sub,
+                                             double value, double reward) {
+  const int depth = w.depth, vtp = w.vtp, P = T.P;
+  const double disc = T.disc;
+  st.n_nodes = w.leaf + 1;
+  if (depth > st.max_depth) st.max_depth = depth;
+  st.sum_depth += depth;
+  const int cmax = w.levels >> 4;    // wave-uniform number of 16-level chunks - 1 (0 unless a path is > 15 deep)
+  double val = value;
+  int carry_vc2 = 0, carry_pslot = -1;       // lane 0 of the chunk below (deeper), for lane 15 of this one
+  double carry_inv = 0.0;
+  for (int c = cmax; c >= 0; --c) {
+    if (c != cmax) { wave_sync(); L = fc2_load_lane<AW>(T, w, c, sub); }
+    const int d = c * 16 + sub;
+    const int ld = depth - c * 16;             // row-uniform: depth of the leaf relative to this chunk
+    const bool active = d <= depth, is_leaf = d == depth;
+    const double rr = is_leaf ? reward : L.rr;
+    const bool same = (L.tp == vtp);
+    const double r_eff = (P == 1 || !same) ? rr : -rr;   // value = (+-reward) + discount * value
+    double my_in = val;
+    const int wm = w.levels - c * 16;           // deepest leaf of the wave relative to this chunk (wave-uniform)
+    value_chain(r_eff, disc, ld, sub, wm > 15 ? 15 : (wm < 0 ? 0 : wm), val, my_in);
+    if (sub == 0) my_in = val;
+    if (c > 0 && ld >= 0) val = bcast_d<0>(r_eff) + disc * val;   // hand the value to the chunk above
+    const int vc2 = L.vc + 1;
+    const double vs2 = L.vs + ((P == 1 || same) ? my_in : -my_in);
+    double qv = 0.0;
+    if (active) {
+      const double mean = div_by(vs2, (double)vc2, L.inv_vc2);
+      qv = rr + disc * ((P == 1) ? mean : -mean);
+      if (is_leaf) {
+        Fc2Node r;
+        r.value_sum = vs2; r.reward = reward; r.visit = vc2; r.to_play = vtp; r.parent = L.par; r.parent_slot = L.pslot;
+        T.nodes[L.nd] = r;
+        T.slots[L.par * AW + L.pslot].child = L.nd;
+      } else {
+        T.nodes[L.nd].value_sum = vs2;
+        T.nodes[L.nd].visit = vc2;
+      }
+      if (d > 0) {
+        Fc2Slot* ps = T.slots + (L.par * AW + L.pslot);
+        ps->q = qv;
+        ps->n = vc2;
+      }
+      // MinMaxStats.update (self_play.py:562-564): pure min / max over the path nodes, order-free
+      __hip_atomic_fetch_min(&T.mm[0], qv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_max(&T.mm[1], qv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // prior scores of this node's child slots at its new visit count N = vc2 (see header).  The slot on the
+    // path just received the child's new visit count: taken from the lane above instead of LDS.
+    if constexpr (AW <= 4) {
+      const int ch_vc2 = shl1_i(vc2, carry_vc2), ch_slot = shl1_i(L.pslot, carry_pslot);
+      const double ch_inv = shl1_d(L.inv_vc3, carry_inv);
+      if (active && !is_leaf) {
+        const int nslots = (L.nd == 0) ? st.root_n : T.A;
+#pragma unroll
+        for (int s = 0; s < AW; ++s) {
+          if (s < nslots) {
+            const bool on_path = (s == ch_slot);
+            const int ns = on_path ? ch_vc2 : L.sn[s];
+            const double iv = on_path ? ch_inv : L.sinv[s];
+            T.slots[L.nd * AW + s].ps = prior_score(L.pb, L.sv, ns, iv, L.sprior[s]);
+          }
+        }
+      }
+      carry_vc2 = bcast_i<0>(vc2); carry_pslot = bcast_i<0>(L.pslot); carry_inv = bcast_d<0>(L.inv_vc3);
+    } else {
+      wave_sync();
+      if (active && !is_leaf) {
+        Fc2Slot* sp = T.slots + L.nd * AW;
+        const int nslots = (L.nd == 0) ? st.root_n : T.A;
+        for (int s = 0; s < nslots; ++s) {
+          const int ns = sp[s].n;
+          sp[s].ps = prior_score(L.pb, L.sv, ns, T.inv_y[ns + 1], sp[s].prior);
+        }
+      }
+    }
+  }
+  wave_sync();
+}
+
 template <class Net, int AW, bool PROFILE>
 __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -230,119 +457,23 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
   MZX_PROF(1)
 
   // ---- simulations (self_play.py:319-355)
+  Fc2Tree T;
+  T.slots = slots; T.nodes = nodes; T.path = path; T.roota = roota; T.mm = mm;
+  T.pbc = pbc; T.sqt = sqt; T.inv_y = inv_y; T.pb_leaf = pb_leaf; T.disc = disc; T.A = A; T.NN = NN; T.P = P;
+  Fc2Row st;
+  st.n_nodes = n_nodes; st.tape_pos = tape_pos; st.flags = flags; st.ties = ties; st.max_depth = max_depth;
+  st.sum_depth = sum_depth; st.root_n = root_n; st.root_to_play = root_to_play;
   const int num_sims = a.f.p.num_sims;
   for (int sim = 0; sim < num_sims; ++sim) {
-    // ------------------------------------------------------------- select (self_play.py:325-334, :363-404)
-    const double2 mmv = *(const double2*)mm;   // MinMaxStats after the previous back-propagation
-    const double mn = mmv.x, mx = mmv.y;
-    const double dd = mx - mn;                 // MinMaxStats.normalize divisor, same for every node of this walk
-    const double yd = recip_refined(dd);       // (garbage while max <= min: results discarded like the reference's branch)
-    const bool norm_on = mx > mn;
-    // Slots that do not exist (root slots beyond the legal actions, padding up to AW) carry a prior score of
-    // -inf and n = 0, so their score is -inf without a validity test in the walk.  A row that has reached its
-    // leaf keeps executing with its state frozen (one straight-line body per level for the whole wave).
-    int node = 0, depth = 0, slot = 0;
-    int levels = 0;                  // walk iterations = depth of the deepest leaf in this wave (scalar)
-    bool done = false;
-    for (;;) {
-      ++levels;
-      const Fc2Slot* rp = slots + (node * AW + (sub & (AW - 1)));
-      const double ps = rp->ps, q = rp->q;
-      const int n = rp->n, c = rp->child;
-      const double nv = div_by(q - mn, dd, yd);
-      const double v = norm_on ? nv : q;
-      const double wv = ps + v;
-      const double sc = (n > 0) ? wv : ps;
-      int sl, cw;
-      if constexpr (AW == 2) {
-        // two candidates: every lane sees both scores; no ballot
-        const double a0 = bcast_d<0>(sc), a1 = bcast_d<1>(sc);
-        sl = (a1 > a0) ? 1 : 0;
-        if (__builtin_expect(a0 == a1 && !done, 0)) {  // numpy.random.choice([0, 1]): first walk of a search, rare later
-          ++ties;
-          sl = tape_draw(tape, tape_words, tape_pos, flags, 2);
-        }
-        const int c0 = bcast_i<0>(c), c1 = bcast_i<1>(c);
-        cw = sl ? c1 : c0;
-      } else {
-        const double best = row_max_d<AW>(sc);
-        const unsigned bits = row_bits(__ballot(sc == best), row_in_wave) & ((1u << AW) - 1u);
-        const int nbest = __popc(bits);
-        sl = nbest ? (__ffs(bits) - 1) : 0;
-        if (__builtin_expect(nbest > 1 && !done, 0)) {  // numpy.random.choice(ties): k-th maximiser in slot order
-          ++ties;
-          int k = tape_draw(tape, tape_words, tape_pos, flags, nbest);
-          unsigned b = bits;
-          for (; k > 0; --k) b &= b - 1;
-          sl = __ffs(b) - 1;
-        }
-        if constexpr (AW <= 4) cw = pick_i<AW>(c, sl);
-        else cw = perm_i(c, sl, row_in_wave);
-      }
-      const bool act = !done;
-      // entry of the level just decided; a finished row rewrites the entry beyond its leaf (never read)
-      if (sub == 0) path[depth + 1] = make_int2(cw, sl);
-      depth += act ? 1 : 0;
-      slot = act ? sl : slot;
-      node = (act && cw >= 0) ? cw : node;
-      done = done || (cw < 0);
-      if (__all(done)) break;
-    }
-    // players play turn by turn (self_play.py:331-334): the leaf's player follows from the depth
-    const int vtp = (P == 1) ? 0 : ((root_to_play + depth) & 1);
+    const Fc2Walk w = fc2_walk<AW>(T, st, tape, tape_words, sub, row_in_wave);
     MZX_PROF(2)
-    int leaf = n_nodes;
-    if (leaf >= NN) { flags |= TF_NODE_OVERFLOW; leaf = NN - 1; }
-    if (sub == 0) path[depth] = make_int2(leaf, slot);
-    const int parent = node;
-    const int ra = roota[slot < AW ? slot : 0];
-    const int action = (parent == 0) ? ra : slot;
-    const int cmax = levels >> 4;    // wave-uniform number of 16-level chunks - 1 (0 unless a path is > 15 deep)
     wave_sync();
-
-    // Everything back-propagation needs from the tree is independent of the network: complete before it, so that
-    // the LDS latency hides behind recurrent_inference.  Lane j of a chunk owns the path node at depth 16 c + j.
-    struct PathLane {
-      int nd, pslot, par, vc, tp;
-      double vs, rr, inv_vc2, inv_vc3, pb, sv;
-      int sn[AW <= 4 ? AW : 1];
-      double sprior[AW <= 4 ? AW : 1], sinv[AW <= 4 ? AW : 1];
-    };
-    auto load_lane = [&](int c) {
-      PathLane L;
-      const int d = c * 16 + sub;
-      const bool active = d <= depth, is_leaf = d == depth;
-      L.nd = 0; L.pslot = 0; L.par = 0; L.vc = 0; L.tp = vtp; L.vs = 0.0; L.rr = 0.0;
-      if (active) {
-        const int2 pe = path[d];
-        L.nd = pe.x; L.pslot = pe.y;
-        if (d > 0) L.par = path[d - 1].x;
-      }
-      if (active && !is_leaf) {
-        const Fc2Node* np = nodes + L.nd;
-        L.vs = np->value_sum; L.rr = np->reward; L.vc = np->visit;
-        if (P == 2) L.tp = np->to_play;
-      }
-      L.inv_vc2 = inv_y[L.vc + 1];        // reciprocal of this node's visit count after the update
-      L.inv_vc3 = inv_y[L.vc + 2];        // ... and of (that + 1): what its PARENT's prior score divides by
-      L.pb = pbc[L.vc + 1]; L.sv = sqt[L.vc + 1];
-      if constexpr (AW <= 4) {
-#pragma unroll
-        for (int s = 0; s < AW; ++s) {
-          L.sn[s] = 0; L.sprior[s] = 0.0;
-          if (active && !is_leaf && s < A) { L.sn[s] = slots[L.nd * AW + s].n; L.sprior[s] = slots[L.nd * AW + s].prior; }
-        }
-#pragma unroll
-        for (int s = 0; s < AW; ++s) L.sinv[s] = inv_y[L.sn[s] + 1];
-      }
-      return L;
-    };
-    PathLane L = load_lane(cmax);
+    const Fc2Lane<AW> L = fc2_load_lane<AW>(T, w, w.levels >> 4, sub);
     MZX_PROF(7)
 
     // ------------------------------------------------------------- recurrent_inference (models.py:192-195)
     NetOut o;
-    net.recurrent(hidden + parent * E, action, hidden + leaf * E, scr, sub, o);
+    net.recurrent(hidden + w.parent * E, w.action, hidden + w.leaf * E, scr, sub, o);
     MZX_PROF(3)
 
     // ------------------------------------------------------------- expand (self_play.py:451-465)
@@ -351,95 +482,16 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
       const float m = row_max_w<AW>(in ? o.policy : -MZX_INF);
       const float e = in ? mzx_expf(o.policy - m) : 0.f;
       const float den = row_sum_w<AW>(e);
-      if (sub < AW) {
-        Fc2Slot s;
-        s.prior = in ? (double)mzx_div(e, den) : 0.0;
-        s.q = 0.0; s.n = 0; s.child = -1;
-        s.ps = in ? pb_leaf * s.prior : -MZX_INF;   // prior score once the leaf has its first visit (N = 1, n = 0)
-        slots[leaf * AW + sub] = s;
-      }
+      fc2_expand<AW>(T, w.leaf, sub, in, (double)mzx_div(e, den));
     }
     MZX_PROF(4)
 
     // ------------------------------------------------------------- backpropagate (self_play.py:406-430)
-    n_nodes = leaf + 1;
-    if (depth > max_depth) max_depth = depth;
-    sum_depth += depth;
-    const double reward = (double)o.reward;
-    double val = (double)o.value;
-    int carry_vc2 = 0, carry_pslot = -1;       // lane 0 of the chunk below (deeper), for lane 15 of this one
-    double carry_inv = 0.0;
-    for (int c = cmax; c >= 0; --c) {
-      if (c != cmax) { wave_sync(); L = load_lane(c); }
-      const int d = c * 16 + sub;
-      const int ld = depth - c * 16;             // row-uniform: depth of the leaf relative to this chunk
-      const bool active = d <= depth, is_leaf = d == depth;
-      const double rr = is_leaf ? reward : L.rr;
-      const bool same = (L.tp == vtp);
-      const double r_eff = (P == 1 || !same) ? rr : -rr;   // value = (+-reward) + discount * value
-      double my_in = val;
-      const int wm = levels - c * 16;             // deepest leaf of the wave relative to this chunk (wave-uniform)
-      value_chain(r_eff, disc, ld, sub, wm > 15 ? 15 : (wm < 0 ? 0 : wm), val, my_in);
-      if (sub == 0) my_in = val;
-      if (c > 0 && ld >= 0) val = bcast_d<0>(r_eff) + disc * val;   // hand the value to the chunk above
-      MZX_PROF(8)
-      const int vc2 = L.vc + 1;
-      const double vs2 = L.vs + ((P == 1 || same) ? my_in : -my_in);
-      double qv = 0.0;
-      if (active) {
-        const double mean = div_by(vs2, (double)vc2, L.inv_vc2);
-        qv = rr + disc * ((P == 1) ? mean : -mean);
-        if (is_leaf) {
-          Fc2Node r;
-          r.value_sum = vs2; r.reward = reward; r.visit = vc2; r.to_play = vtp; r.parent = L.par; r.parent_slot = L.pslot;
-          nodes[L.nd] = r;
-          slots[L.par * AW + L.pslot].child = L.nd;
-        } else {
-          nodes[L.nd].value_sum = vs2;
-          nodes[L.nd].visit = vc2;
-        }
-        if (d > 0) {
-          Fc2Slot* ps = slots + (L.par * AW + L.pslot);
-          ps->q = qv;
-          ps->n = vc2;
-        }
-        // MinMaxStats.update (self_play.py:562-564): pure min / max over the path nodes, order-free
-        __hip_atomic_fetch_min(&mm[0], qv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_max(&mm[1], qv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      // prior scores of this node's child slots at its new visit count N = vc2 (see header).  The slot on the
-      // path just received the child's new visit count: taken from the lane above instead of LDS.
-      if constexpr (AW <= 4) {
-        const int ch_vc2 = shl1_i(vc2, carry_vc2), ch_slot = shl1_i(L.pslot, carry_pslot);
-        const double ch_inv = shl1_d(L.inv_vc3, carry_inv);
-        if (active && !is_leaf) {
-          const int nslots = (L.nd == 0) ? root_n : A;
-#pragma unroll
-          for (int s = 0; s < AW; ++s) {
-            if (s < nslots) {
-              const bool on_path = (s == ch_slot);
-              const int ns = on_path ? ch_vc2 : L.sn[s];
-              const double iv = on_path ? ch_inv : L.sinv[s];
-              slots[L.nd * AW + s].ps = prior_score(L.pb, L.sv, ns, iv, L.sprior[s]);
-            }
-          }
-        }
-        carry_vc2 = bcast_i<0>(vc2); carry_pslot = bcast_i<0>(L.pslot); carry_inv = bcast_d<0>(L.inv_vc3);
-      } else {
-        wave_sync();
-        if (active && !is_leaf) {
-          Fc2Slot* sp = slots + L.nd * AW;
-          const int nslots = (L.nd == 0) ? root_n : A;
-          for (int s = 0; s < nslots; ++s) {
-            const int ns = sp[s].n;
-            sp[s].ps = prior_score(L.pb, L.sv, ns, inv_y[ns + 1], sp[s].prior);
-          }
-        }
-      }
-    }
-    wave_sync();
+    fc2_backprop<AW>(T, st, w, L, sub, (double)o.value, (double)o.reward);
     MZX_PROF(5)
   }
+  n_nodes = st.n_nodes; tape_pos = st.tape_pos; flags = st.flags; ties = st.ties; max_depth = st.max_depth;
+  sum_depth = st.sum_depth;
 
   // ---- results (FinalizeOp)
   if (sub == 0) {
