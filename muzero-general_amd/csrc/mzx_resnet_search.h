@@ -20,7 +20,7 @@
 // The root (initial_inference + root expansion) and the result gathering remain the
 // kernels of the generic path: 4 launches per move instead of 3 * num_simulations + 4.
 #pragma once
-#include "mzx_fused_fc.h"
+#include "mzx_fused_fc2.h"
 
 namespace mzx {
 
@@ -148,8 +148,18 @@ __device__ __forceinline__ float row_decode_wide(const float* lg, int F, int sup
   return support_inverse_transform(row_sum(num));
 }
 
-// AW: lanes that can hold a child slot (4, 16), or 0 = wide (several slots per lane, any support size)
-template <bool WLDS, int NW, int AW, int MM>
+// floats of LDS per tree / per workgroup for the record form of an LDS-resident tree (TREC kernels)
+__host__ __device__ inline int64_t rz_trec_tree_floats(int N, int AW) {
+  auto al16 = [](int64_t x) { return (x + 15) & ~int64_t(15); };
+  return (int64_t(32) * N * AW + int64_t(32) * N + al16(int64_t(8) * (N + 1)) + al16(int64_t(4) * AW) + 16) / 4;
+}
+inline int64_t rz_trec_extra_floats(int N) { return 2 * (int64_t)(N + 2); }   // refined-reciprocal table
+
+// AW: lanes that can hold a child slot (4, 16), or 0 = wide (several slots per lane, any support size).
+// TREC: the workgroup's trees live in LDS as the 32-byte slot / node records of mzx_fused_fc2.h (cached prior
+// scores, hoisted division halves, operands of back-propagation fetched before the network) instead of the
+// arena's struct-of-arrays slab; converted from / to the arena layout at the ends of the launch.
+template <bool WLDS, int NW, int AW, int MM, bool TREC = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 rz_search_kernel(const RzSearchArgs sa) {
   constexpr int NT = NW * 64;
@@ -182,7 +192,48 @@ rz_search_kernel(const RzSearchArgs sa) {
   // chain of dependent reads per level -- an LDS round trip instead of an L2 one), staged in and out once.
   double* tree_lds = tables + ntab;
   const int slab8 = (int)(sa.L.tree_bytes >> 3);      // tree_bytes is a multiple of 8
-  if (sa.tree_lds) {
+  constexpr int RW = (AW == 0) ? 16 : AW;             // record lanes per node (TREC)
+  Fc2Tree FT;
+  Fc2Row rst;
+  if constexpr (TREC) {
+    const int NNr = sa.p.num_nodes;
+    double* inv_y = tree_lds;                                       // [NN + 2]
+    for (int i = tid; i < NNr + 2; i += NT) inv_y[i] = recip_refined((double)(i > 0 ? i : 1));
+    char* rec = (char*)(inv_y + NNr + 2) + (size_t)(row_valid ? row : 0) * (size_t)(4 * rz_trec_tree_floats(NNr, RW));
+    FT.slots = (Fc2Slot*)rec;
+    FT.nodes = (Fc2Node*)(rec + (size_t)32 * NNr * RW);
+    FT.path = (int2*)((char*)FT.nodes + (size_t)32 * NNr);
+    FT.roota = (int32_t*)((char*)FT.path + (((size_t)8 * (NNr + 1) + 15) & ~(size_t)15));
+    FT.mm = (double*)((char*)FT.roota + (((size_t)4 * RW + 15) & ~(size_t)15));
+    FT.pbc = tables; FT.sqt = tables + (NNr + 1); FT.inv_y = inv_y;
+    FT.disc = p.discount; FT.A = p.num_actions; FT.NN = NNr; FT.P = p.num_players;
+    __syncthreads();
+    FT.pb_leaf = FT.pbc[1] * div_by(FT.sqt[1], 1.0, inv_y[1]);
+    if (row_valid) {   // arena tree (as RootInitOp left it: normally the root alone) -> records
+      const int nn = t.meta(TM_N_NODES), rootn = t.meta(TM_ROOT_N);
+      for (int n = sub; n < nn; n += FUSED_ROW) {
+        Fc2Node r;
+        r.value_sum = t.value_sum(n); r.reward = t.reward(n); r.visit = t.visit(n); r.to_play = t.to_play(n);
+        r.parent = t.parent(n); r.parent_slot = t.parent_slot(n);
+        FT.nodes[n] = r;
+        const int nc = (n == 0) ? rootn : FT.A;
+        for (int s2 = 0; s2 < RW; ++s2) {
+          Fc2Slot q;
+          const bool in = s2 < nc;
+          q.prior = in ? t.prior(n, s2) : 0.0; q.q = in ? t.slot_q(n, s2) : 0.0;
+          q.n = in ? t.slot_visit(n, s2) : 0; q.child = in ? t.child(n, s2) : -1;
+          q.ps = in ? prior_score(FT.pbc[r.visit], FT.sqt[r.visit], q.n, inv_y[q.n + 1], q.prior) : -MZX_INF;
+          FT.slots[n * RW + s2] = q;
+        }
+      }
+      if (sub < RW) FT.roota[sub] = (sub < rootn) ? t.root_action(sub) : -1;
+      if (sub == 0) { FT.path[0] = make_int2(0, -1); FT.mm[0] = t.mm_min(); FT.mm[1] = t.mm_max(); }
+      rst.n_nodes = nn; rst.tape_pos = t.meta(TM_TAPE_POS); rst.flags = t.meta(TM_FLAGS); rst.ties = t.meta(TM_TIE_DRAWS);
+      rst.max_depth = t.meta(TM_MAX_DEPTH); rst.sum_depth = t.meta(TM_SUM_DEPTH); rst.root_n = rootn;
+      rst.root_to_play = t.to_play(0);
+    }
+    __syncthreads();
+  } else if (sa.tree_lds) {
     const double* src = (const double*)(sa.trees + (size_t)b0 * sa.L.tree_bytes);
     for (int i = tid; i < ntree * slab8; i += NT) tree_lds[i] = src[i];
     t.base = (char*)(tree_lds + (size_t)(row_valid ? row : 0) * slab8);
@@ -190,7 +241,7 @@ rz_search_kernel(const RzSearchArgs sa) {
   }
   const uint32_t* tape = sa.tape + (size_t)tree * p.tape_words;
   RowState st;
-  if (row_valid) load_state(t, st);
+  if (!TREC && row_valid) load_state(t, st);
   const int F = a.out_n[0], A = a.out_n[2];
   __syncthreads();
   // cycle profile (mode flag 8): thread 0 accumulates the shader clock per phase
@@ -203,10 +254,19 @@ rz_search_kernel(const RzSearchArgs sa) {
   for (int sim = 0; sim < sa.num_sims; ++sim) {
     // ---- selection (self_play.py:325-334)
     RowSel sel;
+    Fc2Walk wk;
+    Fc2Lane<RW> lane_ops;
     if (row_valid) {
-      if constexpr (AW == 0) sel = row_select_wide(t, p, tape, sub, row_in_wave, sa.sim0 + sim, st);
-      else sel = row_select<AW>(t, p, tape, sub, row_in_wave, sa.sim0 + sim, st);
-      if (sub == 0) { sel_parent[row] = sel.c.parent; sel_action[row] = sel.action; sel_leaf[row] = sel.c.leaf; }
+      if constexpr (TREC) {
+        wk = fc2_walk<RW>(FT, rst, tape, p.tape_words, sub, row_in_wave);
+        if (sub == 0) { sel_parent[row] = wk.parent; sel_action[row] = wk.action; sel_leaf[row] = wk.leaf; }
+        wave_sync();
+        lane_ops = fc2_load_lane<RW>(FT, wk, wk.levels >> 4, sub);   // hides behind the network
+      } else {
+        if constexpr (AW == 0) sel = row_select_wide(t, p, tape, sub, row_in_wave, sa.sim0 + sim, st);
+        else sel = row_select<AW>(t, p, tape, sub, row_in_wave, sa.sim0 + sim, st);
+        if (sub == 0) { sel_parent[row] = sel.c.parent; sel_action[row] = sel.action; sel_leaf[row] = sel.c.leaf; }
+      }
     }
     RZS_PROF(0)
     __syncthreads();
@@ -257,9 +317,11 @@ rz_search_kernel(const RzSearchArgs sa) {
         const float m = row_max(in ? lg : -MZX_INF);
         const float e = in ? mzx_expf(lg - m) : 0.f;
         const float den = row_sum(e);
-        if (in) tree_init_slot(t, sel.c.leaf, sub, (double)mzx_div(e, den));
+        if constexpr (TREC) fc2_expand<RW>(FT, wk.leaf, sub, in, (double)mzx_div(e, den));
+        else if (in) tree_init_slot(t, sel.c.leaf, sub, (double)mzx_div(e, den));
       }
-      row_backprop(t, p, sel, sub, row_in_wave, (double)value, (double)reward, st);
+      if constexpr (TREC) fc2_backprop<RW>(FT, rst, wk, lane_ops, sub, (double)value, (double)reward);
+      else row_backprop(t, p, sel, sub, row_in_wave, (double)value, (double)reward, st);
     }
     RZS_PROF(4)
     __syncthreads();
@@ -267,6 +329,27 @@ rz_search_kernel(const RzSearchArgs sa) {
   }
 #undef RZS_PROF
   if (prof) for (int k = 0; k < 8; ++k) sa.prof[blockIdx.x * 8 + k] = pc[k];
+  if constexpr (TREC) {
+    if (row_valid) {   // records -> the arena's TreeLayout (what FinalizeOp and mzx_search_dump read)
+      wave_sync();
+      for (int n = sub; n < rst.n_nodes; n += FUSED_ROW) {
+        const Fc2Node r = FT.nodes[n];
+        t.value_sum(n) = r.value_sum; t.reward(n) = r.reward; t.visit(n) = r.visit; t.to_play(n) = r.to_play;
+        t.parent(n) = r.parent; t.parent_slot(n) = r.parent_slot;
+        const int nc = (n == 0) ? rst.root_n : FT.A;
+        for (int s2 = 0; s2 < nc; ++s2) {
+          const Fc2Slot q = FT.slots[n * RW + s2];
+          t.prior(n, s2) = q.prior; t.slot_q(n, s2) = q.q; t.slot_visit(n, s2) = q.n; t.child(n, s2) = q.child;
+        }
+      }
+      if (sub == 0) {
+        t.mm_min() = FT.mm[0]; t.mm_max() = FT.mm[1];
+        t.meta(TM_N_NODES) = rst.n_nodes; t.meta(TM_TAPE_POS) = rst.tape_pos; t.meta(TM_FLAGS) = rst.flags;
+        t.meta(TM_TIE_DRAWS) = rst.ties; t.meta(TM_MAX_DEPTH) = rst.max_depth; t.meta(TM_SUM_DEPTH) = rst.sum_depth;
+      }
+    }
+    return;
+  }
   if (row_valid && sub == 0) store_state(t, st);
   if (sa.tree_lds) {
     __syncthreads();
@@ -275,16 +358,16 @@ rz_search_kernel(const RzSearchArgs sa) {
   }
 }
 
-template <bool WLDS, int NW, int AW, int MM>
+template <bool WLDS, int NW, int AW, int MM, bool TREC = false>
 inline int rz_search_launch_k(const RzSearchArgs& sa, unsigned grid, size_t lds_bytes, stream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)rz_search_kernel<WLDS, NW, AW, MM>,
+    hipError_t e = hipFuncSetAttribute((const void*)rz_search_kernel<WLDS, NW, AW, MM, TREC>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((rz_search_kernel<WLDS, NW, AW, MM>), dim3(grid), dim3(NW * 64), lds_bytes, stream, sa);
+  hipLaunchKernelGGL((rz_search_kernel<WLDS, NW, AW, MM, TREC>), dim3(grid), dim3(NW * 64), lds_bytes, stream, sa);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("residual search kernel launch failed: %s (grid %u, %d threads, %zu bytes of LDS, %d trees per workgroup, "
@@ -298,6 +381,11 @@ template <bool WLDS, int NW, int MM>
 inline int rz_search_launch_aw(const RzSearchArgs& sa, unsigned grid, size_t lds, stream_t stream) {
   const bool wide = sa.p.num_actions > FUSED_ROW || 2 * sa.p.support_size + 1 > 2 * FUSED_ROW;
   if (wide) return rz_search_launch_k<WLDS, NW, 0, MM>(sa, grid, lds, stream);
+  if constexpr (NW == 4 && MM == 3) {   // record-form LDS trees: the small-network kernels (tree side 14-18 % of a simulation)
+    if (sa.tree_lds == 2)
+      return sa.p.num_actions <= 4 ? rz_search_launch_k<WLDS, NW, 4, MM, true>(sa, grid, lds, stream)
+                                   : rz_search_launch_k<WLDS, NW, 16, MM, true>(sa, grid, lds, stream);
+  }
   if (sa.p.num_actions <= 4) return rz_search_launch_k<WLDS, NW, 4, MM>(sa, grid, lds, stream);
   return rz_search_launch_k<WLDS, NW, 16, MM>(sa, grid, lds, stream);
 }
@@ -358,6 +446,22 @@ inline int rz_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, 
       const bool fits = (int64_t)L1.lds + 4 * (extra + slab_floats * L1.a.T) <= RZ_LDS_BUDGET;   // (one tree per workgroup is not re-checked by rz_prepare)
       if (fits && L1.a.T == L.a.T && L1.eight == L.eight && L1.small == L.small) { L = L1; tree_lds = true; }
     }
+    // record-form trees (mzx_fused_fc2.h) for the small-network kernels when they fit beside the engine's image
+    bool tree_rec = false;
+    size_t rec_lds = 0;
+    const int A_ = s->p.num_actions;
+    const bool narrow = A_ <= FUSED_ROW && 2 * s->p.support_size + 1 <= 2 * FUSED_ROW;
+    if (narrow && L.small && !L.eight && rz_env_int("MZX_RZ_TREE_REC", 1) != 0) {
+      const int RW = A_ <= 4 ? 4 : 16;
+      const int64_t rec_floats = rz_trec_tree_floats(s->p.num_nodes, RW);
+      const int64_t extra2 = extra + rz_trec_extra_floats(s->p.num_nodes);
+      const RzLaunch L2 = rz_prepare(net, R, nr.in, nr, B, &ir, rec_floats, extra2);
+      const bool fits = (int64_t)L2.lds + 4 * (extra2 + rec_floats * L2.a.T) <= RZ_LDS_BUDGET;
+      if (fits && L2.small && !L2.eight && L2.a.T >= (tree_lds ? L.a.T : 1)) {
+        L = L2; tree_rec = true; tree_lds = false;
+        rec_lds = (size_t)4 * (extra2 + rec_floats * L2.a.T);
+      }
+    }
     RzSearchArgs sa;
     sa.net = L.a;
     sa.p = v.p;
@@ -368,8 +472,8 @@ inline int rz_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, 
     sa.sim0 = 0;
     // mode flag 8: per-workgroup phase cycle counters in the (otherwise unused) network workspace region
     sa.prof = ((s->mode & 8) && s->ws_floats >= (int64_t)L.grid * 8) ? (uint32_t*)((char*)d_arena + s->off_ws) : nullptr;
-    sa.tree_lds = tree_lds ? 1 : 0;
-    const size_t lds = L.lds + (size_t)4 * (extra + (tree_lds ? slab_floats * L.a.T : 0));
+    sa.tree_lds = tree_rec ? 2 : (tree_lds ? 1 : 0);
+    const size_t lds = tree_rec ? L.lds + rec_lds : L.lds + (size_t)4 * (extra + (tree_lds ? slab_floats * L.a.T : 0));
     if (L.small) rc = L.wlds ? rz_search_launch_aw<true, 4, 3>(sa, L.grid, lds, stream) : rz_search_launch_aw<false, 4, 3>(sa, L.grid, lds, stream);
     else if (L.wlds) rc = L.eight ? rz_search_launch_aw<true, 8, 8>(sa, L.grid, lds, stream) : rz_search_launch_aw<true, 4, 8>(sa, L.grid, lds, stream);
     else rc = L.eight ? rz_search_launch_aw<false, 8, 8>(sa, L.grid, lds, stream) : rz_search_launch_aw<false, 4, 8>(sa, L.grid, lds, stream);
