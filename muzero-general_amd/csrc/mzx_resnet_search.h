@@ -155,6 +155,62 @@ __host__ __device__ inline int64_t rz_trec_tree_floats(int N, int AW) {
 }
 inline int64_t rz_trec_extra_floats(int N) { return 2 * (int64_t)(N + 2); }   // refined-reciprocal table
 
+// Arena tree (TreeLayout, as RootInitOp left it: normally the root alone) -> the slot / node records of
+// mzx_fused_fc2.h in LDS, and back (what FinalizeOp and mzx_search_dump read).  Called by the 16-lane row of the tree.
+template <int RW>
+__device__ __forceinline__ void fc2_from_arena(const Fc2Tree& FT, Fc2Row& rst, const TreeRef& t, int sub) {
+  const int nn = t.meta(TM_N_NODES), rootn = t.meta(TM_ROOT_N);
+  for (int n = sub; n < nn; n += FUSED_ROW) {
+    Fc2Node r;
+    r.value_sum = t.value_sum(n); r.reward = t.reward(n); r.visit = t.visit(n); r.to_play = t.to_play(n);
+    r.parent = t.parent(n); r.parent_slot = t.parent_slot(n);
+    FT.nodes[n] = r;
+    const int nc = (n == 0) ? rootn : FT.A;
+    for (int s2 = 0; s2 < RW; ++s2) {
+      Fc2Slot q;
+      const bool in = s2 < nc;
+      q.prior = in ? t.prior(n, s2) : 0.0; q.q = in ? t.slot_q(n, s2) : 0.0;
+      q.n = in ? t.slot_visit(n, s2) : 0; q.child = in ? t.child(n, s2) : -1;
+      q.ps = in ? prior_score(FT.pbc[r.visit], FT.sqt[r.visit], q.n, FT.inv_y[q.n + 1], q.prior) : -MZX_INF;
+      FT.slots[n * RW + s2] = q;
+    }
+  }
+  if (sub < RW) FT.roota[sub] = (sub < rootn) ? t.root_action(sub) : -1;
+  if (sub == 0) { FT.path[0] = make_int2(0, -1); FT.mm[0] = t.mm_min(); FT.mm[1] = t.mm_max(); }
+  rst.n_nodes = nn; rst.tape_pos = t.meta(TM_TAPE_POS); rst.flags = t.meta(TM_FLAGS); rst.ties = t.meta(TM_TIE_DRAWS);
+  rst.max_depth = t.meta(TM_MAX_DEPTH); rst.sum_depth = t.meta(TM_SUM_DEPTH); rst.root_n = rootn;
+  rst.root_to_play = t.to_play(0);
+}
+
+template <int RW>
+__device__ __forceinline__ void fc2_to_arena(const Fc2Tree& FT, const Fc2Row& rst, const TreeRef& t, int sub) {
+  for (int n = sub; n < rst.n_nodes; n += FUSED_ROW) {
+    const Fc2Node r = FT.nodes[n];
+    t.value_sum(n) = r.value_sum; t.reward(n) = r.reward; t.visit(n) = r.visit; t.to_play(n) = r.to_play;
+    t.parent(n) = r.parent; t.parent_slot(n) = r.parent_slot;
+    const int nc = (n == 0) ? rst.root_n : FT.A;
+    for (int s2 = 0; s2 < nc; ++s2) {
+      const Fc2Slot q = FT.slots[n * RW + s2];
+      t.prior(n, s2) = q.prior; t.slot_q(n, s2) = q.q; t.slot_visit(n, s2) = q.n; t.child(n, s2) = q.child;
+    }
+  }
+  if (sub == 0) {
+    t.mm_min() = FT.mm[0]; t.mm_max() = FT.mm[1];
+    t.meta(TM_N_NODES) = rst.n_nodes; t.meta(TM_TAPE_POS) = rst.tape_pos; t.meta(TM_FLAGS) = rst.flags;
+    t.meta(TM_TIE_DRAWS) = rst.ties; t.meta(TM_MAX_DEPTH) = rst.max_depth; t.meta(TM_SUM_DEPTH) = rst.sum_depth;
+  }
+}
+
+// Carves one tree's records out of `rec` (rz_trec_tree_floats(NN, RW) floats)
+template <int RW>
+__device__ __forceinline__ void fc2_carve(Fc2Tree& FT, char* rec, int NN) {
+  FT.slots = (Fc2Slot*)rec;
+  FT.nodes = (Fc2Node*)(rec + (size_t)32 * NN * RW);
+  FT.path = (int2*)((char*)FT.nodes + (size_t)32 * NN);
+  FT.roota = (int32_t*)((char*)FT.path + (((size_t)8 * (NN + 1) + 15) & ~(size_t)15));
+  FT.mm = (double*)((char*)FT.roota + (((size_t)4 * RW + 15) & ~(size_t)15));
+}
+
 // AW: lanes that can hold a child slot (4, 16), or 0 = wide (several slots per lane, any support size).
 // TREC: the workgroup's trees live in LDS as the 32-byte slot / node records of mzx_fused_fc2.h (cached prior
 // scores, hoisted division halves, operands of back-propagation fetched before the network) instead of the
@@ -200,38 +256,12 @@ rz_search_kernel(const RzSearchArgs sa) {
     double* inv_y = tree_lds;                                       // [NN + 2]
     for (int i = tid; i < NNr + 2; i += NT) inv_y[i] = recip_refined((double)(i > 0 ? i : 1));
     char* rec = (char*)(inv_y + NNr + 2) + (size_t)(row_valid ? row : 0) * (size_t)(4 * rz_trec_tree_floats(NNr, RW));
-    FT.slots = (Fc2Slot*)rec;
-    FT.nodes = (Fc2Node*)(rec + (size_t)32 * NNr * RW);
-    FT.path = (int2*)((char*)FT.nodes + (size_t)32 * NNr);
-    FT.roota = (int32_t*)((char*)FT.path + (((size_t)8 * (NNr + 1) + 15) & ~(size_t)15));
-    FT.mm = (double*)((char*)FT.roota + (((size_t)4 * RW + 15) & ~(size_t)15));
+    fc2_carve<RW>(FT, rec, NNr);
     FT.pbc = tables; FT.sqt = tables + (NNr + 1); FT.inv_y = inv_y;
     FT.disc = p.discount; FT.A = p.num_actions; FT.NN = NNr; FT.P = p.num_players;
     __syncthreads();
     FT.pb_leaf = FT.pbc[1] * div_by(FT.sqt[1], 1.0, inv_y[1]);
-    if (row_valid) {   // arena tree (as RootInitOp left it: normally the root alone) -> records
-      const int nn = t.meta(TM_N_NODES), rootn = t.meta(TM_ROOT_N);
-      for (int n = sub; n < nn; n += FUSED_ROW) {
-        Fc2Node r;
-        r.value_sum = t.value_sum(n); r.reward = t.reward(n); r.visit = t.visit(n); r.to_play = t.to_play(n);
-        r.parent = t.parent(n); r.parent_slot = t.parent_slot(n);
-        FT.nodes[n] = r;
-        const int nc = (n == 0) ? rootn : FT.A;
-        for (int s2 = 0; s2 < RW; ++s2) {
-          Fc2Slot q;
-          const bool in = s2 < nc;
-          q.prior = in ? t.prior(n, s2) : 0.0; q.q = in ? t.slot_q(n, s2) : 0.0;
-          q.n = in ? t.slot_visit(n, s2) : 0; q.child = in ? t.child(n, s2) : -1;
-          q.ps = in ? prior_score(FT.pbc[r.visit], FT.sqt[r.visit], q.n, inv_y[q.n + 1], q.prior) : -MZX_INF;
-          FT.slots[n * RW + s2] = q;
-        }
-      }
-      if (sub < RW) FT.roota[sub] = (sub < rootn) ? t.root_action(sub) : -1;
-      if (sub == 0) { FT.path[0] = make_int2(0, -1); FT.mm[0] = t.mm_min(); FT.mm[1] = t.mm_max(); }
-      rst.n_nodes = nn; rst.tape_pos = t.meta(TM_TAPE_POS); rst.flags = t.meta(TM_FLAGS); rst.ties = t.meta(TM_TIE_DRAWS);
-      rst.max_depth = t.meta(TM_MAX_DEPTH); rst.sum_depth = t.meta(TM_SUM_DEPTH); rst.root_n = rootn;
-      rst.root_to_play = t.to_play(0);
-    }
+    if (row_valid) fc2_from_arena<RW>(FT, rst, t, sub);
     __syncthreads();
   } else if (sa.tree_lds) {
     const double* src = (const double*)(sa.trees + (size_t)b0 * sa.L.tree_bytes);
@@ -330,24 +360,7 @@ rz_search_kernel(const RzSearchArgs sa) {
 #undef RZS_PROF
   if (prof) for (int k = 0; k < 8; ++k) sa.prof[blockIdx.x * 8 + k] = pc[k];
   if constexpr (TREC) {
-    if (row_valid) {   // records -> the arena's TreeLayout (what FinalizeOp and mzx_search_dump read)
-      wave_sync();
-      for (int n = sub; n < rst.n_nodes; n += FUSED_ROW) {
-        const Fc2Node r = FT.nodes[n];
-        t.value_sum(n) = r.value_sum; t.reward(n) = r.reward; t.visit(n) = r.visit; t.to_play(n) = r.to_play;
-        t.parent(n) = r.parent; t.parent_slot(n) = r.parent_slot;
-        const int nc = (n == 0) ? rst.root_n : FT.A;
-        for (int s2 = 0; s2 < nc; ++s2) {
-          const Fc2Slot q = FT.slots[n * RW + s2];
-          t.prior(n, s2) = q.prior; t.slot_q(n, s2) = q.q; t.slot_visit(n, s2) = q.n; t.child(n, s2) = q.child;
-        }
-      }
-      if (sub == 0) {
-        t.mm_min() = FT.mm[0]; t.mm_max() = FT.mm[1];
-        t.meta(TM_N_NODES) = rst.n_nodes; t.meta(TM_TAPE_POS) = rst.tape_pos; t.meta(TM_FLAGS) = rst.flags;
-        t.meta(TM_TIE_DRAWS) = rst.ties; t.meta(TM_MAX_DEPTH) = rst.max_depth; t.meta(TM_SUM_DEPTH) = rst.sum_depth;
-      }
-    }
+    if (row_valid) { wave_sync(); fc2_to_arena<RW>(FT, rst, t, sub); }
     return;
   }
   if (row_valid && sub == 0) store_state(t, st);
@@ -389,6 +402,14 @@ inline int rz_search_launch_aw(const RzSearchArgs& sa, unsigned grid, size_t lds
   if (sa.p.num_actions <= 4) return rz_search_launch_k<WLDS, NW, 4, MM>(sa, grid, lds, stream);
   return rz_search_launch_k<WLDS, NW, 16, MM>(sa, grid, lds, stream);
 }
+
+#endif  // !MZX_HOSTCHECK
+}  // namespace mzx
+
+#include "mzx_resnet_wave.h"   // small boards: a wave per tree (needs RzSearchArgs and the fc2 <-> arena conversions above)
+
+namespace mzx {
+#ifndef MZX_HOSTCHECK
 
 inline bool rz_search_supported(const mzx_search* s) {
   const mzx_net* net = s->net;
@@ -460,6 +481,25 @@ inline int rz_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, 
       if (fits && L2.small && !L2.eight && L2.a.T >= (tree_lds ? L.a.T : 1)) {
         L = L2; tree_rec = true; tree_lds = false;
         rec_lds = (size_t)4 * (extra2 + rec_floats * L2.a.T);
+      }
+    }
+    {   // small boards: a wave per tree, no workgroup barriers (mzx_resnet_wave.h)
+      RzWaveArgs wa;
+      memset(&wa, 0, sizeof(wa));
+      unsigned wgrid = 0;
+      size_t wlds = 0;
+      if (rz_wave_plan(s, R, L.a, wa, wgrid, wlds)) {
+        wa.s.p = v.p;
+        wa.s.L = s->L;
+        wa.s.trees = v.arena.trees;
+        wa.s.tape = io->d_tape;
+        wa.s.num_sims = s->p.num_sims;
+        wa.s.sim0 = 0;
+        wa.s.prof = ((s->mode & 8) && s->ws_floats >= (int64_t)wgrid * 8) ? (uint32_t*)((char*)d_arena + s->off_ws) : nullptr;
+        wa.s.tree_lds = 2;
+        rc = rz_wave_launch(wa, wgrid, wlds, stream);
+        if (rc) return rc;
+        return search_finish(s, io, d_arena, stream);
       }
     }
     RzSearchArgs sa;

@@ -1,0 +1,636 @@
+// mzx_resnet_wave.h -- MCTS.run (/root/reference/self_play.py:319-355) for residual networks on SMALL boards
+// (H * W <= 16: one MFMA row tile per tree; tic-tac-toe, BASELINE config C3): a WAVE owns a tree for the whole
+// search.
+//
+// mzx_resnet_search.h spreads the (tree, position) rows of a workgroup's trees over its waves and separates
+// the operators of recurrent_inference (models.py:555-623) by workgroup barriers; on a 3 x 3 board the layer
+// GEMMs are one row tile each, so a simulation there is 9 barrier slots of ~4.6 k cycles of which the MFMAs
+// are ~1.2 k.  Here the 16 rows of a row tile are ONE tree's positions: every operator of the program --
+// 3x3 / 1x1 convolutions (rows = positions) and the head MLPs (a tile with one valid row) -- reads and writes
+// only the wave's own LDS regions, so the four waves of a workgroup run four independent searches without a
+// single workgroup barrier after set-up, each on its own SIMD and MFMA pipe:
+//   * tree: the 32-byte slot / node records of mzx_fused_fc2.h in LDS (fc2_walk / fc2_expand / fc2_backprop:
+//     the binary64 operations of mzx_tree.h in the reference's order), converted from / to the arena's
+//     TreeLayout at the ends of the launch;
+//   * network: the operator table of mzx_resnet_fused.h (rz_plan) interpreted per wave with the K loop and the
+//     epilogue of rz_gemm_tiles<1> -- the same MFMA sequence per output element, so the logits are bit-identical
+//     to the workgroup engine's -- but with the row addresses of the wave's tile held in registers for the whole
+//     launch instead of being re-read per operator;
+//   * weights: as many packed B-fragment images as fit beside the four trees stay in LDS (the 3x3 convolutions
+//     of C3), the rest is streamed from L2 by the four-chunk ring of the K loop.
+// (Included by mzx_resnet_search.h between its kernels and its host driver.)
+#pragma once
+
+namespace mzx {
+
+#ifndef MZX_HOSTCHECK
+
+constexpr int RZW_WAVES = 4;
+
+struct RzWaveArgs {
+  RzSearchArgs s;
+  int32_t wl[RZ_MAX_OPS];   // float offset of operator o's packed weights inside the LDS weight area, -1: read from L2
+  int32_t wl_floats;        // size of the LDS weight area
+};
+
+// Operator classes, decided once per launch: the operators of the reference's residual network at <= 16 channels
+// get straight-line code (K loop fully unrolled, every per-layer option a compile-time constant); anything else
+// runs on the generic interpreter (rzw_gemm / rzw_scale) -- same arithmetic either way.
+enum RzwClass {
+  RZW_GENERIC = 0,    // any GEMM
+  RZW_SCALE_GEN,      // any scaling operator
+  RZW_SCALE16,        // scaling, <= 16 planes of <= 16 positions: in registers
+  RZW_CONV,           // 3x3, <= 16 -> <= 16 channels, folded BatchNorm, ReLU
+  RZW_CONV_ASUM,      // ... + the action plane of the dynamics input
+  RZW_CONV_RES,       // ... + residual
+  RZW_CONV1,          // 1x1 head convolution, bias, flat output
+  RZW_FC9_ELU,        // head MLP layer, 129 .. 144 inputs (nine 16-deep chunks), <= 16 outputs, ELU
+  RZW_FC1,            // head MLP layer, <= 16 inputs, any outputs, no activation
+};
+
+struct RzwOp {          // compact descriptor in LDS, fetched into scalar registers per operator
+  int32_t cls, in_off, out_off, res_off;
+  int32_t w_lds, w_off, p0, p1;       // weights: LDS float offset (-1: L2) / offset in the global image; p0, p1: alpha, beta or bias
+  int32_t asum_off, wchunks, cout, nt_total;
+  int32_t store_hidden, channels, pad0, pad1;
+};
+static_assert(sizeof(RzwOp) == 64, "RzwOp is fetched as four 16-byte LDS reads");
+
+struct RzWaveLayout { int optab, simg, tables, inv_y, wlds, wave0, wave_stride, o_scratch, o_reg, o_tree, total; };   // floats
+
+// LDS of a workgroup: rowaddr[16], compact operator table, small image, UCB tables, reciprocals, weights, then
+// per wave {scaling scratch + action value, the program's regions, the tree's records}
+__host__ __device__ inline RzWaveLayout rzw_layout(int n_ops, int small_floats, int NN, int Cs, int tree_floats, int rec_floats,
+                                                   int wl_floats) {
+  RzWaveLayout y;
+  int c = 16;
+  y.optab = c; c += n_ops * 16;
+  y.simg = c; c += (small_floats + 3) & ~3;
+  y.tables = c; c += (4 * (NN + 1) + 3) & ~3;
+  y.inv_y = c; c += (2 * (NN + 2) + 3) & ~3;
+  y.wlds = c; c += (wl_floats + 3) & ~3;
+  y.wave0 = c;
+  int w = 0;
+  y.o_scratch = w; w += (2 * Cs + 4 + 3) & ~3;
+  y.o_reg = w; w += (tree_floats + 3) & ~3;
+  y.o_tree = w; w += (rec_floats + 3) & ~3;
+  y.wave_stride = w;
+  y.total = c + RZW_WAVES * w;
+  return y;
+}
+
+// operator descriptor -> scalar registers (the LDS copy of the table is read by every lane at the same address)
+__device__ __forceinline__ RzOp rzw_fetch_op(const float* image, int o) {
+  const int* w = (const int*)image + o * (int)(sizeof(RzOp) / 4);
+  int v[sizeof(RzOp) / 4];
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(RzOp) / 4); ++k) v[k] = __builtin_amdgcn_readfirstlane(w[k]);
+  RzOp op;
+  __builtin_memcpy(&op, v, sizeof(RzOp));
+  return op;
+}
+
+// One column tile of a layer GEMM on the wave's row tile: K loop + epilogue of rz_gemm_tiles<1, *, true>
+// (mzx_resnet_fused.h) with T = 1 -- same MFMA order (K-steps alternate between two accumulator tiles that are
+// added at the end), same epilogue arithmetic.  `ra_lane` = activation address of row lane & 15, `ra4` = those
+// of the four rows 4 * (lane >> 4) + r this lane holds in the D fragment.
+typedef int rzw_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void rzw_gemm(const RzOp& op, const RzArgs& a, float* reg, const float* simg, const float* wsrc,
+                                         const float* scratch, int lane, int ra_lane, const rzw_i32x4& ra4, int nt) {
+  const bool pos_rows = (op.rows == RZ_ROWS_POS);
+  const int rows = pos_rows ? a.HW : 1;
+  const float* in = reg + op.in_off;
+  const int abase = (pos_rows ? ra_lane : 0) + 4 * (lane >> 4);
+  const f32x4* wp = (const f32x4*)(wsrc) + (size_t)nt * op.wchunks * 64 + lane;
+  const int* tbl = (const int*)simg + op.aoff_off;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](const f32x4& av, const f32x4& bv) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc, 0, 0, 0);
+    acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc_odd, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc, 0, 0, 0);
+    acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc_odd, 0, 0, 0);
+  };
+  auto load_a = [&](int off, f32x4& av) { av = *(const f32x4*)(in + abase + off); };
+  const int wlast = op.wchunks - 1;
+  auto load_b = [&](int c, f32x4& bv) { bv = wp[(size_t)(c < wlast ? c : wlast) * 64]; };
+  // what the epilogue needs that does not depend on the accumulators, before the K loop
+  const int n = nt * 16 + (lane & 15);
+  const bool padded = (op.out_layout == RZ_OUT_PADDED);
+  const float* res = (op.res_off >= 0) ? reg + op.res_off : nullptr;
+  const int m0 = (lane >> 4) * 4;
+  float rs[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) rs[r] = res ? res[ra4[r] + n] : 0.f;
+  {
+    f32x4 A0, A1, A2, A3, B0, B1, B2, B3;
+    const int nch = op.nchunks;
+    {
+      const rzw_i32x4 q = *(const rzw_i32x4*)tbl;   // chunks 0 .. 3
+      load_b(0, B0); load_a(q[0], A0);
+      load_b(1, B1); load_a(q[1], A1);
+      load_b(2, B2); load_a(q[2], A2);
+      load_b(3, B3); load_a(q[3], A3);
+    }
+    for (int c = 0; c < nch; c += 4) {
+      const rzw_i32x4 q = *(const rzw_i32x4*)(tbl + c + 4);   // chunks c + 4 .. c + 7 (entries past the end repeat the last)
+      __builtin_amdgcn_sched_barrier(0);
+      compute(A0, B0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(c + 4, B0); load_a(q[0], A0);
+      if (c + 1 >= nch) break;
+      __builtin_amdgcn_sched_barrier(0);
+      compute(A1, B1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(c + 5, B1); load_a(q[1], A1);
+      if (c + 2 >= nch) break;
+      __builtin_amdgcn_sched_barrier(0);
+      compute(A2, B2);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(c + 6, B2); load_a(q[2], A2);
+      if (c + 3 >= nch) break;
+      __builtin_amdgcn_sched_barrier(0);
+      compute(A3, B3);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(c + 7, B3); load_a(q[3], A3);
+    }
+  }
+  acc = acc + acc_odd;
+  // ---- epilogue (rz_gemm_tiles): action term, folded BatchNorm, bias, residual, activation
+  const bool nv = n < op.cout;
+  float al = 1.f, be = 0.f, bi = 0.f;
+  if (op.alpha_off >= 0) { al = simg[op.alpha_off + n]; be = simg[op.beta_off + n]; }
+  if (op.bias_off >= 0) bi = simg[op.bias_off + n];
+  const float floor_v = (op.act == RZ_ACT_RELU) ? 0.f : -MZX_INF;
+  float* out = reg + op.out_off;
+  const int nstride = (!padded && pos_rows) ? a.HW : 1;
+  int base[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int p = (m0 + r < a.HW) ? m0 + r : 0;
+    base[r] = padded ? ra4[r] : (pos_rows ? p : (m0 + r) * op.out_tstride);
+  }
+  if (op.asum_off >= 0) {   // action plane of the dynamics input (first layer only)
+    const float actval = scratch[2 * a.Cs];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = (m0 + r < a.HW) ? m0 + r : 0;
+      acc[r] += actval * simg[op.asum_off + n * a.HW + p];
+    }
+  }
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x = acc[r] * al + be;
+    x = x + bi;
+    x = x + rs[r];
+    v[r] = fmaxf(x, floor_v);
+  }
+  if (op.act == RZ_ACT_ELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = mzx_elu(v[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (m0 + r < rows && nv) out[base[r] + n * nstride] = v[r];
+}
+
+// per-plane min-max scaling (models.py:527-553, :574-599) of the wave's tree + hidden-state store (rz_scale, one wave)
+__device__ __forceinline__ void rzw_scale(const RzOp& op, const RzArgs& a, float* reg, float* scratch, const int* rowaddr,
+                                          int lane, float* hid) {
+  const int C = op.channels;
+  const float* in = reg + op.in_off;
+  float* out = reg + op.out_off;
+  const int sub = lane & 15, grp = lane >> 4;
+  for (int base = 0; base < C; base += 4) {
+    const int c = base + grp;
+    const bool valid = c < C;
+    const int cc = valid ? c : 0;
+    float lo = MZX_INF, hi = -MZX_INF;
+    for (int p = sub; p < a.HW; p += 16) {
+      const float v = in[rowaddr[p] + cc];
+      lo = fminf(lo, v); hi = fmaxf(hi, v);
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+      lo = fminf(lo, __shfl_xor(lo, m, 16));
+      hi = fmaxf(hi, __shfl_xor(hi, m, 16));
+    }
+    if (valid && sub == 0) {
+      float sc = hi - lo;
+      if (sc < 1e-5f) sc += 1e-5f;
+      scratch[2 * c] = lo;
+      scratch[2 * c + 1] = sc;
+    }
+  }
+  wave_sync();
+  const int per_tree = C * a.HW;
+  for (int rem = lane; rem < per_tree; rem += 64) {
+    const int c = rz_div(rem, a.HW, a.magic_hw), p = rem - c * a.HW;
+    const int ra = rowaddr[p] + c;
+    const float y = (in[ra] - scratch[2 * c]) / scratch[2 * c + 1];
+    out[ra] = y;
+    if (hid) hid[rem] = y;
+  }
+}
+
+__device__ __forceinline__ RzwOp rzw_fetch(const RzwOp* tab, int o) {
+  const int* w = (const int*)(tab + o);
+  int v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = __builtin_amdgcn_readfirstlane(w[k]);
+  RzwOp q;
+  __builtin_memcpy(&q, v, sizeof(RzwOp));
+  return q;
+}
+
+__device__ __forceinline__ int rzw_classify(const RzOp& op, int HW) {
+  if (op.kind != RZ_GEMM) return (op.channels <= 16 && HW <= 16) ? RZW_SCALE16 : RZW_SCALE_GEN;
+  const bool pos = op.rows == RZ_ROWS_POS, padded = op.out_layout == RZ_OUT_PADDED;
+  const int taps = op.taps & 0xFF;
+  const bool bn = op.alpha_off >= 0, bias = op.bias_off >= 0, res = op.res_off >= 0, asum = op.asum_off >= 0;
+  if (pos && taps == 9 && op.cchunks == 1 && op.cout <= 16 && padded && bn && !bias && op.act == RZ_ACT_RELU) {
+    if (res) return asum ? RZW_GENERIC : RZW_CONV_RES;
+    return asum ? RZW_CONV_ASUM : RZW_CONV;
+  }
+  if (bn || res || asum || !bias || padded) return RZW_GENERIC;
+  if (pos && taps == 1 && op.cchunks == 1 && op.cout <= 16 && op.act == RZ_ACT_NONE) return RZW_CONV1;
+  if (!pos && op.nchunks == 9 && op.cout <= 16 && op.act == RZ_ACT_ELU) return RZW_FC9_ELU;
+  if (!pos && op.nchunks == 1 && op.act == RZ_ACT_NONE) return RZW_FC1;
+  return RZW_GENERIC;
+}
+
+// lane constants of the wave's row tile, for the whole launch
+struct RzwLane {
+  int lane, g4, HW, Cs;
+  int ra_lane;          // activation address of row lane & 15 (A operand)
+  rzw_i32x4 ra4;        // ... of rows 4 * (lane >> 4) + r (D fragment)
+  int atap[9];          // ra_lane + 4 * (lane >> 4) + offset of tap c of a 3x3 convolution with one channel chunk
+  int rsc[4];           // activation address of position (lane >> 4) + 4 k (scaling operator)
+};
+
+enum { RZW_K_TAP9 = 0, RZW_K_LIN1 = 1, RZW_K_LIN9 = 2 };
+enum { RZW_EP_BN_RELU = 0, RZW_EP_BN_RELU_ASUM, RZW_EP_BN_RES_RELU, RZW_EP_BIAS_POS, RZW_EP_BIAS_ELU_TREE, RZW_EP_BIAS_TREE };
+
+// rzw_gemm with the K structure and the epilogue options as compile-time constants: every fragment of the
+// operator is requested up front (nine A + nine B quads at most), the MFMAs follow back to back in the order of
+// rz_gemm_tiles<1> (chunk by chunk, K-steps alternating between the two accumulator tiles), the epilogue is the
+// same sequence of fp32 operations with absent terms as literal 1.f / 0.f.
+template <int KS, int EP>
+__device__ __forceinline__ void rzw_gemm_s(const RzwOp& q, float* reg, const float* simg, const f32x4* wp, const float* scratch,
+                                           const RzwLane& k, int nt) {
+  constexpr bool POS = (EP <= RZW_EP_BIAS_POS);
+  constexpr bool BN = (EP <= RZW_EP_BN_RES_RELU);
+  constexpr int NCH = (KS == RZW_K_LIN1) ? 1 : 9;
+  const float* in = reg + q.in_off;
+  wp += (size_t)nt * q.wchunks * 64;
+  const int n = nt * 16 + (k.lane & 15);
+  f32x4 A[NCH], B[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {   // chunk 0 first: LDS answers in request order
+    const int at = (KS == RZW_K_TAP9) ? k.atap[c] : (POS ? k.ra_lane : 0) + k.g4 + c * 16;
+    B[c] = wp[c * 64];
+    A[c] = *(const f32x4*)(in + at);
+    if (c == 0) __builtin_amdgcn_sched_barrier(0);
+  }
+  // epilogue operands: their LDS round trips hide under the MFMAs
+  float al = 1.f, be = 0.f, bi = 0.f;
+  if (BN) { al = simg[q.p0 + n]; be = simg[q.p1 + n]; } else { bi = simg[q.p0 + n]; }
+  float rs[4] = {0.f, 0.f, 0.f, 0.f}, as[4] = {0.f, 0.f, 0.f, 0.f};
+  float actval = 0.f;
+  if (EP == RZW_EP_BN_RES_RELU) {
+    const float* res = reg + q.res_off;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rs[r] = res[k.ra4[r] + n];
+  }
+  if (EP == RZW_EP_BN_RELU_ASUM) {
+    actval = scratch[2 * k.Cs];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) as[r] = simg[q.asum_off + n * k.HW + ((k.g4 + r < k.HW) ? k.g4 + r : 0)];
+  }
+  // every request above is issued before the first MFMA (the scheduler would otherwise re-serialise them into a
+  // load -> wait -> four MFMAs chain per chunk, one LDS round trip each)
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][0], B[c][0], acc, 0, 0, 0);
+    acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][1], B[c][1], acc_odd, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][2], B[c][2], acc, 0, 0, 0);
+    acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][3], B[c][3], acc_odd, 0, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  acc = acc + acc_odd;
+  const bool nv = n < q.cout;
+  float* out = reg + q.out_off;
+  if (EP == RZW_EP_BN_RELU_ASUM) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += actval * as[r];
+  }
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x = acc[r] * al + be;
+    x = x + bi;
+    x = x + rs[r];
+    v[r] = fmaxf(x, BN ? 0.f : -MZX_INF);
+  }
+  if (EP == RZW_EP_BIAS_ELU_TREE) v[0] = mzx_elu(v[0]);
+  if (BN) {                                   // padded position-major output
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (k.g4 + r < k.HW && nv) out[k.ra4[r] + n] = v[r];
+  } else if (EP == RZW_EP_BIAS_POS) {         // flat [channel][position]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (k.g4 + r < k.HW && nv) out[k.g4 + r + n * k.HW] = v[r];
+  } else {                                    // one valid row: the tree
+    if (k.g4 == 0 && nv) out[n] = v[0];
+  }
+}
+
+// rzw_scale for <= 16 planes of <= 16 positions, in registers: lane (g, c) holds positions g, g + 4, g + 8, g + 12 of
+// plane c (minimum / maximum are exact in any order)
+__device__ __forceinline__ void rzw_scale16(const RzwOp& q, float* reg, const RzwLane& k, float* hid) {
+  const float* in = reg + q.in_off;
+  float* out = reg + q.out_off;
+  const int c = k.lane & 15, g = k.lane >> 4;
+  const bool cv = c < q.channels;
+  float v[4];
+  float lo = MZX_INF, hi = -MZX_INF;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool valid = cv && g + 4 * j < k.HW;
+    v[j] = in[k.rsc[j] + (cv ? c : 0)];
+    lo = valid ? fminf(lo, v[j]) : lo;
+    hi = valid ? fmaxf(hi, v[j]) : hi;
+  }
+  lo = fminf(lo, __shfl_xor(lo, 16)); hi = fmaxf(hi, __shfl_xor(hi, 16));
+  lo = fminf(lo, __shfl_xor(lo, 32)); hi = fmaxf(hi, __shfl_xor(hi, 32));
+  float sc = hi - lo;
+  if (sc < 1e-5f) sc += 1e-5f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = g + 4 * j;
+    if (cv && p < k.HW) {
+      const float y = (v[j] - lo) / sc;
+      out[k.rsc[j] + c] = y;
+      if (hid) hid[c * k.HW + p] = y;
+    }
+  }
+}
+
+// AW: lanes that hold a child slot (4 or 16)
+template <int AW>
+__global__ void __launch_bounds__(RZW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+rz_wave_search_kernel(const RzWaveArgs wa) {
+  constexpr int NT = RZW_WAVES * 64;
+  extern __shared__ __attribute__((aligned(16))) float rz_lds[];
+  const RzSearchArgs& sa = wa.s;
+  const RzArgs& a = sa.net;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NN = sa.p.num_nodes;
+  const RzWaveLayout y = rzw_layout(a.n_ops, a.small_floats, NN, a.Cs, a.tree_floats, (int)rz_trec_tree_floats(NN, AW), wa.wl_floats);
+  int* rowaddr = (int*)rz_lds;            // [16]
+  RzwOp* optab = (RzwOp*)(rz_lds + y.optab);
+  float* simg = rz_lds + y.simg;
+  double* tables = (double*)(rz_lds + y.tables);
+  double* inv_y = (double*)(rz_lds + y.inv_y);
+  float* wlds = rz_lds + y.wlds;
+  float* mine = rz_lds + y.wave0 + wave * y.wave_stride;
+  float* scratch = mine + y.o_scratch;
+  float* reg = mine + y.o_reg;
+
+  // ---- once per launch, the whole workgroup: program image, tables, LDS-resident weights, zeroed regions
+  {
+    const f32x4* src = (const f32x4*)a.small;
+    f32x4* dst = (f32x4*)simg;
+    for (int i = tid; i < a.small_floats / 4; i += NT) dst[i] = src[i];
+  }
+  for (int i = tid; i < 2 * (NN + 1); i += NT) tables[i] = sa.p.pbc_table[i];   // pbc[NN + 1] then sqrt[NN + 1], contiguous
+  for (int i = tid; i < NN + 2; i += NT) inv_y[i] = recip_refined((double)(i > 0 ? i : 1));
+  if (tid < a.n_ops) {
+    const RzOp op = ((const RzOp*)a.small)[tid];
+    RzwOp q;
+    q.cls = rzw_classify(op, a.HW);
+    q.in_off = op.in_off; q.out_off = op.out_off; q.res_off = op.res_off;
+    q.w_lds = wa.wl[tid]; q.w_off = op.w_off;
+    q.p0 = (op.alpha_off >= 0) ? op.alpha_off : op.bias_off; q.p1 = op.beta_off;
+    q.asum_off = op.asum_off; q.wchunks = op.wchunks; q.cout = op.cout; q.nt_total = (op.cout + 15) >> 4;
+    q.store_hidden = op.store_hidden; q.channels = op.channels; q.pad0 = 0; q.pad1 = 0;
+    optab[tid] = q;
+  }
+  for (int o = 0; o < a.n_ops; ++o) {
+    const int at = wa.wl[o];
+    if (at < 0) continue;
+    const RzOp* gop = (const RzOp*)a.small + o;
+    const int nfl = ((gop->cout + 15) >> 4) * gop->wchunks * 256;
+    const f32x4* src = (const f32x4*)(a.weights + gop->w_off);
+    f32x4* dst = (f32x4*)(wlds + at);
+    for (int i = tid; i < nfl / 4; i += NT) dst[i] = src[i];
+  }
+  for (int w = 0; w < RZW_WAVES; ++w) {   // halo positions, pad channels and pad words stay zero for the whole launch
+    f32x4* z = (f32x4*)(rz_lds + y.wave0 + w * y.wave_stride + y.o_scratch);
+    for (int i = tid; i < y.o_tree / 4; i += NT) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (tid < 16) {
+    int ra = (a.PW + 1) * a.Cs;           // rows beyond the board: a valid address, never stored to
+    if (tid < a.HW) {
+      const int yy = rz_div(tid, a.W, a.magic_w), xx = tid - yy * a.W;
+      ra = ((yy + 1) * a.PW + xx + 1) * a.Cs;
+    }
+    rowaddr[tid] = ra;
+  }
+  __syncthreads();
+  const int tree = blockIdx.x * RZW_WAVES + wave;
+  if (tree >= a.batch) return;            // whole waves; no workgroup barrier below
+
+  // ---- the wave's tree: arena -> records.  All four 16-lane rows of the wave run the tree code on the SAME tree
+  // (identical values, identical stores): no lane masks around the row-wide DPP / ballot operations.
+  const int sub = lane & (FUSED_ROW - 1), row_in_wave = lane >> 4;
+  TreeRef t;
+  t.base = sa.trees + (size_t)tree * sa.L.tree_bytes;
+  t.L = sa.L;
+  Fc2Tree FT;
+  fc2_carve<AW>(FT, (char*)(mine + y.o_tree), NN);
+  FT.pbc = tables; FT.sqt = tables + (NN + 1); FT.inv_y = inv_y;
+  FT.disc = sa.p.discount; FT.A = sa.p.num_actions; FT.NN = NN; FT.P = sa.p.num_players;
+  FT.pb_leaf = FT.pbc[1] * div_by(FT.sqt[1], 1.0, inv_y[1]);
+  Fc2Row rst;
+  fc2_from_arena<AW>(FT, rst, t, sub);
+  wave_sync();
+  const uint32_t* tape = sa.tape + (size_t)tree * sa.p.tape_words;
+  const int F = a.out_n[0], A = a.out_n[2];
+  const int support = sa.p.support_size;
+  // rows of the wave's tile, for the whole launch
+  const int ra_lane = rowaddr[lane & 15];
+  const rzw_i32x4 ra4 = *(const rzw_i32x4*)(rowaddr + (lane >> 4) * 4);
+  RzwLane kl;
+  kl.lane = lane; kl.g4 = 4 * (lane >> 4); kl.HW = a.HW; kl.Cs = a.Cs; kl.ra_lane = ra_lane; kl.ra4 = ra4;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) kl.atap[c] = ra_lane + kl.g4 + (c / 3 - 1) * a.PW * a.Cs + (c % 3 - 1) * a.Cs;   // rz_aoff_entry, one chunk per tap
+#pragma unroll
+  for (int j = 0; j < 4; ++j) kl.rsc[j] = rowaddr[((lane >> 4) + 4 * j) & 15];
+  const int per_tree = a.in_channels * a.HW;
+
+  uint32_t pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = 0;
+  const bool prof = sa.prof != nullptr && tid == 0;
+  if (prof) t_last = __builtin_readcyclecounter();
+#define RZW_PROF(k) if (prof) { const unsigned long long _t = __builtin_readcyclecounter(); pc[k] += (uint32_t)(_t - t_last); t_last = _t; }
+
+  for (int sim = 0; sim < sa.num_sims; ++sim) {
+    // ---- selection (self_play.py:325-334)
+    const Fc2Walk wk = fc2_walk<AW>(FT, rst, tape, sa.p.tape_words, sub, row_in_wave);
+    wave_sync();
+    const Fc2Lane<AW> lane_ops = fc2_load_lane<AW>(FT, wk, wk.levels >> 4, sub);   // hides behind the network
+    RZW_PROF(0)
+
+    // ---- parent state [C][H][W] (arena) -> position-major region, action value of the dynamics input
+    {
+      if (lane == 0) scratch[2 * a.Cs] = a.use_action ? (float)wk.action / (float)a.num_actions : 0.f;
+      const float* src = a.in + ((int64_t)tree * a.in_nodes + wk.parent) * per_tree;
+      float* dst = reg + a.in_off;
+      for (int i = lane; i < per_tree; i += 64) {
+        const int c = rz_div(i, a.HW, a.magic_hw), p = i - c * a.HW;
+        dst[rowaddr[p] + c] = src[i];
+      }
+    }
+    wave_sync();
+    RZW_PROF(2)
+
+    // ---- recurrent_inference (models.py:620-623): the operator table in schedule order, one wave
+    float* hid = a.hidden_out + ((int64_t)tree * a.out_nodes + wk.leaf) * a.hidden_floats;
+#define RZW_CALL(KS, EP)                                                                                        \
+  for (int nt = 0; nt < q.nt_total; ++nt) {                                                                     \
+    if (q.w_lds >= 0) rzw_gemm_s<KS, EP>(q, reg, simg, (const f32x4*)(wlds + q.w_lds) + lane, scratch, kl, nt);  \
+    else rzw_gemm_s<KS, EP>(q, reg, simg, (const f32x4*)(a.weights + q.w_off) + lane, scratch, kl, nt);          \
+  }
+    for (int o = 0; o < a.n_ops; ++o) {
+      const RzwOp q = rzw_fetch(optab, o);
+      RZW_PROF(3)   // descriptor fetches (+ the fence below)
+      switch (q.cls) {
+        case RZW_CONV: RZW_CALL(RZW_K_TAP9, RZW_EP_BN_RELU) break;
+        case RZW_CONV_ASUM: RZW_CALL(RZW_K_TAP9, RZW_EP_BN_RELU_ASUM) break;
+        case RZW_CONV_RES: RZW_CALL(RZW_K_TAP9, RZW_EP_BN_RES_RELU) break;
+        case RZW_CONV1: RZW_CALL(RZW_K_LIN1, RZW_EP_BIAS_POS) break;
+        case RZW_FC9_ELU: RZW_CALL(RZW_K_LIN9, RZW_EP_BIAS_ELU_TREE) break;
+        case RZW_FC1: RZW_CALL(RZW_K_LIN1, RZW_EP_BIAS_TREE) break;
+        case RZW_SCALE16: rzw_scale16(q, reg, kl, q.store_hidden ? hid : nullptr); break;
+        case RZW_SCALE_GEN: {
+          const RzOp op = rzw_fetch_op(simg, o);
+          rzw_scale(op, a, reg, scratch, rowaddr, lane, op.store_hidden ? hid : nullptr);
+          break;
+        }
+        default: {   // any other GEMM: the interpreter
+          const RzOp op = rzw_fetch_op(simg, o);
+          if (q.w_lds >= 0) {   // two call sites: the address space of the B fragments is known in each (ds_read / global_load)
+            for (int nt = 0; nt < q.nt_total; ++nt) rzw_gemm(op, a, reg, simg, wlds + q.w_lds, scratch, lane, ra_lane, ra4, nt);
+          } else {
+            for (int nt = 0; nt < q.nt_total; ++nt) rzw_gemm(op, a, reg, simg, a.weights + op.w_off, scratch, lane, ra_lane, ra4, nt);
+          }
+          break;
+        }
+      }
+      wave_sync();
+      // profile: 9-chunk GEMMs from LDS weights / from L2, short GEMMs, scaling
+      if (prof) {
+        const int pk = (q.cls == RZW_SCALE16 || q.cls == RZW_SCALE_GEN) ? 7
+                       : ((q.cls == RZW_CONV1 || q.cls == RZW_FC1) ? 6 : (q.w_lds >= 0 ? 1 : 5));
+        RZW_PROF(pk)
+      }
+    }
+#undef RZW_CALL
+    // the leaf's state must have left the wave before a later simulation gathers it (what the workgroup
+    // barrier of rz_search_kernel implies)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    RZW_PROF(3)
+
+    // ---- decode, expand, back-propagate (self_play.py:343-353)
+    {
+      const float* vl = reg + a.out_off[0];
+      const float* rl = reg + a.out_off[1];
+      const float* pl = reg + a.out_off[2];
+      const float value = row_decode2(sub < F ? vl[sub] : 0.f, sub + 16 < F ? vl[sub + 16] : 0.f, F, support, sub);
+      const float reward = row_decode2(sub < F ? rl[sub] : 0.f, sub + 16 < F ? rl[sub + 16] : 0.f, F, support, sub);
+      const bool in = sub < A;
+      const float lg = in ? pl[sub] : 0.f;
+      const float m = row_max(in ? lg : -MZX_INF);
+      const float e = in ? mzx_expf(lg - m) : 0.f;
+      const float den = row_sum(e);
+      fc2_expand<AW>(FT, wk.leaf, sub, in, (double)mzx_div(e, den));
+      fc2_backprop<AW>(FT, rst, wk, lane_ops, sub, (double)value, (double)reward);
+    }
+    wave_sync();
+    RZW_PROF(4)
+  }
+#undef RZW_PROF
+  if (prof) for (int k = 0; k < 8; ++k) sa.prof[blockIdx.x * 8 + k] = pc[k];
+  wave_sync();
+  fc2_to_arena<AW>(FT, rst, t, sub);
+}
+
+template <int AW>
+inline int rz_wave_launch_k(const RzWaveArgs& wa, unsigned grid, size_t lds_bytes, stream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)rz_wave_search_kernel<AW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((rz_wave_search_kernel<AW>), dim3(grid), dim3(RZW_WAVES * 64), lds_bytes, stream, wa);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("wave-private search kernel launch failed: %s (grid %u, %zu bytes of LDS)", hipGetErrorString(e), grid, lds_bytes);
+    return MZX_ERR_RUNTIME;
+  }
+  return MZX_OK;
+}
+
+// Plans the launch; false: the configuration is not one for this kernel (the caller uses rz_search_kernel).
+// MZX_RZ_WAVE=0: A/B knob.
+inline bool rz_wave_plan(const mzx_search* s, const RzProgram& R, const RzArgs& base, RzWaveArgs& wa, unsigned& grid,
+                         size_t& lds_bytes) {
+  const RzGeometry& g = s->net->rz.g;
+  const int A = s->p.num_actions;
+  if (g.HW > 16 || A > FUSED_ROW || 2 * s->p.support_size + 1 > 2 * FUSED_ROW) return false;
+  if (rz_env_int("MZX_RZ_WAVE", 1) == 0) return false;
+  const int AW = A <= 4 ? 4 : 16;
+  const int NN = s->p.num_nodes;
+  wa.s.net = base;
+  RzArgs& a = wa.s.net;
+  a.T = 1;
+  a.mpad = 16;
+  a.small_floats = R.small_floats;      // with the A-fragment offset tables
+  const int rec_floats = (int)rz_trec_tree_floats(NN, AW);
+  const int64_t fixed = rzw_layout(a.n_ops, a.small_floats, NN, a.Cs, a.tree_floats, rec_floats, 0).total;
+  if (4 * fixed > RZ_LDS_BUDGET) return false;
+  // weights into LDS, greedily in schedule order while they fit (shared packs once)
+  int64_t room = RZ_LDS_BUDGET / 4 - fixed;
+  int used = 0;
+  for (int o = 0; o < RZ_MAX_OPS; ++o) wa.wl[o] = -1;
+  for (int o = 0; o < R.n_ops; ++o) {
+    const RzOp& op = R.ops[o];
+    if (op.kind != RZ_GEMM) continue;
+    int shared = -1;
+    for (int q = 0; q < o; ++q)
+      if (R.ops[q].kind == RZ_GEMM && R.ops[q].w_off == op.w_off && wa.wl[q] >= 0) shared = wa.wl[q];
+    if (shared >= 0) { wa.wl[o] = shared; continue; }
+    const int nfl = ((op.cout + 15) / 16) * op.wchunks * 256;
+    if (used + nfl <= room) { wa.wl[o] = used; used += nfl; }
+  }
+  wa.wl_floats = used;
+  grid = (unsigned)((s->p.num_trees + RZW_WAVES - 1) / RZW_WAVES);
+  lds_bytes = (size_t)4 * rzw_layout(a.n_ops, a.small_floats, NN, a.Cs, a.tree_floats, rec_floats, used).total;
+  return true;
+}
+
+inline int rz_wave_launch(const RzWaveArgs& wa, unsigned grid, size_t lds_bytes, stream_t stream) {
+  return wa.s.p.num_actions <= 4 ? rz_wave_launch_k<4>(wa, grid, lds_bytes, stream)
+                                 : rz_wave_launch_k<16>(wa, grid, lds_bytes, stream);
+}
+
+#endif  // !MZX_HOSTCHECK
+
+}  // namespace mzx

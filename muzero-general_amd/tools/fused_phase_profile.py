@@ -63,7 +63,17 @@ def residual(args):
     torch.cuda.synchronize()
     off = engine.arena_offsets(B)
     raw = engine.arena(B)[off["workspace"]: off["workspace"] + 256 * 8 * 4].view(torch.int32).cpu().numpy().reshape(-1, 8)
-    raw = raw[((raw[:, :6] > 0) & (raw[:, :6] < 2 ** 29)).all(1)]   # workgroups that wrote counters (the region is shared with the stem's workspace)
+    raw = raw[((raw[:, [0, 2, 3, 4]] > 0) & (raw < 2 ** 29).all(1, keepdims=True)).all(1)]   # workgroups that wrote counters (the region is shared with the stem's workspace)
+    if (raw[:, 6:] > 0).any():   # wave-per-tree kernel (mzx_resnet_wave.h): the network by operator class, no barriers
+        S = cfg.num_simulations
+        mean = raw.mean(0)
+        names8 = ["select + fetch of the path", "9-chunk GEMMs, weights in LDS", "gather parent state -> LDS", "descriptor fetches + fence",
+                  "decode + expand + backpropagate", "9-chunk GEMMs, weights from L2", "short GEMMs (1 chunk)", "min-max scaling + state store"]
+        print(f"{args.workload}: {B} trees x {S} sims, {len(raw)} workgroups sampled (wave 0), mean leaf depth {res.sum_depth.mean() / S:.2f}, wave-per-tree kernel")
+        for k, nm in enumerate(names8):
+            print(f"  {nm:38s} {mean[k] / S:10.0f} cycles per simulation  ({100 * mean[k] / mean.sum():5.1f}%)")
+        print(f"  total                                  {mean.sum() / S:10.0f} cycles per simulation = {mean.sum() / S / 2.4e3:.2f} us at 2.4 GHz")
+        return
     S = cfg.num_simulations
     names = ["select (lane-parallel)              ", "barrier after select", "gather parent states -> LDS", "network layers",
              "decode + expand + backpropagate", "barrier"]
