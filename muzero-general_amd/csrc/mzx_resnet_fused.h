@@ -559,6 +559,7 @@ struct RzArgs {
   int32_t dump_op;                // >= 0: stop after this op and copy its output to `dump`; -2: cycle profile
                                   // (workgroup 0 writes s_memtime stamps after staging, input load and each op)
   int32_t w_floats, small_floats; // sizes of the program's weight image / small image
+  int32_t fast;                   // 1: operators of a fast class run rz_gemm_fast (MZX_RZ_FAST=0: A/B knob)
   const float* in;
   const int32_t* in_node;
   const int32_t* out_node;
@@ -569,6 +570,42 @@ struct RzArgs {
   const float* weights;           // the program's weight image (global)
   const float* small;             // the program's small image (global): RzOp table, epilogue parameters
 };
+
+
+// ---------------------------------------------------------------------------
+// Operator classes, decided once per launch.  The layer GEMMs of the reference's residual network at <= 16
+// channels get straight-line code when a wave's share of the operator is ONE row tile (small boards: C3, C5) --
+// K loop fully unrolled with every fragment requested up front, every per-layer option a compile-time constant
+// -- because on those networks a layer is ~1.2 k cycles of MFMA inside ~3-4 k cycles of interpretation (descriptor
+// decode, offset tables, option tests executed by a lone wave per SIMD).  Same MFMA order and epilogue arithmetic
+// as rz_gemm_tiles<1>: the results are bit-identical.  Anything else runs on the interpreter.
+enum RzFastClass {
+  RZ_FAST_NONE = 0,   // any GEMM: rz_gemm_tiles
+  RZ_FAST_SCALE_GEN,  // (wave kernel) any scaling operator
+  RZ_FAST_SCALE16,    // (wave kernel) scaling, <= 16 planes of <= 16 positions: in registers
+  RZ_FAST_CONV,       // 3x3, <= 16 -> <= 16 channels, folded BatchNorm, ReLU
+  RZ_FAST_CONV_ASUM,  // ... + the action plane of the dynamics input
+  RZ_FAST_CONV_RES,   // ... + residual
+  RZ_FAST_CONV1,      // 1x1 head convolution, <= 16 -> <= 16 channels, bias, flat output
+  RZ_FAST_FC9_ELU,    // head MLP layer, 129 .. 144 inputs (nine 16-deep chunks), <= 16 outputs, ELU
+  RZ_FAST_FC1,        // head MLP layer, <= 16 inputs, any number of outputs, no activation
+};
+
+MZX_HD inline int rz_classify(const RzOp& op, int HW) {
+  if (op.kind != RZ_GEMM) return (op.channels <= 16 && HW <= 16) ? RZ_FAST_SCALE16 : RZ_FAST_SCALE_GEN;
+  const bool pos = op.rows == RZ_ROWS_POS, padded = op.out_layout == RZ_OUT_PADDED;
+  const int taps = op.taps & 0xFF;
+  const bool bn = op.alpha_off >= 0, bias = op.bias_off >= 0, res = op.res_off >= 0, asum = op.asum_off >= 0;
+  if (pos && taps == 9 && op.cchunks == 1 && op.cout <= 16 && padded && bn && !bias && op.act == RZ_ACT_RELU) {
+    if (res) return asum ? RZ_FAST_NONE : RZ_FAST_CONV_RES;
+    return asum ? RZ_FAST_CONV_ASUM : RZ_FAST_CONV;
+  }
+  if (bn || res || asum || !bias || padded) return RZ_FAST_NONE;
+  if (pos && taps == 1 && op.cchunks == 1 && op.cout <= 16 && op.act == RZ_ACT_NONE) return RZ_FAST_CONV1;
+  if (!pos && op.nchunks == 9 && op.cout <= 16 && op.act == RZ_ACT_ELU) return RZ_FAST_FC9_ELU;
+  if (!pos && op.nchunks == 1 && op.act == RZ_ACT_NONE) return RZ_FAST_FC1;
+  return RZ_FAST_NONE;
+}
 
 #ifndef MZX_HOSTCHECK
 
@@ -854,11 +891,105 @@ __device__ __forceinline__ unsigned rz_work_word(const RzOp& op, int T, int HW, 
          ((unsigned)wm << 16) | ((unsigned)waves_m << 20);
 }
 
+enum { RZ_K_TAP9 = 0, RZ_K_LIN1 = 1, RZ_K_LIN9 = 2 };
+enum { RZ_EP_BN_RELU = 0, RZ_EP_BN_RELU_ASUM, RZ_EP_BN_RES_RELU, RZ_EP_BIAS_POS, RZ_EP_BIAS_ELU_TREE, RZ_EP_BIAS_TREE };
+
+// One row tile x one column tile of an operator of a fast class (see RzFastClass): rz_gemm_tiles<1> with the K
+// structure and the epilogue options as template parameters.
+template <int KS, int EP, bool WLDS>
+__device__ __forceinline__ void rz_gemm_fast(const RzOp& op, const RzArgs& a, const RzCtx& cx, int nt, int mt0) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  constexpr bool POS = (EP <= RZ_EP_BIAS_POS);
+  constexpr bool BN = (EP <= RZ_EP_BN_RES_RELU);
+  constexpr int NCH = (KS == RZ_K_LIN1) ? 1 : 9;
+  const int lane = cx.lane, T = cx.T, g4 = 4 * (lane >> 4);
+  const int rows = POS ? T * a.HW : T;
+  const float* in = cx.reg + T * op.in_off;
+  int m = mt0 * 16 + (lane & 15);
+  if (m >= rows) m = 0;
+  const int abase = (POS ? cx.rowaddr[m] : m * op.in_tstride) + g4;
+  const f32x4* wp = (const f32x4*)((WLDS ? cx.wlds : a.weights) + op.w_off) + (size_t)nt * op.wchunks * 64 + lane;
+  const int n = nt * 16 + (lane & 15);
+  const int m0 = mt0 * 16 + g4;
+  const int pwcs = a.PW * a.Cs;
+  f32x4 A[NCH], B[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {   // chunk 0 first: LDS answers in request order
+    const int off = (KS == RZ_K_TAP9) ? (c / 3 - 1) * pwcs + (c % 3 - 1) * a.Cs : c * 16;   // rz_aoff_entry, one chunk per tap
+    B[c] = wp[c * 64];
+    A[c] = *(const f32x4*)(in + abase + off);
+    if (c == 0) __builtin_amdgcn_sched_barrier(0);
+  }
+  // epilogue operands: their LDS round trips hide under the MFMAs
+  const int* rowo = cx.rowout ? cx.rowout : cx.rowaddr;
+  i32x4 ra4 = i32x4{0, 0, 0, 0}, tp4 = i32x4{0, 0, 0, 0};
+  if (POS && EP != RZ_EP_BIAS_POS) ra4 = *(const i32x4*)(rowo + m0);
+  if (EP == RZ_EP_BIAS_POS || EP == RZ_EP_BN_RELU_ASUM) tp4 = *(const i32x4*)(cx.rowtp + m0);
+  float al = 1.f, be = 0.f, bi = 0.f;
+  if (BN) { al = cx.simg[op.alpha_off + n]; be = cx.simg[op.beta_off + n]; } else { bi = cx.simg[op.bias_off + n]; }
+  float rs[4] = {0.f, 0.f, 0.f, 0.f}, as[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
+  if (EP == RZ_EP_BN_RES_RELU) {
+    const float* res = cx.reg + T * op.res_off;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rs[r] = res[ra4[r] + n];
+  }
+  if (EP == RZ_EP_BN_RELU_ASUM) {
+    const float* actval = cx.scratch + 2 * T * a.Cs;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { av[r] = actval[tp4[r] >> 16]; as[r] = cx.simg[op.asum_off + n * a.HW + (tp4[r] & 0xFFFF)]; }
+  }
+  // every request above is issued before the first MFMA (the scheduler would otherwise re-serialise them into a
+  // load -> wait -> four MFMAs chain per chunk, one LDS round trip each)
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][0], B[c][0], acc, 0, 0, 0);
+    acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][1], B[c][1], acc_odd, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][2], B[c][2], acc, 0, 0, 0);
+    acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][3], B[c][3], acc_odd, 0, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  acc = acc + acc_odd;
+  const bool nv = n < op.cout;
+  float* out = cx.reg + T * op.out_off;
+  if (EP == RZ_EP_BN_RELU_ASUM) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += av[r] * as[r];
+  }
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x = acc[r] * al + be;
+    x = x + bi;
+    x = x + rs[r];
+    v[r] = fmaxf(x, BN ? 0.f : -MZX_INF);
+  }
+  if (EP == RZ_EP_BIAS_ELU_TREE) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = mzx_elu(v[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int at;
+    if (BN) at = ra4[r] + n;                                                          // padded position-major output
+    else if (EP == RZ_EP_BIAS_POS) at = (tp4[r] >> 16) * op.out_tstride + (tp4[r] & 0xFFFF) + n * a.HW;   // flat [channel][position]
+    else at = (m0 + r) * op.out_tstride + n;                                          // rows = trees
+    if (m0 + r < rows && nv) out[at] = v[r];
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ int rz_op_class(const RzArgs& a, const RzCtx& cx, int o) {
+  if (NW != 4 || a.fast == 0) return RZ_FAST_NONE;
+  return __builtin_amdgcn_readfirstlane((int)cx.work[a.n_ops * NW + o]);
+}
+
 // MM: the most row tiles one wave ever gets in this launch (host-checked).  Kernels for small activation
 // matrices are instantiated with MM = 3: without the code of the 4..8-tile variants the kernel is half the
 // size and the per-operator dispatch -- exposed on the latency-bound small networks -- is shorter.
 template <bool WLDS, int NW, int MM>
-__device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const RzCtx& cx, unsigned w) {
+__device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const RzCtx& cx, unsigned w, int cls = RZ_FAST_NONE) {
 #ifdef MZX_RZ_EXPERIMENT
   if (cx.fine && cx.tid == 0) cx.fine[7] = __builtin_readcyclecounter() + (unsigned long long)(op.kind & 0);   // after the descriptor fetch
 #endif
@@ -867,6 +998,21 @@ __device__ __forceinline__ void rz_gemm(const RzOp& op, const RzArgs& a, const R
   const int cnt1 = (int)((w >> 4) & 15u), wn = (int)((w >> 8) & 15u), waves_n = (int)((w >> 12) & 15u);
   const int wm = (int)((w >> 16) & 15u), waves_m = (int)((w >> 20) & 15u);
   const int nt_total = (op.cout + 15) >> 4;
+  if constexpr (NW == 4 && MM == 3) {   // the kernels of the small networks
+    if (cls >= RZ_FAST_CONV && cnt0 == 1 && cnt1 == 0) {
+      for (int nt = wn; nt < nt_total; nt += waves_n) {
+        switch (cls) {
+          case RZ_FAST_CONV: rz_gemm_fast<RZ_K_TAP9, RZ_EP_BN_RELU, WLDS>(op, a, cx, nt, wm); break;
+          case RZ_FAST_CONV_ASUM: rz_gemm_fast<RZ_K_TAP9, RZ_EP_BN_RELU_ASUM, WLDS>(op, a, cx, nt, wm); break;
+          case RZ_FAST_CONV_RES: rz_gemm_fast<RZ_K_TAP9, RZ_EP_BN_RES_RELU, WLDS>(op, a, cx, nt, wm); break;
+          case RZ_FAST_CONV1: rz_gemm_fast<RZ_K_LIN1, RZ_EP_BIAS_POS, WLDS>(op, a, cx, nt, wm); break;
+          case RZ_FAST_FC9_ELU: rz_gemm_fast<RZ_K_LIN9, RZ_EP_BIAS_ELU_TREE, WLDS>(op, a, cx, nt, wm); break;
+          default: rz_gemm_fast<RZ_K_LIN1, RZ_EP_BIAS_TREE, WLDS>(op, a, cx, nt, wm); break;
+        }
+      }
+      return;
+    }
+  }
   for (int nt = wn; nt < nt_total; nt += waves_n) {
     for (int g = 0; g < 2; ++g) {
       const int cnt = g ? cnt1 : cnt0;   // wave-uniform
@@ -983,6 +1129,8 @@ __device__ __forceinline__ void rz_setup(const RzArgs& a, const RzCtx& cx) {
     unsigned* work = (unsigned*)cx.work;
     const RzOp* ops = (const RzOp*)a.small;
     for (int i = tid; i < a.n_ops * NW; i += NT) work[i] = rz_work_word(ops[i / NW], T, a.HW, NW, i % NW);
+    // operator classes (RzFastClass) behind the work words of the 4-wave kernels (the table is sized for 8 waves)
+    if (NW == 4) for (int i = tid; i < a.n_ops; i += NT) work[a.n_ops * NW + i] = (unsigned)rz_classify(ops[i], a.HW);
   }
   int* rowaddr = (int*)cx.rowaddr;
   int* rowtp = (int*)cx.rowtp;
@@ -1072,7 +1220,7 @@ rz_network_kernel(const RzArgs a) {
     do {
       const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)cx.work[o * NW + cx.wave]);
       const RzOp op = rz_fetch_op(cx.simg, o);   // from the LDS-resident program image
-      if (op.kind == RZ_GEMM) rz_gemm<WLDS, NW, MM>(op, a, cxo, w);
+      if (op.kind == RZ_GEMM) rz_gemm<WLDS, NW, MM>(op, a, cxo, w, rz_op_class<NW>(a, cx, o));
       else rz_scale<NW>(op, a, cx, b0, ntree, a.out_node, false);
       last = ((op.sched >> 16) & 1u) != 0;
       ++o;
@@ -1200,6 +1348,7 @@ inline RzLaunch rz_prepare(const mzx_net* net, const RzProgram& R, const float* 
   a.out_nodes = ix ? ix->out_nodes : 1;
   a.dump_op = -1;
   a.dbg = rz_env_int("MZX_RZ_DBG", 0);
+  a.fast = rz_env_int("MZX_RZ_FAST", 1) != 0 ? 1 : 0;
   a.w_floats = R.w_floats;
   a.small_floats = tables ? R.small_floats : R.aoff_base;
   a.in = in;

@@ -313,7 +313,7 @@ rz_search_kernel(const RzSearchArgs sa) {
       do {
         const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)cx.work[o * NW + cx.wave]);
         const RzOp op = rz_fetch_op(cx.simg, o);
-        if (op.kind == RZ_GEMM) { if (!RZ_DBG(a, 4)) rz_gemm<WLDS, NW, MM>(op, a, cx, w); }
+        if (op.kind == RZ_GEMM) { if (!RZ_DBG(a, 4)) rz_gemm<WLDS, NW, MM>(op, a, cx, w, rz_op_class<NW>(a, cx, o)); }
         else rz_scale<NW>(op, a, cx, b0, ntree, sel_leaf, true);
         last = ((op.sched >> 16) & 1u) != 0;
         ++o;

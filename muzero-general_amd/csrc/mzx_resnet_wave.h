@@ -26,6 +26,7 @@ namespace mzx {
 #ifndef MZX_HOSTCHECK
 
 constexpr int RZW_WAVES = 4;
+typedef int rzw_i32x4 __attribute__((ext_vector_type(4)));
 
 struct RzWaveArgs {
   RzSearchArgs s;
@@ -33,28 +34,15 @@ struct RzWaveArgs {
   int32_t wl_floats;        // size of the LDS weight area
 };
 
-// Operator classes, decided once per launch: the operators of the reference's residual network at <= 16 channels
-// get straight-line code (K loop fully unrolled, every per-layer option a compile-time constant); anything else
-// runs on the generic interpreter (rzw_gemm / rzw_scale) -- same arithmetic either way.
-enum RzwClass {
-  RZW_GENERIC = 0,    // any GEMM
-  RZW_SCALE_GEN,      // any scaling operator
-  RZW_SCALE16,        // scaling, <= 16 planes of <= 16 positions: in registers
-  RZW_CONV,           // 3x3, <= 16 -> <= 16 channels, folded BatchNorm, ReLU
-  RZW_CONV_ASUM,      // ... + the action plane of the dynamics input
-  RZW_CONV_RES,       // ... + residual
-  RZW_CONV1,          // 1x1 head convolution, bias, flat output
-  RZW_FC9_ELU,        // head MLP layer, 129 .. 144 inputs (nine 16-deep chunks), <= 16 outputs, ELU
-  RZW_FC1,            // head MLP layer, <= 16 inputs, any outputs, no activation
+struct RzwOp {          // compact descriptor in LDS: three 16-byte reads, requested one operator ahead
+  int32_t head;         // class | column tiles << 4 | weights in LDS << 8 | store_hidden << 9 | wchunks << 16: the only
+                        // word that has to reach a scalar register (branches, loop count)
+  int32_t in_off, out_off, res_off;
+  int32_t w_at, p0, p1, asum_off;     // w_at: float offset of the packed weights in the LDS weight area / the global image;
+                                      // p0, p1: alpha, beta or bias
+  int32_t cout, channels, pad0, pad1;
 };
-
-struct RzwOp {          // compact descriptor in LDS, fetched into scalar registers per operator
-  int32_t cls, in_off, out_off, res_off;
-  int32_t w_lds, w_off, p0, p1;       // weights: LDS float offset (-1: L2) / offset in the global image; p0, p1: alpha, beta or bias
-  int32_t asum_off, wchunks, cout, nt_total;
-  int32_t store_hidden, channels, pad0, pad1;
-};
-static_assert(sizeof(RzwOp) == 64, "RzwOp is fetched as four 16-byte LDS reads");
+static_assert(sizeof(RzwOp) == 48, "RzwOp is fetched as three 16-byte LDS reads");
 
 struct RzWaveLayout { int optab, simg, tables, inv_y, wlds, wave0, wave_stride, o_scratch, o_reg, o_tree, total; };   // floats
 
@@ -64,7 +52,7 @@ __host__ __device__ inline RzWaveLayout rzw_layout(int n_ops, int small_floats, 
                                                    int wl_floats) {
   RzWaveLayout y;
   int c = 16;
-  y.optab = c; c += n_ops * 16;
+  y.optab = c; c += n_ops * 12;
   y.simg = c; c += (small_floats + 3) & ~3;
   y.tables = c; c += (4 * (NN + 1) + 3) & ~3;
   y.inv_y = c; c += (2 * (NN + 2) + 3) & ~3;
@@ -94,7 +82,6 @@ __device__ __forceinline__ RzOp rzw_fetch_op(const float* image, int o) {
 // (mzx_resnet_fused.h) with T = 1 -- same MFMA order (K-steps alternate between two accumulator tiles that are
 // added at the end), same epilogue arithmetic.  `ra_lane` = activation address of row lane & 15, `ra4` = those
 // of the four rows 4 * (lane >> 4) + r this lane holds in the D fragment.
-typedef int rzw_i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void rzw_gemm(const RzOp& op, const RzArgs& a, float* reg, const float* simg, const float* wsrc,
                                          const float* scratch, int lane, int ra_lane, const rzw_i32x4& ra4, int nt) {
   const bool pos_rows = (op.rows == RZ_ROWS_POS);
@@ -234,29 +221,13 @@ __device__ __forceinline__ void rzw_scale(const RzOp& op, const RzArgs& a, float
 }
 
 __device__ __forceinline__ RzwOp rzw_fetch(const RzwOp* tab, int o) {
-  const int* w = (const int*)(tab + o);
-  int v[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) v[k] = __builtin_amdgcn_readfirstlane(w[k]);
+  const rzw_i32x4* w = (const rzw_i32x4*)(tab + o);
+  const rzw_i32x4 w0 = w[0], w1 = w[1], w2 = w[2];
   RzwOp q;
-  __builtin_memcpy(&q, v, sizeof(RzwOp));
+  q.head = w0[0]; q.in_off = w0[1]; q.out_off = w0[2]; q.res_off = w0[3];
+  q.w_at = w1[0]; q.p0 = w1[1]; q.p1 = w1[2]; q.asum_off = w1[3];
+  q.cout = w2[0]; q.channels = w2[1]; q.pad0 = 0; q.pad1 = 0;
   return q;
-}
-
-__device__ __forceinline__ int rzw_classify(const RzOp& op, int HW) {
-  if (op.kind != RZ_GEMM) return (op.channels <= 16 && HW <= 16) ? RZW_SCALE16 : RZW_SCALE_GEN;
-  const bool pos = op.rows == RZ_ROWS_POS, padded = op.out_layout == RZ_OUT_PADDED;
-  const int taps = op.taps & 0xFF;
-  const bool bn = op.alpha_off >= 0, bias = op.bias_off >= 0, res = op.res_off >= 0, asum = op.asum_off >= 0;
-  if (pos && taps == 9 && op.cchunks == 1 && op.cout <= 16 && padded && bn && !bias && op.act == RZ_ACT_RELU) {
-    if (res) return asum ? RZW_GENERIC : RZW_CONV_RES;
-    return asum ? RZW_CONV_ASUM : RZW_CONV;
-  }
-  if (bn || res || asum || !bias || padded) return RZW_GENERIC;
-  if (pos && taps == 1 && op.cchunks == 1 && op.cout <= 16 && op.act == RZ_ACT_NONE) return RZW_CONV1;
-  if (!pos && op.nchunks == 9 && op.cout <= 16 && op.act == RZ_ACT_ELU) return RZW_FC9_ELU;
-  if (!pos && op.nchunks == 1 && op.act == RZ_ACT_NONE) return RZW_FC1;
-  return RZW_GENERIC;
 }
 
 // lane constants of the wave's row tile, for the whole launch
@@ -276,13 +247,13 @@ enum { RZW_EP_BN_RELU = 0, RZW_EP_BN_RELU_ASUM, RZW_EP_BN_RES_RELU, RZW_EP_BIAS_
 // rz_gemm_tiles<1> (chunk by chunk, K-steps alternating between the two accumulator tiles), the epilogue is the
 // same sequence of fp32 operations with absent terms as literal 1.f / 0.f.
 template <int KS, int EP>
-__device__ __forceinline__ void rzw_gemm_s(const RzwOp& q, float* reg, const float* simg, const f32x4* wp, const float* scratch,
-                                           const RzwLane& k, int nt) {
+__device__ __forceinline__ void rzw_gemm_s(const RzwOp& q, int wchunks, float* reg, const float* simg, const f32x4* wp,
+                                           const float* scratch, const RzwLane& k, int nt) {
   constexpr bool POS = (EP <= RZW_EP_BIAS_POS);
   constexpr bool BN = (EP <= RZW_EP_BN_RES_RELU);
   constexpr int NCH = (KS == RZW_K_LIN1) ? 1 : 9;
   const float* in = reg + q.in_off;
-  wp += (size_t)nt * q.wchunks * 64;
+  wp += (size_t)nt * wchunks * 64;
   const int n = nt * 16 + (k.lane & 15);
   f32x4 A[NCH], B[NCH];
 #pragma unroll
@@ -411,12 +382,13 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
   if (tid < a.n_ops) {
     const RzOp op = ((const RzOp*)a.small)[tid];
     RzwOp q;
-    q.cls = rzw_classify(op, a.HW);
+    const int wl = wa.wl[tid];
+    q.head = rz_classify(op, a.HW) | (((op.cout + 15) >> 4) << 4) | ((wl >= 0 ? 1 : 0) << 8) |
+             ((op.store_hidden ? 1 : 0) << 9) | (op.wchunks << 16);
     q.in_off = op.in_off; q.out_off = op.out_off; q.res_off = op.res_off;
-    q.w_lds = wa.wl[tid]; q.w_off = op.w_off;
+    q.w_at = (wl >= 0) ? wl : op.w_off;
     q.p0 = (op.alpha_off >= 0) ? op.alpha_off : op.bias_off; q.p1 = op.beta_off;
-    q.asum_off = op.asum_off; q.wchunks = op.wchunks; q.cout = op.cout; q.nt_total = (op.cout + 15) >> 4;
-    q.store_hidden = op.store_hidden; q.channels = op.channels; q.pad0 = 0; q.pad1 = 0;
+    q.asum_off = op.asum_off; q.cout = op.cout; q.channels = op.channels; q.pad0 = 0; q.pad1 = 0;
     optab[tid] = q;
   }
   for (int o = 0; o < a.n_ops; ++o) {
@@ -478,6 +450,7 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
   if (prof) t_last = __builtin_readcyclecounter();
 #define RZW_PROF(k) if (prof) { const unsigned long long _t = __builtin_readcyclecounter(); pc[k] += (uint32_t)(_t - t_last); t_last = _t; }
 
+  RzwOp qnext = rzw_fetch(optab, 0);
   for (int sim = 0; sim < sa.num_sims; ++sim) {
     // ---- selection (self_play.py:325-334)
     const Fc2Walk wk = fc2_walk<AW>(FT, rst, tape, sa.p.tape_words, sub, row_in_wave);
@@ -500,33 +473,39 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
 
     // ---- recurrent_inference (models.py:620-623): the operator table in schedule order, one wave
     float* hid = a.hidden_out + ((int64_t)tree * a.out_nodes + wk.leaf) * a.hidden_floats;
-#define RZW_CALL(KS, EP)                                                                                        \
-  for (int nt = 0; nt < q.nt_total; ++nt) {                                                                     \
-    if (q.w_lds >= 0) rzw_gemm_s<KS, EP>(q, reg, simg, (const f32x4*)(wlds + q.w_lds) + lane, scratch, kl, nt);  \
-    else rzw_gemm_s<KS, EP>(q, reg, simg, (const f32x4*)(a.weights + q.w_off) + lane, scratch, kl, nt);          \
+#define RZW_CALL(KS, EP)                                                                                          \
+  for (int nt = 0; nt < nt_total; ++nt) {                                                                         \
+    if (w_in_lds) rzw_gemm_s<KS, EP>(q, wchunks, reg, simg, (const f32x4*)(wlds + q.w_at) + lane, scratch, kl, nt); \
+    else rzw_gemm_s<KS, EP>(q, wchunks, reg, simg, (const f32x4*)(a.weights + q.w_at) + lane, scratch, kl, nt);    \
   }
     for (int o = 0; o < a.n_ops; ++o) {
-      const RzwOp q = rzw_fetch(optab, o);
-      RZW_PROF(3)   // descriptor fetches (+ the fence below)
-      switch (q.cls) {
-        case RZW_CONV: RZW_CALL(RZW_K_TAP9, RZW_EP_BN_RELU) break;
-        case RZW_CONV_ASUM: RZW_CALL(RZW_K_TAP9, RZW_EP_BN_RELU_ASUM) break;
-        case RZW_CONV_RES: RZW_CALL(RZW_K_TAP9, RZW_EP_BN_RES_RELU) break;
-        case RZW_CONV1: RZW_CALL(RZW_K_LIN1, RZW_EP_BIAS_POS) break;
-        case RZW_FC9_ELU: RZW_CALL(RZW_K_LIN9, RZW_EP_BIAS_ELU_TREE) break;
-        case RZW_FC1: RZW_CALL(RZW_K_LIN1, RZW_EP_BIAS_TREE) break;
-        case RZW_SCALE16: rzw_scale16(q, reg, kl, q.store_hidden ? hid : nullptr); break;
-        case RZW_SCALE_GEN: {
+      const RzwOp q = qnext;
+      const int head = __builtin_amdgcn_readfirstlane(q.head);
+      qnext = rzw_fetch(optab, o + 1 < a.n_ops ? o + 1 : 0);   // in flight while this operator runs
+      __builtin_amdgcn_sched_barrier(0);
+      const int cls = head & 15, nt_total = (head >> 4) & 15, wchunks = head >> 16;
+      const bool w_in_lds = (head >> 8) & 1, store_hidden = (head >> 9) & 1;
+      RZW_PROF(3)   // descriptor (+ the fence below)
+      switch (cls) {
+        case RZ_FAST_CONV: RZW_CALL(RZW_K_TAP9, RZW_EP_BN_RELU) break;
+        case RZ_FAST_CONV_ASUM: RZW_CALL(RZW_K_TAP9, RZW_EP_BN_RELU_ASUM) break;
+        case RZ_FAST_CONV_RES: RZW_CALL(RZW_K_TAP9, RZW_EP_BN_RES_RELU) break;
+        case RZ_FAST_CONV1: RZW_CALL(RZW_K_LIN1, RZW_EP_BIAS_POS) break;
+        case RZ_FAST_FC9_ELU: RZW_CALL(RZW_K_LIN9, RZW_EP_BIAS_ELU_TREE) break;
+        case RZ_FAST_FC1: RZW_CALL(RZW_K_LIN1, RZW_EP_BIAS_TREE) break;
+        case RZ_FAST_SCALE16: rzw_scale16(q, reg, kl, store_hidden ? hid : nullptr); break;
+        case RZ_FAST_SCALE_GEN: {
           const RzOp op = rzw_fetch_op(simg, o);
           rzw_scale(op, a, reg, scratch, rowaddr, lane, op.store_hidden ? hid : nullptr);
           break;
         }
         default: {   // any other GEMM: the interpreter
           const RzOp op = rzw_fetch_op(simg, o);
-          if (q.w_lds >= 0) {   // two call sites: the address space of the B fragments is known in each (ds_read / global_load)
-            for (int nt = 0; nt < q.nt_total; ++nt) rzw_gemm(op, a, reg, simg, wlds + q.w_lds, scratch, lane, ra_lane, ra4, nt);
+          const int at = __builtin_amdgcn_readfirstlane(q.w_at);
+          if (w_in_lds) {   // two call sites: the address space of the B fragments is known in each (ds_read / global_load)
+            for (int nt = 0; nt < nt_total; ++nt) rzw_gemm(op, a, reg, simg, wlds + at, scratch, lane, ra_lane, ra4, nt);
           } else {
-            for (int nt = 0; nt < q.nt_total; ++nt) rzw_gemm(op, a, reg, simg, a.weights + op.w_off, scratch, lane, ra_lane, ra4, nt);
+            for (int nt = 0; nt < nt_total; ++nt) rzw_gemm(op, a, reg, simg, a.weights + op.w_off, scratch, lane, ra_lane, ra4, nt);
           }
           break;
         }
@@ -534,8 +513,7 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
       wave_sync();
       // profile: 9-chunk GEMMs from LDS weights / from L2, short GEMMs, scaling
       if (prof) {
-        const int pk = (q.cls == RZW_SCALE16 || q.cls == RZW_SCALE_GEN) ? 7
-                       : ((q.cls == RZW_CONV1 || q.cls == RZW_FC1) ? 6 : (q.w_lds >= 0 ? 1 : 5));
+        const int pk = (cls == RZ_FAST_SCALE16 || cls == RZ_FAST_SCALE_GEN) ? 7 : ((cls == RZ_FAST_CONV1 || cls == RZ_FAST_FC1) ? 6 : (w_in_lds ? 1 : 5));
         RZW_PROF(pk)
       }
     }
