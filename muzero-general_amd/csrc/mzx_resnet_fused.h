@@ -661,16 +661,22 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
   // instructions of tap decode per chunk, which the small layers cannot hide behind four MFMAs
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const int* tbl = (const int*)cx.simg + op.aoff_off;
-  // With a single row tile consecutive MFMAs would form one dependent chain (40-cycle accumulator latency
-  // against a 32-cycle issue interval): K-steps then alternate between two accumulator tiles that are added
-  // at the end.
-  f32x4 acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Summation order of an output element: the K-steps of a chunk alternate between two accumulator tiles that are
+  // added at the end.  With a single row tile consecutive MFMAs would otherwise form one dependent chain (40-cycle
+  // accumulator latency against a 32-cycle issue interval); the 4-wave kernels (TBL) do the same for every tile
+  // count, so that their results -- and the wave-per-tree kernel's (mzx_resnet_wave.h), all one-tile GEMMs -- do
+  // not depend on how many row tiles a wave happens to own (trees per workgroup, operators sharing a slot).  The
+  // 8-wave kernels sit at the register limit and keep one accumulator per tile beyond the first.
+  constexpr bool ALT = TBL || MT == 1;
+  f32x4 acc_odd[ALT ? MT : 1];
+#pragma unroll
+  for (int i = 0; i < (ALT ? MT : 1); ++i) acc_odd[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto compute = [&](const f32x4 (&av)[MT], const f32x4& bv, bool) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        if (MT == 1 && (j & 1)) acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][j], bv[j], acc_odd, 0, 0, 0);
+        if (ALT && (j & 1)) acc_odd[ALT ? i : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][j], bv[j], acc_odd[ALT ? i : 0], 0, 0, 0);
         else acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][j], bv[j], acc[i], 0, 0, 0);
       }
   };
@@ -785,7 +791,10 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
     }
   }
   }
-  if (MT == 1) acc[0] = acc[0] + acc_odd;
+  if (ALT) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = acc[i] + acc_odd[ALT ? i : 0];
+  }
   RZ_FINE(3)
   if (RZ_DBG(a, 2)) return;
   // ---- epilogue: every per-layer variation (BatchNorm or not, bias or not, residual or not, ReLU or not,
