@@ -350,8 +350,8 @@ __device__ __forceinline__ void rzw_scale16(const RzwOp& q, float* reg, const Rz
   }
 }
 
-// AW: lanes that hold a child slot (4 or 16)
-template <int AW>
+// AW: lanes that hold a child slot (4 or 16); PROFILE: per-phase cycle counters of wave 0 (mode flag 8)
+template <int AW, bool PROFILE>
 __global__ void __launch_bounds__(RZW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 rz_wave_search_kernel(const RzWaveArgs wa) {
   constexpr int NT = RZW_WAVES * 64;
@@ -446,26 +446,43 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
 
   uint32_t pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = 0;
-  const bool prof = sa.prof != nullptr && tid == 0;
+  const bool prof = PROFILE && sa.prof != nullptr && tid == 0;
   if (prof) t_last = __builtin_readcyclecounter();
-#define RZW_PROF(k) if (prof) { const unsigned long long _t = __builtin_readcyclecounter(); pc[k] += (uint32_t)(_t - t_last); t_last = _t; }
+#define RZW_PROF(k) if (PROFILE && prof) { const unsigned long long _t = __builtin_readcyclecounter(); pc[k] += (uint32_t)(_t - t_last); t_last = _t; }
+  // parent-state gather: element lane + 64 u of [C][H][W] -> its position-major LDS offset, for the whole launch
+  int gat[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = lane + 64 * u;
+    const int c = rz_div(i, a.HW, a.magic_hw), p = i - c * a.HW;
+    gat[u] = (i < per_tree) ? rowaddr[p < a.HW ? p : 0] + c : -1;
+  }
 
   RzwOp qnext = rzw_fetch(optab, 0);
   for (int sim = 0; sim < sa.num_sims; ++sim) {
     // ---- selection (self_play.py:325-334)
     const Fc2Walk wk = fc2_walk<AW>(FT, rst, tape, sa.p.tape_words, sub, row_in_wave);
+    // ---- parent state [C][H][W] (arena) -> position-major region: the loads leave before the path fetch
+    const float* src = a.in + ((int64_t)tree * a.in_nodes + wk.parent) * per_tree;
+    float gv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (per_tree <= 256) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (gat[u] >= 0) gv[u] = src[lane + 64 * u];
+    }
     wave_sync();
     const Fc2Lane<AW> lane_ops = fc2_load_lane<AW>(FT, wk, wk.levels >> 4, sub);   // hides behind the network
     RZW_PROF(0)
-
-    // ---- parent state [C][H][W] (arena) -> position-major region, action value of the dynamics input
     {
-      if (lane == 0) scratch[2 * a.Cs] = a.use_action ? (float)wk.action / (float)a.num_actions : 0.f;
-      const float* src = a.in + ((int64_t)tree * a.in_nodes + wk.parent) * per_tree;
+      if (lane == 0) scratch[2 * a.Cs] = a.use_action ? (float)wk.action / (float)a.num_actions : 0.f;   // action value of the dynamics input
       float* dst = reg + a.in_off;
-      for (int i = lane; i < per_tree; i += 64) {
-        const int c = rz_div(i, a.HW, a.magic_hw), p = i - c * a.HW;
-        dst[rowaddr[p] + c] = src[i];
+      if (per_tree <= 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (gat[u] >= 0) dst[gat[u]] = gv[u];
+      } else {
+        for (int i = lane; i < per_tree; i += 64) {
+          const int c = rz_div(i, a.HW, a.magic_hw), p = i - c * a.HW;
+          dst[rowaddr[p] + c] = src[i];
+        }
       }
     }
     wave_sync();
@@ -548,16 +565,16 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
   fc2_to_arena<AW>(FT, rst, t, sub);
 }
 
-template <int AW>
+template <int AW, bool PROFILE>
 inline int rz_wave_launch_k(const RzWaveArgs& wa, unsigned grid, size_t lds_bytes, stream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)rz_wave_search_kernel<AW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)rz_wave_search_kernel<AW, PROFILE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((rz_wave_search_kernel<AW>), dim3(grid), dim3(RZW_WAVES * 64), lds_bytes, stream, wa);
+  hipLaunchKernelGGL((rz_wave_search_kernel<AW, PROFILE>), dim3(grid), dim3(RZW_WAVES * 64), lds_bytes, stream, wa);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("wave-private search kernel launch failed: %s (grid %u, %zu bytes of LDS)", hipGetErrorString(e), grid, lds_bytes);
@@ -605,8 +622,12 @@ inline bool rz_wave_plan(const mzx_search* s, const RzProgram& R, const RzArgs& 
 }
 
 inline int rz_wave_launch(const RzWaveArgs& wa, unsigned grid, size_t lds_bytes, stream_t stream) {
-  return wa.s.p.num_actions <= 4 ? rz_wave_launch_k<4>(wa, grid, lds_bytes, stream)
-                                 : rz_wave_launch_k<16>(wa, grid, lds_bytes, stream);
+  if (wa.s.prof) {
+    return wa.s.p.num_actions <= 4 ? rz_wave_launch_k<4, true>(wa, grid, lds_bytes, stream)
+                                   : rz_wave_launch_k<16, true>(wa, grid, lds_bytes, stream);
+  }
+  return wa.s.p.num_actions <= 4 ? rz_wave_launch_k<4, false>(wa, grid, lds_bytes, stream)
+                                 : rz_wave_launch_k<16, false>(wa, grid, lds_bytes, stream);
 }
 
 #endif  // !MZX_HOSTCHECK
