@@ -469,6 +469,9 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     try:  # PMC-measured HBM bytes per launch of this kernel (collected by a separate rocprofv3 --pmc run)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             key = "fused-lds" if fused else ("residual-whole-search" if fused_kind == 2 else "generic-per-op")
+            if fused_kind == 2 and (cfg.network == "resnet" and net.hidden_size // max(1, cfg.channels) <= 16 and A <= 16
+                                    and 2 * cfg.support_size + 1 <= 32 and os.environ.get("MZX_RZ_WAVE", "1") != "0"):
+                key = "residual-wave-per-tree"
             entry = json.load(f).get(f"{workload}:{key}")
         if not fused and fused_kind != 2 and net_fused:
             entry = None
@@ -488,6 +491,10 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         "note": "tree bytes per simulation x B x S / HIP-event time of one search launch; trees live in "
                 "LDS in the fused kernel, so this is algorithmic traffic, not HBM traffic (DESIGN.md)",
     }
+    # boards of <= 16 positions with <= 16 actions and a support of <= 32 bins run the wave-per-tree kernel
+    # (csrc/mzx_resnet_wave.h: rz_wave_plan)
+    wave_kernel = (cfg.network == "resnet" and net.hidden_size // max(1, cfg.channels) <= 16 and A <= 16
+                   and 2 * cfg.support_size + 1 <= 32 and os.environ.get("MZX_RZ_WAVE", "1") != "0")
     if cfg.network == "resnet":  # dense contractions: FP32 MFMA roofline
         f_init = int(lib.mzx_net_flops(net.handle, 0))
         f_rec = int(lib.mzx_net_flops(net.handle, 1))
@@ -496,7 +503,8 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         roofline = {
             "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "whole step: root kernels + mzx::rz_search_kernel (all simulations, one launch)" if fused_kind == 2
+            "kernel": ("whole step: root kernels + " + ("mzx::rz_wave_search_kernel (a wave per tree)" if wave_kernel else "mzx::rz_search_kernel")
+                       + " (all simulations, one launch)") if fused_kind == 2
                       else "whole step: select / rz_network_kernel (fused MFMA network) / expand+backprop per simulation"
                       if net_fused else "whole step (one kernel per operator)",
             "launch_ms": launch_ms, "flops_per_simulation": f_rec, "flops_initial_inference": f_init,

@@ -488,7 +488,9 @@ inline int rz_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, 
       memset(&wa, 0, sizeof(wa));
       unsigned wgrid = 0;
       size_t wlds = 0;
-      if (rz_wave_plan(s, R, L.a, wa, wgrid, wlds)) {
+      const bool wave_k = rz_wave_plan(s, R, L.a, wa, wgrid, wlds);
+      const bool tile_k = !wave_k && rz_tile_plan(s, R, L.a, wa, wgrid, wlds);
+      if (wave_k || tile_k) {
         wa.s.p = v.p;
         wa.s.L = s->L;
         wa.s.trees = v.arena.trees;
@@ -497,7 +499,7 @@ inline int rz_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, 
         wa.s.sim0 = 0;
         wa.s.prof = ((s->mode & 8) && s->ws_floats >= (int64_t)wgrid * 8) ? (uint32_t*)((char*)d_arena + s->off_ws) : nullptr;
         wa.s.tree_lds = 2;
-        rc = rz_wave_launch(wa, wgrid, wlds, stream);
+        rc = wave_k ? rz_wave_launch(wa, wgrid, wlds, stream) : rz_tile_launch(wa, wgrid, wlds, stream);
         if (rc) return rc;
         return search_finish(s, io, d_arena, stream);
       }

@@ -35,7 +35,7 @@ struct RzWaveArgs {
 };
 
 struct RzwOp {          // compact descriptor in LDS: three 16-byte reads, requested one operator ahead
-  int32_t head;         // class | column tiles << 4 | weights in LDS << 8 | store_hidden << 9 | wchunks << 16: the only
+  int32_t head;         // class | weights in LDS << 4 | store_hidden << 5 | column tiles << 8 | wchunks << 16: the only
                         // word that has to reach a scalar register (branches, loop count)
   int32_t in_off, out_off, res_off;
   int32_t w_at, p0, p1, asum_off;     // w_at: float offset of the packed weights in the LDS weight area / the global image;
@@ -233,6 +233,7 @@ __device__ __forceinline__ RzwOp rzw_fetch(const RzwOp* tab, int o) {
 // lane constants of the wave's row tile, for the whole launch
 struct RzwLane {
   int lane, g4, HW, Cs;
+  int m0;               // position of this lane's first D row: 16 * (row tile of the wave) + g4
   int ra_lane;          // activation address of row lane & 15 (A operand)
   rzw_i32x4 ra4;        // ... of rows 4 * (lane >> 4) + r (D fragment)
   int atap[9];          // ra_lane + 4 * (lane >> 4) + offset of tap c of a 3x3 convolution with one channel chunk
@@ -276,7 +277,7 @@ __device__ __forceinline__ void rzw_gemm_s(const RzwOp& q, int wchunks, float* r
   if (EP == RZW_EP_BN_RELU_ASUM) {
     actval = scratch[2 * k.Cs];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) as[r] = simg[q.asum_off + n * k.HW + ((k.g4 + r < k.HW) ? k.g4 + r : 0)];
+    for (int r = 0; r < 4; ++r) as[r] = simg[q.asum_off + n * k.HW + ((k.m0 + r < k.HW) ? k.m0 + r : 0)];
   }
   // every request above is issued before the first MFMA (the scheduler would otherwise re-serialise them into a
   // load -> wait -> four MFMAs chain per chunk, one LDS round trip each)
@@ -309,13 +310,13 @@ __device__ __forceinline__ void rzw_gemm_s(const RzwOp& q, int wchunks, float* r
   if (BN) {                                   // padded position-major output
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (k.g4 + r < k.HW && nv) out[k.ra4[r] + n] = v[r];
+      if (k.m0 + r < k.HW && nv) out[k.ra4[r] + n] = v[r];
   } else if (EP == RZW_EP_BIAS_POS) {         // flat [channel][position]
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (k.g4 + r < k.HW && nv) out[k.g4 + r + n * k.HW] = v[r];
+      if (k.m0 + r < k.HW && nv) out[k.m0 + r + n * k.HW] = v[r];
   } else {                                    // one valid row: the tree
-    if (k.g4 == 0 && nv) out[n] = v[0];
+    if (k.g4 == 0 && nv) out[n] = v[0];   // (head layers run on one wave: row 0 of ITS tile is the tree)
   }
 }
 
@@ -383,8 +384,8 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
     const RzOp op = ((const RzOp*)a.small)[tid];
     RzwOp q;
     const int wl = wa.wl[tid];
-    q.head = rz_classify(op, a.HW) | (((op.cout + 15) >> 4) << 4) | ((wl >= 0 ? 1 : 0) << 8) |
-             ((op.store_hidden ? 1 : 0) << 9) | (op.wchunks << 16);
+    q.head = rz_classify(op, a.HW) | ((wl >= 0 ? 1 : 0) << 4) | ((op.store_hidden ? 1 : 0) << 5) |
+             (((op.cout + 15) >> 4) << 8) | (op.wchunks << 16);
     q.in_off = op.in_off; q.out_off = op.out_off; q.res_off = op.res_off;
     q.w_at = (wl >= 0) ? wl : op.w_off;
     q.p0 = (op.alpha_off >= 0) ? op.alpha_off : op.bias_off; q.p1 = op.beta_off;
@@ -437,7 +438,7 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
   const int ra_lane = rowaddr[lane & 15];
   const rzw_i32x4 ra4 = *(const rzw_i32x4*)(rowaddr + (lane >> 4) * 4);
   RzwLane kl;
-  kl.lane = lane; kl.g4 = 4 * (lane >> 4); kl.HW = a.HW; kl.Cs = a.Cs; kl.ra_lane = ra_lane; kl.ra4 = ra4;
+  kl.lane = lane; kl.g4 = 4 * (lane >> 4); kl.m0 = kl.g4; kl.HW = a.HW; kl.Cs = a.Cs; kl.ra_lane = ra_lane; kl.ra4 = ra4;
 #pragma unroll
   for (int c = 0; c < 9; ++c) kl.atap[c] = ra_lane + kl.g4 + (c / 3 - 1) * a.PW * a.Cs + (c % 3 - 1) * a.Cs;   // rz_aoff_entry, one chunk per tap
 #pragma unroll
@@ -500,8 +501,8 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
       const int head = __builtin_amdgcn_readfirstlane(q.head);
       qnext = rzw_fetch(optab, o + 1 < a.n_ops ? o + 1 : 0);   // in flight while this operator runs
       __builtin_amdgcn_sched_barrier(0);
-      const int cls = head & 15, nt_total = (head >> 4) & 15, wchunks = head >> 16;
-      const bool w_in_lds = (head >> 8) & 1, store_hidden = (head >> 9) & 1;
+      const int cls = head & 15, nt_total = (head >> 8) & 255, wchunks = (head >> 16) & 0xFFFF;
+      const bool w_in_lds = (head >> 4) & 1, store_hidden = (head >> 5) & 1;
       RZW_PROF(3)   // descriptor (+ the fence below)
       switch (cls) {
         case RZ_FAST_CONV: RZW_CALL(RZW_K_TAP9, RZW_EP_BN_RELU) break;
@@ -628,6 +629,338 @@ inline int rz_wave_launch(const RzWaveArgs& wa, unsigned grid, size_t lds_bytes,
   }
   return wa.s.p.num_actions <= 4 ? rz_wave_launch_k<4, false>(wa, grid, lds_bytes, stream)
                                  : rz_wave_launch_k<16, false>(wa, grid, lds_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------
+// Boards of 17 .. 64 positions (2 .. 4 row tiles per tree; breakout's 6 x 6 hidden state, BASELINE C5): a WORKGROUP
+// per tree, a row tile per wave, the same lean operator loop -- compact descriptors, operator classes, row
+// addresses in registers -- with one workgroup barrier per operator (a 3x3 convolution reads its neighbours' rows).
+// Wave 0 walks and updates the tree (records of mzx_fused_fc2.h); head layers with many column tiles (a 601-bin
+// support is 38 of them) are spread over the four waves; the value and reward supports are decoded by two waves
+// side by side.  Only programs made of fast-class operators run here (rz_tile_plan), anything else stays on
+// rz_search_kernel.
+
+struct RzTileLayout { int optab, simg, tables, inv_y, wlds, scratch, reg, tree, total; };   // floats
+
+// LDS of a workgroup: rowaddr[64] + hand-off words [16], compact operator table, small image, UCB tables,
+// reciprocals, weights, scaling scratch + action value, the program's regions, the tree's records
+__host__ __device__ inline RzTileLayout rzt_layout(int n_ops, int small_floats, int NN, int Cs, int tree_floats, int rec_floats,
+                                                   int wl_floats) {
+  RzTileLayout y;
+  int c = 64 + 16;
+  y.optab = c; c += n_ops * 12;
+  y.simg = c; c += (small_floats + 3) & ~3;
+  y.tables = c; c += (4 * (NN + 1) + 3) & ~3;
+  y.inv_y = c; c += (2 * (NN + 2) + 3) & ~3;
+  y.wlds = c; c += (wl_floats + 3) & ~3;
+  y.scratch = c; c += (2 * Cs + 4 + 3) & ~3;
+  y.reg = c; c += (tree_floats + 3) & ~3;
+  y.tree = c; c += (rec_floats + 3) & ~3;
+  y.total = c;
+  return y;
+}
+
+// rz_scale of one tree by the whole workgroup (contains a workgroup barrier)
+__device__ __forceinline__ void rzt_scale(const RzwOp& q, const RzArgs& a, float* reg, float* scratch, const int* rowaddr, int tid,
+                                          float* hid) {
+  constexpr int NT = RZW_WAVES * 64;
+  const int C = q.channels;
+  const float* in = reg + q.in_off;
+  float* out = reg + q.out_off;
+  const int sub = tid & 15, grp = tid >> 4;
+  for (int base = 0; base < C; base += NT / 16) {
+    const int c = base + grp;
+    const bool valid = c < C;
+    const int cc = valid ? c : 0;
+    float lo = MZX_INF, hi = -MZX_INF;
+    for (int p = sub; p < a.HW; p += 16) {
+      const float v = in[rowaddr[p] + cc];
+      lo = fminf(lo, v); hi = fmaxf(hi, v);
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+      lo = fminf(lo, __shfl_xor(lo, m, 16));
+      hi = fmaxf(hi, __shfl_xor(hi, m, 16));
+    }
+    if (valid && sub == 0) {
+      float sc = hi - lo;
+      if (sc < 1e-5f) sc += 1e-5f;
+      scratch[2 * c] = lo;
+      scratch[2 * c + 1] = sc;
+    }
+  }
+  __syncthreads();
+  const int per_tree = C * a.HW;
+  for (int rem = tid; rem < per_tree; rem += NT) {
+    const int c = rz_div(rem, a.HW, a.magic_hw), p = rem - c * a.HW;
+    const int ra = rowaddr[p] + c;
+    const float y = (in[ra] - scratch[2 * c]) / scratch[2 * c + 1];
+    out[ra] = y;
+    if (hid) hid[rem] = y;
+  }
+}
+
+template <int AW, bool PROFILE>
+__global__ void __launch_bounds__(RZW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+rz_tile_search_kernel(const RzWaveArgs wa) {
+  constexpr int NT = RZW_WAVES * 64;
+  extern __shared__ __attribute__((aligned(16))) float rz_lds[];
+  const RzSearchArgs& sa = wa.s;
+  const RzArgs& a = sa.net;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NN = sa.p.num_nodes;
+  const RzTileLayout y = rzt_layout(a.n_ops, a.small_floats, NN, a.Cs, a.tree_floats, (int)rz_trec_tree_floats(NN, AW), wa.wl_floats);
+  int* rowaddr = (int*)rz_lds;            // [64]
+  int* hand = rowaddr + 64;               // [16]: parent, action, leaf | value, reward (float bits)
+  RzwOp* optab = (RzwOp*)(rz_lds + y.optab);
+  float* simg = rz_lds + y.simg;
+  double* tables = (double*)(rz_lds + y.tables);
+  double* inv_y = (double*)(rz_lds + y.inv_y);
+  float* wlds = rz_lds + y.wlds;
+  float* scratch = rz_lds + y.scratch;
+  float* reg = rz_lds + y.reg;
+  const int tree = blockIdx.x;
+
+  // ---- once per launch
+  {
+    const f32x4* src = (const f32x4*)a.small;
+    f32x4* dst = (f32x4*)simg;
+    for (int i = tid; i < a.small_floats / 4; i += NT) dst[i] = src[i];
+  }
+  for (int i = tid; i < 2 * (NN + 1); i += NT) tables[i] = sa.p.pbc_table[i];
+  for (int i = tid; i < NN + 2; i += NT) inv_y[i] = recip_refined((double)(i > 0 ? i : 1));
+  if (tid < a.n_ops) {
+    const RzOp op = ((const RzOp*)a.small)[tid];
+    RzwOp q;
+    const int wl = wa.wl[tid];
+    q.head = rz_classify(op, 0x7FFFFFFF) | ((wl >= 0 ? 1 : 0) << 4) | ((op.store_hidden ? 1 : 0) << 5) |
+             (((op.cout + 15) >> 4) << 8) | (op.wchunks << 16);
+    q.in_off = op.in_off; q.out_off = op.out_off; q.res_off = op.res_off;
+    q.w_at = (wl >= 0) ? wl : op.w_off;
+    q.p0 = (op.alpha_off >= 0) ? op.alpha_off : op.bias_off; q.p1 = op.beta_off;
+    q.asum_off = op.asum_off; q.cout = op.cout; q.channels = op.channels; q.pad0 = 0; q.pad1 = 0;
+    optab[tid] = q;
+  }
+  for (int o = 0; o < a.n_ops; ++o) {
+    const int at = wa.wl[o];
+    if (at < 0) continue;
+    const RzOp* gop = (const RzOp*)a.small + o;
+    const int nfl = ((gop->cout + 15) >> 4) * gop->wchunks * 256;
+    const f32x4* src = (const f32x4*)(a.weights + gop->w_off);
+    f32x4* dst = (f32x4*)(wlds + at);
+    for (int i = tid; i < nfl / 4; i += NT) dst[i] = src[i];
+  }
+  {
+    f32x4* z = (f32x4*)scratch;             // scratch + regions: halo positions, pad channels and pad words stay zero
+    for (int i = tid; i < (y.tree - y.scratch) / 4; i += NT) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (tid < 64) {
+    int ra = (a.PW + 1) * a.Cs;
+    if (tid < a.HW) {
+      const int yy = rz_div(tid, a.W, a.magic_w), xx = tid - yy * a.W;
+      ra = ((yy + 1) * a.PW + xx + 1) * a.Cs;
+    }
+    rowaddr[tid] = ra;
+  }
+  __syncthreads();
+
+  const int sub = lane & (FUSED_ROW - 1), row_in_wave = lane >> 4;
+  TreeRef t;
+  t.base = sa.trees + (size_t)tree * sa.L.tree_bytes;
+  t.L = sa.L;
+  Fc2Tree FT;
+  fc2_carve<AW>(FT, (char*)(rz_lds + y.tree), NN);
+  FT.pbc = tables; FT.sqt = tables + (NN + 1); FT.inv_y = inv_y;
+  FT.disc = sa.p.discount; FT.A = sa.p.num_actions; FT.NN = NN; FT.P = sa.p.num_players;
+  FT.pb_leaf = FT.pbc[1] * div_by(FT.sqt[1], 1.0, inv_y[1]);
+  Fc2Row rst;
+  rst.n_nodes = 0; rst.tape_pos = 0; rst.flags = 0; rst.ties = 0; rst.max_depth = 0; rst.sum_depth = 0; rst.root_n = 0; rst.root_to_play = 0;
+  if (wave == 0) { fc2_from_arena<AW>(FT, rst, t, sub); wave_sync(); }   // all four rows of wave 0 on the same tree (see rz_wave_search_kernel)
+  const uint32_t* tape = sa.tape + (size_t)tree * sa.p.tape_words;
+  const int F = a.out_n[0], A = a.out_n[2];
+  const int support = sa.p.support_size;
+  // rows of the wave's tile, for the whole launch
+  const bool tile_valid = 16 * wave < a.HW;
+  RzwLane kl;
+  kl.lane = lane; kl.g4 = 4 * (lane >> 4); kl.m0 = 16 * wave + kl.g4; kl.HW = a.HW; kl.Cs = a.Cs;
+  kl.ra_lane = rowaddr[(16 * wave + (lane & 15)) & 63];
+  kl.ra4 = *(const rzw_i32x4*)(rowaddr + ((16 * wave + kl.g4) & 63));
+#pragma unroll
+  for (int c = 0; c < 9; ++c) kl.atap[c] = kl.ra_lane + kl.g4 + (c / 3 - 1) * a.PW * a.Cs + (c % 3 - 1) * a.Cs;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) kl.rsc[j] = 0;
+  // head layers (rows = the tree) read row 0 of the tile: their A address does not involve the tile
+  const int per_tree = a.in_channels * a.HW;
+  int gat[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = tid + NT * u;
+    const int c = rz_div(i, a.HW, a.magic_hw), p = i - c * a.HW;
+    gat[u] = (i < per_tree) ? rowaddr[p < a.HW ? p : 0] + c : -1;
+  }
+
+  uint32_t pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = 0;
+  const bool prof = PROFILE && sa.prof != nullptr && tid == 0;
+  if (prof) t_last = __builtin_readcyclecounter();
+#define RZT_PROF(k) if (PROFILE && prof) { const unsigned long long _t = __builtin_readcyclecounter(); pc[k] += (uint32_t)(_t - t_last); t_last = _t; }
+
+  RzwOp qnext = rzw_fetch(optab, 0);
+  for (int sim = 0; sim < sa.num_sims; ++sim) {
+    // ---- selection (self_play.py:325-334), wave 0
+    Fc2Walk wk;
+    Fc2Lane<AW> lane_ops;
+    if (wave == 0) {
+      wk = fc2_walk<AW>(FT, rst, tape, sa.p.tape_words, sub, row_in_wave);
+      if (lane == 0) { hand[0] = wk.parent; hand[1] = wk.action; hand[2] = wk.leaf; }
+      wave_sync();
+      lane_ops = fc2_load_lane<AW>(FT, wk, wk.levels >> 4, sub);
+    }
+    RZT_PROF(0)
+    __syncthreads();
+    const int parent = hand[0], action = hand[1], leaf = hand[2];
+    // ---- parent state [C][H][W] (arena) -> position-major region
+    {
+      const float* src = a.in + ((int64_t)tree * a.in_nodes + parent) * per_tree;
+      float* dst = reg + a.in_off;
+      if (tid == 0) scratch[2 * a.Cs] = a.use_action ? (float)action / (float)a.num_actions : 0.f;
+      if (per_tree <= 4 * NT) {
+        float gv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (gat[u] >= 0) gv[u] = src[tid + NT * u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (gat[u] >= 0) dst[gat[u]] = gv[u];
+      } else {
+        for (int i = tid; i < per_tree; i += NT) {
+          const int c = rz_div(i, a.HW, a.magic_hw), p = i - c * a.HW;
+          dst[rowaddr[p] + c] = src[i];
+        }
+      }
+    }
+    __syncthreads();
+    RZT_PROF(2)
+
+    // ---- recurrent_inference: the operator table in schedule order, one barrier per operator
+    float* hid = a.hidden_out + ((int64_t)tree * a.out_nodes + leaf) * a.hidden_floats;
+#define RZT_CALL(KS, EP, NT0, NTSTEP)                                                                              \
+  for (int nt = (NT0); nt < nt_total; nt += (NTSTEP)) {                                                           \
+    if (w_in_lds) rzw_gemm_s<KS, EP>(q, wchunks, reg, simg, (const f32x4*)(wlds + q.w_at) + lane, scratch, kl, nt); \
+    else rzw_gemm_s<KS, EP>(q, wchunks, reg, simg, (const f32x4*)(a.weights + q.w_at) + lane, scratch, kl, nt);    \
+  }
+    for (int o = 0; o < a.n_ops; ++o) {
+      const RzwOp q = qnext;
+      const int head = __builtin_amdgcn_readfirstlane(q.head);
+      qnext = rzw_fetch(optab, o + 1 < a.n_ops ? o + 1 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+      const int cls = head & 15, nt_total = (head >> 8) & 255, wchunks = (head >> 16) & 0xFFFF;
+      const bool w_in_lds = (head >> 4) & 1, store_hidden = (head >> 5) & 1;
+      switch (cls) {
+        case RZ_FAST_CONV: if (tile_valid) { RZT_CALL(RZW_K_TAP9, RZW_EP_BN_RELU, 0, 1) } break;
+        case RZ_FAST_CONV_ASUM: if (tile_valid) { RZT_CALL(RZW_K_TAP9, RZW_EP_BN_RELU_ASUM, 0, 1) } break;
+        case RZ_FAST_CONV_RES: if (tile_valid) { RZT_CALL(RZW_K_TAP9, RZW_EP_BN_RES_RELU, 0, 1) } break;
+        case RZ_FAST_CONV1: if (tile_valid) { RZT_CALL(RZW_K_LIN1, RZW_EP_BIAS_POS, 0, 1) } break;
+        case RZ_FAST_FC9_ELU: RZT_CALL(RZW_K_LIN9, RZW_EP_BIAS_ELU_TREE, wave, RZW_WAVES) break;
+        case RZ_FAST_FC1: RZT_CALL(RZW_K_LIN1, RZW_EP_BIAS_TREE, wave, RZW_WAVES) break;
+        default: rzt_scale(q, a, reg, scratch, rowaddr, tid, store_hidden ? hid : nullptr); break;
+      }
+      __syncthreads();
+    }
+#undef RZT_CALL
+    RZT_PROF(3)
+
+    // ---- decode (value on wave 0, reward on wave 1), expand, back-propagate (self_play.py:343-353)
+    if (wave <= 1) {
+      const float* lg = reg + a.out_off[wave];    // 0: value, 1: reward
+      const float x = (F <= 2 * FUSED_ROW) ? row_decode2(sub < F ? lg[sub] : 0.f, sub + 16 < F ? lg[sub + 16] : 0.f, F, support, sub)
+                                            : row_decode_wide(lg, F, support, sub);
+      if (lane == 0) hand[4 + wave] = __builtin_bit_cast(int, x);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const float value = __builtin_bit_cast(float, hand[4]), reward = __builtin_bit_cast(float, hand[5]);
+      const float* pl = reg + a.out_off[2];
+      const bool in = sub < A;
+      const float lgp = in ? pl[sub] : 0.f;
+      const float m = row_max(in ? lgp : -MZX_INF);
+      const float e = in ? mzx_expf(lgp - m) : 0.f;
+      const float den = row_sum(e);
+      fc2_expand<AW>(FT, wk.leaf, sub, in, (double)mzx_div(e, den));
+      fc2_backprop<AW>(FT, rst, wk, lane_ops, sub, (double)value, (double)reward);
+      wave_sync();
+    }
+    RZT_PROF(4)
+  }
+#undef RZT_PROF
+  if (prof) for (int k = 0; k < 8; ++k) sa.prof[blockIdx.x * 8 + k] = pc[k];
+  if (wave == 0) { wave_sync(); fc2_to_arena<AW>(FT, rst, t, sub); }
+}
+
+template <int AW, bool PROFILE>
+inline int rz_tile_launch_k(const RzWaveArgs& wa, unsigned grid, size_t lds_bytes, stream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)rz_tile_search_kernel<AW, PROFILE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((rz_tile_search_kernel<AW, PROFILE>), dim3(grid), dim3(RZW_WAVES * 64), lds_bytes, stream, wa);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("tile-per-wave search kernel launch failed: %s (grid %u, %zu bytes of LDS)", hipGetErrorString(e), grid, lds_bytes);
+    return MZX_ERR_RUNTIME;
+  }
+  return MZX_OK;
+}
+
+// Plans the launch of rz_tile_search_kernel; false: not a configuration for it.  MZX_RZ_TILE=0: A/B knob.
+inline bool rz_tile_plan(const mzx_search* s, const RzProgram& R, const RzArgs& base, RzWaveArgs& wa, unsigned& grid,
+                         size_t& lds_bytes) {
+  const RzGeometry& g = s->net->rz.g;
+  const int A = s->p.num_actions;
+  if (g.HW <= 16 || g.HW > 16 * RZW_WAVES || A > FUSED_ROW) return false;
+  if (rz_env_int("MZX_RZ_TILE", 1) == 0) return false;
+  for (int o = 0; o < R.n_ops; ++o) {     // every operator of a class this kernel has code for
+    const int cls = rz_classify(R.ops[o], 0x7FFFFFFF);
+    if (cls == RZ_FAST_NONE) return false;
+    if (R.ops[o].kind == RZ_GEMM && ((R.ops[o].cout + 15) / 16 > 255 || R.ops[o].wchunks > 0x7FFF)) return false;   // fields of RzwOp::head
+  }
+  const int AW = A <= 4 ? 4 : 16;
+  const int NN = s->p.num_nodes;
+  wa.s.net = base;
+  RzArgs& a = wa.s.net;
+  a.T = 1;
+  a.mpad = 64;
+  a.small_floats = R.small_floats;
+  const int rec_floats = (int)rz_trec_tree_floats(NN, AW);
+  const int64_t fixed = rzt_layout(a.n_ops, a.small_floats, NN, a.Cs, a.tree_floats, rec_floats, 0).total;
+  if (4 * fixed > RZ_LDS_BUDGET) return false;
+  int64_t room = RZ_LDS_BUDGET / 4 - fixed;
+  int used = 0;
+  for (int o = 0; o < RZ_MAX_OPS; ++o) wa.wl[o] = -1;
+  for (int o = 0; o < R.n_ops; ++o) {
+    const RzOp& op = R.ops[o];
+    if (op.kind != RZ_GEMM) continue;
+    int shared = -1;
+    for (int q = 0; q < o; ++q)
+      if (R.ops[q].kind == RZ_GEMM && R.ops[q].w_off == op.w_off && wa.wl[q] >= 0) shared = wa.wl[q];
+    if (shared >= 0) { wa.wl[o] = shared; continue; }
+    const int nfl = ((op.cout + 15) / 16) * op.wchunks * 256;
+    if (used + nfl <= room) { wa.wl[o] = used; used += nfl; }
+  }
+  wa.wl_floats = used;
+  grid = (unsigned)s->p.num_trees;
+  lds_bytes = (size_t)4 * rzt_layout(a.n_ops, a.small_floats, NN, a.Cs, a.tree_floats, rec_floats, used).total;
+  return true;
+}
+
+inline int rz_tile_launch(const RzWaveArgs& wa, unsigned grid, size_t lds_bytes, stream_t stream) {
+  if (wa.s.prof) {
+    return wa.s.p.num_actions <= 4 ? rz_tile_launch_k<4, true>(wa, grid, lds_bytes, stream)
+                                   : rz_tile_launch_k<16, true>(wa, grid, lds_bytes, stream);
+  }
+  return wa.s.p.num_actions <= 4 ? rz_tile_launch_k<4, false>(wa, grid, lds_bytes, stream)
+                                 : rz_tile_launch_k<16, false>(wa, grid, lds_bytes, stream);
 }
 
 #endif  // !MZX_HOSTCHECK
