@@ -30,6 +30,7 @@ typedef int rzw_i32x4 __attribute__((ext_vector_type(4)));
 
 struct RzWaveArgs {
   RzSearchArgs s;
+  int32_t fc1_valu;           // tile kernel: 1 = head layers with <= 16 inputs on the vector ALUs (MZX_RZ_FC1_VALU=0: A/B knob)
   int32_t wl[RZ_MAX_OPS];   // float offset of operator o's packed weights inside the LDS weight area, -1: read from L2
   int32_t wl_floats;        // size of the LDS weight area
 };
@@ -385,7 +386,7 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
     RzwOp q;
     const int wl = wa.wl[tid];
     q.head = rz_classify(op, a.HW) | ((wl >= 0 ? 1 : 0) << 4) | ((op.store_hidden ? 1 : 0) << 5) |
-             (((op.cout + 15) >> 4) << 8) | (op.wchunks << 16);
+             (((op.cout + 15) >> 4) << 8) | ((op.wchunks & 0xFFF) << 16);
     q.in_off = op.in_off; q.out_off = op.out_off; q.res_off = op.res_off;
     q.w_at = (wl >= 0) ? wl : op.w_off;
     q.p0 = (op.alpha_off >= 0) ? op.alpha_off : op.bias_off; q.p1 = op.beta_off;
@@ -501,7 +502,7 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
       const int head = __builtin_amdgcn_readfirstlane(q.head);
       qnext = rzw_fetch(optab, o + 1 < a.n_ops ? o + 1 : 0);   // in flight while this operator runs
       __builtin_amdgcn_sched_barrier(0);
-      const int cls = head & 15, nt_total = (head >> 8) & 255, wchunks = (head >> 16) & 0xFFFF;
+      const int cls = head & 15, nt_total = (head >> 8) & 255, wchunks = (head >> 16) & 0xFFF;
       const bool w_in_lds = (head >> 4) & 1, store_hidden = (head >> 5) & 1;
       RZW_PROF(3)   // descriptor (+ the fence below)
       switch (cls) {
@@ -700,6 +701,33 @@ __device__ __forceinline__ void rzt_scale(const RzwOp& q, const RzArgs& a, float
   }
 }
 
+// RZ_FAST_FC1 (a head layer with <= 16 inputs) on the vector ALUs, one output per thread: with a 601-bin support the
+// layer is 38 column tiles of four MFMAs at one valid row in sixteen.  Same bits as the matrix path: the f32 MFMA
+// accumulates its four products in k order with one rounding each (a k-ordered fmaf chain), the K-steps of the
+// chunk alternate between the two accumulators of rz_gemm_tiles<1>, then the same epilogue.
+__device__ __forceinline__ void rzt_fc1_valu(const RzwOp& q, int wchunks, float* reg, const float* simg, const f32x4* wbase, int tid) {
+  const f32x4* xin = (const f32x4*)(reg + q.in_off);       // 16 inputs, row 0
+  const f32x4 x0 = xin[0], x1 = xin[1], x2 = xin[2], x3 = xin[3];   // x[4 g + j] = xg[j]
+  for (int n = tid; n < q.cout; n += RZW_WAVES * 64) {
+    const f32x4* w = wbase + (size_t)(n >> 4) * wchunks * 64 + (n & 15);
+    const f32x4 w0 = w[0], w1 = w[16], w2 = w[32], w3 = w[48];      // W[4 g + j][n] = wg[j]
+    const float bi = simg[q.p0 + n];
+    float acc = 0.f, odd = 0.f;
+    acc = __builtin_fmaf(x0[0], w0[0], acc); acc = __builtin_fmaf(x1[0], w1[0], acc);
+    acc = __builtin_fmaf(x2[0], w2[0], acc); acc = __builtin_fmaf(x3[0], w3[0], acc);
+    odd = __builtin_fmaf(x0[1], w0[1], odd); odd = __builtin_fmaf(x1[1], w1[1], odd);
+    odd = __builtin_fmaf(x2[1], w2[1], odd); odd = __builtin_fmaf(x3[1], w3[1], odd);
+    acc = __builtin_fmaf(x0[2], w0[2], acc); acc = __builtin_fmaf(x1[2], w1[2], acc);
+    acc = __builtin_fmaf(x2[2], w2[2], acc); acc = __builtin_fmaf(x3[2], w3[2], acc);
+    odd = __builtin_fmaf(x0[3], w0[3], odd); odd = __builtin_fmaf(x1[3], w1[3], odd);
+    odd = __builtin_fmaf(x2[3], w2[3], odd); odd = __builtin_fmaf(x3[3], w3[3], odd);
+    float xv = (acc + odd) * 1.f + 0.f;
+    xv = xv + bi;
+    xv = xv + 0.f;
+    reg[q.out_off + n] = fmaxf(xv, -MZX_INF);
+  }
+}
+
 template <int AW, bool PROFILE>
 __global__ void __launch_bounds__(RZW_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 rz_tile_search_kernel(const RzWaveArgs wa) {
@@ -733,8 +761,16 @@ rz_tile_search_kernel(const RzWaveArgs wa) {
     const RzOp op = ((const RzOp*)a.small)[tid];
     RzwOp q;
     const int wl = wa.wl[tid];
-    q.head = rz_classify(op, 0x7FFFFFFF) | ((wl >= 0 ? 1 : 0) << 4) | ((op.store_hidden ? 1 : 0) << 5) |
-             (((op.cout + 15) >> 4) << 8) | (op.wchunks << 16);
+    // slots (rz_schedule): operators of a slot are independent -- no barrier between them, position-row operators on
+    // the tile waves, the k-th tree-row operator (a head MLP layer) of the slot on wave 3 - k
+    const RzOp* ops = (const RzOp*)a.small;
+    int first = tid;
+    while (first > 0 && ((ops[first - 1].sched >> 16) & 1u) == 0) --first;
+    int kth = 0;
+    for (int i = first; i < tid; ++i) kth += (ops[i].kind == RZ_GEMM && ops[i].rows == RZ_ROWS_TREE) ? 1 : 0;
+    const int last = (int)((op.sched >> 16) & 1u), alone = (last && first == tid) ? 1 : 0;
+    q.head = rz_classify(op, 0x7FFFFFFF) | ((wl >= 0 ? 1 : 0) << 4) | ((op.store_hidden ? 1 : 0) << 5) | (last << 6) | (alone << 7) |
+             (((op.cout + 15) >> 4) << 8) | ((op.wchunks & 0xFFF) << 16) | (((RZW_WAVES - 1 - kth) & 3) << 28);
     q.in_off = op.in_off; q.out_off = op.out_off; q.res_off = op.res_off;
     q.w_at = (wl >= 0) ? wl : op.w_off;
     q.p0 = (op.alpha_off >= 0) ? op.alpha_off : op.bias_off; q.p1 = op.beta_off;
@@ -852,18 +888,32 @@ rz_tile_search_kernel(const RzWaveArgs wa) {
       const int head = __builtin_amdgcn_readfirstlane(q.head);
       qnext = rzw_fetch(optab, o + 1 < a.n_ops ? o + 1 : 0);
       __builtin_amdgcn_sched_barrier(0);
-      const int cls = head & 15, nt_total = (head >> 8) & 255, wchunks = (head >> 16) & 0xFFFF;
+      const int cls = head & 15, nt_total = (head >> 8) & 255, wchunks = (head >> 16) & 0xFFF;
       const bool w_in_lds = (head >> 4) & 1, store_hidden = (head >> 5) & 1;
+      const bool last = (head >> 6) & 1, alone = (head >> 7) & 1;
+      const int twave = (head >> 28) & 3;
       switch (cls) {
         case RZ_FAST_CONV: if (tile_valid) { RZT_CALL(RZW_K_TAP9, RZW_EP_BN_RELU, 0, 1) } break;
         case RZ_FAST_CONV_ASUM: if (tile_valid) { RZT_CALL(RZW_K_TAP9, RZW_EP_BN_RELU_ASUM, 0, 1) } break;
         case RZ_FAST_CONV_RES: if (tile_valid) { RZT_CALL(RZW_K_TAP9, RZW_EP_BN_RES_RELU, 0, 1) } break;
         case RZ_FAST_CONV1: if (tile_valid) { RZT_CALL(RZW_K_LIN1, RZW_EP_BIAS_POS, 0, 1) } break;
-        case RZ_FAST_FC9_ELU: RZT_CALL(RZW_K_LIN9, RZW_EP_BIAS_ELU_TREE, wave, RZW_WAVES) break;
-        case RZ_FAST_FC1: RZT_CALL(RZW_K_LIN1, RZW_EP_BIAS_TREE, wave, RZW_WAVES) break;
+        case RZ_FAST_FC9_ELU:
+          if (alone) { RZT_CALL(RZW_K_LIN9, RZW_EP_BIAS_ELU_TREE, wave, RZW_WAVES) }
+          else if (wave == twave) { RZT_CALL(RZW_K_LIN9, RZW_EP_BIAS_ELU_TREE, 0, 1) }
+          break;
+        case RZ_FAST_FC1:
+          if (alone && wa.fc1_valu) {   // (MZX_RZ_FC1_VALU=0: the matrix path, A/B)
+            if (w_in_lds) rzt_fc1_valu(q, wchunks, reg, simg, (const f32x4*)(wlds + q.w_at), tid);
+            else rzt_fc1_valu(q, wchunks, reg, simg, (const f32x4*)(a.weights + q.w_at), tid);
+          } else if (alone) {
+            RZT_CALL(RZW_K_LIN1, RZW_EP_BIAS_TREE, wave, RZW_WAVES)
+          } else if (wave == twave) {
+            RZT_CALL(RZW_K_LIN1, RZW_EP_BIAS_TREE, 0, 1)
+          }
+          break;
         default: rzt_scale(q, a, reg, scratch, rowaddr, tid, store_hidden ? hid : nullptr); break;
       }
-      __syncthreads();
+      if (last) __syncthreads();
     }
 #undef RZT_CALL
     RZT_PROF(3)
@@ -949,6 +999,7 @@ inline bool rz_tile_plan(const mzx_search* s, const RzProgram& R, const RzArgs& 
     if (used + nfl <= room) { wa.wl[o] = used; used += nfl; }
   }
   wa.wl_floats = used;
+  wa.fc1_valu = rz_env_int("MZX_RZ_FC1_VALU", 1) != 0 ? 1 : 0;
   grid = (unsigned)s->p.num_trees;
   lds_bytes = (size_t)4 * rzt_layout(a.n_ops, a.small_floats, NN, a.Cs, a.tree_floats, rec_floats, used).total;
   return true;
