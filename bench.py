@@ -465,12 +465,13 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     Hf, L = net.hidden_size, mean_leaf_depth
     bytes_per_sim = 28 * A * L + 29 * (L + 1) + (8 * A + 16) + 8 * Hf
     achieved = bytes_per_sim * B * S / (launch_ms * 1e-3) / 1e9
+    ran = lib.mzx_search_kernel_name(handle)      # the search kernel the last step launched
+    ran = ran.decode() if ran else ""
     traffic, traffic_src = None, None
     try:  # PMC-measured HBM bytes per launch of this kernel (collected by a separate rocprofv3 --pmc run)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             key = "fused-lds" if fused else ("residual-whole-search" if fused_kind == 2 else "generic-per-op")
-            if fused_kind == 2 and (cfg.network == "resnet" and net.hidden_size // max(1, cfg.channels) <= 16 and A <= 16
-                                    and 2 * cfg.support_size + 1 <= 32 and os.environ.get("MZX_RZ_WAVE", "1") != "0"):
+            if fused_kind == 2 and ran == "mzx::rz_wave_search_kernel":
                 key = "residual-wave-per-tree"
             entry = json.load(f).get(f"{workload}:{key}")
         if not fused and fused_kind != 2 and net_fused:
@@ -486,15 +487,11 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": bytes_per_sim * B * S,
-        "kernel": "mzx::fused_fc_search" if fused else "whole step (one kernel per operator)",
+        "kernel": ran if fused else "whole step (one kernel per operator)",
         "launch_ms": launch_ms, "algorithmic_bytes_per_sim": bytes_per_sim,
         "note": "tree bytes per simulation x B x S / HIP-event time of one search launch; trees live in "
                 "LDS in the fused kernel, so this is algorithmic traffic, not HBM traffic (DESIGN.md)",
     }
-    # boards of <= 16 positions with <= 16 actions and a support of <= 32 bins run the wave-per-tree kernel
-    # (csrc/mzx_resnet_wave.h: rz_wave_plan)
-    wave_kernel = (cfg.network == "resnet" and net.hidden_size // max(1, cfg.channels) <= 16 and A <= 16
-                   and 2 * cfg.support_size + 1 <= 32 and os.environ.get("MZX_RZ_WAVE", "1") != "0")
     if cfg.network == "resnet":  # dense contractions: FP32 MFMA roofline
         f_init = int(lib.mzx_net_flops(net.handle, 0))
         f_rec = int(lib.mzx_net_flops(net.handle, 1))
@@ -503,8 +500,7 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         roofline = {
             "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": ("whole step: root kernels + " + ("mzx::rz_wave_search_kernel (a wave per tree)" if wave_kernel else "mzx::rz_search_kernel")
-                       + " (all simulations, one launch)") if fused_kind == 2
+            "kernel": ("whole step: root kernels + " + ran + " (all simulations, one launch)") if fused_kind == 2
                       else "whole step: select / rz_network_kernel (fused MFMA network) / expand+backprop per simulation"
                       if net_fused else "whole step (one kernel per operator)",
             "launch_ms": launch_ms, "flops_per_simulation": f_rec, "flops_initial_inference": f_init,

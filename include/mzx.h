@@ -216,6 +216,9 @@ int mzx_search_run_from_roots(mzx_search* s, const mzx_search_io* io, const floa
  *      csrc/mzx_fused_fc.h) instead of the cached-prior-score kernel (csrc/mzx_fused_fc2.h): A/B measurements
  * Default: 1 when supported, else 0. */
 int mzx_search_fused_supported(const mzx_search* s);
+/* Name of the search kernel the last mzx_search_run of this handle launched ("" before the first run): which of the
+ * whole-search kernels a configuration is routed to is decided per launch (network family, board size, LDS fit). */
+const char* mzx_search_kernel_name(const mzx_search* s);
 int mzx_search_set_mode(mzx_search* s, int32_t mode);
 /* Byte offsets inside the arena (diagnostics): out[0..6] = (unused, 0), trees, hidden states,
  * network workspace, bytes per tree, workspace bytes, total bytes. */

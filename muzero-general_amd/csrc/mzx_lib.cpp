@@ -293,6 +293,8 @@ int64_t mzx_search_arena_bytes(const mzx_search* s) { return s ? s->arena_bytes 
 
 int mzx_search_fused_supported(const mzx_search* s) { return s ? s->fused_ok : 0; }
 
+const char* mzx_search_kernel_name(const mzx_search* s) { return s ? s->last_kernel : ""; }
+
 int mzx_search_arena_offsets(const mzx_search* s, int64_t out[8]) {
   if (!s || !out) { set_error("null argument"); return MZX_ERR_INVALID; }
   out[0] = s->off_tables; out[1] = s->off_trees; out[2] = s->off_hidden; out[3] = s->off_ws;
@@ -331,9 +333,13 @@ int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_
   }
 #ifndef MZX_HOSTCHECK
   if ((s->mode & 1) && s->fused_ok == 1)
+  {
+    s->last_kernel = (s->mode & 16) ? "mzx::fused_fc_search" : "mzx::fc2_search_kernel";
     return (s->mode & 16) ? fused_fc_run(s, io, d_arena, (stream_t)stream) : fc2_run(s, io, d_arena, (stream_t)stream);
+  }
   if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) return rz_search_run(s, io, d_arena, (stream_t)stream);
 #endif
+  s->last_kernel = "one kernel per step of a simulation (select / network / expand + back-propagate)";
   return search_run_generic(s, io, d_arena, (stream_t)stream);
 }
 

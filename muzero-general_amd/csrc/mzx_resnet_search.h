@@ -499,11 +499,13 @@ inline int rz_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, 
         wa.s.sim0 = 0;
         wa.s.prof = ((s->mode & 8) && s->ws_floats >= (int64_t)wgrid * 8) ? (uint32_t*)((char*)d_arena + s->off_ws) : nullptr;
         wa.s.tree_lds = 2;
+        s->last_kernel = wave_k ? "mzx::rz_wave_search_kernel" : "mzx::rz_tile_search_kernel";
         rc = wave_k ? rz_wave_launch(wa, wgrid, wlds, stream) : rz_tile_launch(wa, wgrid, wlds, stream);
         if (rc) return rc;
         return search_finish(s, io, d_arena, stream);
       }
     }
+    s->last_kernel = "mzx::rz_search_kernel";
     RzSearchArgs sa;
     sa.net = L.a;
     sa.p = v.p;

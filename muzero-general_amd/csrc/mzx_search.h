@@ -25,6 +25,7 @@ struct mzx_search {
   double* d_tables = nullptr;
   int32_t mode = 0;
   int32_t fused_ok = 0;
+  const char* last_kernel = "";   // search kernel of the last mzx_search_run (mzx_search_kernel_name)
 };
 
 namespace mzx {

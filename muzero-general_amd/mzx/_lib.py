@@ -97,6 +97,7 @@ PROTOTYPES = {
     "mzx_search_run": (ctypes.c_int, [c_vp, ctypes.POINTER(SearchIO), c_vp, c_i64, c_vp]),
     "mzx_search_run_from_roots": (ctypes.c_int, [c_vp, ctypes.POINTER(SearchIO), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mzx_search_fused_supported": (ctypes.c_int, [c_vp]),
+    "mzx_search_kernel_name": (ctypes.c_char_p, [c_vp]),
     "mzx_search_set_mode": (ctypes.c_int, [c_vp, c_i32]),
     "mzx_search_arena_offsets": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64 * 8)]),
     "mzx_search_lockstep_begin": (ctypes.c_int, [c_vp, ctypes.POINTER(SearchIO), c_vp, c_vp, c_vp, c_i64, c_vp]),
