@@ -513,6 +513,78 @@ def _compare_modes(cfg, net, B, legal, to_play, noise, seeds):
     return r1
 
 
+def _kernel_name(backend, engine, B):
+    name = backend.lib.mzx_search_kernel_name(engine.handle(B))
+    return name.decode() if name else ""
+
+
+# Shapes no BASELINE configuration has, chosen so that every operator of recurrent_inference belongs to a fast class
+# (head MLP inputs = reduced channels x positions in 129..144, one hidden layer of <= 16): they are routed to the
+# small-board kernels of csrc/mzx_resnet_wave.h and exercise their geometry edges.
+SMALL_BOARD_CASES = {
+    # 4 x 4 = 16 positions: every row of the wave's tile is valid; 16 actions (16-lane child records); channel counts
+    # below 16 (padded K chunks / column tiles); two residual blocks
+    "wave-4x4": (lambda: configs.tictactoe(observation_shape=(3, 4, 4), action_space=list(range(16)), channels=12, blocks=2,
+                                           reduced_channels_reward=9, reduced_channels_value=9, reduced_channels_policy=9,
+                                           resnet_fc_reward_layers=[8], resnet_fc_value_layers=[16], resnet_fc_policy_layers=[5]),
+                 "mzx::rz_wave_search_kernel"),
+    # 2 x 3 board, 6 actions, one player
+    "wave-2x3": (lambda: configs.tictactoe(observation_shape=(2, 2, 3), action_space=list(range(6)), players=list(range(1)),
+                                           channels=16, blocks=1, reduced_channels_reward=24, reduced_channels_value=23,
+                                           reduced_channels_policy=22, resnet_fc_reward_layers=[16], resnet_fc_value_layers=[16],
+                                           resnet_fc_policy_layers=[16], discount=0.997),
+                 "mzx::rz_wave_search_kernel"),   # 22..24 reduced channels: the 1x1 head convolutions (two column tiles) are not of
+                                                  # a fast class and run on the wave kernel's interpreter (rzw_gemm)
+    # 3 x 6 = 18 positions: two row tiles, the second with two valid rows; 6 actions (16-lane records in the tile kernel)
+    "tile-3x6": (lambda: configs.tictactoe(observation_shape=(3, 3, 6), action_space=list(range(6)), channels=16, blocks=1,
+                                           reduced_channels_reward=8, reduced_channels_value=8, reduced_channels_policy=8,
+                                           resnet_fc_reward_layers=[16], resnet_fc_value_layers=[16], resnet_fc_policy_layers=[16]),
+                 "mzx::rz_tile_search_kernel"),
+    # 6 x 8 = 48 positions: three full row tiles, 4 actions (4-lane records), an 81-bin support (wide decode)
+    "tile-6x8": (lambda: configs.tictactoe(observation_shape=(2, 6, 8), action_space=list(range(4)), players=list(range(1)),
+                                           channels=8, blocks=2, reduced_channels_reward=3, reduced_channels_value=3,
+                                           reduced_channels_policy=3, resnet_fc_reward_layers=[16], resnet_fc_value_layers=[16],
+                                           resnet_fc_policy_layers=[16], support_size=40, discount=0.997),
+                 "mzx::rz_tile_search_kernel"),
+}
+
+
+@pytest.mark.parametrize("case", sorted(SMALL_BOARD_CASES))
+def test_small_board_kernels_other_shapes(backend, case):
+    """Wave-per-tree / tile-per-wave whole-search kernels == generic path, bit for bit, on boards and head shapes of
+    their own, and the launch is routed to the kernel the shape is meant for (no silent fall-back)."""
+    make, want_kernel = SMALL_BOARD_CASES[case]
+    cfg = make()
+    cfg.num_simulations = 20
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 21))
+    B = 37
+    A = len(cfg.action_space)
+    rs = numpy.random.RandomState(7)
+    legal = [sorted(rs.choice(A, size=rs.randint(1, A + 1), replace=False).tolist()) for _ in range(B)]
+    to_play = [int(i % len(cfg.players)) for i in range(B)]
+    res = _compare_modes(cfg, net, B, legal, to_play, True, [300 + i for i in range(B)])
+    assert (res.visit_counts.sum(1) == cfg.num_simulations).all()
+    engine = self_play.BatchedMCTS(cfg, net, B)
+    obs = synthetic.observations(B, net.input_shape, seed=B + 1)
+    engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(300 + i) for i in range(B)])
+    assert _kernel_name(backend, engine, B) == want_kernel
+
+
+def test_baseline_configurations_are_routed_to_their_kernels(backend):
+    want = {"cartpole": "mzx::fc2_search_kernel", "tictactoe": "mzx::rz_wave_search_kernel",
+            "connect4": "mzx::rz_search_kernel", "breakout": "mzx::rz_tile_search_kernel"}
+    for name, kernel in want.items():
+        cfg = configs.BY_NAME[name](num_simulations=3)
+        net = models.MuZeroNetwork(cfg)
+        net.set_weights(synthetic.fill_state_dict(net.state_dict(), 2))
+        B = 8
+        engine = self_play.BatchedMCTS(cfg, net, B)
+        obs = synthetic.observations(B, net.input_shape, seed=1)
+        engine.run(list(obs), [list(cfg.action_space)] * B, [0] * B, True, [numpy.random.RandomState(i) for i in range(B)])
+        assert _kernel_name(backend, engine, B) == kernel, name
+
+
 @pytest.mark.parametrize("net_name", ["cartpole", "tictactoe"])
 @pytest.mark.parametrize("B,S,noise", [(1, 1, True), (1, 40, False), (17, 3, True), (257, 7, False)])
 def test_whole_search_kernels_edge_shapes(backend, net_name, B, S, noise):
