@@ -593,6 +593,8 @@ inline bool rz_wave_plan(const mzx_search* s, const RzProgram& R, const RzArgs& 
   const int A = s->p.num_actions;
   if (g.HW > 16 || A > FUSED_ROW || 2 * s->p.support_size + 1 > 2 * FUSED_ROW) return false;
   if (rz_env_int("MZX_RZ_WAVE", 1) == 0) return false;
+  for (int o = 0; o < R.n_ops; ++o)     // fields of RzwOp::head
+    if (R.ops[o].kind == RZ_GEMM && (R.ops[o].cout + 15) / 16 > 255) return false;
   const int AW = A <= 4 ? 4 : 16;
   const int NN = s->p.num_nodes;
   wa.s.net = base;
