@@ -473,6 +473,8 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
             key = "fused-lds" if fused else ("residual-whole-search" if fused_kind == 2 else "generic-per-op")
             if fused_kind == 2 and ran == "mzx::rz_wave_search_kernel":
                 key = "residual-wave-per-tree"
+            if fused_kind == 2 and ran == "mzx::rz_tile_search_kernel":
+                key = "residual-tile-per-wave"
             entry = json.load(f).get(f"{workload}:{key}")
         if not fused and fused_kind != 2 and net_fused:
             entry = None
