@@ -585,6 +585,36 @@ def test_baseline_configurations_are_routed_to_their_kernels(backend):
         assert _kernel_name(backend, engine, B) == kernel, name
 
 
+@pytest.mark.parametrize("name", ["tictactoe", "breakout"])
+def test_tie_tape_overflow_through_the_small_board_kernels(backend, name):
+    """
+    A network whose priors are all equal ties at every selection level: the tie tape of a tree overflows, the kernel
+    flags it (TF_TAPE_OVERFLOW in the tree's records -> arena meta), BatchedMCTS.run re-runs the flagged trees with a
+    longer tape.  Short tape == long tape, on the wave-per-tree (tic-tac-toe) and tile-per-wave (breakout) kernels.
+    """
+    cfg = configs.BY_NAME[name](num_simulations=20)
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights({k: torch.zeros_like(v) for k, v in net.state_dict().items()})
+    B = 5
+    obs = synthetic.observations(B, net.input_shape, seed=3)
+    legal = [list(cfg.action_space)] * B
+    outs = []
+    old = self_play.TAPE_WORDS
+    try:
+        for words in (4, 4096):
+            self_play.TAPE_WORDS = words
+            engine = self_play.BatchedMCTS(cfg, net, B)
+            res = engine.run(list(obs), legal, [0] * B, True, [numpy.random.RandomState(40 + i) for i in range(B)])
+            outs.append(res)
+    finally:
+        self_play.TAPE_WORDS = old
+    short, long_ = outs
+    assert (short.tape_used > 4).any()
+    assert numpy.array_equal(short.visit_counts, long_.visit_counts)
+    assert numpy.array_equal(short.root_values.view(numpy.int64), long_.root_values.view(numpy.int64))
+    assert numpy.array_equal(short.tape_used, long_.tape_used) and (short.flags == 0).all()
+
+
 @pytest.mark.parametrize("net_name", ["cartpole", "tictactoe"])
 @pytest.mark.parametrize("B,S,noise", [(1, 1, True), (1, 40, False), (17, 3, True), (257, 7, False)])
 def test_whole_search_kernels_edge_shapes(backend, net_name, B, S, noise):
