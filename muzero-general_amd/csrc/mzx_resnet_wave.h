@@ -12,12 +12,16 @@
 //   * tree: the 32-byte slot / node records of mzx_fused_fc2.h in LDS (fc2_walk / fc2_expand / fc2_backprop:
 //     the binary64 operations of mzx_tree.h in the reference's order), converted from / to the arena's
 //     TreeLayout at the ends of the launch;
-//   * network: the operator table of mzx_resnet_fused.h (rz_plan) interpreted per wave with the K loop and the
-//     epilogue of rz_gemm_tiles<1> -- the same MFMA sequence per output element, so the logits are bit-identical
-//     to the workgroup engine's -- but with the row addresses of the wave's tile held in registers for the whole
-//     launch instead of being re-read per operator;
+//   * network: the operator table of mzx_resnet_fused.h (rz_plan) as a table of 12-word descriptors, one scalar
+//     word each; operators of a fast class (RzFastClass) run straight-line code (rzw_gemm_s: every fragment
+//     requested up front, 36 MFMAs back to back, constant epilogue), the others the interpreter (rzw_gemm: the K
+//     loop and epilogue of rz_gemm_tiles<1>); either way the same MFMA sequence per output element as the workgroup
+//     engine, so the logits are bit-identical to its -- with the row addresses of the wave's tile held in registers
+//     for the whole launch instead of being re-read per operator;
 //   * weights: as many packed B-fragment images as fit beside the four trees stay in LDS (the 3x3 convolutions
-//     of C3), the rest is streamed from L2 by the four-chunk ring of the K loop.
+//     of C3), the rest is streamed from L2.
+// Second kernel of this file, rz_tile_search_kernel: boards of 17-64 positions (breakout's 6 x 6 hidden state, C5) --
+// a workgroup per tree, a row tile per wave, the same operator loop with one barrier per slot.
 // (Included by mzx_resnet_search.h between its kernels and its host driver.)
 #pragma once
 
