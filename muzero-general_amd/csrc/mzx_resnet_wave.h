@@ -34,6 +34,7 @@ typedef int rzw_i32x4 __attribute__((ext_vector_type(4)));
 
 struct RzWaveArgs {
   RzSearchArgs s;
+  int32_t dual;             // wave kernel: 1 = two operators of a slot in flight together (MZX_RZ_DUAL=0: A/B knob)
   int32_t fc1_valu;           // tile kernel: 1 = head layers with <= 16 inputs on the vector ALUs (MZX_RZ_FC1_VALU=0: A/B knob)
   int32_t wl[RZ_MAX_OPS];   // float offset of operator o's packed weights inside the LDS weight area, -1: read from L2
   int32_t wl_floats;        // size of the LDS weight area
@@ -51,12 +52,12 @@ static_assert(sizeof(RzwOp) == 48, "RzwOp is fetched as three 16-byte LDS reads"
 
 struct RzWaveLayout { int optab, simg, tables, inv_y, wlds, wave0, wave_stride, o_scratch, o_reg, o_tree, total; };   // floats
 
-// LDS of a workgroup: rowaddr[16], compact operator table, small image, UCB tables, reciprocals, weights, then
-// per wave {scaling scratch + action value, the program's regions, the tree's records}
+// LDS of a workgroup: rowaddr[16], operator roles [RZ_MAX_OPS], compact operator table, small image, UCB tables,
+// reciprocals, weights, then per wave {scaling scratch + action value, the program's regions, the tree's records}
 __host__ __device__ inline RzWaveLayout rzw_layout(int n_ops, int small_floats, int NN, int Cs, int tree_floats, int rec_floats,
                                                    int wl_floats) {
   RzWaveLayout y;
-  int c = 16;
+  int c = 16 + RZ_MAX_OPS;
   y.optab = c; c += n_ops * 12;
   y.simg = c; c += (small_floats + 3) & ~3;
   y.tables = c; c += (4 * (NN + 1) + 3) & ~3;
@@ -231,7 +232,7 @@ __device__ __forceinline__ RzwOp rzw_fetch(const RzwOp* tab, int o) {
   RzwOp q;
   q.head = w0[0]; q.in_off = w0[1]; q.out_off = w0[2]; q.res_off = w0[3];
   q.w_at = w1[0]; q.p0 = w1[1]; q.p1 = w1[2]; q.asum_off = w1[3];
-  q.cout = w2[0]; q.channels = w2[1]; q.pad0 = 0; q.pad1 = 0;
+  q.cout = w2[0]; q.channels = w2[1]; q.pad0 = w2[2]; q.pad1 = w2[3];
   return q;
 }
 
@@ -246,83 +247,128 @@ struct RzwLane {
 };
 
 enum { RZW_K_TAP9 = 0, RZW_K_LIN1 = 1, RZW_K_LIN9 = 2 };
+// two slot-mates in flight together: classes behind RzFastClass's in the class field of the FIRST descriptor of the pair
+enum { RZW_DUAL_CONV_CONV1 = 9, RZW_DUAL_CONVRES_FC9, RZW_DUAL_CONV1_CONV1, RZW_DUAL_FC9_FC9, RZW_DUAL_FC1_FC1 };
 enum { RZW_EP_BN_RELU = 0, RZW_EP_BN_RELU_ASUM, RZW_EP_BN_RES_RELU, RZW_EP_BIAS_POS, RZW_EP_BIAS_ELU_TREE, RZW_EP_BIAS_TREE };
 
-// rzw_gemm with the K structure and the epilogue options as compile-time constants: every fragment of the
-// operator is requested up front (nine A + nine B quads at most), the MFMAs follow back to back in the order of
-// rz_gemm_tiles<1> (chunk by chunk, K-steps alternating between the two accumulator tiles), the epilogue is the
-// same sequence of fp32 operations with absent terms as literal 1.f / 0.f.
+// rzw_gemm with the K structure and the epilogue options as compile-time constants, as three phases of an
+// operator in flight: every fragment of the operator is requested up front (nine A + nine B quads at most), the
+// MFMAs follow back to back in the order of rz_gemm_tiles<1> (chunk by chunk, K-steps alternating between the two
+// accumulator tiles), the epilogue is the same sequence of fp32 operations with absent terms as literal 1.f / 0.f.
 template <int KS, int EP>
-__device__ __forceinline__ void rzw_gemm_s(const RzwOp& q, int wchunks, float* reg, const float* simg, const f32x4* wp,
-                                           const float* scratch, const RzwLane& k, int nt) {
-  constexpr bool POS = (EP <= RZW_EP_BIAS_POS);
-  constexpr bool BN = (EP <= RZW_EP_BN_RES_RELU);
-  constexpr int NCH = (KS == RZW_K_LIN1) ? 1 : 9;
-  const float* in = reg + q.in_off;
-  wp += (size_t)nt * wchunks * 64;
-  const int n = nt * 16 + (k.lane & 15);
+struct RzwGemm {
+  static constexpr bool POS = (EP <= RZW_EP_BIAS_POS);
+  static constexpr bool BN = (EP <= RZW_EP_BN_RES_RELU);
+  static constexpr int NCH = (KS == RZW_K_LIN1) ? 1 : 9;
   f32x4 A[NCH], B[NCH];
+  f32x4 acc, acc_odd;
+  float al, be, bi, actval;
+  float rs[4], as[4];
+  int n;
+
+  __device__ __forceinline__ void load(const RzwOp& q, int wchunks, const float* reg, const float* simg, const f32x4* wp,
+                                       const float* scratch, const RzwLane& k, int nt) {
+    const float* in = reg + q.in_off;
+    wp += (size_t)nt * wchunks * 64;
+    n = nt * 16 + (k.lane & 15);
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {   // chunk 0 first: LDS answers in request order
-    const int at = (KS == RZW_K_TAP9) ? k.atap[c] : (POS ? k.ra_lane : 0) + k.g4 + c * 16;
-    B[c] = wp[c * 64];
-    A[c] = *(const f32x4*)(in + at);
-    if (c == 0) __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < NCH; ++c) {   // chunk 0 first: LDS answers in request order
+      const int at = (KS == RZW_K_TAP9) ? k.atap[c] : (POS ? k.ra_lane : 0) + k.g4 + c * 16;
+      B[c] = wp[c * 64];
+      A[c] = *(const f32x4*)(in + at);
+      if (c == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    // epilogue operands: their LDS round trips hide under the MFMAs
+    al = 1.f; be = 0.f; bi = 0.f; actval = 0.f;
+    if (BN) { al = simg[q.p0 + n]; be = simg[q.p1 + n]; } else { bi = simg[q.p0 + n]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { rs[r] = 0.f; as[r] = 0.f; }
+    if (EP == RZW_EP_BN_RES_RELU) {
+      const float* res = reg + q.res_off;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rs[r] = res[k.ra4[r] + n];
+    }
+    if (EP == RZW_EP_BN_RELU_ASUM) {
+      actval = scratch[2 * k.Cs];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) as[r] = simg[q.asum_off + n * k.HW + ((k.m0 + r < k.HW) ? k.m0 + r : 0)];
+    }
+    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // epilogue operands: their LDS round trips hide under the MFMAs
-  float al = 1.f, be = 0.f, bi = 0.f;
-  if (BN) { al = simg[q.p0 + n]; be = simg[q.p1 + n]; } else { bi = simg[q.p0 + n]; }
-  float rs[4] = {0.f, 0.f, 0.f, 0.f}, as[4] = {0.f, 0.f, 0.f, 0.f};
-  float actval = 0.f;
-  if (EP == RZW_EP_BN_RES_RELU) {
-    const float* res = reg + q.res_off;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) rs[r] = res[k.ra4[r] + n];
-  }
-  if (EP == RZW_EP_BN_RELU_ASUM) {
-    actval = scratch[2 * k.Cs];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) as[r] = simg[q.asum_off + n * k.HW + ((k.m0 + r < k.HW) ? k.m0 + r : 0)];
-  }
-  // every request above is issued before the first MFMA (the scheduler would otherwise re-serialise them into a
-  // load -> wait -> four MFMAs chain per chunk, one LDS round trip each)
-  __builtin_amdgcn_sched_barrier(0);
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
+  __device__ __forceinline__ void mfma(int c) {   // the four K-steps of chunk c
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][0], B[c][0], acc, 0, 0, 0);
     acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][1], B[c][1], acc_odd, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][2], B[c][2], acc, 0, 0, 0);
     acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][3], B[c][3], acc_odd, 0, 0, 0);
   }
+  __device__ __forceinline__ void finish(const RzwOp& q, float* reg, const RzwLane& k) {
+    acc = acc + acc_odd;
+    const bool nv = n < q.cout;
+    float* out = reg + q.out_off;
+    if (EP == RZW_EP_BN_RELU_ASUM) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += actval * as[r];
+    }
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = acc[r] * al + be;
+      x = x + bi;
+      x = x + rs[r];
+      v[r] = fmaxf(x, BN ? 0.f : -MZX_INF);
+    }
+    if (EP == RZW_EP_BIAS_ELU_TREE) v[0] = mzx_elu(v[0]);
+    if (BN) {                                   // padded position-major output
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (k.m0 + r < k.HW && nv) out[k.ra4[r] + n] = v[r];
+    } else if (EP == RZW_EP_BIAS_POS) {         // flat [channel][position]
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (k.m0 + r < k.HW && nv) out[k.m0 + r + n * k.HW] = v[r];
+    } else {                                    // one valid row: the tree
+      if (k.g4 == 0 && nv) out[n] = v[0];   // (head layers run on one wave: row 0 of ITS tile is the tree)
+    }
+  }
+};
+
+template <int KS, int EP>
+__device__ __forceinline__ void rzw_gemm_s(const RzwOp& q, int wchunks, float* reg, const float* simg, const f32x4* wp,
+                                           const float* scratch, const RzwLane& k, int nt) {
+  RzwGemm<KS, EP> g;
+  g.load(q, wchunks, reg, simg, wp, scratch, k, nt);
+  // every request is issued before the first MFMA (the scheduler would otherwise re-serialise them into a
+  // load -> wait -> four MFMAs chain per chunk, one LDS round trip each)
   __builtin_amdgcn_sched_barrier(0);
-  acc = acc + acc_odd;
-  const bool nv = n < q.cout;
-  float* out = reg + q.out_off;
-  if (EP == RZW_EP_BN_RELU_ASUM) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] += actval * as[r];
+  for (int c = 0; c < RzwGemm<KS, EP>::NCH; ++c) g.mfma(c);
+  __builtin_amdgcn_sched_barrier(0);
+  g.finish(q, reg, k);
+}
+
+// Two INDEPENDENT operators (members of one slot of rz_schedule: neither reads or writes a region the other writes)
+// in flight together in one wave: both operators' requests, then their MFMAs chunk by chunk in turn, then both
+// epilogues.  A lone wave cannot overlap the ~1 k cycles of request / drain / store latency of an operator with
+// anything else; the second operator's do overlap with the first one's MFMAs.  Every output element is computed by
+// the same instruction sequence as alone.
+template <int KS1, int EP1, int KS2, int EP2>
+__device__ __forceinline__ void rzw_gemm_dual(const RzwOp& q1, int wch1, const f32x4* wp1, const RzwOp& q2, int wch2, const f32x4* wp2,
+                                              float* reg, const float* simg, const float* scratch, const RzwLane& k) {
+  RzwGemm<KS1, EP1> g1;
+  RzwGemm<KS2, EP2> g2;
+  g1.load(q1, wch1, reg, simg, wp1, scratch, k, 0);
+  g2.load(q2, wch2, reg, simg, wp2, scratch, k, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  constexpr int N1 = RzwGemm<KS1, EP1>::NCH, N2 = RzwGemm<KS2, EP2>::NCH;
+#pragma unroll
+  for (int c = 0; c < (N1 > N2 ? N1 : N2); ++c) {
+    if (c < N1) g1.mfma(c);
+    if (c < N2) g2.mfma(c);
   }
-  float v[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float x = acc[r] * al + be;
-    x = x + bi;
-    x = x + rs[r];
-    v[r] = fmaxf(x, BN ? 0.f : -MZX_INF);
-  }
-  if (EP == RZW_EP_BIAS_ELU_TREE) v[0] = mzx_elu(v[0]);
-  if (BN) {                                   // padded position-major output
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (k.m0 + r < k.HW && nv) out[k.ra4[r] + n] = v[r];
-  } else if (EP == RZW_EP_BIAS_POS) {         // flat [channel][position]
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (k.m0 + r < k.HW && nv) out[k.m0 + r + n * k.HW] = v[r];
-  } else {                                    // one valid row: the tree
-    if (k.g4 == 0 && nv) out[n] = v[0];   // (head layers run on one wave: row 0 of ITS tile is the tree)
-  }
+  __builtin_amdgcn_sched_barrier(0);
+  g1.finish(q1, reg, k);
+  g2.finish(q2, reg, k);
 }
 
 // rzw_scale for <= 16 planes of <= 16 positions, in registers: lane (g, c) holds positions g, g + 4, g + 8, g + 12 of
@@ -368,6 +414,7 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
   const int NN = sa.p.num_nodes;
   const RzWaveLayout y = rzw_layout(a.n_ops, a.small_floats, NN, a.Cs, a.tree_floats, (int)rz_trec_tree_floats(NN, AW), wa.wl_floats);
   int* rowaddr = (int*)rz_lds;            // [16]
+  int* roles = rowaddr + 16;              // [RZ_MAX_OPS]: 0 an operator on its own, 1 first of a pair, 2 second of a pair
   RzwOp* optab = (RzwOp*)(rz_lds + y.optab);
   float* simg = rz_lds + y.simg;
   double* tables = (double*)(rz_lds + y.tables);
@@ -385,17 +432,65 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
   }
   for (int i = tid; i < 2 * (NN + 1); i += NT) tables[i] = sa.p.pbc_table[i];   // pbc[NN + 1] then sqrt[NN + 1], contiguous
   for (int i = tid; i < NN + 2; i += NT) inv_y[i] = recip_refined((double)(i > 0 ? i : 1));
-  if (tid < a.n_ops) {
-    const RzOp op = ((const RzOp*)a.small)[tid];
+  // Operator table.  Two operators of one slot (rz_schedule: neither reads nor writes a region the other writes) run
+  // as a PAIR when there is code that keeps both in flight (rzw_gemm_dual): the first descriptor of the pair carries
+  // the pair's class, the second follows it in the table.  Decided per slot from its first operator on, in parallel.
+  const RzOp* gops = (const RzOp*)a.small;
+  auto desc = [&](int o) {
+    const RzOp op = gops[o];
     RzwOp q;
-    const int wl = wa.wl[tid];
+    const int wl = wa.wl[o];
     q.head = rz_classify(op, a.HW) | ((wl >= 0 ? 1 : 0) << 4) | ((op.store_hidden ? 1 : 0) << 5) |
              (((op.cout + 15) >> 4) << 8) | ((op.wchunks & 0xFFF) << 16);
     q.in_off = op.in_off; q.out_off = op.out_off; q.res_off = op.res_off;
     q.w_at = (wl >= 0) ? wl : op.w_off;
     q.p0 = (op.alpha_off >= 0) ? op.alpha_off : op.bias_off; q.p1 = op.beta_off;
-    q.asum_off = op.asum_off; q.cout = op.cout; q.channels = op.channels; q.pad0 = 0; q.pad1 = 0;
-    optab[tid] = q;
+    q.asum_off = op.asum_off; q.cout = op.cout; q.channels = op.channels; q.pad0 = o; q.pad1 = 0;
+    return q;
+  };
+  // class of the pair (i, i + 1), 0: none; `swap`: the second operator leads (its weights are the LDS-resident ones)
+  auto pair_class = [&](int i, bool& swap) {
+    swap = false;
+    if (!wa.dual || i + 1 >= a.n_ops || ((gops[i].sched >> 16) & 1u)) return 0;
+    const RzOp &x = gops[i], &z = gops[i + 1];
+    const int cx_ = rz_classify(x, a.HW), cz = rz_classify(z, a.HW);
+    const int ntx = (x.cout + 15) >> 4, ntz = (z.cout + 15) >> 4;
+    const bool lx = wa.wl[i] >= 0, lz = wa.wl[i + 1] >= 0;
+    const bool mixed_ok = lx || !lz;                 // (L2, LDS) is not instantiated
+    if (cx_ == RZ_FAST_CONV && cz == RZ_FAST_CONV1 && ntx == 1 && ntz == 1 && mixed_ok) return (int)RZW_DUAL_CONV_CONV1;
+    if (cx_ == RZ_FAST_CONV_RES && cz == RZ_FAST_FC9_ELU && ntx == 1 && ntz == 1 && mixed_ok) return (int)RZW_DUAL_CONVRES_FC9;
+    swap = !mixed_ok;
+    if (cx_ == RZ_FAST_CONV1 && cz == RZ_FAST_CONV1 && ntx == 1 && ntz == 1) return (int)RZW_DUAL_CONV1_CONV1;
+    if (cx_ == RZ_FAST_FC9_ELU && cz == RZ_FAST_FC9_ELU && ntx == 1 && ntz == 1) return (int)RZW_DUAL_FC9_FC9;
+    if (cx_ == RZ_FAST_FC1 && cz == RZ_FAST_FC1) return (int)RZW_DUAL_FC1_FC1;
+    swap = false;
+    return 0;
+  };
+  if (tid < a.n_ops) {
+    int first = tid;                                  // first operator of this one's slot
+    while (first > 0 && ((gops[first - 1].sched >> 16) & 1u) == 0) --first;
+    int role = 0;
+    for (int i = first; i <= tid;) {                  // greedy from the slot's first operator
+      bool sw;
+      if (pair_class(i, sw)) { if (i == tid) role = 1; else if (i + 1 == tid) role = 2; i += 2; }
+      else ++i;
+    }
+    roles[tid] = role;
+  }
+  __syncthreads();
+  if (tid < a.n_ops && roles[tid] != 2) {
+    const int role = roles[tid];
+    RzwOp q1 = desc(tid);
+    if (role == 1) {
+      bool sw;
+      const int dc = pair_class(tid, sw);
+      RzwOp q2 = desc(tid + 1);
+      if (sw) { const RzwOp t = q1; q1 = q2; q2 = t; }
+      q1.head = (q1.head & ~15) | dc;
+      q1.pad1 = q2.head;                              // the scalar word of the second descriptor rides with the first
+      optab[tid + 1] = q2;
+    }
+    optab[tid] = q1;
   }
   for (int o = 0; o < a.n_ops; ++o) {
     const int at = wa.wl[o];
@@ -501,15 +596,50 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
     if (w_in_lds) rzw_gemm_s<KS, EP>(q, wchunks, reg, simg, (const f32x4*)(wlds + q.w_at) + lane, scratch, kl, nt); \
     else rzw_gemm_s<KS, EP>(q, wchunks, reg, simg, (const f32x4*)(a.weights + q.w_at) + lane, scratch, kl, nt);    \
   }
-    for (int o = 0; o < a.n_ops; ++o) {
+#define RZW_DUAL(K1, E1, K2, E2)                                                                                          \
+  {                                                                                                                     \
+    if (w_in_lds && l2) rzw_gemm_dual<K1, E1, K2, E2>(q, wchunks, (const f32x4*)(wlds + q.w_at) + lane, q2, wch2,         \
+                                                      (const f32x4*)(wlds + q2.w_at) + lane, reg, simg, scratch, kl);    \
+    else if (w_in_lds) rzw_gemm_dual<K1, E1, K2, E2>(q, wchunks, (const f32x4*)(wlds + q.w_at) + lane, q2, wch2,          \
+                                                     (const f32x4*)(a.weights + q2.w_at) + lane, reg, simg, scratch, kl); \
+    else rzw_gemm_dual<K1, E1, K2, E2>(q, wchunks, (const f32x4*)(a.weights + q.w_at) + lane, q2, wch2,                   \
+                                       (const f32x4*)(a.weights + q2.w_at) + lane, reg, simg, scratch, kl);              \
+  }
+    for (int i = 0; i < a.n_ops;) {
       const RzwOp q = qnext;
       const int head = __builtin_amdgcn_readfirstlane(q.head);
-      qnext = rzw_fetch(optab, o + 1 < a.n_ops ? o + 1 : 0);   // in flight while this operator runs
+      const int cls = head & 15;
+      const int used = (cls >= RZW_DUAL_CONV_CONV1) ? 2 : 1;
+      const int nxt = (i + used < a.n_ops) ? i + used : 0;
+      qnext = rzw_fetch(optab, nxt);                           // in flight while this entry runs
       __builtin_amdgcn_sched_barrier(0);
-      const int cls = head & 15, nt_total = (head >> 8) & 255, wchunks = (head >> 16) & 0xFFF;
+      const int nt_total = (head >> 8) & 255, wchunks = (head >> 16) & 0xFFF;
       const bool w_in_lds = (head >> 4) & 1, store_hidden = (head >> 5) & 1;
       RZW_PROF(3)   // descriptor (+ the fence below)
-      switch (cls) {
+      if (used == 2) {   // ---- two slot-mates in flight together
+        const RzwOp q2 = rzw_fetch(optab, i + 1);              // its fields are first needed after the first operator's requests
+        const int head2 = __builtin_amdgcn_readfirstlane(q.pad1);
+        const int nt2 = (head2 >> 8) & 255, wch2 = (head2 >> 16) & 0xFFF;
+        const bool l2 = (head2 >> 4) & 1;
+        switch (cls) {
+          case RZW_DUAL_CONV_CONV1: RZW_DUAL(RZW_K_TAP9, RZW_EP_BN_RELU, RZW_K_LIN1, RZW_EP_BIAS_POS) break;
+          case RZW_DUAL_CONVRES_FC9: RZW_DUAL(RZW_K_TAP9, RZW_EP_BN_RES_RELU, RZW_K_LIN9, RZW_EP_BIAS_ELU_TREE) break;
+          case RZW_DUAL_CONV1_CONV1: RZW_DUAL(RZW_K_LIN1, RZW_EP_BIAS_POS, RZW_K_LIN1, RZW_EP_BIAS_POS) break;
+          case RZW_DUAL_FC9_FC9: RZW_DUAL(RZW_K_LIN9, RZW_EP_BIAS_ELU_TREE, RZW_K_LIN9, RZW_EP_BIAS_ELU_TREE) break;
+          default: {   // RZW_DUAL_FC1_FC1: column tile 0 of both together, further column tiles after
+            RZW_DUAL(RZW_K_LIN1, RZW_EP_BIAS_TREE, RZW_K_LIN1, RZW_EP_BIAS_TREE)
+            for (int nt = 1; nt < nt_total; ++nt) {
+              if (w_in_lds) rzw_gemm_s<RZW_K_LIN1, RZW_EP_BIAS_TREE>(q, wchunks, reg, simg, (const f32x4*)(wlds + q.w_at) + lane, scratch, kl, nt);
+              else rzw_gemm_s<RZW_K_LIN1, RZW_EP_BIAS_TREE>(q, wchunks, reg, simg, (const f32x4*)(a.weights + q.w_at) + lane, scratch, kl, nt);
+            }
+            for (int nt = 1; nt < nt2; ++nt) {
+              if (l2) rzw_gemm_s<RZW_K_LIN1, RZW_EP_BIAS_TREE>(q2, wch2, reg, simg, (const f32x4*)(wlds + q2.w_at) + lane, scratch, kl, nt);
+              else rzw_gemm_s<RZW_K_LIN1, RZW_EP_BIAS_TREE>(q2, wch2, reg, simg, (const f32x4*)(a.weights + q2.w_at) + lane, scratch, kl, nt);
+            }
+            break;
+          }
+        }
+      } else switch (cls) {
         case RZ_FAST_CONV: RZW_CALL(RZW_K_TAP9, RZW_EP_BN_RELU) break;
         case RZ_FAST_CONV_ASUM: RZW_CALL(RZW_K_TAP9, RZW_EP_BN_RELU_ASUM) break;
         case RZ_FAST_CONV_RES: RZW_CALL(RZW_K_TAP9, RZW_EP_BN_RES_RELU) break;
@@ -518,11 +648,13 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
         case RZ_FAST_FC1: RZW_CALL(RZW_K_LIN1, RZW_EP_BIAS_TREE) break;
         case RZ_FAST_SCALE16: rzw_scale16(q, reg, kl, store_hidden ? hid : nullptr); break;
         case RZ_FAST_SCALE_GEN: {
+          const int o = __builtin_amdgcn_readfirstlane(q.pad0);
           const RzOp op = rzw_fetch_op(simg, o);
           rzw_scale(op, a, reg, scratch, rowaddr, lane, op.store_hidden ? hid : nullptr);
           break;
         }
         default: {   // any other GEMM: the interpreter
+          const int o = __builtin_amdgcn_readfirstlane(q.pad0);
           const RzOp op = rzw_fetch_op(simg, o);
           const int at = __builtin_amdgcn_readfirstlane(q.w_at);
           if (w_in_lds) {   // two call sites: the address space of the B fragments is known in each (ds_read / global_load)
@@ -539,8 +671,10 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
         const int pk = (cls == RZ_FAST_SCALE16 || cls == RZ_FAST_SCALE_GEN) ? 7 : ((cls == RZ_FAST_CONV1 || cls == RZ_FAST_FC1) ? 6 : (w_in_lds ? 1 : 5));
         RZW_PROF(pk)
       }
+      i += used;
     }
 #undef RZW_CALL
+#undef RZW_DUAL
     // the leaf's state must have left the wave before a later simulation gathers it (what the workgroup
     // barrier of rz_search_kernel implies)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -624,6 +758,7 @@ inline bool rz_wave_plan(const mzx_search* s, const RzProgram& R, const RzArgs& 
     if (used + nfl <= room) { wa.wl[o] = used; used += nfl; }
   }
   wa.wl_floats = used;
+  wa.dual = rz_env_int("MZX_RZ_DUAL", 1) != 0 ? 1 : 0;
   grid = (unsigned)((s->p.num_trees + RZW_WAVES - 1) / RZW_WAVES);
   lds_bytes = (size_t)4 * rzw_layout(a.n_ops, a.small_floats, NN, a.Cs, a.tree_floats, rec_floats, used).total;
   return true;
