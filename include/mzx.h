@@ -106,6 +106,17 @@ int mzx_net_set_weights(mzx_net* net, const float* d_flat, int64_t n_floats,
 int mzx_net_fused_supported(const mzx_net* net);
 int mzx_net_set_mode(mzx_net* net, int32_t mode);
 
+/* Residual networks the fused engine cannot hold in LDS (reference games/gomoku.py:56-64 -- 128 channels x 6
+ * blocks on 11 x 11 -- and games/atari.py:61-69 -- 256 channels x 16 blocks, 256-wide heads; models.py:436-623)
+ * run on the STREAMED MFMA engine: one FP32-MFMA implicit-GEMM launch per convolution / Linear layer over the
+ * whole batch.  mzx_net_streamed_supported: bit 0 = initial_inference, bit 1 = recurrent_inference run there
+ * by default (mode 0 still forces one element kernel per operator; mzx_net_set_mode(3) routes EVERY residual
+ * program there, fused-capable ones included -- the A/B and parity knob).  mzx_net_streamed_plan: the workgroup tiling of
+ * operator `op`: {kind, in_layout, out_layout, res_layout, taps, stride, cin, cout, hin, win, hout, wout, T, th,
+ * tw, tiles_x, tiles_y, PH, PW, chunks per phase, phases, rows, row tiles, LDS bytes}. */
+int mzx_net_streamed_supported(const mzx_net* net);
+int mzx_net_streamed_plan(const mzx_net* net, int32_t recurrent, int32_t op, int32_t out[24]);
+
 /* initial_inference(observation) (models.py:172-190 / :601-618).
  * d_observation [batch][input_size]; outputs value_logits [batch][2s+1],
  * policy_logits [batch][A], hidden [batch][hidden_size].  The reward of the

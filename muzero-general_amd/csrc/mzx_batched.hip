@@ -1,0 +1,512 @@
+// mzx_batched.hip -- kernels of the STREAMED residual-network engine (plan: mzx_resnet_batched.h).
+//
+// rb_gemm_kernel<MT, NT>: one layer of MuZeroResidualNetwork (models.py:206-623) -- 3x3 convolution with folded
+// BatchNorm / residual / ReLU / action plane, 1x1 head convolution, Linear (+ ELU) -- as an FP32-MFMA implicit GEMM
+// over the whole batch.  A 512-thread workgroup (8 waves, two per SIMD) owns a tile of up to 144 GEMM rows =
+// (sample, output position) pairs and up to 16 column tiles of 16 output channels:
+//   * the tile's input patch (with the 3x3 halo, out-of-image cells zero) is staged ONCE into LDS, position-major
+//     [cell][Cs] with Cs = 8 mod 16 floats -- a 3x3 tap is a constant LDS offset, no bounds tests in the K loop;
+//     patches that do not fit are staged in channel groups (phases), accumulators live across phases;
+//   * K runs over (tap, 16-channel chunk): lane (row l & 15, group g = l >> 4) reads channels 4g..4g+3 of its row
+//     with one ds_read_b128 = the A operands of four v_mfma_f32_16x16x4_f32 K-steps; B fragments come pre-packed
+//     in the same lane order (RzPackOp), 16 bytes per lane per chunk, straight from L2 (every workgroup streams the
+//     layer's weights once; all workgroups read the same image, so it stays L2-resident); both operand sets are
+//     double-buffered in registers one chunk ahead;
+//   * waves take column tiles first (each wave streams a disjoint slice of the weights), row tiles next; a wave
+//     owns up to 9 x 2 accumulator tiles, one B fragment feeds up to nine MFMAs;
+//   * epilogue in registers in the per-operator kernels' order (mzx_ops.h): action term, alpha * acc + beta, bias,
+//     residual, ReLU / ELU; the D fragment goes to global memory position-major (16 lanes = 64 contiguous bytes)
+//     or NCHW (head tensors).
+// The f32 MFMA is a k-ordered fmaf chain; only the summation ORDER differs from ATen's / Conv3x3Op's.
+// Roofline: FP32 matrix pipe, 157.3 TFLOP/s dense.
+#include <hip/hip_runtime.h>
+
+#include "mzx_pack.h"
+#include "mzx_resnet_batched.h"
+
+namespace mzx {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RB_THREADS = 512;
+
+struct RbTensor {
+  const float* p;
+  const int32_t* node;   // node of sample b inside [batch][nodes][sstride] (null: node 0)
+  int64_t sstride;       // floats per node
+  int32_t nodes;
+  int32_t layout;        // RbLayout
+};
+
+struct RbGemmArgs {
+  RbTensor x, res;       // res.p null: no residual
+  float* y;
+  int64_t y_sstride;
+  const float* wpack;
+  const float* alpha;    // folded BatchNorm (null: none)
+  const float* beta;
+  const float* bias;     // null: none
+  const float* asum;     // [cout][hout * wout] tap sums of the action plane (null: none)
+  const int32_t* action;
+  int32_t num_actions, batch;
+  int32_t cin, cout, hin, win, hout, wout, stride, taps;
+  int32_t T, th, tw, tiles_x, tiles_y, PH, PW, Cs, cpg, phases, cchunks, wchunks, rows, mtiles;
+  int32_t ntiles, ntiles_wg, WN, WM, y_layout, act, x_vec;
+  uint32_t magic_thw, magic_tw, magic_phw, magic_pw;   // ceil(2^32 / d)
+};
+
+__device__ __forceinline__ int rb_div(int x, int d, uint32_t magic) {
+  return d == 1 ? x : (int)__umulhi((unsigned)x, magic);
+}
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(RB_THREADS) rb_gemm_kernel(const RbGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float rb_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mpad = a.mtiles * 16, Tpad = (a.T + 1) & ~1;
+  int* rowaddr = (int*)rb_lds;
+  int* rowt = rowaddr + mpad;
+  int* rowpos = rowt + mpad;
+  long long* soff_x = (long long*)(rowpos + mpad);
+  long long* soff_r = soff_x + Tpad;
+  float* tile = (float*)(soff_r + Tpad);
+
+  const int nsp = a.tiles_x * a.tiles_y;
+  const int sg = blockIdx.x / nsp, sp = blockIdx.x - sg * nsp;
+  const int tyi = sp / a.tiles_x, txi = sp - tyi * a.tiles_x;
+  const int ty0 = tyi * a.th, tx0 = txi * a.tw;
+  const int b0 = sg * a.T;
+  const int pad = a.taps == 9 ? 1 : 0;
+  const int thw = a.th * a.tw, phw = a.PH * a.PW, cells = a.T * phw;
+  const int HWo = a.hout * a.wout;
+
+  // ---- row tables, per-sample offsets
+  for (int m = tid; m < mpad; m += RB_THREADS) {
+    const int t = rb_div(m, thw, a.magic_thw), r = m - t * thw;
+    const int ty = rb_div(r, a.tw, a.magic_tw), tx = r - ty * a.tw;
+    const int oy = ty0 + ty, ox = tx0 + tx;
+    const bool valid = m < a.rows;
+    const bool ok = valid && (b0 + t) < a.batch && oy < a.hout && ox < a.wout;
+    rowaddr[m] = valid ? ((t * a.PH + ty * a.stride + pad) * a.PW + tx * a.stride + pad) * a.Cs : 0;
+    rowt[m] = valid ? t : 0;
+    rowpos[m] = ok ? oy * a.wout + ox : -1;
+  }
+  for (int t = tid; t < a.T; t += RB_THREADS) {
+    const int b = (b0 + t < a.batch) ? b0 + t : a.batch - 1;
+    soff_x[t] = ((long long)b * a.x.nodes + (a.x.node ? a.x.node[b] : 0)) * a.x.sstride;
+    soff_r[t] = a.res.p ? ((long long)b * a.res.nodes + (a.res.node ? a.res.node[b] : 0)) * a.res.sstride : 0;
+  }
+  __syncthreads();
+
+  // ---- this wave's tiles
+  const int wn = wave % a.WN, wm = wave / a.WN;
+  const int nt_first = wn * NT;                               // first column tile inside the workgroup's share
+  const bool active = wm < a.WM && nt_first < a.ntiles_wg && (blockIdx.y * a.ntiles_wg + nt_first) < a.ntiles &&
+                      wm * MT < a.mtiles;
+  int ra[MT];
+  const float* wp[NT];
+  bool nvalid[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int mt = wm * MT + i;
+    ra[i] = ((active && mt < a.mtiles) ? rowaddr[mt * 16 + (lane & 15)] : 0) + 4 * (lane >> 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int nt = blockIdx.y * a.ntiles_wg + nt_first + j;
+    nvalid[j] = active && (nt_first + j) < a.ntiles_wg && nt < a.ntiles;
+    wp[j] = a.wpack + ((size_t)(nvalid[j] ? nt : 0) * a.wchunks) * 256 + lane * 4;
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* xp = a.x.p;
+  const int gy0 = ty0 * a.stride - pad, gx0 = tx0 * a.stride - pad;
+
+  for (int g = 0; g < a.phases; ++g) {
+    const int c0 = g * a.cpg * 16;
+    const int cw = min(a.cpg * 16, a.cchunks * 16 - c0);   // channels of this phase (padded to whole chunks)
+    const int q = cw >> 2;
+    if (g > 0) __syncthreads();                            // every wave is done reading the previous group
+    // ---- stage the input patch: tile[cell][c - c0], zero outside the image / beyond cin
+    if (a.x.layout == RB_NHWC) {
+      const uint32_t magic_q = (uint32_t)((0x100000000ull + (uint64_t)q - 1) / (uint64_t)q);
+      const int total = cells * q;
+      for (int i0 = tid; i0 < total; i0 += 4 * RB_THREADS) {
+        f32x4 v[4];
+        int at[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = i0 + u * RB_THREADS;
+          at[u] = -1;
+          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (idx < total) {
+            const int cell = rb_div(idx, q, magic_q), k = idx - cell * q;
+            const int t = rb_div(cell, phw, a.magic_phw), rem = cell - t * phw;
+            const int iy = rb_div(rem, a.PW, a.magic_pw), ix = rem - iy * a.PW;
+            const int gy = gy0 + iy, gx = gx0 + ix, c = c0 + 4 * k;
+            at[u] = cell * a.Cs + 4 * k;
+            if (b0 + t < a.batch && gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win && c < a.cin) {
+              const float* src = xp + soff_x[t] + ((long long)gy * a.win + gx) * a.cin + c;
+              if (a.x_vec && c + 3 < a.cin) v[u] = *(const f32x4*)src;
+              else {
+                v[u][0] = src[0];
+                if (c + 1 < a.cin) v[u][1] = src[1];
+                if (c + 2 < a.cin) v[u][2] = src[2];
+                if (c + 3 < a.cin) v[u][3] = src[3];
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (at[u] >= 0) *(f32x4*)(tile + at[u]) = v[u];
+      }
+    } else {
+      // NCHW source: consecutive threads take consecutive cells of one channel quad (coalesced along x)
+      const uint32_t magic_cells = (uint32_t)((0x100000000ull + (uint64_t)cells - 1) / (uint64_t)cells);
+      const long long plane = (long long)a.hin * a.win;
+      const int total = cells * q;
+      for (int i0 = tid; i0 < total; i0 += 2 * RB_THREADS) {
+        f32x4 v[2];
+        int at[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int idx = i0 + u * RB_THREADS;
+          at[u] = -1;
+          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (idx < total) {
+            const int k = rb_div(idx, cells, magic_cells), cell = idx - k * cells;
+            const int t = rb_div(cell, phw, a.magic_phw), rem = cell - t * phw;
+            const int iy = rb_div(rem, a.PW, a.magic_pw), ix = rem - iy * a.PW;
+            const int gy = gy0 + iy, gx = gx0 + ix, c = c0 + 4 * k;
+            at[u] = cell * a.Cs + 4 * k;
+            if (b0 + t < a.batch && gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win && c < a.cin) {
+              const float* src = xp + soff_x[t] + (long long)c * plane + (long long)gy * a.win + gx;
+              v[u][0] = src[0];
+              if (c + 1 < a.cin) v[u][1] = src[plane];
+              if (c + 2 < a.cin) v[u][2] = src[2 * plane];
+              if (c + 3 < a.cin) v[u][3] = src[3 * plane];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (at[u] >= 0) *(f32x4*)(tile + at[u]) = v[u];
+      }
+    }
+    __syncthreads();
+
+    // ---- K loop of this phase: (tap, chunk) pairs, operands one chunk ahead in registers
+    if (active) {
+      const int cpg_g = cw >> 4;
+      const int n_it = a.taps * cpg_g;
+      int tap = 0, cc = 0;
+      f32x4 fa0[MT], fa1[MT], fb0[NT], fb1[NT];
+      auto load = [&](f32x4 (&fa)[MT], f32x4 (&fb)[NT]) {
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        const int aoff = (a.taps == 9 ? ((ky - 1) * a.PW + (kx - 1)) * a.Cs : 0) + cc * 16;
+        const size_t widx = (size_t)(tap * a.cchunks + g * a.cpg + cc) * 256;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j] = *(const f32x4*)(wp[j] + widx);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i] = *(const f32x4*)(tile + ra[i] + aoff);
+        if (++cc == cpg_g) { cc = 0; ++tap; }
+      };
+      auto mma = [&](const f32x4 (&fa)[MT], const f32x4 (&fb)[NT]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][k], fb[j][k], acc[i][j], 0, 0, 0);
+      };
+      // branch-free steady state (the wait counters of the next chunk's loads stay exact), one- or two-chunk tail
+      load(fa0, fb0);
+      int it = 0;
+      for (; it + 2 < n_it; it += 2) {
+        load(fa1, fb1);
+        mma(fa0, fb0);
+        load(fa0, fb0);
+        mma(fa1, fb1);
+      }
+      if (it + 1 < n_it) {
+        load(fa1, fb1);
+        mma(fa0, fb0);
+        mma(fa1, fb1);
+      } else {
+        mma(fa0, fb0);
+      }
+    }
+  }
+
+  // ---- epilogue
+  if (!active) return;
+  const int n_lane = lane & 15, rq = 4 * (lane >> 4);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    if (!nvalid[j]) continue;
+    const int n = (blockIdx.y * a.ntiles_wg + nt_first + j) * 16 + n_lane;
+    if (n >= a.cout) continue;
+    const float al = a.alpha ? a.alpha[n] : 1.f, be = a.alpha ? a.beta[n] : 0.f;
+    const float bi = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int mt = wm * MT + i;
+      if (mt >= a.mtiles) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mt * 16 + rq + r;
+        const int pos = rowpos[m];
+        if (pos < 0) continue;
+        const int t = rowt[m], b = b0 + t;
+        float v = acc[i][j][r];
+        if (a.asum) v += ((float)a.action[b] / (float)a.num_actions) * a.asum[(size_t)n * HWo + pos];
+        if (a.alpha) v = v * al + be;
+        if (a.bias) v += bi;
+        if (a.res.p)
+          v += a.res.p[soff_r[t] + (a.res.layout == RB_NHWC ? (long long)pos * a.cout + n : (long long)n * HWo + pos)];
+        if (a.act == RZ_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (a.act == RZ_ACT_ELU) v = mzx_elu(v);
+        a.y[(long long)b * a.y_sstride + (a.y_layout == RB_NHWC ? (long long)pos * a.cout + n : (long long)n * HWo + pos)] = v;
+      }
+    }
+  }
+}
+
+// Per-plane min-max scaling of the hidden state (models.py:527-553, :574-599; MinMaxScaleOp's arithmetic): one
+// workgroup per sample, NHWC or NCHW in, NCHW out (into the search arena's node store when `node` is set).
+struct RbScaleArgs {
+  RbTensor x;
+  float* y;
+  const int32_t* y_node;
+  int64_t y_sstride;
+  int32_t y_nodes, C, HW;
+};
+
+__global__ void __launch_bounds__(256) rb_scale_kernel(const RbScaleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float rb_lds[];
+  float* lo = rb_lds;
+  float* sc = lo + a.C;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* xb = a.x.p + ((long long)b * a.x.nodes + (a.x.node ? a.x.node[b] : 0)) * a.x.sstride;
+  float* yb = a.y + ((long long)b * a.y_nodes + (a.y_node ? a.y_node[b] : 0)) * a.y_sstride;
+  const bool nhwc = a.x.layout == RB_NHWC;
+  for (int c = tid; c < a.C; c += 256) {
+    float l = nhwc ? xb[c] : xb[(long long)c * a.HW], h = l;
+    for (int p = 1; p < a.HW; ++p) {
+      const float v = nhwc ? xb[(long long)p * a.C + c] : xb[(long long)c * a.HW + p];
+      l = fminf(l, v);
+      h = fmaxf(h, v);
+    }
+    float s = h - l;
+    if (s < 1e-5f) s += 1e-5f;
+    lo[c] = l;
+    sc[c] = s;
+  }
+  __syncthreads();
+  const int total = a.C * a.HW;
+  for (int i = tid; i < total; i += 256) {
+    const int c = i / a.HW, p = i - c * a.HW;
+    const float v = nhwc ? xb[(long long)p * a.C + c] : xb[i];
+    yb[i] = mzx_div(v - lo[c], sc[c]);
+  }
+}
+
+// AvgPool2d(kernel 3, stride 2, padding 1), count_include_pad=True (AvgPoolOp), position-major tensors.
+struct RbPoolOp {
+  const float* x;
+  float* y;
+  int32_t batch, C, hin, win, hout, wout;
+  MZX_HD size_t size() const { return (size_t)batch * hout * wout * C; }
+  MZX_HD void operator()(size_t i) const {
+    const int c = (int)(i % C);
+    const int ox = (int)((i / C) % wout), oy = (int)((i / ((size_t)C * wout)) % hout);
+    const int64_t b = (int64_t)(i / ((size_t)C * wout * hout));
+    const float* xb = x + b * hin * win * C + c;
+    float acc = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 + ky - 1;
+      if (iy < 0 || iy >= hin) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 + kx - 1;
+        if (ix < 0 || ix >= win) continue;
+        acc += xb[((int64_t)iy * win + ix) * C];
+      }
+    }
+    y[i] = acc / 9.0f;
+  }
+};
+
+// [batch][HW][C] -> [batch][C][HW] (diagnostic dumps: the per-operator kernels' layout)
+struct RbToNchwOp {
+  const float* x;
+  float* y;
+  int32_t batch, C, HW;
+  MZX_HD size_t size() const { return (size_t)batch * C * HW; }
+  MZX_HD void operator()(size_t i) const {
+    const int p = (int)(i % HW), c = (int)((i / HW) % C);
+    const int64_t b = (int64_t)(i / ((size_t)HW * C));
+    y[i] = x[(b * HW + p) * C + c];
+  }
+};
+
+uint32_t rb_magic(int d) { return d > 1 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u; }
+
+typedef void (*RbGemmFn)(const RbGemmArgs);
+
+template <int NT>
+RbGemmFn rb_pick_mt(int mt) {
+  switch (mt) {
+    case 1: return rb_gemm_kernel<1, NT>;
+    case 2: return rb_gemm_kernel<2, NT>;
+    case 3: return rb_gemm_kernel<3, NT>;
+    case 4: return rb_gemm_kernel<4, NT>;
+    case 5: return rb_gemm_kernel<5, NT>;
+    case 6: return rb_gemm_kernel<6, NT>;
+    case 7: return rb_gemm_kernel<7, NT>;
+    case 8: return rb_gemm_kernel<8, NT>;
+    default: return rb_gemm_kernel<9, NT>;
+  }
+}
+
+int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
+  // column tiles per workgroup: up to 16 (two per wave); split further while the grid would leave CUs idle
+  const int groups_m = ((batch + o.T - 1) / o.T) * o.tiles_x * o.tiles_y;
+  int ntiles_wg = std::min(o.ntiles, 16);
+  while (ntiles_wg > 1 && (int64_t)groups_m * ((o.ntiles + ntiles_wg - 1) / ntiles_wg) < 256) ntiles_wg = (ntiles_wg + 1) / 2;
+  const int nsplit = (o.ntiles + ntiles_wg - 1) / ntiles_wg;
+  const int NT = ntiles_wg > 8 ? 2 : 1;
+  const int WN = std::min(8, (ntiles_wg + NT - 1) / NT);
+  const int WM = std::max(1, std::min(8 / WN, o.mtiles));
+  const int MT = (o.mtiles + WM - 1) / WM;
+  a.ntiles_wg = ntiles_wg; a.WN = WN; a.WM = WM;
+  RbGemmFn fn = NT == 2 ? rb_pick_mt<2>(MT) : rb_pick_mt<1>(MT);
+  hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS_BUDGET);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+  void* params[] = {(void*)&a};
+  e = hipLaunchKernel((const void*)fn, dim3(groups_m, nsplit), dim3(RB_THREADS), params, (size_t)o.lds_bytes, stream);
+  if (e != hipSuccess) { set_error("streamed GEMM launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+  return MZX_OK;
+}
+
+}  // namespace
+
+int rb_refresh_derived(const mzx_net* net, const float* d_flat, float* d_derived, stream_t stream) {
+  for (const RzPack& p : net->rb.packs) {
+    RzPackOp op;
+    op.W = d_flat + p.src; op.out = d_derived + p.dst;
+    op.taps = p.taps; op.cin = p.cin; op.cin_total = p.cin_total; op.cchunks = p.cchunks; op.cout = p.cout;
+    op.nchunks = p.nchunks; op.wchunks = p.wchunks; op.ntiles = p.ntiles;
+    if (int rc = launch<256>(op, stream)) { set_error("launch failed: %s", runtime_error_string(rc)); return MZX_ERR_RUNTIME; }
+  }
+  for (const RzAsum& q : net->rb.asums) {
+    RzAsumOp op;
+    op.W = d_flat + q.src; op.out = d_derived + q.dst; op.cout = q.cout; op.cin_total = q.cin_total; op.H = q.H; op.Wd = q.W;
+    if (int rc = launch<256>(op, stream)) { set_error("launch failed: %s", runtime_error_string(rc)); return MZX_ERR_RUNTIME; }
+  }
+  return MZX_OK;
+}
+
+int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int batch, stream_t stream,
+                   const NetIndex* ix, int n_ops, float* dump) {
+  const std::vector<OpDesc>& prog = recurrent ? net->prog_recurrent : net->prog_initial;
+  const RbProgram& R = recurrent ? net->rb.recurrent : net->rb.initial;
+  const float* flat = net->d_flat;
+  const float* der = net->d_derived;
+  const int count = n_ops < 0 ? (int)prog.size() : n_ops;
+  const int64_t in_floats = recurrent ? net->hidden_size : net->input_size;
+  // logical buffer -> tensor (per-sample stride `dense` for workspace temporaries and head outputs)
+  auto tensor = [&](int id, int64_t dense, int layout) {
+    RbTensor t;
+    t.p = resolve(net, nb, id, batch); t.node = nullptr; t.nodes = 1; t.sstride = dense; t.layout = layout;
+    if (id == BUF_IN) { t.sstride = in_floats; if (ix) { t.node = ix->in_node; t.nodes = ix->in_nodes; } }
+    if (id == BUF_HIDDEN) { t.sstride = net->hidden_size; if (ix) { t.node = ix->out_node; t.nodes = ix->out_nodes; } }
+    return t;
+  };
+  for (int k = 0; k < count; ++k) {
+    const OpDesc& d = prog[k];
+    const RbOp& o = R.ops[k];
+    int rc = 0;
+    if (o.kind == RB_GEMM) {
+      RbGemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.x = tensor(d.in, (int64_t)o.cin * o.hin * o.win, o.in_layout);
+      if (d.res != -100) a.res = tensor(d.res, (int64_t)o.cout * o.hout * o.wout, o.res_layout);
+      a.y = resolve(net, nb, d.out, batch);
+      a.y_sstride = (int64_t)o.cout * o.hout * o.wout;
+      a.y_layout = o.out_layout;
+      a.wpack = der + o.w_off;
+      if (d.kind == OP_CONV3 && d.bn.channels) { a.alpha = der + d.bn.alpha; a.beta = der + d.bn.beta; }
+      if (d.kind != OP_CONV3) a.bias = flat + d.b;
+      if (o.asum_off >= 0) { a.asum = der + o.asum_off; a.action = nb.action; a.num_actions = net->cfg.action_space_size; }
+      a.batch = batch;
+      a.cin = o.cin; a.cout = o.cout; a.hin = o.hin; a.win = o.win; a.hout = o.hout; a.wout = o.wout;
+      a.stride = o.stride; a.taps = o.taps;
+      a.T = o.T; a.th = o.th; a.tw = o.tw; a.tiles_x = o.tiles_x; a.tiles_y = o.tiles_y; a.PH = o.PH; a.PW = o.PW;
+      a.Cs = o.Cs; a.cpg = o.cpg; a.phases = o.phases; a.cchunks = o.cchunks; a.wchunks = o.wchunks;
+      a.rows = o.rows; a.mtiles = o.mtiles; a.ntiles = o.ntiles; a.act = o.act;
+      a.x_vec = (o.in_layout == RB_NHWC && o.cin % 4 == 0 && a.x.sstride % 4 == 0 && ((uintptr_t)a.x.p % 16) == 0) ? 1 : 0;
+      a.magic_thw = rb_magic(o.th * o.tw); a.magic_tw = rb_magic(o.tw);
+      a.magic_phw = rb_magic(o.PH * o.PW); a.magic_pw = rb_magic(o.PW);
+      rc = rb_launch_gemm(a, o, batch, stream);
+      if (rc) return rc;
+      continue;
+    }
+    if (o.kind == RB_SCALE) {
+      RbScaleArgs s;
+      s.x = tensor(d.in, (int64_t)d.groups_per_sample * d.len, o.in_layout);
+      const RbTensor y = tensor(d.out, (int64_t)d.groups_per_sample * d.len, RB_NCHW);
+      s.y = const_cast<float*>(y.p); s.y_node = y.node; s.y_nodes = y.nodes; s.y_sstride = y.sstride;
+      s.C = d.groups_per_sample; s.HW = d.len;
+      hipLaunchKernelGGL(rb_scale_kernel, dim3(batch), dim3(256), (size_t)(2 * s.C * sizeof(float)), stream, s);
+      rc = (int)hipGetLastError();
+    } else if (o.kind == RB_POOL && o.in_layout == RB_NHWC) {
+      RbPoolOp op;
+      op.x = resolve(net, nb, d.in, batch); op.y = resolve(net, nb, d.out, batch);
+      op.batch = batch; op.C = d.cin; op.hin = d.hin; op.win = d.win; op.hout = d.hout; op.wout = d.wout;
+      rc = launch<256>(op, stream);
+    } else {
+      if (ix && ((d.in == BUF_IN && ix->in_nodes != 1) ||
+                 ((d.in == BUF_HIDDEN || d.out == BUF_HIDDEN) && ix->out_nodes != 1))) {
+        set_error("operator %d of the streamed engine does not take indexed hidden states", k);
+        return MZX_ERR_INVALID;
+      }
+      const std::vector<OpDesc> one(prog.begin() + k, prog.begin() + k + 1);
+      const int r2 = run_program(net, one, nb, batch, stream);
+      if (r2) return r2;
+    }
+    if (rc) { set_error("kernel launch failed: %s", runtime_error_string(rc)); return MZX_ERR_RUNTIME; }
+  }
+  if (dump && count > 0) {   // diagnostics: the last operator's output in the per-operator kernels' layout
+    const OpDesc& d = prog[count - 1];
+    const RbOp& o = R.ops[count - 1];
+    const float* src = resolve(net, nb, d.out, batch);
+    int rc = 0;
+    const bool spatial = d.kind == OP_CONV3 || d.kind == OP_POOL;
+    if (spatial && o.out_layout == RB_NHWC) {
+      RbToNchwOp op;
+      op.x = src; op.y = dump; op.batch = batch; op.C = d.cout; op.HW = d.hout * d.wout;
+      rc = launch<256>(op, stream);
+    } else {
+      int64_t per = 0;
+      switch (d.kind) {
+        case OP_LINEAR: per = d.out_features; break;
+        case OP_CONV1: per = (int64_t)d.cout * d.hin; break;
+        case OP_SCALE: per = (int64_t)d.groups_per_sample * d.len; break;
+        default: per = (int64_t)d.cout * d.hout * d.wout; break;
+      }
+      rc = copy_d2d(dump, src, sizeof(float) * per * batch, stream);
+    }
+    if (rc) { set_error("dump failed: %s", runtime_error_string(rc)); return MZX_ERR_RUNTIME; }
+  }
+  return MZX_OK;
+}
+
+}  // namespace mzx

@@ -1,0 +1,60 @@
+// mzx_batched_plan.h -- descriptor types of the STREAMED residual-network engine
+// (mzx_resnet_batched.h / mzx_batched.hip); kept apart so that `struct mzx_net` can embed them.
+//
+// The LDS-resident engine (mzx_resnet_fused.h) keeps a tile of trees inside ONE workgroup for a whole
+// inference; it needs three activation slots of the network's width in 160 KB of LDS.  The reference's
+// larger configurations -- games/gomoku.py:56-64 (128 channels x 6 blocks on 11 x 11), games/atari.py:61-69
+// (256 channels x 16 blocks, 256-wide heads) -- do not fit.  This engine runs them layer by layer: every
+// 3x3 convolution, 1x1 head convolution and Linear layer of models.py:206-623 is one FP32-MFMA implicit GEMM
+// launch over ALL samples (M = batch x positions, N = Cout, K = taps x Cin), activations streaming through
+// L2 / HBM between layers in a position-major (NHWC) layout.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "mzx_resnet_plan.h"
+
+namespace mzx {
+
+constexpr int RB_MAX_ROWS = 144;              // GEMM rows of a workgroup: nine 16-row MFMA tiles
+constexpr int RB_MT = 9;                      // row tiles a wave can own
+constexpr int RB_LDS_BUDGET = 156 * 1024;     // bytes of dynamic LDS a workgroup may ask for
+
+enum RbLayout { RB_NHWC = 0, RB_NCHW = 1 };   // [sample][position][channel] / [sample][channel][position]
+enum RbKind { RB_GEMM = 0, RB_SCALE = 1, RB_POOL = 2, RB_FUNCTOR = 3 };
+
+// One operator of a program (index-aligned with mzx_net::prog_initial / prog_recurrent).
+struct RbOp {
+  int32_t kind = RB_FUNCTOR;
+  int32_t in_layout = RB_NCHW, out_layout = RB_NCHW, res_layout = RB_NCHW;
+  // ---- RB_GEMM: D[rows x cout] = A[rows x taps*cin] . B, rows = (sample, output position)
+  int32_t taps = 1, stride = 1, cin = 0, cin_total = 0, cout = 0, hin = 1, win = 1, hout = 1, wout = 1;
+  int32_t cchunks = 0;     // 16-channel K chunks per tap (cin padded to a multiple of 16)
+  int32_t nchunks = 0, wchunks = 0, ntiles = 0;
+  // workgroup tile: T whole samples (small maps) or one th x tw patch of output positions of one sample
+  int32_t T = 1, th = 1, tw = 1, tiles_x = 1, tiles_y = 1;
+  int32_t PH = 1, PW = 1;  // input patch incl. the halo of a 3x3 kernel, cells per sample
+  int32_t cpg = 1;         // K chunks (of 16 channels) staged in LDS per phase
+  int32_t phases = 1;      // ceil(cchunks / cpg): the input patch is staged in channel groups when it does not fit
+  int32_t Cs = 24;         // LDS floats per cell: 16 * cpg + 8 (16-byte reads of 16 consecutive cells on distinct banks)
+  int32_t rows = 1, mtiles = 1, lds_bytes = 0;
+  int64_t w_off = -1;      // derived buffer: B fragments in v_mfma_f32_16x16x4_f32 lane order (RzPackOp)
+  int64_t asum_off = -1;   // derived buffer: border-aware tap sums of the action plane's weights [cout][H*W]
+  int32_t act = 0;         // RzAct
+};
+
+struct RbProgram {
+  int32_t ok = 0;
+  std::vector<RbOp> ops;
+};
+
+struct RbPlan {
+  int32_t ok = 0;
+  RbProgram initial, recurrent;
+  std::vector<RzPack> packs;
+  std::vector<RzAsum> asums;
+  int64_t derived_floats = 0;   // end of this engine's part of the derived buffer
+};
+
+}  // namespace mzx

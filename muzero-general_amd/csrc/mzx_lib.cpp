@@ -63,6 +63,7 @@ int mzx_net_create(const mzx_net_config* cfg, mzx_net** out) {
   NetBuilder b(net);
   if (!b.build()) { delete net; return MZX_ERR_INVALID; }
   rz_plan(net);
+  rb_plan(net);
   *out = net;
   return MZX_OK;
 }
@@ -74,7 +75,8 @@ int64_t mzx_net_num_params(const mzx_net* net) { return net ? net->num_params : 
 int64_t mzx_net_hidden_size(const mzx_net* net) { return net ? net->hidden_size : 0; }
 int64_t mzx_net_input_size(const mzx_net* net) { return net ? net->input_size : 0; }
 static int64_t derived_total(const mzx_net* net) {
-  const int64_t n = net->rz.ok ? net->rz.derived_floats : net->derived_floats;
+  int64_t n = net->rz.ok ? net->rz.derived_floats : net->derived_floats;
+  if (net->rb.ok && net->rb.derived_floats > n) n = net->rb.derived_floats;
   return n > 0 ? n : 1;
 }
 int64_t mzx_net_derived_floats(const mzx_net* net) { return net ? derived_total(net) : 0; }
@@ -135,6 +137,12 @@ int mzx_net_set_weights(mzx_net* net, const float* d_flat, int64_t n_floats, flo
                                 (stream_t)stream));
       }
   }
+#ifndef MZX_HOSTCHECK
+  if (net->rb.ok) {  // streamed MFMA engine: fragment-ordered weights, action tap sums
+    const int rc = rb_refresh_derived(net, d_flat, d_derived, (stream_t)stream);
+    if (rc) return rc;
+  }
+#endif
   return MZX_OK;
 }
 
@@ -143,11 +151,31 @@ int mzx_net_fused_supported(const mzx_net* net) {
   return (net->rz.initial.ok ? 1 : 0) | (net->rz.recurrent.ok ? 2 : 0);
 }
 
+int mzx_net_streamed_supported(const mzx_net* net) {
+  if (!net || !net->rb.ok) return 0;
+  const bool fi = net->rz.ok && net->rz.initial.ok, fr = net->rz.ok && net->rz.recurrent.ok;
+  return ((net->rb.initial.ok && !fi) ? 1 : 0) | ((net->rb.recurrent.ok && !fr) ? 2 : 0);
+}
+
+int mzx_net_streamed_plan(const mzx_net* net, int32_t recurrent, int32_t op, int32_t out[24]) {
+  if (!net || !out) { set_error("null argument"); return MZX_ERR_INVALID; }
+  const RbProgram& R = recurrent ? net->rb.recurrent : net->rb.initial;
+  if (!net->rb.ok || !R.ok || op < 0 || op >= (int32_t)R.ops.size()) { set_error("no streamed plan for this operator"); return MZX_ERR_INVALID; }
+  const RbOp& o = R.ops[op];
+  const int32_t v[24] = {o.kind, o.in_layout, o.out_layout, o.res_layout, o.taps, o.stride, o.cin, o.cout, o.hin, o.win,
+                         o.hout, o.wout, o.T, o.th, o.tw, o.tiles_x, o.tiles_y, o.PH, o.PW, o.cpg, o.phases, o.rows,
+                         o.mtiles, o.lds_bytes};
+  for (int k = 0; k < 24; ++k) out[k] = v[k];
+  return MZX_OK;
+}
+
 int mzx_net_set_mode(mzx_net* net, int32_t mode) {
   if (!net) { set_error("null network handle"); return MZX_ERR_INVALID; }
-  if (mode != 0 && mode != 1 && mode != 2) { set_error("network mode is 0 (one kernel per operator), 1 (fused engine) or 2 (fused, 4-wave workgroups)"); return MZX_ERR_INVALID; }
+  if (mode < 0 || mode > 3) { set_error("network mode is 0 (one kernel per operator), 1 (fused engine, streamed engine for what it cannot hold), 2 (fused, 4-wave workgroups) or 3 (streamed engine for everything)"); return MZX_ERR_INVALID; }
+  if (mode == 3 && !net->rb.ok) { set_error("the streamed engine runs residual networks only"); return MZX_ERR_INVALID; }
   net->rz_mode = mode ? 1 : 0;
   net->rz_waves = (mode == 2) ? 4 : 0;
+  net->rb_force = (mode == 3) ? 1 : 0;
   return MZX_OK;
 }
 
@@ -340,6 +368,9 @@ int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_
   if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) return rz_search_run(s, io, d_arena, (stream_t)stream);
 #endif
   s->last_kernel = "one kernel per step of a simulation (select / network / expand + back-propagate)";
+#ifndef MZX_HOSTCHECK
+  if (rb_enabled(s->net, true)) s->last_kernel = "mzx::rb_gemm_kernel (streamed FP32-MFMA layers) between per-simulation tree kernels";
+#endif
   return search_run_generic(s, io, d_arena, (stream_t)stream);
 }
 

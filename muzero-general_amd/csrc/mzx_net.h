@@ -17,6 +17,7 @@
 #include "mzx_launch.h"
 #include "mzx_ops.h"
 #include "mzx_resnet_plan.h"
+#include "mzx_batched_plan.h"
 
 namespace mzx {
 
@@ -68,6 +69,8 @@ struct mzx_net {
   mzx::RzPlan rz;          // fused residual-network engine (mzx_resnet_fused.h)
   int32_t rz_mode = 1;     // 0: one kernel per operator, 1: fused engine where planned
   int32_t rz_waves = 0;    // 0: automatic, 4: force 256-thread workgroups (A/B measurements)
+  int32_t rb_force = 0;    // 1: every program on the streamed engine (mzx_net_set_mode(3))
+  mzx::RbPlan rb;          // streamed MFMA engine for residual networks the fused engine cannot hold (mzx_resnet_batched.h)
 };
 
 namespace mzx {

@@ -1,0 +1,194 @@
+// mzx_resnet_batched.h -- host side of the STREAMED residual-network engine: planner and entry points.
+//
+// Which networks come here: every MuZeroResidualNetwork (models.py:436-623) whose inference the LDS-resident
+// engine (mzx_resnet_fused.h) cannot hold -- the reference's games/gomoku.py (128 ch x 6 blocks, 11 x 11) and
+// games/atari.py (256 ch x 16 blocks, "resnet" down-sampling stem, 256-wide heads) as shipped.  Each operator of
+// the program built by mzx_net.h becomes one launch over the whole batch:
+//   conv3x3 (:206-209, stride 1 | 2, folded BatchNorm, residual, ReLU, action plane)   rb_gemm_kernel, 9 taps
+//   conv1x1 head (:369-389, :404-433), Linear (:630-642)                               rb_gemm_kernel, 1 tap
+//   per-plane min-max scaling (:527-553, :574-599)                                     rb_scale_kernel
+//   AvgPool2d of the stem (:233-275)                                                   element kernel, NHWC
+// Activations between operators are position-major ([sample][y][x][channel]) so that a workgroup's input patch is
+// staged into LDS with 16-byte copies; observations and hidden states keep the reference's NCHW layout at the
+// boundary (the first convolution gathers, the scaling operator writes NCHW -- straight into / out of the search
+// arena's per-node store, NetIndex).
+#pragma once
+#include <algorithm>
+#include <map>
+#include <tuple>
+
+#include "mzx_net.h"
+
+namespace mzx {
+
+inline int rb_round16(int x) { return (x + 15) & ~15; }
+
+// LDS bytes of a workgroup: row tables (3 ints per padded row), per-sample offsets (2 x int64), the staged patch
+inline int64_t rb_lds_bytes(int T, int mtiles, int cells, int Cs) {
+  return (int64_t)3 * 16 * mtiles * 4 + (int64_t)2 * ((T + 1) & ~1) * 8 + (int64_t)cells * Cs * 4;
+}
+
+// Workgroup tile of a GEMM operator: T whole samples per workgroup when a sample's output positions fit RB_MAX_ROWS
+// rows, else one th x tw patch of one sample; the input patch (with the 3x3 halo) is staged in `phases` channel
+// groups of `cpg` 16-channel chunks.  Maximises MFMA row-tile occupancy, then prefers fewer phases and more rows
+// (every workgroup streams the whole B matrix once: traffic per flop ~ 1 / rows).
+inline bool rb_choose_tile(RbOp& o) {
+  const int pad = o.taps == 9 ? 1 : 0;
+  const int HWo = o.hout * o.wout;
+  double best = -1.0;
+  RbOp pick = o;
+  auto consider = [&](int T, int th, int tw) {
+    const int PH = (th - 1) * o.stride + 1 + 2 * pad, PW = (tw - 1) * o.stride + 1 + 2 * pad;
+    const int cells = T * PH * PW;
+    const int rows = T * th * tw, mtiles = (rows + 15) / 16;
+    if (rows > RB_MAX_ROWS) return;
+    int cpg = o.cchunks;
+    while (cpg >= 1 && rb_lds_bytes(T, mtiles, cells, 16 * cpg + 8) > RB_LDS_BUDGET) --cpg;
+    if (cpg < 1) return;
+    const int phases = (o.cchunks + cpg - 1) / cpg;
+    cpg = (o.cchunks + phases - 1) / phases;
+    const int tiles_x = (o.wout + tw - 1) / tw, tiles_y = (o.hout + th - 1) / th;
+    const double eff = (double)(T * HWo) / ((double)tiles_x * tiles_y * mtiles * 16);
+    const double score = eff * (1.0 - 0.02 * (phases - 1)) * ((double)rows / (rows + 8.0)) -
+                         1e-7 * (double)cells * phases;   // ties: the smaller staged patch
+    if (score > best) {
+      best = score;
+      pick.T = T; pick.th = th; pick.tw = tw; pick.tiles_x = tiles_x; pick.tiles_y = tiles_y;
+      pick.PH = PH; pick.PW = PW; pick.cpg = cpg; pick.phases = phases; pick.Cs = 16 * cpg + 8;
+      pick.rows = rows; pick.mtiles = mtiles;
+      pick.lds_bytes = (int32_t)rb_lds_bytes(T, mtiles, cells, pick.Cs);
+    }
+  };
+  if (HWo <= RB_MAX_ROWS) {
+    for (int T = 1; T * HWo <= RB_MAX_ROWS; ++T) consider(T, o.hout, o.wout);
+  } else {
+    for (int tw = 1; tw <= std::min(o.wout, RB_MAX_ROWS); ++tw)
+      for (int th = 1; th <= o.hout && th * tw <= RB_MAX_ROWS; ++th) consider(1, th, tw);
+  }
+  if (best < 0.0) return false;
+  o = pick;
+  return true;
+}
+
+// Plans one program; `layout` carries the layout of every logical buffer written so far.
+inline bool rb_build_program(mzx_net* net, const std::vector<OpDesc>& prog, RbPlan& P, RbProgram& R, int64_t& cursor,
+                             std::map<std::tuple<int64_t, int, int>, int64_t>& packed) {
+  R.ops.clear();
+  std::map<int, int> layout;
+  auto layout_of = [&](int id) {
+    if (id == BUF_IN || id == BUF_HIDDEN) return (int)RB_NCHW;
+    auto it = layout.find(id);
+    return it == layout.end() ? (int)RB_NCHW : it->second;
+  };
+  auto add_pack = [&](int64_t src, int taps, int cin, int cin_total, int cout) {
+    const auto key = std::make_tuple(src, cin, taps);
+    auto it = packed.find(key);
+    if (it != packed.end()) return it->second;
+    RzPack p;
+    p.src = src; p.taps = taps; p.cin = cin; p.cin_total = cin_total;
+    p.cchunks = rb_round16(cin) / 16; p.cout = cout;
+    p.nchunks = taps * p.cchunks; p.wchunks = p.nchunks; p.ntiles = (cout + 15) / 16;
+    p.dst = cursor;
+    cursor += (int64_t)p.ntiles * p.wchunks * 256;
+    P.packs.push_back(p);
+    packed[key] = p.dst;
+    return p.dst;
+  };
+  for (const OpDesc& d : prog) {
+    RbOp o;
+    o.in_layout = layout_of(d.in);
+    o.res_layout = (d.res == -100) ? (int)RB_NCHW : layout_of(d.res);
+    switch (d.kind) {
+      case OP_CONV3: {
+        o.kind = RB_GEMM; o.taps = 9; o.stride = d.stride;
+        o.cin_total = d.cin; o.cin = d.use_action ? d.cin - 1 : d.cin; o.cout = d.cout;
+        o.hin = d.hin; o.win = d.win; o.hout = d.hout; o.wout = d.wout;
+        o.act = d.relu ? RZ_ACT_RELU : RZ_ACT_NONE;
+        o.out_layout = RB_NHWC;
+        if (d.use_action) {
+          RzAsum q;
+          q.src = d.w; q.dst = cursor; q.cout = d.cout; q.cin_total = d.cin; q.H = d.hin; q.W = d.win;
+          cursor += (int64_t)d.cout * d.hin * d.win;
+          cursor = (cursor + 3) & ~int64_t(3);
+          P.asums.push_back(q);
+          o.asum_off = q.dst;
+        }
+        break;
+      }
+      case OP_CONV1: {
+        o.kind = RB_GEMM; o.taps = 1; o.stride = 1;
+        o.cin_total = o.cin = d.cin; o.cout = d.cout;
+        o.hin = o.hout = d.hin; o.win = o.wout = 1;
+        o.act = RZ_ACT_NONE;
+        o.out_layout = RB_NCHW;          // the head MLP reads view(-1, R * H * W): (channel, position) order
+        break;
+      }
+      case OP_LINEAR: {
+        if (d.use_action) return false;  // fully connected dynamics only; never part of a residual network
+        o.kind = RB_GEMM; o.taps = 1; o.stride = 1;
+        o.cin_total = d.w_stride; o.cin = d.in_features; o.cout = d.out_features;
+        o.act = d.elu ? RZ_ACT_ELU : RZ_ACT_NONE;
+        o.in_layout = RB_NHWC; o.out_layout = RB_NHWC;   // one position per sample: both layouts coincide
+        break;
+      }
+      case OP_SCALE: o.kind = RB_SCALE; o.out_layout = RB_NCHW; break;
+      case OP_POOL: o.kind = RB_POOL; o.out_layout = o.in_layout; break;
+      default:   // DownsampleCNN pieces (models.py:278-297): per-operator kernels, NCHW in and out
+        if (o.in_layout != RB_NCHW) return false;
+        o.kind = RB_FUNCTOR; o.out_layout = RB_NCHW;
+        break;
+    }
+    if (o.kind == RB_GEMM) {
+      o.cchunks = rb_round16(o.cin) / 16;
+      o.nchunks = o.taps * o.cchunks; o.wchunks = o.nchunks; o.ntiles = (o.cout + 15) / 16;
+      if (!rb_choose_tile(o)) return false;
+      o.w_off = add_pack(d.w, o.taps, o.cin, o.cin_total, o.cout);
+    }
+    if (d.out >= 0) layout[d.out] = o.out_layout;
+    R.ops.push_back(o);
+  }
+  R.ok = 1;
+  return true;
+}
+
+// Plans both programs of every residual network; called by mzx_net_create after rz_plan.  By default a program
+// runs here when the fused engine does not take it; mzx_net_set_mode(3) routes every program here (A/B, parity of
+// this engine against the reference's small configurations).
+inline void rb_plan(mzx_net* net) {
+  RbPlan& P = net->rb;
+  P = RbPlan();
+  if (net->cfg.network != 1) return;
+  int64_t cursor = net->rz.ok ? net->rz.derived_floats : net->derived_floats;
+  cursor = (cursor + 63) & ~int64_t(63);     // 256-byte aligned fragment images
+  std::map<std::tuple<int64_t, int, int>, int64_t> packed;
+  if (!rb_build_program(net, net->prog_initial, P, P.initial, cursor, packed)) P.initial.ok = 0;
+  if (!rb_build_program(net, net->prog_recurrent, P, P.recurrent, cursor, packed)) P.recurrent.ok = 0;
+  if (!P.initial.ok && !P.recurrent.ok) { P = RbPlan(); return; }
+  P.derived_floats = cursor;
+  P.ok = 1;
+}
+
+// True when inference `recurrent` of `net` runs on the streamed engine (mode 0 = one element kernel per operator
+// stays available as the A/B reference).
+inline bool rb_enabled(const mzx_net* net, bool recurrent) {
+#ifdef MZX_HOSTCHECK
+  (void)net; (void)recurrent;
+  return false;
+#else
+  if (!net->rb.ok || !net->rz_mode) return false;
+  if (!(recurrent ? net->rb.recurrent.ok : net->rb.initial.ok)) return false;
+  if (net->rb_force) return true;
+  return !(net->rz.ok && (recurrent ? net->rz.recurrent.ok : net->rz.initial.ok));
+#endif
+}
+
+#ifndef MZX_HOSTCHECK
+// Defined in mzx_batched.hip.  Runs operators [0, n_ops) of the program (n_ops < 0: all of it).  With `ix`, sample b
+// reads hidden-state node ix->in_node[b] of nb.in and writes node ix->out_node[b] of nb.hidden.
+int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int batch, stream_t stream,
+                   const NetIndex* ix, int n_ops = -1, float* dump = nullptr);
+// Packs the B fragments / action tap sums of the plan into the derived buffer (mzx_net_set_weights).
+int rb_refresh_derived(const mzx_net* net, const float* d_flat, float* d_derived, stream_t stream);
+#endif
+
+}  // namespace mzx

@@ -49,65 +49,12 @@
 #include <map>
 
 #include "mzx_net.h"
+#include "mzx_pack.h"
+#include "mzx_resnet_batched.h"
 
 namespace mzx {
 
 constexpr int RZ_LDS_BUDGET = 160 * 1024 - 1024;
-
-// ---------------------------------------------------------------------------
-// weight packing (runs once per set_weights; element functor, also built by hostcheck)
-
-struct RzPackOp {
-  const float* W;   // [cout][cin_total][taps]
-  float* out;       // [ntiles][wchunks][64 lanes][4], chunks >= nchunks are zero
-  int32_t taps, cin, cin_total, cchunks, cout, nchunks, wchunks, ntiles;
-
-  MZX_HD size_t size() const { return (size_t)ntiles * wchunks * 256; }
-  MZX_HD void operator()(size_t i) const {
-    const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
-    const int c = (int)((i >> 8) % wchunks), nt = (int)((i >> 8) / wchunks);
-    if (c >= nchunks) { out[i] = 0.f; return; }
-    const int tap = c / cchunks, cc = c % cchunks;
-    const int ci = cc * 16 + 4 * (lane >> 4) + j;      // K-step j of the chunk, B row lane >> 4
-    const int n = nt * 16 + (lane & 15);
-    float v = 0.f;
-    if (ci < cin && n < cout) v = W[((int64_t)n * cin_total + ci) * taps + tap];
-    out[i] = v;
-  }
-};
-
-struct RzCopyOp {
-  const float* src;
-  float* dst;
-  int32_t n, npad;
-  MZX_HD size_t size() const { return (size_t)npad; }
-  MZX_HD void operator()(size_t i) const { dst[i] = ((int)i < n) ? src[i] : 0.f; }
-};
-
-// out[co][pos] = sum over the 3x3 taps that stay inside the board of W[co][cin_total - 1][ky][kx]
-struct RzAsumOp {
-  const float* W;
-  float* out;
-  int32_t cout, cin_total, H, Wd;
-
-  MZX_HD size_t size() const { return (size_t)cout * H * Wd; }
-  MZX_HD void operator()(size_t i) const {
-    const int p = (int)(i % (H * Wd)), co = (int)(i / (H * Wd));
-    const int y = p / Wd, x = p % Wd;
-    const float* w = W + ((int64_t)co * cin_total + (cin_total - 1)) * 9;
-    float acc = 0.f;
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = y + ky - 1;
-      if (iy < 0 || iy >= H) continue;
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = x + kx - 1;
-        if (ix < 0 || ix >= Wd) continue;
-        acc += w[ky * 3 + kx];
-      }
-    }
-    out[i] = acc;
-  }
-};
 
 // ---------------------------------------------------------------------------
 // host planner: operator program (mzx_net.h) -> fused program
@@ -528,14 +475,6 @@ inline void rz_plan(mzx_net* net) {
   P.derived_floats = cursor;
   P.ok = 1;
 }
-
-// Per-sample indirection through the search arena's hidden-state store [B][nodes][Hf]:
-// sample b reads node in_node[b] and writes node out_node[b] (null: dense [B][Hf] tensors).
-struct NetIndex {
-  const int32_t* in_node = nullptr;    // null: node 0
-  const int32_t* out_node = nullptr;   // null: node 0
-  int32_t in_nodes = 1, out_nodes = 1; // nodes per sample of nb.in / nb.hidden (1 = dense tensors)
-};
 
 // Latency experiments (profiles/r01_rz_latency_experiments.txt) are compiled in only on request: even a
 // never-taken uniform branch per layer costs a few percent on small networks.
@@ -1621,6 +1560,7 @@ inline bool rz_enabled(const mzx_net* net, bool recurrent) {
   return false;
 #else
   if (!net->rz.ok || !net->rz_mode) return false;
+  if (net->rb_force && net->rb.ok && (recurrent ? net->rb.recurrent.ok : net->rb.initial.ok)) return false;
   return recurrent ? net->rz.recurrent.ok != 0 : net->rz.initial.ok != 0;
 #endif
 }
@@ -1644,8 +1584,9 @@ inline int run_network(const mzx_net* net, bool recurrent, const NetBuffers& nb,
     }
     return rz_launch(net, R, in, nb, batch, ix, stream);
   }
+  if (rb_enabled(net, recurrent)) return rb_run_program(net, recurrent, nb, batch, stream, ix);
 #endif
-  if (ix && (ix->in_nodes != 1 || ix->out_nodes != 1)) { set_error("indexed inference needs the fused engine"); return MZX_ERR_INVALID; }
+  if (ix && (ix->in_nodes != 1 || ix->out_nodes != 1)) { set_error("indexed inference needs an MFMA engine"); return MZX_ERR_INVALID; }
   return run_program(net, prog, nb, batch, stream);
 }
 
@@ -1667,6 +1608,10 @@ inline int run_network_prefix(const mzx_net* net, bool recurrent, int fused, int
   if (fused == 2) per = 0;
   if (out_floats < per * batch) { set_error("prefix output buffer too small (%lld floats per sample)", (long long)per); return MZX_ERR_WORKSPACE; }
 #ifndef MZX_HOSTCHECK
+  if (fused && rb_enabled(net, recurrent)) {   // streamed engine: output of operator n_ops - 1 in the per-operator layout
+    if (fused == 2) { set_error("no cycle profile on the streamed engine"); return MZX_ERR_INVALID; }
+    return rb_run_program(net, recurrent, nb, batch, stream, nullptr, n_ops, d_out);
+  }
   if (fused) {
     const RzProgram& R = recurrent ? net->rz.recurrent : net->rz.initial;
     if (!net->rz.ok || !R.ok) { set_error("fused engine does not cover this operator"); return MZX_ERR_INVALID; }

@@ -126,4 +126,12 @@ struct RzPlan {
   int64_t derived_floats = 0;             // packed weights + tables appended to the derived buffer
 };
 
+// Per-sample indirection through the search arena's hidden-state store [B][nodes][Hf]:
+// sample b reads node in_node[b] and writes node out_node[b] (null: dense [B][Hf] tensors).
+struct NetIndex {
+  const int32_t* in_node = nullptr;    // null: node 0
+  const int32_t* out_node = nullptr;   // null: node 0
+  int32_t in_nodes = 1, out_nodes = 1; // nodes per sample of nb.in / nb.hidden (1 = dense tensors)
+};
+
 }  // namespace mzx

@@ -135,7 +135,7 @@ inline int search_run_generic(mzx_search* s, const mzx_search_io* io, void* d_ar
 
   // With the fused network engine the per-node hidden states are read from / written to the arena
   // store [B][N][Hf] directly (NetIndex); the per-operator engine goes through dense staging copies.
-  const bool ix_init = rz_enabled(net, false), ix_rec = rz_enabled(net, true);
+  const bool ix_init = rz_enabled(net, false) || rb_enabled(net, false), ix_rec = rz_enabled(net, true) || rb_enabled(net, true);
   NetIndex ix;
   ix.in_nodes = 1; ix.out_nodes = s->p.num_nodes;   // root: dense observation in, node 0 out
 

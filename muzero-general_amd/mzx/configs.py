@@ -61,7 +61,7 @@ class HotPathConfig:
             elif trained_steps < 750e3:
                 return 0.5
             return 0.25
-        # games/cartpole.py:115-128
+        # games/cartpole.py:115-128, games/gomoku.py:115-128
         if trained_steps < 0.5 * self.training_steps:
             return 1.0
         elif trained_steps < 0.75 * self.training_steps:
@@ -146,5 +146,39 @@ def lunarlander(**kw):
     return HotPathConfig(**base)
 
 
-BY_NAME = {"cartpole": cartpole, "tictactoe": tictactoe, "connect4": connect4, "breakout": breakout,
+def gomoku(**kw):
+    """games/gomoku.py:11-112 AS SHIPPED -- 128 channels x 6 blocks on an 11 x 11 board, 121 actions, 400 simulations:
+    too wide for the LDS-resident engine, runs on the streamed MFMA engine (csrc/mzx_batched.hip)."""
+    base = dict(
+        observation_shape=(3, 11, 11), action_space=list(range(11 * 11)), players=list(range(2)),
+        opponent="random", max_moves=121, num_simulations=400, discount=1, root_dirichlet_alpha=0.3,
+        network="resnet", downsample=False, blocks=6, channels=128,
+        reduced_channels_reward=2, reduced_channels_value=2, reduced_channels_policy=4,
+        resnet_fc_reward_layers=[64], resnet_fc_value_layers=[64], resnet_fc_policy_layers=[64],
+        encoding_size=32, fc_dynamics_layers=[64], fc_reward_layers=[64],
+        fc_value_layers=[], fc_policy_layers=[], training_steps=10000,
+        use_last_model_value=False, ratio=1,   # temperature: the fractions schedule (games/gomoku.py:115-128)
+    )
+    base.update(kw)
+    return HotPathConfig(**base)
+
+
+def atari(**kw):
+    """games/atari.py:17-114 AS SHIPPED -- the paper-scale network: 256 channels x 16 blocks behind the "resnet"
+    down-sampling stem, 32 stacked 96 x 96 x 3 frames, 256-channel head convolutions, [256, 256] head MLPs, support
+    300 (73.5 M parameters).  Streamed MFMA engine (csrc/mzx_batched.hip)."""
+    base = dict(
+        observation_shape=(3, 96, 96), action_space=list(range(4)), players=list(range(1)),
+        stacked_observations=32, max_moves=27000, num_simulations=50, discount=0.997, root_dirichlet_alpha=0.25,
+        network="resnet", support_size=300, downsample="resnet", blocks=16, channels=256,
+        reduced_channels_reward=256, reduced_channels_value=256, reduced_channels_policy=256,
+        resnet_fc_reward_layers=[256, 256], resnet_fc_value_layers=[256, 256], resnet_fc_policy_layers=[256, 256],
+        encoding_size=10, fc_dynamics_layers=[16], fc_reward_layers=[16], fc_value_layers=[], fc_policy_layers=[],
+        training_steps=int(1000e3), temperature_schedule="breakout",
+    )
+    base.update(kw)
+    return HotPathConfig(**base)
+
+
+BY_NAME = {"gomoku": gomoku, "atari": atari, "cartpole": cartpole, "tictactoe": tictactoe, "connect4": connect4, "breakout": breakout,
            "lunarlander": lunarlander}

@@ -244,6 +244,21 @@ class HipNetwork:
         """bit 0: initial_inference, bit 1: recurrent_inference run on the fused MFMA engine."""
         return int(self.backend.lib.mzx_net_fused_supported(self.handle))
 
+    def streamed_supported(self):
+        """bit 0: initial_inference, bit 1: recurrent_inference run on the streamed MFMA engine (large residual nets)."""
+        return int(self.backend.lib.mzx_net_streamed_supported(self.handle))
+
+    STREAMED_PLAN_FIELDS = ("kind", "in_layout", "out_layout", "res_layout", "taps", "stride", "cin", "cout", "hin",
+                            "win", "hout", "wout", "T", "th", "tw", "tiles_x", "tiles_y", "PH", "PW", "cpg", "phases",
+                            "rows", "mtiles", "lds_bytes")
+
+    def streamed_plan(self, recurrent, op):
+        """Workgroup tiling of operator `op` on the streamed engine (dict, see include/mzx.h)."""
+        out = (ctypes.c_int32 * 24)()
+        self.backend.lib.check(self.backend.lib.mzx_net_streamed_plan(self.handle, int(bool(recurrent)), int(op),
+                                                                      ctypes.byref(out)))
+        return dict(zip(self.STREAMED_PLAN_FIELDS, list(out)))
+
     def set_mode(self, mode):
         """0 = one kernel per operator, 1 = fused engine where available (default)."""
         self.backend.lib.check(self.backend.lib.mzx_net_set_mode(self.handle, int(mode)))

@@ -310,6 +310,11 @@ class BatchedMCTS:
             self._handles[key] = h
         return self._handles[key]
 
+    def kernel_name(self, num_trees):
+        """The search kernel the last ``run`` of this shard size launched (``mzx_search_kernel_name``)."""
+        name = self.backend.lib.mzx_search_kernel_name(self.handle(num_trees))
+        return name.decode() if name else ""
+
     def arena(self, num_trees):
         need = self.backend.lib.mzx_search_arena_bytes(self.handle(num_trees))
         if self._arena is None or self._arena.numel() < need:

@@ -164,7 +164,8 @@ def make_tree_fixture(name, game, n_cases, weight_seed, legal_fn, overrides=None
             sd[k] = torch.zeros_like(sd[k])
         net.set_weights(sd)
     cases = {}
-    obs_all = synthetic.observations(n_cases, cfg.observation_shape, seed=123)
+    c_in = cfg.observation_shape[0] * (cfg.stacked_observations + 1) + cfg.stacked_observations
+    obs_all = synthetic.observations(n_cases, (c_in,) + tuple(cfg.observation_shape[1:]), seed=123)
     meta = dict(game=game, weight_seed=weight_seed, n_cases=n_cases,
                 num_simulations=cfg.num_simulations, overrides=overrides or {},
                 zero_keys=list(zero_keys), cases=[])
@@ -175,7 +176,8 @@ def make_tree_fixture(name, game, n_cases, weight_seed, legal_fn, overrides=None
         tr = trace_search(models, self_play, cfg, net, obs_all[c], legal, to_play, rng_seed)
         for k, v in tr.items():
             cases[f"c{c}_{k}"] = v
-        cases[f"c{c}_obs"] = obs_all[c]
+        if obs_all[c].size <= 100000:   # larger ones: synthetic.observations(n_cases, stacked shape, seed=123)[c]
+            cases[f"c{c}_obs"] = obs_all[c]
         meta["cases"].append(dict(legal=list(legal), to_play=int(to_play), rng_seed=rng_seed))
     if state_dict is not None:  # ship the trained weights (small): flat, in state_dict key order
         cases["flat_weights"] = numpy.concatenate(
@@ -185,7 +187,7 @@ def make_tree_fixture(name, game, n_cases, weight_seed, legal_fn, overrides=None
     print("tree", name, "cases", n_cases, "nodes", tr["visit"].shape[0])
 
 
-def make_net_fixture(name, game, weight_seed, batch, overrides=None, state_dict=None):
+def make_net_fixture(name, game, weight_seed, batch, overrides=None, state_dict=None, store_obs=True):
     models, _ = ref_shim.load()
     cfg = _config(game, **(overrides or {}))
     net = _reference_model(models, cfg, weight_seed)
@@ -197,7 +199,12 @@ def make_net_fixture(name, game, weight_seed, batch, overrides=None, state_dict=
     rs = numpy.random.RandomState(7)
     act1 = rs.randint(0, A, size=(batch, 1))
     act2 = rs.randint(0, A, size=(batch, 1))
-    data = dict(obs=obs, act1=act1.astype(numpy.int32), act2=act2.astype(numpy.int32))
+    data = dict(act1=act1.astype(numpy.int32), act2=act2.astype(numpy.int32))
+    if store_obs:
+        data["obs"] = obs
+    else:   # large observations are rebuilt by the test: synthetic.observations(batch, shape, seed=321)
+        data["obs_shape"] = numpy.array(obs.shape, numpy.int64)
+        data["obs_seed"] = numpy.int64(321)
     with torch.no_grad():
         o = net.initial_inference(torch.tensor(obs))
         r1 = net.recurrent_inference(o[3], torch.tensor(act1))
@@ -419,8 +426,31 @@ def make_replay_batch_fixture():
     print("replay batch cases", len(cases))
 
 
+def make_large_residual_fixtures():
+    """
+    The reference's two large residual configurations AS SHIPPED (games/gomoku.py:56-64: 128 channels x 6 blocks
+    on 11 x 11; games/atari.py:61-69: 256 channels x 16 blocks behind the "resnet" down-sampling stem, 256-wide
+    heads): head outputs of models.py and whole-search traces of self_play.py on seeded weights.  These are the
+    networks the streamed MFMA engine (csrc/mzx_batched.hip) exists for.
+    """
+    def subset(c, cfg):
+        rs = numpy.random.RandomState(70 + c)
+        k = rs.randint(2, len(cfg.action_space) + 1)
+        return sorted(rs.choice(cfg.action_space, size=k, replace=False).tolist())
+
+    make_net_fixture("resnet_gomoku", "gomoku", 28, 3)
+    make_net_fixture("resnet_atari", "atari", 29, 2, store_obs=False)
+    make_tree_fixture("gomoku", "gomoku", 2, 17, subset, overrides=dict(num_simulations=48),
+                      players_fn=lambda c, cfg: c % 2)
+    make_tree_fixture("atari", "atari", 1, 18, lambda c, cfg: list(cfg.action_space),
+                      overrides=dict(num_simulations=12))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--large-residual" in sys.argv:
+        make_large_residual_fixtures()
+        return
     full = lambda c, cfg: list(cfg.action_space)
 
     def subset(c, cfg):  # ragged legal sets incl. a single legal action
@@ -492,6 +522,7 @@ def main():
     make_virtual_fixture("cartpole", "cartpole", 41, 3, 4)
     make_virtual_fixture("tictactoe", "tictactoe", 42, 4, 3)
     make_replay_batch_fixture()
+    make_large_residual_fixtures()
 
 
 if __name__ == "__main__":

@@ -17,7 +17,7 @@ ATTRS = ["observation_shape", "action_space", "players", "stacked_observations",
 
 
 @pytest.mark.reference
-@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "breakout", "lunarlander"])
+@pytest.mark.parametrize("name", ["cartpole", "tictactoe", "connect4", "breakout", "lunarlander", "gomoku", "atari"])
 def test_restated_configs_equal_the_reference_game_files(name):
     ref = ref_shim.muzero_config(name)
     ours = configs.BY_NAME[name]()

@@ -34,10 +34,10 @@ def test_which_networks_are_fused(lib):
     # a board too large for one workgroup's LDS image falls back to the per-operator engine
     h = _create(lib, configs.connect4(observation_shape=(3, 19, 19), action_space=list(range(361))))
     assert lib.mzx_net_fused_supported(h) == 0
-    unfused = lib.mzx_net_derived_floats(h)          # folded BatchNorm terms only
+    unfused = lib.mzx_net_derived_floats(h)          # folded BatchNorm terms + the streamed engine's fragment images
     lib.mzx_net_destroy(h)
     h = _create(lib, configs.connect4())
-    assert lib.mzx_net_derived_floats(h) > unfused + 900000   # + the packed weight images of both programs (26 conv layers x 36 864 floats)
+    assert lib.mzx_net_derived_floats(h) > unfused + 700000   # + the fused engine's images of both programs (26 conv layers x 36 864 floats; the 19 x 19 net's wider head MLPs take ~170 k of the difference back)
     lib.mzx_net_destroy(h)
 
 

@@ -1,0 +1,192 @@
+"""
+GPU parity of the STREAMED MFMA engine (csrc/mzx_batched.hip, -m gpu), through the C ABI:
+  * the reference's two large residual configurations AS SHIPPED (games/gomoku.py, games/atari.py) against
+    fixtures the unmodified reference produced (oracle/make_golden.py --large-residual): heads <= 1e-4, whole
+    searches with identical visit counts;
+  * every operator of both programs against the one-element-kernel-per-operator engine (mode 0), on shapes that
+    exercise whole-sample tiles, patch tiles with halos, channel phases, strides, ragged channel counts;
+  * the reference's SMALL configurations forced onto this engine (mode 3) against their reference fixtures, so
+    that the same goldens pin both MFMA engines.
+"""
+import json
+import os
+
+import numpy
+import pytest
+import torch
+
+import lockstep
+import test_hostcheck_search as common
+from conftest import GOLDEN
+from mzx import _lib, configs, models, self_play, synthetic
+from oracle import mcts_oracle, net_oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def backend():
+    return _lib.default_backend()
+
+
+def _fixture_obs(z):
+    if "obs" in z.files:
+        return z["obs"]
+    return synthetic.observations(int(z["obs_shape"][0]), tuple(int(v) for v in z["obs_shape"][1:]), seed=int(z["obs_seed"]))
+
+
+@pytest.mark.parametrize("name,mode", [("resnet_gomoku", 1), ("resnet_atari", 1), ("resnet_tictactoe", 3),
+                                       ("resnet_connect4", 3), ("resnet_breakout", 3), ("resnet_breakout_cnn", 3),
+                                       ("resnet_cnn_small", 3)])
+def test_streamed_heads_within_tolerance(backend, name, mode):
+    z = numpy.load(os.path.join(GOLDEN, f"net_{name}.npz"))
+    meta = json.loads(str(z["meta"]))
+    cfg = configs.BY_NAME[meta["game"]](**meta["overrides"])
+    net = models.MuZeroNetwork(cfg)
+    if mode == 1:
+        assert net.fused_supported() == 0 and net.streamed_supported() == 3   # as shipped: too large for the LDS engine
+    net.set_mode(mode)
+    assert [k for k, _, _ in meta["keys"]] == list(net.state_dict().keys())
+    sd = synthetic.fill_state_dict(net.state_dict(), meta["weight_seed"])
+    net.set_weights(sd)
+    obs = _fixture_obs(z)
+    o = net.initial_inference(torch.tensor(obs))
+    r1 = net.recurrent_inference(o[3], torch.tensor(z["act1"]))
+    r2 = net.recurrent_inference(r1[3], torch.tensor(z["act2"]))
+    o1 = net.initial_inference(torch.tensor(obs[:1]))
+    for tag, res in (("init", o), ("rec1", r1), ("rec2", r2), ("init_b1", o1)):
+        for key, t in zip(("value", "reward", "policy", "hidden"), res):
+            ref, got = z[f"{tag}_{key}"], t.cpu().numpy()
+            assert got.shape == ref.shape
+            if key == "reward" and tag.startswith("init"):
+                assert numpy.array_equal(got, ref)
+            else:
+                err = numpy.abs(got - ref).max()
+                print(f"{name} {tag} {key}: max abs error {err:.2e}")
+                assert err < TOL, (name, tag, key, err)
+        vs = models.support_to_scalar(res[0], cfg.support_size).cpu().numpy()
+        assert numpy.allclose(vs, z[f"{tag}_value_scalar"], atol=3 * TOL, rtol=3 * TOL)
+
+
+STREAMED_CASES = {
+    # as shipped (whole-sample tiles, one phase; NCHW gather of the hidden state, action plane)
+    "gomoku": (lambda: configs.gomoku(), 5),
+    # 64 channels on 19 x 19: patch tiles with halos crossing tile borders, ragged last tiles
+    "go19": (lambda: configs.connect4(observation_shape=(3, 19, 19), action_space=list(range(361))), 3),
+    # channel counts that are no multiple of 16 / 4, stacked observations, non-square board, wide heads
+    "odd": (lambda: configs.gomoku(channels=70, observation_shape=(5, 13, 9), action_space=list(range(117)),
+                                   stacked_observations=2, reduced_channels_value=33, reduced_channels_policy=48,
+                                   resnet_fc_value_layers=[200, 77], support_size=40, blocks=2), 7),
+    # the atari architecture at reduced width: stride-2 stem convolutions, pooling, channel phases at 6 x 6
+    "atari_narrow": (lambda: configs.atari(channels=96, blocks=2, stacked_observations=3, reduced_channels_reward=40,
+                                           reduced_channels_value=40, reduced_channels_policy=24,
+                                           resnet_fc_reward_layers=[72], resnet_fc_value_layers=[72, 40],
+                                           resnet_fc_policy_layers=[56], support_size=50), 3),
+    # small configurations that normally run on the LDS engine
+    "tictactoe": (lambda: configs.tictactoe(), 37),
+    "connect4": (lambda: configs.connect4(), 37),
+    "breakout": (lambda: configs.breakout(), 3),
+}
+
+
+@pytest.mark.parametrize("name", sorted(STREAMED_CASES))
+def test_streamed_operator_by_operator(backend, name):
+    """Bisection harness: the output tensor of EVERY operator of both programs, streamed engine vs element kernels."""
+    make, B = STREAMED_CASES[name]
+    cfg = make()
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 31))
+    net.set_mode(3)
+    rs = numpy.random.RandomState(5)
+    obs = torch.tensor(rs.rand(B, *net.input_shape).astype(numpy.float32))
+    hid = torch.tensor(rs.rand(B, *net.hidden_shape).astype(numpy.float32))
+    act = torch.tensor(rs.randint(0, len(cfg.action_space), size=B).astype(numpy.int32))
+    for recurrent, x, a in ((0, obs, None), (1, hid, act)):
+        worst = 0.0
+        for n_ops in range(1, net.num_operators(recurrent) + 1):
+            got = net.debug_prefix(recurrent, 1, n_ops, x, a).cpu().numpy()
+            want = net.debug_prefix(recurrent, 0, n_ops, x, a).cpu().numpy()
+            err = numpy.abs(got - want).max()
+            scale = 1.0 + numpy.abs(want).max()
+            worst = max(worst, err / scale)
+            assert err < 2e-5 * scale, (name, "recurrent" if recurrent else "initial", n_ops, err)
+        print(f"{name} {'recurrent' if recurrent else 'initial'}: worst relative operator error {worst:.2e}")
+
+
+def test_atari_as_shipped_operator_by_operator(backend):
+    """games/atari.py:61-69 unchanged (256 channels x 16 blocks, 73.5 M parameters): every 5th operator + the heads."""
+    cfg = configs.atari()
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 29))
+    assert net.streamed_supported() == 3
+    B = 2
+    rs = numpy.random.RandomState(6)
+    obs = torch.tensor(rs.rand(B, *net.input_shape).astype(numpy.float32))
+    hid = torch.tensor(rs.rand(B, *net.hidden_shape).astype(numpy.float32))
+    act = torch.tensor(rs.randint(0, 4, size=B).astype(numpy.int32))
+    for recurrent, x, a in ((0, obs, None), (1, hid, act)):
+        n = net.num_operators(recurrent)
+        picks = sorted(set(list(range(1, n + 1, 5)) + list(range(n - 12, n + 1))))
+        for n_ops in picks:
+            got = net.debug_prefix(recurrent, 1, n_ops, x, a).cpu().numpy()
+            want = net.debug_prefix(recurrent, 0, n_ops, x, a).cpu().numpy()
+            err = numpy.abs(got - want).max()
+            assert err < 2e-5 * (1.0 + numpy.abs(want).max()), ("atari", recurrent, n_ops, err)
+
+
+@pytest.mark.parametrize("name", ["gomoku", "atari"])
+def test_streamed_search_matches_reference(backend, name):
+    """MCTS.run of the unmodified reference on the shipped architecture (tree_<name>.npz): identical visit counts."""
+    z, meta, cfg = lockstep.load_fixture(name)
+    cfg.num_simulations = meta["num_simulations"]
+    net = common.build_model(backend, cfg, meta["weight_seed"])
+    assert net.streamed_supported() == 3
+    cases = meta["cases"]
+    B = len(cases)
+    c_in = cfg.observation_shape[0] * (cfg.stacked_observations + 1) + cfg.stacked_observations
+    all_obs = synthetic.observations(B, (c_in,) + tuple(cfg.observation_shape[1:]), seed=123)
+    engine = self_play.BatchedMCTS(cfg, net, B)
+    rngs = [numpy.random.RandomState(c["rng_seed"]) for c in cases]
+    res = engine.run([all_obs[c] for c in range(B)], [c["legal"] for c in cases], [c["to_play"] for c in cases], True, rngs)
+    assert "rb_gemm_kernel" in engine.kernel_name(B)
+    A = len(cfg.action_space)
+    for c, case in enumerate(cases):
+        g = lambda k: z[f"c{c}_{k}"]
+        want = numpy.zeros(A, numpy.int32)
+        for s, a in enumerate(case["legal"]):
+            ch = g("child")[0, s]
+            want[a] = g("visit")[ch] if ch >= 0 else 0
+        assert numpy.array_equal(res.visit_counts[c], want), (name, c)
+        want_rv = g("value_sum")[0] / g("visit")[0]
+        assert abs(res.root_values[c] - want_rv) < 1e-4 * max(1.0, abs(want_rv))
+        assert res.max_tree_depth[c] == int(g("max_tree_depth"))
+
+
+def test_gomoku_search_against_oracle_at_size(backend):
+    """64 gomoku trees x 60 simulations on the shipped network: sampled trees against the CPU oracle."""
+    cfg = configs.gomoku(num_simulations=60)
+    net = models.MuZeroNetwork(cfg)
+    sd = synthetic.fill_state_dict(net.state_dict(), 9)
+    net.set_weights(sd)
+    B = 64
+    obs = synthetic.observations(B, net.input_shape, seed=4)
+    rs = numpy.random.RandomState(2)
+    legal = [sorted(rs.choice(121, size=rs.randint(2, 122), replace=False).tolist()) for _ in range(B)]
+    to_play = [int(i % 2) for i in range(B)]
+    engine = self_play.BatchedMCTS(cfg, net, B)
+    res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(3000 + i) for i in range(B)])
+    assert (res.visit_counts.sum(1) == 60).all() and (res.flags == 0).all()
+    onet = net_oracle.make_oracle_network(cfg, sd)
+    same = 0
+    sample = list(range(0, B, 8))
+    for i in sample:
+        ev = net_oracle.NetworkEvaluator(onet, cfg.support_size)
+        tree = mcts_oracle.run_search(cfg, ev, obs[i], legal[i], to_play[i], True, numpy.random.RandomState(3000 + i))
+        want = tree.root_visit_counts(cfg.action_space)
+        same += int(list(res.visit_counts[i]) == want)
+        rv = tree.node_value(0)
+        assert abs(res.root_values[i] - rv) < 2e-3 * max(1.0, abs(rv)), (i, res.root_values[i], rv)
+    print(f"gomoku at size: {same}/{len(sample)} sampled trees with identical visit counts")
+    assert same >= len(sample) - 1

@@ -21,7 +21,7 @@ FIELDS = ["observation_shape", "action_space", "players", "stacked_observations"
           "fc_reward_layers", "fc_value_layers", "fc_policy_layers", "training_steps", "muzero_player", "opponent"]
 
 
-@pytest.mark.parametrize("game", ["cartpole", "tictactoe", "connect4", "breakout"])
+@pytest.mark.parametrize("game", ["cartpole", "tictactoe", "connect4", "breakout", "gomoku", "atari"])
 def test_hot_path_configs_equal_reference(game):
     ref = ref_shim.game_module(game).MuZeroConfig()
     mine = configs.BY_NAME[game]()

@@ -1,0 +1,100 @@
+"""
+Host-side planning of the streamed MFMA engine (csrc/mzx_resnet_batched.h: rb_plan) through the C ABI, no GPU:
+which of the reference's configurations go there (games/gomoku.py, games/atari.py as shipped), that every planned
+workgroup tile fits the LDS budget and the 144-row / 9-tile limits of rb_gemm_kernel, and that the tiling covers
+every output position of every layer.
+"""
+import ctypes
+
+import pytest
+
+from mzx import _lib, configs, models
+
+FIELDS = models.HipNetwork.STREAMED_PLAN_FIELDS
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.Library(_lib.LIB_PATH)
+
+
+def _create(lib, cfg):
+    c = models.net_config_from(cfg)
+    h = ctypes.c_void_p()
+    lib.check(lib.mzx_net_create(ctypes.byref(c), ctypes.byref(h)))
+    return h
+
+
+def _plan(lib, h, recurrent, op):
+    out = (ctypes.c_int32 * 24)()
+    lib.check(lib.mzx_net_streamed_plan(h, recurrent, op, ctypes.byref(out)))
+    return dict(zip(FIELDS, list(out)))
+
+
+def test_which_networks_are_streamed(lib):
+    for name, fused, streamed in (("cartpole", 0, 0), ("tictactoe", 3, 0), ("connect4", 3, 0), ("breakout", 3, 0),
+                                  ("gomoku", 0, 3), ("atari", 0, 3)):
+        h = _create(lib, configs.BY_NAME[name]())
+        assert lib.mzx_net_fused_supported(h) == fused, name
+        assert lib.mzx_net_streamed_supported(h) == streamed, name
+        lib.mzx_net_destroy(h)
+    # a 64-channel network on a 19 x 19 board: too large for the LDS engine, streamed
+    h = _create(lib, configs.connect4(observation_shape=(3, 19, 19), action_space=list(range(361))))
+    assert lib.mzx_net_fused_supported(h) == 0 and lib.mzx_net_streamed_supported(h) == 3
+    lib.mzx_net_destroy(h)
+
+
+@pytest.mark.parametrize("name", ["gomoku", "atari", "go19", "wide_heads", "odd_channels"])
+def test_streamed_tiles_fit_the_kernel(lib, name):
+    cfg = {
+        "gomoku": configs.gomoku, "atari": configs.atari,
+        "go19": lambda: configs.connect4(observation_shape=(3, 19, 19), action_space=list(range(361))),
+        "wide_heads": lambda: configs.gomoku(reduced_channels_value=48, reduced_channels_policy=33, support_size=300,
+                                             resnet_fc_value_layers=[200, 77]),
+        "odd_channels": lambda: configs.gomoku(channels=70, observation_shape=(5, 13, 9), action_space=list(range(117)),
+                                               stacked_observations=2),
+    }[name]()
+    h = _create(lib, cfg)
+    assert lib.mzx_net_streamed_supported(h) == 3
+    derived = lib.mzx_net_derived_floats(h)
+    gemm_weights = 0
+    for recurrent in (0, 1):
+        n = lib.mzx_net_num_operators(h, recurrent)
+        kinds = []
+        for op in range(n):
+            p = _plan(lib, h, recurrent, op)
+            kinds.append(p["kind"])
+            if p["kind"] != 0:
+                continue
+            pad = 1 if p["taps"] == 9 else 0
+            assert p["lds_bytes"] <= 156 * 1024
+            assert p["rows"] == p["T"] * p["th"] * p["tw"] <= 144 and p["mtiles"] == (p["rows"] + 15) // 16 <= 9
+            assert p["PH"] == (p["th"] - 1) * p["stride"] + 1 + 2 * pad and p["PW"] == (p["tw"] - 1) * p["stride"] + 1 + 2 * pad
+            assert p["tiles_x"] * p["tw"] >= p["wout"] and p["tiles_y"] * p["th"] >= p["hout"]
+            assert (p["tiles_x"] - 1) * p["tw"] < p["wout"] and (p["tiles_y"] - 1) * p["th"] < p["hout"]
+            if p["T"] > 1:
+                assert p["tiles_x"] == p["tiles_y"] == 1
+            cchunks = (p["cin"] + 15) // 16
+            assert p["cpg"] * p["phases"] >= cchunks and p["cpg"] * (p["phases"] - 1) < cchunks
+            gemm_weights += p["taps"] * cchunks * 16 * ((p["cout"] + 15) // 16) * 16
+        assert kinds.count(0) >= 10 and kinds.count(1) == 1      # GEMM layers, one scaling operator
+    assert derived * 2 >= gemm_weights // 2       # the packed images exist (prediction weights shared by both programs)
+    lib.mzx_net_destroy(h)
+
+
+def test_gomoku_and_atari_tiles_as_designed(lib):
+    """The hot layers: gomoku 128 -> 128 on 11 x 11 = one sample per workgroup, one phase; atari 256 -> 256 on
+    6 x 6 = four samples (nine full row tiles), two channel phases."""
+    h = _create(lib, configs.gomoku())
+    p = _plan(lib, h, 1, 1)
+    assert (p["taps"], p["cin"], p["cout"], p["T"], p["rows"], p["mtiles"], p["phases"]) == (9, 128, 128, 1, 121, 8, 1)
+    assert p["in_layout"] == 0 and p["out_layout"] == 0
+    p0 = _plan(lib, h, 1, 0)
+    assert p0["in_layout"] == 1 and p0["cin"] == 128      # dynamics input: NCHW hidden state, action plane folded away
+    lib.mzx_net_destroy(h)
+    h = _create(lib, configs.atari())
+    p = _plan(lib, h, 1, 1)
+    assert (p["taps"], p["cin"], p["cout"], p["T"], p["rows"], p["mtiles"], p["phases"]) == (9, 256, 256, 4, 144, 9, 2)
+    s = _plan(lib, h, 0, 0)                                # stem: 131 -> 128 channels, stride 2, 96 x 96 -> 48 x 48
+    assert (s["stride"], s["cin"], s["cout"], s["hout"], s["wout"]) == (2, 131, 128, 48, 48) and s["T"] == 1
+    lib.mzx_net_destroy(h)
