@@ -59,6 +59,9 @@ WORKLOADS = {
     "c3": ("tictactoe", {}, 1024, "C3 Tic-tac-toe MuZeroResidualNetwork, 1024 trees x 25 sims per GPU"),
     "c4": ("connect4", {}, 1024, "C4 Connect4 ResNet, 1024 trees x 200 sims per GPU"),
     "c5": ("breakout", {"num_simulations": 50}, 64, "C5 Breakout ResNet (resnet stem), 64 trees x 50 sims per GPU"),
+    # the reference's large residual configurations as shipped (streamed MFMA engine, csrc/mzx_batched.hip)
+    "gomoku": ("gomoku", {}, 512, "games/gomoku.py as shipped: 128 ch x 6 blocks, 11 x 11, 512 trees x 400 sims per GPU"),
+    "atari": ("atari", {}, 256, "games/atari.py as shipped: 256 ch x 16 blocks, 96 x 96 x 131 input, 256 trees x 50 sims per GPU"),
 }
 
 
@@ -75,7 +78,7 @@ def parse():
     ap.add_argument("--trees", type=int, default=None, help="trees per GPU (default: the workload's)")
     ap.add_argument("--mode", default="auto", choices=["auto", "generic", "fused", "fused-v1"],
                     help="fused-v1: first-generation fully connected whole-search kernel (A/B)")
-    ap.add_argument("--net-mode", default="fused", choices=["fused", "fused-4wave", "per-operator"],
+    ap.add_argument("--net-mode", default="fused", choices=["fused", "fused-4wave", "per-operator", "streamed"],
                     help="residual networks: fused MFMA engine (default) or one kernel per operator")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall budget of each CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=None)
@@ -388,7 +391,11 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         net.set_mode(0)
     elif args.net_mode == "fused-4wave" and net.fused_supported():
         net.set_mode(2)
-    net_fused = bool(net.fused_supported()) and args.net_mode != "per-operator"
+    elif args.net_mode == "streamed" and cfg.network == "resnet":
+        net.set_mode(3)          # every layer on the streamed MFMA engine (A/B against the LDS-resident engine)
+    streamed = cfg.network == "resnet" and args.net_mode != "per-operator" and (
+        args.net_mode == "streamed" or bool(net.streamed_supported()))
+    net_fused = bool(net.fused_supported()) and args.net_mode not in ("per-operator", "streamed")
     mode = {"auto": None, "generic": 0, "fused": 1, "fused-v1": 17}[args.mode]
     engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
     handle = engine.handle(B)
@@ -482,7 +489,8 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
             traffic, traffic_src = entry["bytes"], entry["source"]
     except (OSError, ValueError):
         pass
-    kernel_name = ("fused-lds" if fused else
+    kernel_name = ("per-sim launches + streamed MFMA layers (rb_gemm_kernel)" if streamed else
+                   "fused-lds" if fused else
                    "residual whole-search kernel (arena trees, fused MFMA network)" if fused_kind == 2 else
                    "per-sim launches + fused-mfma network" if net_fused else "generic-per-op")
     roofline = {
@@ -502,7 +510,8 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         roofline = {
             "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": ("whole step: root kernels + " + ran + " (all simulations, one launch)") if fused_kind == 2
+            "kernel": "whole step: select / one mzx::rb_gemm_kernel launch per layer / expand+backprop per simulation" if streamed
+                      else ("whole step: root kernels + " + ran + " (all simulations, one launch)") if fused_kind == 2
                       else "whole step: select / rz_network_kernel (fused MFMA network) / expand+backprop per simulation"
                       if net_fused else "whole step (one kernel per operator)",
             "launch_ms": launch_ms, "flops_per_simulation": f_rec, "flops_initial_inference": f_init,

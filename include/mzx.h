@@ -215,8 +215,10 @@ int mzx_search_run_from_roots(mzx_search* s, const mzx_search_io* io, const floa
 /* Which implementation mzx_search_run uses, a set of flags:
  *   1  whole-search kernel: every simulation of the move in one launch.  mzx_search_fused_supported
  *      returns 1 for the LDS-resident fully connected kernel, 2 for the residual-network kernel
- *      (trees in the arena, network on the fused MFMA engine), 0 if neither applies;
- *      0 = generic path (select / network / expand+backpropagate launches per simulation)
+ *      (trees in the arena, network on the fused MFMA engine), 3 for networks that run layer by layer on
+ *      the streamed MFMA engine (per simulation: a 16-lane row per tree selects, one launch per layer,
+ *      a row per tree expands and back-propagates; csrc/mzx_row_search.h), 0 if none applies;
+ *      0 = generic path (select / network / expand+backpropagate launches per simulation, one thread per tree)
  *   2  (fused) also export the finished trees to the arena so mzx_search_dump works
  *   4  (fused) force the LDS-weight engine even when a register-resident
  *      specialisation matches the network shape

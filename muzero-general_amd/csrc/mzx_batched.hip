@@ -15,11 +15,13 @@
 //   * waves take column tiles first (each wave streams a disjoint slice of the weights), row tiles next; a wave
 //     owns up to 9 x 2 accumulator tiles, one B fragment feeds up to nine MFMAs;
 //   * epilogue in registers in the per-operator kernels' order (mzx_ops.h): action term, alpha * acc + beta, bias,
-//     residual, ReLU / ELU; the D fragment goes to global memory position-major (16 lanes = 64 contiguous bytes)
-//     or NCHW (head tensors).
+//     residual, ReLU / ELU.  The weight fragment is the MFMA's FIRST operand (D = (A . B)^T), so a lane ends up with
+//     four consecutive output channels of ONE position: one 16-byte residual load and one 16-byte store per lane
+//     and tile, position-major (NHWC), or four position-coalesced scalar stores (NCHW head tensors).
 // The f32 MFMA is a k-ordered fmaf chain; only the summation ORDER differs from ATen's / Conv3x3Op's.
 // Roofline: FP32 matrix pipe, 157.3 TFLOP/s dense.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 
 #include "mzx_pack.h"
 #include "mzx_resnet_batched.h"
@@ -53,7 +55,9 @@ struct RbGemmArgs {
   int32_t num_actions, batch;
   int32_t cin, cout, hin, win, hout, wout, stride, taps;
   int32_t T, th, tw, tiles_x, tiles_y, PH, PW, Cs, cpg, phases, cchunks, wchunks, rows, mtiles;
-  int32_t ntiles, ntiles_wg, WN, WM, y_layout, act, x_vec;
+  int32_t ntiles, ntiles_wg, WN, WM, y_layout, act, x_vec, y_vec, r_vec;   // *_vec: 16-byte accesses are aligned
+  unsigned long long* stamps;   // diagnostics (env MZX_RB_STAMPS): s_memtime of the phases, wave 0 of the first 64 workgroups
+  int32_t dbg;           // latency experiments (env MZX_RB_DBG): 1 skip the K loops, 2 skip the epilogue, 4 skip the staging
   uint32_t magic_thw, magic_tw, magic_phw, magic_pw;   // ceil(2^32 / d)
 };
 
@@ -61,8 +65,19 @@ __device__ __forceinline__ int rb_div(int x, int d, uint32_t magic) {
   return d == 1 ? x : (int)__umulhi((unsigned)x, magic);
 }
 
+// Two workgroups share a CU (their LDS tiles are planned for it, RB_LDS_BUDGET): one stages its patch or writes its
+// outputs while the other keeps the matrix pipes busy.  Four waves per SIMD = 128 registers per lane, which the
+// tilings with at most nine accumulator tiles per wave fit; the 2 x 9 tilings (wide layers) run one workgroup per CU.
+constexpr int RB_STAMP_WGS = 64, RB_STAMP_SLOTS = 24;
+#define RB_STAMP(slot)                                                                                   \
+  do {                                                                                                   \
+    if (a.stamps && blockIdx.y == 0 && blockIdx.x < RB_STAMP_WGS && (tid & 63) == 0 && (slot) < RB_STAMP_SLOTS)  \
+      a.stamps[((size_t)blockIdx.x * 8 + (tid >> 6)) * RB_STAMP_SLOTS + (slot)] = __builtin_readcyclecounter();   \
+  } while (0)
+
 template <int MT, int NT>
-__global__ void __launch_bounds__(RB_THREADS) rb_gemm_kernel(const RbGemmArgs a) {
+__global__ void __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(MT * NT <= 9 ? 4 : 2, MT * NT <= 9 ? 4 : 2)))
+rb_gemm_kernel(const RbGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float rb_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mpad = a.mtiles * 16, Tpad = (a.T + 1) & ~1;
@@ -81,6 +96,7 @@ __global__ void __launch_bounds__(RB_THREADS) rb_gemm_kernel(const RbGemmArgs a)
   const int pad = a.taps == 9 ? 1 : 0;
   const int thw = a.th * a.tw, phw = a.PH * a.PW, cells = a.T * phw;
   const int HWo = a.hout * a.wout;
+  RB_STAMP(0);
 
   // ---- row tables, per-sample offsets
   for (int m = tid; m < mpad; m += RB_THREADS) {
@@ -134,7 +150,8 @@ __global__ void __launch_bounds__(RB_THREADS) rb_gemm_kernel(const RbGemmArgs a)
     const int q = cw >> 2;
     if (g > 0) __syncthreads();                            // every wave is done reading the previous group
     // ---- stage the input patch: tile[cell][c - c0], zero outside the image / beyond cin
-    if (a.x.layout == RB_NHWC) {
+    if (a.dbg & 4) {
+    } else if (a.x.layout == RB_NHWC) {
       const uint32_t magic_q = (uint32_t)((0x100000000ull + (uint64_t)q - 1) / (uint64_t)q);
       const int total = cells * q;
       for (int i0 = tid; i0 < total; i0 += 4 * RB_THREADS) {
@@ -201,9 +218,10 @@ __global__ void __launch_bounds__(RB_THREADS) rb_gemm_kernel(const RbGemmArgs a)
       }
     }
     __syncthreads();
+    RB_STAMP(1 + 2 * g);
 
     // ---- K loop of this phase: (tap, chunk) pairs, operands one chunk ahead in registers
-    if (active) {
+    if (active && !(a.dbg & 1)) {
       const int cpg_g = cw >> 4;
       const int n_it = a.taps * cpg_g;
       int tap = 0, cc = 0;
@@ -225,7 +243,7 @@ __global__ void __launch_bounds__(RB_THREADS) rb_gemm_kernel(const RbGemmArgs a)
           for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][k], fb[j][k], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][k], fa[i][k], acc[i][j], 0, 0, 0);
       };
       // branch-free steady state (the wait counters of the next chunk's loads stay exact), one- or two-chunk tail
       load(fa0, fb0);
@@ -244,40 +262,81 @@ __global__ void __launch_bounds__(RB_THREADS) rb_gemm_kernel(const RbGemmArgs a)
         mma(fa0, fb0);
       }
     }
+    RB_STAMP(2 + 2 * g);
   }
 
-  // ---- epilogue
-  if (!active) return;
-  const int n_lane = lane & 15, rq = 4 * (lane >> 4);
+  // ---- epilogue.  The MFMAs were issued with the weight fragment as the FIRST operand: D = (A . B)^T, so lane l
+  // holds position row l & 15 of the tile and four CONSECUTIVE output channels 4 (l >> 4) .. + 3 -- one 16-byte
+  // residual load and one 16-byte store per lane and tile (16 lanes x 4 groups = 64 contiguous bytes per position).
+  if (!active || (a.dbg & 2)) return;
+  const int m_lane = lane & 15, nq = 4 * (lane >> 4);
+  const bool y_vec = a.y_vec != 0, r_vec = a.r_vec != 0;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     if (!nvalid[j]) continue;
-    const int n = (blockIdx.y * a.ntiles_wg + nt_first + j) * 16 + n_lane;
-    if (n >= a.cout) continue;
-    const float al = a.alpha ? a.alpha[n] : 1.f, be = a.alpha ? a.beta[n] : 0.f;
-    const float bi = a.bias ? a.bias[n] : 0.f;
+    const int n0 = (blockIdx.y * a.ntiles_wg + nt_first + j) * 16 + nq;
+    if (n0 >= a.cout) continue;
+    float al[4], be[4], bi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = n0 + u < a.cout;
+      al[u] = (a.alpha && ok) ? a.alpha[n0 + u] : 1.f;
+      be[u] = (a.alpha && ok) ? a.beta[n0 + u] : 0.f;
+      bi[u] = (a.bias && ok) ? a.bias[n0 + u] : 0.f;
+    }
+    // residuals of every tile first (independent loads in flight together), then arithmetic and stores
+    int pos_i[MT], t_i[MT];
+    f32x4 rv[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int mt = wm * MT + i;
-      if (mt >= a.mtiles) continue;
+      pos_i[i] = mt < a.mtiles ? rowpos[mt * 16 + m_lane] : -1;
+      t_i[i] = mt < a.mtiles ? rowt[mt * 16 + m_lane] : 0;
+      rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.res.p && pos_i[i] >= 0) {
+        const float* rp = a.res.p + soff_r[t_i[i]];
+        if (r_vec) rv[i] = *(const f32x4*)(rp + (long long)pos_i[i] * a.cout + n0);
+        else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = mt * 16 + rq + r;
-        const int pos = rowpos[m];
-        if (pos < 0) continue;
-        const int t = rowt[m], b = b0 + t;
-        float v = acc[i][j][r];
-        if (a.asum) v += ((float)a.action[b] / (float)a.num_actions) * a.asum[(size_t)n * HWo + pos];
-        if (a.alpha) v = v * al + be;
-        if (a.bias) v += bi;
-        if (a.res.p)
-          v += a.res.p[soff_r[t] + (a.res.layout == RB_NHWC ? (long long)pos * a.cout + n : (long long)n * HWo + pos)];
-        if (a.act == RZ_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (a.act == RZ_ACT_ELU) v = mzx_elu(v);
-        a.y[(long long)b * a.y_sstride + (a.y_layout == RB_NHWC ? (long long)pos * a.cout + n : (long long)n * HWo + pos)] = v;
+          for (int u = 0; u < 4; ++u)
+            if (n0 + u < a.cout)
+              rv[i][u] = rp[a.res.layout == RB_NHWC ? (long long)pos_i[i] * a.cout + n0 + u : (long long)(n0 + u) * HWo + pos_i[i]];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int pos = pos_i[i];
+      if (pos < 0) continue;
+      const int b = b0 + t_i[i];
+      f32x4 v = acc[i][j];
+      if (a.asum) {
+        const float av = (float)a.action[b] / (float)a.num_actions;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (n0 + u < a.cout) v[u] += av * a.asum[(size_t)(n0 + u) * HWo + pos];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float x = v[u];
+        if (a.alpha) x = x * al[u] + be[u];
+        if (a.bias) x += bi[u];
+        if (a.res.p) x += rv[i][u];
+        if (a.act == RZ_ACT_RELU) x = fmaxf(x, 0.f);
+        else if (a.act == RZ_ACT_ELU) x = mzx_elu(x);
+        v[u] = x;
+      }
+      float* yp = a.y + (long long)b * a.y_sstride;
+      if (y_vec) *(f32x4*)(yp + (long long)pos * a.cout + n0) = v;
+      else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (n0 + u < a.cout)
+            yp[a.y_layout == RB_NHWC ? (long long)pos * a.cout + n0 + u : (long long)(n0 + u) * HWo + pos] = v[u];
       }
     }
   }
+  RB_STAMP(1 + 2 * a.phases);
 }
 
 // Per-plane min-max scaling of the hidden state (models.py:527-553, :574-599; MinMaxScaleOp's arithmetic): one
@@ -387,12 +446,51 @@ int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
   const int WM = std::max(1, std::min(8 / WN, o.mtiles));
   const int MT = (o.mtiles + WM - 1) / WM;
   a.ntiles_wg = ntiles_wg; a.WN = WN; a.WM = WM;
+  static const int dbg = getenv("MZX_RB_DBG") ? atoi(getenv("MZX_RB_DBG")) : 0;
+  a.dbg = dbg;
+  // MZX_RB_STAMPS=<launch number>: phase clocks of that GEMM launch (counted from the first one of the process),
+  // printed to stderr after a blocking copy -- a diagnostic, never set in production
+  static const int stamp_launch = getenv("MZX_RB_STAMPS") ? atoi(getenv("MZX_RB_STAMPS")) : -1;
+  static int launch_no = 0;
+  static unsigned long long* d_stamps = nullptr;
+  const bool stamp = stamp_launch >= 0 && launch_no++ == stamp_launch;
+  const size_t stamp_words = (size_t)RB_STAMP_WGS * 8 * RB_STAMP_SLOTS;
+  if (stamp) {
+    if (!d_stamps && hipMalloc((void**)&d_stamps, stamp_words * 8) != hipSuccess) d_stamps = nullptr;
+    if (d_stamps) (void)hipMemsetAsync(d_stamps, 0, stamp_words * 8, stream);
+    a.stamps = d_stamps;
+  }
   RbGemmFn fn = NT == 2 ? rb_pick_mt<2>(MT) : rb_pick_mt<1>(MT);
-  hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS_BUDGET);
+  hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS_MAX);
   if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
   void* params[] = {(void*)&a};
   e = hipLaunchKernel((const void*)fn, dim3(groups_m, nsplit), dim3(RB_THREADS), params, (size_t)o.lds_bytes, stream);
   if (e != hipSuccess) { set_error("streamed GEMM launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+  if (stamp && d_stamps) {
+    std::vector<unsigned long long> h(stamp_words);
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(h.data(), d_stamps, stamp_words * 8, hipMemcpyDeviceToHost);
+    const int slots = 2 + 2 * o.phases;
+    fprintf(stderr, "rb stamps: launch %d, MT %d NT %d WN %d WM %d, grid %d x %d, lds %d, phases %d, rows %d\n", stamp_launch, MT, NT,
+            WN, WM, groups_m, nsplit, o.lds_bytes, o.phases, o.rows);
+    for (int wg = 0; wg < std::min(groups_m, 8); ++wg)
+      for (int w = 0; w < 8; w += 4) {
+        const unsigned long long* r = h.data() + ((size_t)wg * 8 + w) * RB_STAMP_SLOTS;
+        fprintf(stderr, "  wg %d wave %d: start %llu", wg, w, r[0] - h[0]);
+        for (int k = 1; k < slots; ++k) fprintf(stderr, " +%llu", r[k] - r[k - 1]);
+        fprintf(stderr, "   (tables+stage0, K0, stage1, K1, ..., epilogue)\n");
+      }
+    // mean over the stamped workgroups, wave 0
+    std::vector<double> mean(slots, 0.0);
+    const int nw = std::min(groups_m, RB_STAMP_WGS);
+    for (int wg = 0; wg < nw; ++wg) {
+      const unsigned long long* r = h.data() + (size_t)wg * 8 * RB_STAMP_SLOTS;
+      for (int k = 1; k < slots; ++k) mean[k] += (double)(r[k] - r[k - 1]) / nw;
+    }
+    fprintf(stderr, "  mean over %d workgroups (wave 0):", nw);
+    for (int k = 1; k < slots; ++k) fprintf(stderr, " %.0f", mean[k]);
+    fprintf(stderr, "\n");
+  }
   return MZX_OK;
 }
 
@@ -453,6 +551,8 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
       a.Cs = o.Cs; a.cpg = o.cpg; a.phases = o.phases; a.cchunks = o.cchunks; a.wchunks = o.wchunks;
       a.rows = o.rows; a.mtiles = o.mtiles; a.ntiles = o.ntiles; a.act = o.act;
       a.x_vec = (o.in_layout == RB_NHWC && o.cin % 4 == 0 && a.x.sstride % 4 == 0 && ((uintptr_t)a.x.p % 16) == 0) ? 1 : 0;
+      a.y_vec = (o.out_layout == RB_NHWC && o.cout % 4 == 0 && a.y_sstride % 4 == 0 && ((uintptr_t)a.y % 16) == 0) ? 1 : 0;
+      a.r_vec = (a.res.p && o.res_layout == RB_NHWC && o.cout % 4 == 0 && a.res.sstride % 4 == 0 && ((uintptr_t)a.res.p % 16) == 0) ? 1 : 0;
       a.magic_thw = rb_magic(o.th * o.tw); a.magic_tw = rb_magic(o.tw);
       a.magic_phw = rb_magic(o.PH * o.PW); a.magic_pw = rb_magic(o.PW);
       rc = rb_launch_gemm(a, o, batch, stream);

@@ -19,7 +19,9 @@ namespace mzx {
 
 constexpr int RB_MAX_ROWS = 144;              // GEMM rows of a workgroup: nine 16-row MFMA tiles
 constexpr int RB_MT = 9;                      // row tiles a wave can own
-constexpr int RB_LDS_BUDGET = 156 * 1024;     // bytes of dynamic LDS a workgroup may ask for
+constexpr int RB_LDS_MAX = 156 * 1024;        // bytes of dynamic LDS a workgroup can get (one workgroup per CU)
+constexpr int RB_LDS_BUDGET = 78 * 1024;      // what the planner asks for: TWO workgroups per CU, so that one stages its
+                                              // patch / writes its outputs while the other feeds the matrix pipes
 
 enum RbLayout { RB_NHWC = 0, RB_NCHW = 1 };   // [sample][position][channel] / [sample][channel][position]
 enum RbKind { RB_GEMM = 0, RB_SCALE = 1, RB_POOL = 2, RB_FUNCTOR = 3 };

@@ -15,6 +15,7 @@
 #include "mzx_fused_fc.h"
 #include "mzx_fused_fc2.h"
 #include "mzx_resnet_search.h"
+#include "mzx_row_search.h"
 #endif
 
 namespace mzx {
@@ -305,7 +306,9 @@ int mzx_search_create(const mzx_search_config* cfg, mzx_net* net, mzx_search** o
   search_plan(s);
   if (int rc = upload_tables(s)) { mzx_search_destroy(s); return rc; }
 #ifndef MZX_HOSTCHECK
-  s->fused_ok = fc2_plan(s).ok ? 1 : (rz_search_supported(s) ? 2 : 0);
+  // 1: fully connected whole-search kernel, 2: residual whole-search kernels, 3: row-per-tree kernels around a
+  // network that runs layer by layer on the streamed MFMA engine
+  s->fused_ok = fc2_plan(s).ok ? 1 : (rz_search_supported(s) ? 2 : ((net && net->rb.ok && net->rb.recurrent.ok && row_search_supported(s->p)) ? 3 : 0));
 #endif
   s->mode = s->fused_ok ? 1 : 0;
   *out = s;
@@ -366,10 +369,14 @@ int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_
     return (s->mode & 16) ? fused_fc_run(s, io, d_arena, (stream_t)stream) : fc2_run(s, io, d_arena, (stream_t)stream);
   }
   if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) return rz_search_run(s, io, d_arena, (stream_t)stream);
+  if ((s->mode & 1) && rb_enabled(s->net, true) && row_search_supported(s->p)) {
+    s->last_kernel = "mzx::rb_gemm_kernel (streamed FP32-MFMA layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
+    return search_run_rows(s, io, d_arena, (stream_t)stream);
+  }
 #endif
   s->last_kernel = "one kernel per step of a simulation (select / network / expand + back-propagate)";
 #ifndef MZX_HOSTCHECK
-  if (rb_enabled(s->net, true)) s->last_kernel = "mzx::rb_gemm_kernel (streamed FP32-MFMA layers) between per-simulation tree kernels";
+  if (rb_enabled(s->net, true)) s->last_kernel = "mzx::rb_gemm_kernel (streamed FP32-MFMA layers) between one-thread-per-tree kernels";
 #endif
   return search_run_generic(s, io, d_arena, (stream_t)stream);
 }

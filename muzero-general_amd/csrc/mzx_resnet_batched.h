@@ -13,6 +13,8 @@
 // boundary (the first convolution gathers, the scaling operator writes NCHW -- straight into / out of the search
 // arena's per-node store, NetIndex).
 #pragma once
+#include <stdlib.h>
+
 #include <algorithm>
 #include <map>
 #include <tuple>
@@ -32,6 +34,15 @@ inline int64_t rb_lds_bytes(int T, int mtiles, int cells, int Cs) {
 // rows, else one th x tw patch of one sample; the input patch (with the 3x3 halo) is staged in `phases` channel
 // groups of `cpg` 16-channel chunks.  Maximises MFMA row-tile occupancy, then prefers fewer phases and more rows
 // (every workgroup streams the whole B matrix once: traffic per flop ~ 1 / rows).
+inline int rb_lds_budget() {   // MZX_RB_LDS: A/B knob (bytes), e.g. 159744 = one workgroup per CU
+  static const int v = [] {
+    const char* e = getenv("MZX_RB_LDS");
+    const int x = e ? atoi(e) : RB_LDS_BUDGET;
+    return std::min(std::max(x, 16 * 1024), RB_LDS_MAX);
+  }();
+  return v;
+}
+
 inline bool rb_choose_tile(RbOp& o) {
   const int pad = o.taps == 9 ? 1 : 0;
   const int HWo = o.hout * o.wout;
@@ -43,7 +54,7 @@ inline bool rb_choose_tile(RbOp& o) {
     const int rows = T * th * tw, mtiles = (rows + 15) / 16;
     if (rows > RB_MAX_ROWS) return;
     int cpg = o.cchunks;
-    while (cpg >= 1 && rb_lds_bytes(T, mtiles, cells, 16 * cpg + 8) > RB_LDS_BUDGET) --cpg;
+    while (cpg >= 1 && rb_lds_bytes(T, mtiles, cells, 16 * cpg + 8) > rb_lds_budget()) --cpg;
     if (cpg < 1) return;
     const int phases = (o.cchunks + cpg - 1) / cpg;
     cpg = (o.cchunks + phases - 1) / phases;

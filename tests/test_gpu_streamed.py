@@ -159,13 +159,29 @@ def test_streamed_search_matches_reference(backend, name):
             ch = g("child")[0, s]
             want[a] = g("visit")[ch] if ch >= 0 else 0
         assert numpy.array_equal(res.visit_counts[c], want), (name, c)
+        # decoded scalars: the inverse value transform cancels ~3 digits in fp32; through 25
+        # 128-channel layers two evaluations of the value logits that agree to 1e-5 decode to values 1.5e-4 apart
         want_rv = g("value_sum")[0] / g("visit")[0]
-        assert abs(res.root_values[c] - want_rv) < 1e-4 * max(1.0, abs(want_rv))
+        assert abs(res.root_values[c] - want_rv) < 3e-4 * max(1.0, abs(want_rv))
         assert res.max_tree_depth[c] == int(g("max_tree_depth"))
 
 
+class _Evaluator(net_oracle.NetworkEvaluator):
+    """NetworkEvaluator that feeds the observation in the network's own precision (binary64 yardstick runs)."""
+
+    def initial(self, observation, actions):
+        with torch.no_grad():
+            dtype = getattr(self.net, "dtype", torch.float32)
+            obs = torch.tensor(observation).to(dtype).unsqueeze(0)
+            return self._finish(*self.net.initial_inference(obs), actions)
+
+
 def test_gomoku_search_against_oracle_at_size(backend):
-    """64 gomoku trees x 60 simulations on the shipped network: sampled trees against the CPU oracle."""
+    """
+    64 gomoku trees x 60 simulations on the shipped network: invariants, repeatability, and sampled trees against the
+    CPU oracle simulation by simulation (a diverging tree must diverge at a near-tie of the oracle's UCB scores).
+    """
+    import test_gpu_parity as parity
     cfg = configs.gomoku(num_simulations=60)
     net = models.MuZeroNetwork(cfg)
     sd = synthetic.fill_state_dict(net.state_dict(), 9)
@@ -175,18 +191,93 @@ def test_gomoku_search_against_oracle_at_size(backend):
     rs = numpy.random.RandomState(2)
     legal = [sorted(rs.choice(121, size=rs.randint(2, 122), replace=False).tolist()) for _ in range(B)]
     to_play = [int(i % 2) for i in range(B)]
+    seeds = [3000 + i for i in range(B)]
     engine = self_play.BatchedMCTS(cfg, net, B)
-    res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(3000 + i) for i in range(B)])
-    assert (res.visit_counts.sum(1) == 60).all() and (res.flags == 0).all()
-    onet = net_oracle.make_oracle_network(cfg, sd)
-    same = 0
-    sample = list(range(0, B, 8))
-    for i in sample:
-        ev = net_oracle.NetworkEvaluator(onet, cfg.support_size)
-        tree = mcts_oracle.run_search(cfg, ev, obs[i], legal[i], to_play[i], True, numpy.random.RandomState(3000 + i))
-        want = tree.root_visit_counts(cfg.action_space)
-        same += int(list(res.visit_counts[i]) == want)
-        rv = tree.node_value(0)
-        assert abs(res.root_values[i] - rv) < 2e-3 * max(1.0, abs(rv)), (i, res.root_values[i], rv)
-    print(f"gomoku at size: {same}/{len(sample)} sampled trees with identical visit counts")
-    assert same >= len(sample) - 1
+    res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(s) for s in seeds])
+    assert "rb_gemm_kernel" in engine.kernel_name(B)
+    parity._tree_invariants(cfg, res, 60)
+    for i in range(B):
+        assert set(numpy.nonzero(res.visit_counts[i])[0]).issubset(set(legal[i]))
+    res2 = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(s) for s in seeds])
+    assert numpy.array_equal(res.visit_counts, res2.visit_counts)
+    assert numpy.array_equal(res.root_values.view(numpy.int64), res2.root_values.view(numpy.int64))
+    sample = list(range(0, B, 4))
+    traces = parity._device_trace(lambda n: self_play.BatchedMCTS(cfg, net, n), cfg, [obs[i] for i in sample],
+                                  [legal[i] for i in sample], [to_play[i] for i in sample], [seeds[i] for i in sample])
+    o32 = net_oracle.make_oracle_network(cfg, sd)
+    o64 = net_oracle.make_oracle_network(cfg, sd, dtype=torch.float64)
+    identical = 0
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        for i, got in zip(sample, traces):
+            run = lambda onet: mcts_oracle.run_search(cfg, _Evaluator(onet, cfg.support_size), obs[i], legal[i],
+                                                      to_play[i], True, numpy.random.RandomState(seeds[i]))
+            tree = run(o32)
+            want = [(p, a) for p, a, _ in tree.trace]
+            k = next((k for k in range(len(want)) if k >= len(got) or got[k] != want[k]), None)
+            if k is not None:   # a diverging tree must diverge at a near-tie of the oracle's UCB scores
+                gap, depth = tree.margins[k]
+                print(f"gomoku: tree {i} diverges at simulation {k} (oracle {want[k]}, device {got[k] if k < len(got) else None}); "
+                      f"oracle UCB top-2 margin {gap:.3e} at depth {depth}")
+                assert gap < 5e-4, (i, k, gap)
+                continue
+            identical += 1
+            assert tree.root_visit_counts(cfg.action_space) == list(res.visit_counts[i])
+            assert res.max_tree_depth[i] == tree.max_depth
+            # Root value of a tree that agrees in every simulation.  Yardstick: the SAME search evaluated in binary64.
+            # Random 128-channel weights produce near-flat planes in front of the per-plane min-max scaling
+            # (models.py:541-549), which divides fp32 round-off by the plane's range: on such trees torch's own
+            # fp32 result moves by several 1e-3 with the thread count.  Bound: 3e-3, or 8x the error torch-fp32 has
+            # against binary64 on this very tree.
+            rv32 = tree.node_value(0)
+            t64 = run(o64)
+            tol = 30 * TOL
+            if [(p, a) for p, a, _ in t64.trace] == want:
+                tol = max(tol, 8 * abs(rv32 - t64.node_value(0)))
+                ref = t64.node_value(0)
+            else:
+                ref = rv32
+            err = abs(res.root_values[i] - ref)
+            print(f"gomoku: tree {i} identical in every simulation; root value error {err:.2e} (torch fp32 vs f64 {abs(rv32 - ref):.2e})")
+            assert err < tol * max(1.0, abs(ref)), (i, res.root_values[i], rv32, ref)
+    finally:
+        torch.set_num_threads(threads)
+    print(f"gomoku: {identical}/{len(sample)} sampled trees identical to the oracle in every simulation")
+    assert identical >= (len(sample) * 3) // 4
+
+
+@pytest.mark.parametrize("name,B,S", [("gomoku", 9, 30), ("connect4", 50, 40), ("tictactoe", 7, 25), ("atari_narrow", 5, 12)])
+def test_row_kernels_bit_identical_to_one_thread_per_tree(backend, name, B, S):
+    """
+    The streamed path's tree kernels (a 16-lane row per tree, csrc/mzx_row_search.h) against the generic operators
+    (one thread per tree) around the SAME network engine: every statistic of the finished trees bit for bit.
+    B is no multiple of four (a partial wavefront of rows), ragged legal sets, both players.
+    """
+    make = STREAMED_CASES[name][0]
+    cfg = make()
+    cfg.num_simulations = S
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 12))
+    net.set_mode(3)
+    A = len(cfg.action_space)
+    obs = synthetic.observations(B, net.input_shape, seed=6)
+    rs = numpy.random.RandomState(4)
+    legal = [sorted(rs.choice(A, size=rs.randint(1, A + 1), replace=False).tolist()) for _ in range(B)]
+    to_play = [int(i % len(cfg.players)) for i in range(B)]
+    out = {}
+    for mode in (0, 1):
+        engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
+        res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(500 + i) for i in range(B)])
+        kernel = engine.kernel_name(B)
+        assert ("row_select_kernel" in kernel) == (mode == 1), kernel
+        out[mode] = (res, engine.export_trees(B))
+    (r0, t0), (r1, t1) = out[0], out[1]
+    assert numpy.array_equal(r0.visit_counts, r1.visit_counts)
+    assert numpy.array_equal(r0.root_values.view(numpy.int64), r1.root_values.view(numpy.int64))
+    assert numpy.array_equal(r0.max_tree_depth, r1.max_tree_depth) and numpy.array_equal(r0.tape_used, r1.tape_used)
+    for key in ("visit", "value_sum", "reward", "prior", "child", "parent", "to_play", "minmax", "n_nodes"):
+        a, b = t0[key], t1[key]
+        if a.dtype == numpy.float64:
+            a, b = a.view(numpy.int64), b.view(numpy.int64)
+        assert numpy.array_equal(a, b), (name, key)
