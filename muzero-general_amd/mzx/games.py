@@ -1,0 +1,118 @@
+"""
+Batched-protocol versions of two reference games: a whole self-play shard stepped by ONE object with array
+arithmetic, so that real environments stop being the host bottleneck of the batched search (SURVEY.md section 8f
+row 3).  ``mzx.self_play.SelfPlay`` drives a class with ``batched = True`` through
+
+    Game(seeds)                      one object for len(seeds) games
+    reset()            -> observations [B, *observation_shape]
+    step(actions [B], active=None)   -> (observations [B, ...], rewards [B], done [B]); games with active[i] false
+                                        (finished earlier) are left untouched
+    legal_actions()    -> int32 [B][A], each row the legal actions in increasing order, padded with -1
+    to_play()          -> [B]
+
+Game i of ``TicTacToeBatched`` / ``Connect4Batched`` emits, observation for observation (values AND dtype), reward
+for reward, what ``Game(seed)`` of the reference's games/tictactoe.py:125-351 / games/connect4.py:125-346 emits for
+the same actions (tests/test_batched_games.py runs both side by side against the live files): boards as planes
+[own stones of player 1, stones of player -1, side to move], a win pays 20 / 10 to the player who just moved, a game
+ends on a win or a full board, players alternate 0, 1.  Only the self-play surface is provided (no rendering, no
+human / expert opponents: use the reference's per-object classes for those modes).
+"""
+import numpy
+
+
+class _KInARowBatched:
+    batched = True
+    rows = cols = k = 0
+    gravity = False         # connect4: a stone falls to the lowest empty cell of its column
+    reward_scale = 1
+    obs_dtype = "int32"
+
+    def __init__(self, seeds):
+        self.num_games = len(seeds)
+        R, C, k = self.rows, self.cols, self.k
+        lines = []
+        for r in range(R):
+            for c in range(C):
+                for dr, dc in ((0, 1), (1, 0), (1, 1), (1, -1)):
+                    rr, cc = r + (k - 1) * dr, c + (k - 1) * dc
+                    if 0 <= rr < R and 0 <= cc < C:
+                        lines.append([(r + i * dr) * C + (c + i * dc) for i in range(k)])
+        self._lines = numpy.asarray(lines, numpy.int64)                  # [L][k] flat cell indices
+        self._A = C if self.gravity else R * C
+        self._arange_a = numpy.arange(self._A, dtype=numpy.int32)
+        self._games = numpy.arange(self.num_games)
+        self.reset()
+
+    # ---- plugin surface -------------------------------------------------------------------------------------
+    def reset(self):
+        self.board = numpy.zeros((self.num_games, self.rows * self.cols), numpy.int32)
+        self.player = numpy.ones(self.num_games, numpy.int32)
+        self.height = numpy.zeros((self.num_games, self.cols), numpy.int64)   # stones per column (gravity games)
+        return self._observation()
+
+    def to_play(self):
+        return numpy.where(self.player == 1, 0, 1)
+
+    def legal_actions(self):
+        if self.gravity:
+            free = self.board.reshape(self.num_games, self.rows, self.cols)[:, self.rows - 1, :] == 0
+        else:
+            free = self.board == 0
+        order = numpy.sort(numpy.where(free, self._arange_a[None, :], self._A), axis=1)
+        return numpy.where(order == self._A, -1, order).astype(numpy.int32)
+
+    def step(self, actions, active=None):
+        a = numpy.asarray(actions).astype(numpy.int64)
+        act = numpy.ones(self.num_games, bool) if active is None else numpy.asarray(active, bool)
+        g = self._games[act]
+        col = a[act]
+        if self.gravity:
+            row = self.height[g, col]
+            full = row >= self.rows                       # the reference's loop places nothing in a full column
+            row = numpy.minimum(row, self.rows - 1)
+            cell = row * self.cols + col
+            ok = ~full
+            self.board[g[ok], cell[ok]] = self.player[g[ok]]
+            self.height[g[ok], col[ok]] += 1
+        else:
+            self.board[g, col] = self.player[g]
+        mine = self.board[:, self._lines] == self.player[:, None, None]          # [B][L][k]
+        won = mine.all(2).any(1) & act
+        if self.gravity:
+            no_move = (self.board.reshape(self.num_games, self.rows, self.cols)[:, self.rows - 1, :] != 0).all(1)
+        else:
+            no_move = (self.board != 0).all(1)
+        done = (won | no_move) & act
+        reward = numpy.where(won, self.reward_scale, 0).astype(numpy.int64)
+        self.player = numpy.where(act, -self.player, self.player).astype(numpy.int32)
+        return self._observation(), reward, done
+
+    def close(self):
+        pass
+
+    # ---- helpers --------------------------------------------------------------------------------------------
+    def _observation(self):
+        b = self.board.reshape(self.num_games, self.rows, self.cols)
+        out = numpy.empty((self.num_games, 3, self.rows, self.cols), self.obs_dtype)
+        out[:, 0] = b == 1
+        out[:, 1] = b == -1
+        out[:, 2] = self.player[:, None, None]
+        return out
+
+
+class TicTacToeBatched(_KInARowBatched):
+    """games/tictactoe.py:125-310 for a shard: 3 x 3, three in a row, int32 planes, reward 20 for a win."""
+    rows, cols, k = 3, 3, 3
+    reward_scale = 20
+    obs_dtype = "int32"
+
+
+class Connect4Batched(_KInARowBatched):
+    """games/connect4.py:125-300 for a shard: 6 x 7 with gravity, four in a row, float64 planes, reward 10 for a win."""
+    rows, cols, k = 6, 7, 4
+    gravity = True
+    reward_scale = 10
+    obs_dtype = "float64"
+
+
+BATCHED = {"tictactoe": TicTacToeBatched, "connect4": Connect4Batched}
