@@ -21,7 +21,8 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   "roofline"      algorithmic tree bytes (SURVEY.md section 8d formula, with the measured mean leaf depth) /
                   HIP-event time of the search launch, vs the HBM peak (residual networks: network FLOPs vs the
                   dense FP32-input MFMA peak)
-  "workloads"     the other half of the metric (C4) measured in this invocation, same fields
+  "workloads"     the other BASELINE configurations (C3, C4 = the Connect4 half of the metric, C5) measured in this
+                  invocation, same fields
   "per_rank" / "single_gpu_reference"   N > 1: every rank's own rate, and rank 0 timed alone just before
   "selfplay_end_to_end*"  self-play steps/s through the plugin surface (N = 1)
   "observation_stacker"   the path's HBM-bound kernel (mzx_obs_stack, atari geometry) against the HBM peak
@@ -75,6 +76,9 @@ def parse():
                     help="comma list of further workloads measured in the same invocation and reported under "
                          "'workloads' (default: c4 when the main workload is c2; 'none' = skip)")
     ap.add_argument("--also-steps", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=None,
+                    help="timed blocks of exactly --steps steps each (default: 25 for blocks shorter than 0.1 s, fewer for "
+                         "long ones); the line's value is the MEDIAN block, min / max are reported beside it")
     ap.add_argument("--trees", type=int, default=None, help="trees per GPU (default: the workload's)")
     ap.add_argument("--mode", default="auto", choices=["auto", "generic", "fused", "fused-v1"],
                     help="fused-v1: first-generation fully connected whole-search kernel (A/B)")
@@ -324,20 +328,26 @@ def observation_stacker_leg(backend, games=64, stacked=32, iters=20):
             "algorithmic_bytes_per_launch": nbytes, "launch_ms": ms, "games": games, "stacked_observations": stacked}
 
 
-def selfplay_leg(cfg, net, B, moves, batched=False):
+def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic"):
     """
-    SelfPlay(num_games=B).play_games on the synthetic fixed-shape game (reference plugin surface): what a
-    user of the drop-in engine sees per process -- B Python Game.step calls, per-game numpy-compatible
-    streams (native bank), temperature sampling and GameHistory records around one batched search per move.
+    SelfPlay(num_games=B).play_games: what a user of the drop-in engine sees per process -- game stepping, per-game
+    numpy-compatible streams (native bank), temperature sampling and GameHistory records around one batched search
+    per move.  game = "synthetic": the fixed-shape synthetic game, `moves` moves per game; game = "connect4" /
+    "tictactoe": the real rules (mzx.games: per-object classes with the reference plugin surface, or the batched
+    protocol), whole games to their natural end.
     """
     import copy
 
+    from mzx import games as board_games
     from mzx import self_play, synthetic
 
     c = copy.copy(cfg)
-    c.max_moves = moves
-    make = synthetic.make_synthetic_batched_game if batched else synthetic.make_synthetic_game
-    Game = make(c.observation_shape, len(c.action_space), len(c.players))
+    if game == "synthetic":
+        c.max_moves = moves
+        make = synthetic.make_synthetic_batched_game if batched else synthetic.make_synthetic_game
+        Game = make(c.observation_shape, len(c.action_space), len(c.players))
+    else:
+        Game = (board_games.BATCHED if batched else board_games.PER_OBJECT)[game]
     sp = self_play.SelfPlay({"weights": net.get_weights()}, Game, c, 0, num_games=B, _backend=net.backend)
     sp.play_games(1.0, None, False, "self", 0)          # warm-up (allocations, kernel attributes)
     sp.stats = {"searches": 0, "simulations": 0, "search_seconds": 0.0}
@@ -353,7 +363,8 @@ def selfplay_leg(cfg, net, B, moves, batched=False):
             h.materialize()
     materialize = time.perf_counter() - t1
     return {
-        "steps_per_sec": steps / wall, "sims_per_sec": steps * c.num_simulations / wall, "games": B, "moves_per_game": moves,
+        "steps_per_sec": steps / wall, "sims_per_sec": steps * c.num_simulations / wall, "games": B,
+        "moves_per_game": steps / B, "game": game,
         "wall_s": wall, "search_share": sp.stats["search_seconds"] / wall,
         "materialize_all_histories_s": materialize if batched else 0.0,
         "steps_per_sec_with_all_histories_as_lists": steps / (wall + (materialize if batched else 0.0)),
@@ -450,14 +461,25 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         if rank == 0:
             solo_elapsed, _ = timed(steps)
             solo = B * S * steps / solo_elapsed
-    env.fence()
-    own_elapsed, watch = timed(steps)
-    t_own_done = own_elapsed
-    env.barrier()
-    env.sync()
-    elapsed = env.all_max(t_own_done)
-    per_rank = [B * S * steps / t for t in env.all_gather(own_elapsed)]
-    launch_ms = watch.mean_ms()
+    # R timed blocks of exactly `steps` steps, each bracketed by barrier + synchronize on both sides and reduced with
+    # MAX over the ranks; the line reports the MEDIAN block (one 3 ms sample says little), min / max beside it
+    blocks = []
+    repeats = args.repeats
+    while True:
+        env.fence()
+        own_elapsed, watch = timed(steps)
+        env.barrier()
+        env.sync()
+        elapsed = env.all_max(own_elapsed)
+        blocks.append((elapsed, own_elapsed, watch.mean_ms(), env.all_gather(own_elapsed)))
+        if repeats is None:      # decided from the first block, identically on every rank (elapsed is the all-rank max)
+            repeats = 25 if elapsed < 0.1 else (9 if elapsed < 0.5 else (3 if elapsed < 3.0 else 1))
+        if len(blocks) >= repeats:
+            break
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
+    elapsed, own_elapsed, launch_ms, gathered = blocks[order[len(order) // 2]]
+    per_rank = [B * S * steps / t for t in gathered]
+    block_rates = [world * B * S * steps / b[0] for b in blocks]
 
     # sanity: the timed work is real (every tree ran S simulations, no flags)
     for _, out, _ in sets[: min(n_sets, max(steps, warmup, 1))]:
@@ -530,6 +552,9 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
             "tree_statistics_dtype": "f64", "weights": "synthetic seed 0 (RCCL-broadcast flat buffer)",
             "mean_leaf_depth": L,
         },
+        "repeats": {"n": len(blocks), "steps_per_block": steps, "median": sorted(block_rates)[len(block_rates) // 2],
+                    "min": min(block_rates), "max": max(block_rates), "unit": "sims/s",
+                    "note": "each block = exactly `steps` steps between barrier + synchronize brackets; value / ms_per_step are the median block's"},
         "search_steps_per_sec": world * B * steps / elapsed,
         "weight_broadcast_ms": broadcast_ms,
         "collective_world_size": (torch.distributed.get_world_size() if world > 1 else 1),
@@ -556,19 +581,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env.world}")
     also = args.also
     if also is None:
-        also = "c4" if (args.workload == "c2" and not args.dry_run and args.trees is None) else "none"
+        also = "c3,c4,c5" if (args.workload == "c2" and not args.dry_run and args.trees is None) else "none"
     also = [w for w in also.split(",") if w and w != "none"]
 
     line, cfg, net = run_search_workload(env, args, args.workload, args.steps, args.warmup, args.trees,
                                          solo_reference=True)
     others = []
+    c4_net = None
     for w in also:
         if w not in WORKLOADS:
             raise SystemExit(f"unknown workload {w}")
-        r, _, n2 = run_search_workload(env, args, w, args.also_steps, 1)
-        del n2
+        r, c2_, n2 = run_search_workload(env, args, w, args.also_steps, 1)
+        if w == "c4":
+            c4_net = (c2_, n2)
+        else:
+            del n2
         if r is not None:
             others.append(r)
+    if args.workload == "c4":
+        c4_net = (cfg, net)
     if env.rank == 0:
         if others:
             line["workloads"] = others
@@ -579,6 +610,13 @@ def main():
         if env.world == 1 and args.selfplay_moves > 0:
             line["selfplay_end_to_end"] = selfplay_leg(cfg, net, B, args.selfplay_moves)
             line["selfplay_end_to_end_batched_game"] = selfplay_leg(cfg, net, B, args.selfplay_moves, batched=True)
+            if c4_net is not None and not args.dry_run:
+                # the Connect4 half of BASELINE.json's "self-play steps/sec": whole games with the real rules
+                # (games/connect4.py:125-346 semantics, mzx.games), C4 network, 1024 games per process
+                c4_cfg, c4_model = c4_net
+                line["selfplay_end_to_end_connect4"] = selfplay_leg(c4_cfg, c4_model, WORKLOADS["c4"][2], 0, game="connect4")
+                line["selfplay_end_to_end_connect4_batched_game"] = selfplay_leg(c4_cfg, c4_model, WORKLOADS["c4"][2], 0,
+                                                                                 batched=True, game="connect4")
             if not args.dry_run:
                 line["observation_stacker"] = observation_stacker_leg(net.backend)
         line["cpu_baseline"] = None

@@ -461,8 +461,12 @@ int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
     a.stamps = d_stamps;
   }
   RbGemmFn fn = NT == 2 ? rb_pick_mt<2>(MT) : rb_pick_mt<1>(MT);
-  hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS_MAX);
-  if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+  static std::atomic<uint64_t> lds_attr_done[2][RB_MT + 1];   // per instantiation, one bit per device
+  if (const int ae = allow_large_lds((const void*)fn, RB_LDS_MAX, lds_attr_done[NT - 1][MT])) {
+    set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
+    return MZX_ERR_RUNTIME;
+  }
+  hipError_t e;
   void* params[] = {(void*)&a};
   e = hipLaunchKernel((const void*)fn, dim3(groups_m, nsplit), dim3(RB_THREADS), params, (size_t)o.lds_bytes, stream);
   if (e != hipSuccess) { set_error("streamed GEMM launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }

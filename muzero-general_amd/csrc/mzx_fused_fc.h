@@ -965,12 +965,10 @@ inline int fused_fc_supported(const mzx_search* s) { return fused_plan(s).ok; }
 
 template <class Net, int AW, bool PROFILE>
 inline int fused_launch(const FusedPlan& P, unsigned grid, stream_t stream) {
-  static bool attr_set = false;  // one per instantiation
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)fused_fc_search_kernel<Net, AW, PROFILE>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BUDGET);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
-    attr_set = true;
+  static std::atomic<uint64_t> lds_attr_done{0};   // per instantiation, one bit per device
+  if (const int ae = allow_large_lds((const void*)fused_fc_search_kernel<Net, AW, PROFILE>, FUSED_LDS_BUDGET, lds_attr_done)) {
+    set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
+    return MZX_ERR_RUNTIME;
   }
   hipLaunchKernelGGL((fused_fc_search_kernel<Net, AW, PROFILE>), dim3(grid),
                      dim3(P.args.trees_per_block * FUSED_ROW), (size_t)P.lds_bytes, stream, P.args);

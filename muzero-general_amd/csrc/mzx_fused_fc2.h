@@ -586,12 +586,10 @@ inline Fc2Plan fc2_plan(const mzx_search* s, bool allow_small = true) {
 
 template <class Net, int AW, bool PROFILE>
 inline int fc2_launch(const Fc2Plan& P, unsigned grid, stream_t stream) {
-  static bool attr_set = false;  // one per instantiation
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)fc2_search_kernel<Net, AW, PROFILE>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BUDGET);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
-    attr_set = true;
+  static std::atomic<uint64_t> lds_attr_done{0};   // per instantiation, one bit per device
+  if (const int ae = allow_large_lds((const void*)fc2_search_kernel<Net, AW, PROFILE>, FUSED_LDS_BUDGET, lds_attr_done)) {
+    set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
+    return MZX_ERR_RUNTIME;
   }
   hipLaunchKernelGGL((fc2_search_kernel<Net, AW, PROFILE>), dim3(grid), dim3(P.args.f.trees_per_block * FUSED_ROW),
                      (size_t)P.lds_bytes, stream, P.args);

@@ -8,6 +8,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "mzx_platform.h"
 
 namespace mzx {
@@ -44,6 +46,7 @@ inline int copy_h2d_blocking(void* dst, const void* src, size_t bytes) {
 }
 
 inline const char* runtime_error_string(int) { return "hostcheck"; }
+inline int current_device() { return 0; }
 
 #else
 
@@ -80,6 +83,20 @@ inline int copy_h2d_blocking(void* dst, const void* src, size_t bytes) {
 }
 
 inline const char* runtime_error_string(int e) { return hipGetErrorString((hipError_t)e); }
+inline int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
+
+// Kernels that ask for more than 64 KB of dynamic LDS need hipFuncSetAttribute once PER DEVICE (a process may drive
+// several GPUs); `done` is the instantiation's own bit set of devices already served.  Returns a hipError_t.
+inline int allow_large_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = uint64_t(1) << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return 0;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  done.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
 
 #endif
 

@@ -351,6 +351,10 @@ static int check_search_call(const mzx_search* s, const void* d_arena, int64_t a
     return MZX_ERR_WORKSPACE;
   }
   if (need_net && (!s->net || !s->net->d_flat)) { set_error("search needs a network with bound weights"); return MZX_ERR_INVALID; }
+  if (s->device >= 0 && current_device() != s->device) {   // its tables (and the caller's arena) live on that device
+    set_error("search handle was created on device %d, the current device is %d", s->device, current_device());
+    return MZX_ERR_INVALID;
+  }
   return MZX_OK;
 }
 

@@ -1223,12 +1223,10 @@ inline void rz_choose(const RzGeometry& g, const RzProgram& R, int batch, int& T
 
 template <bool WLDS, int NW, int MM>
 inline int rz_launch_k(const RzArgs& a, unsigned grid, size_t lds_bytes, stream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)rz_network_kernel<WLDS, NW, MM>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
-    attr_set = true;
+  static std::atomic<uint64_t> lds_attr_done{0};   // per instantiation, one bit per device
+  if (const int ae = allow_large_lds((const void*)rz_network_kernel<WLDS, NW, MM>, 160 * 1024, lds_attr_done)) {
+    set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
+    return MZX_ERR_RUNTIME;
   }
   hipLaunchKernelGGL((rz_network_kernel<WLDS, NW, MM>), dim3(grid), dim3(NW * 64), lds_bytes, stream, a);
   hipError_t e = hipGetLastError();
@@ -1474,12 +1472,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
 // (the caller then uses the per-operator kernel).
 inline int rz_stem_launch(const mzx_net* net, const RzStemConv& sc, const OpDesc& d, const float* x, const float* res,
                           float* y, int batch, stream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)rz_stem_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
-    attr_set = true;
+  static std::atomic<uint64_t> lds_attr_done{0};   // per instantiation, one bit per device
+  if (const int ae = allow_large_lds((const void*)rz_stem_conv_kernel, 160 * 1024, lds_attr_done)) {
+    set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
+    return MZX_ERR_RUNTIME;
   }
   RzStemArgs sa;
   memset(&sa, 0, sizeof(sa));

@@ -373,12 +373,10 @@ rz_search_kernel(const RzSearchArgs sa) {
 
 template <bool WLDS, int NW, int AW, int MM, bool TREC = false>
 inline int rz_search_launch_k(const RzSearchArgs& sa, unsigned grid, size_t lds_bytes, stream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)rz_search_kernel<WLDS, NW, AW, MM, TREC>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
-    attr_set = true;
+  static std::atomic<uint64_t> lds_attr_done{0};   // per instantiation, one bit per device
+  if (const int ae = allow_large_lds((const void*)rz_search_kernel<WLDS, NW, AW, MM, TREC>, 160 * 1024, lds_attr_done)) {
+    set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
+    return MZX_ERR_RUNTIME;
   }
   hipLaunchKernelGGL((rz_search_kernel<WLDS, NW, AW, MM, TREC>), dim3(grid), dim3(NW * 64), lds_bytes, stream, sa);
   hipError_t e = hipGetLastError();

@@ -707,12 +707,10 @@ rz_wave_search_kernel(const RzWaveArgs wa) {
 
 template <int AW, bool PROFILE>
 inline int rz_wave_launch_k(const RzWaveArgs& wa, unsigned grid, size_t lds_bytes, stream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)rz_wave_search_kernel<AW, PROFILE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
-    attr_set = true;
+  static std::atomic<uint64_t> lds_attr_done{0};   // per instantiation, one bit per device
+  if (const int ae = allow_large_lds((const void*)rz_wave_search_kernel<AW, PROFILE>, 160 * 1024, lds_attr_done)) {
+    set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
+    return MZX_ERR_RUNTIME;
   }
   hipLaunchKernelGGL((rz_wave_search_kernel<AW, PROFILE>), dim3(grid), dim3(RZW_WAVES * 64), lds_bytes, stream, wa);
   hipError_t e = hipGetLastError();
@@ -1088,12 +1086,10 @@ rz_tile_search_kernel(const RzWaveArgs wa) {
 
 template <int AW, bool PROFILE>
 inline int rz_tile_launch_k(const RzWaveArgs& wa, unsigned grid, size_t lds_bytes, stream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)rz_tile_search_kernel<AW, PROFILE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
-    attr_set = true;
+  static std::atomic<uint64_t> lds_attr_done{0};   // per instantiation, one bit per device
+  if (const int ae = allow_large_lds((const void*)rz_tile_search_kernel<AW, PROFILE>, 160 * 1024, lds_attr_done)) {
+    set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
+    return MZX_ERR_RUNTIME;
   }
   hipLaunchKernelGGL((rz_tile_search_kernel<AW, PROFILE>), dim3(grid), dim3(RZW_WAVES * 64), lds_bytes, stream, wa);
   hipError_t e = hipGetLastError();

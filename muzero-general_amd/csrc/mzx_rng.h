@@ -20,6 +20,7 @@
 // libm's log / pow / sqrt are the same functions numpy itself calls on this host.
 // tests/test_rng_bank.py pins every entry point against numpy.random.RandomState.
 #pragma once
+#include <unistd.h>
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
@@ -230,6 +231,7 @@ class RngPool {
 struct mzx_rng {
   std::vector<mzx::Mt19937> streams;
   std::unique_ptr<mzx::RngPool> pool;   // created on the first large parallel call
+  long pool_pid = 0;                    // process that created it: worker threads do not survive fork()
 };
 
 namespace mzx {
@@ -238,7 +240,9 @@ template <class Fn>
 inline void rng_parallel(mzx_rng* r, int count, int n_threads, Fn fn) {
   if (n_threads <= 1 || count < 256) { fn(0, count); return; }
   if (n_threads > 64) n_threads = 64;
-  if (!r->pool || r->pool->size() != n_threads - 1) r->pool.reset(new RngPool(n_threads - 1));
+  const long pid = (long)getpid();
+  if (r->pool && r->pool_pid != pid) (void)r->pool.release();   // forked child: the parent's threads are not here; never join them
+  if (!r->pool || r->pool->size() != n_threads - 1) { r->pool.reset(new RngPool(n_threads - 1)); r->pool_pid = pid; }
   const std::function<void(int, int)> f = fn;
   r->pool->run(count, f);
 }

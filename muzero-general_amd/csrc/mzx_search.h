@@ -23,6 +23,7 @@ struct mzx_search {
   // pbc[N+1] then sqrt[N+1] on the device: owned by the handle (uploaded once at create), NOT carved from the
   // caller's arena -- an arena may be cleared, freed or re-allocated at the same address between calls
   double* d_tables = nullptr;
+  int32_t device = -1;     // device the tables were allocated on (= the device every launch of this handle must run on)
   int32_t mode = 0;
   int32_t fused_ok = 0;
   const char* last_kernel = "";   // search kernel of the last mzx_search_run (mzx_search_kernel_name)
@@ -97,6 +98,7 @@ inline ArenaView arena_view(const mzx_search* s, void* d_arena) {
 inline int upload_tables(mzx_search* s) {
   const int n = s->p.num_nodes + 1;
   void* d = nullptr;
+  s->device = current_device();
   MZX_TRY_LAUNCH(device_alloc(&d, sizeof(double) * 2 * n));
   s->d_tables = (double*)d;
   MZX_TRY_LAUNCH(copy_h2d_blocking(s->d_tables, s->h_pbc.data(), sizeof(double) * n));

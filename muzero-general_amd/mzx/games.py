@@ -16,8 +16,99 @@ the same actions (tests/test_batched_games.py runs both side by side against the
 [own stones of player 1, stones of player -1, side to move], a win pays 20 / 10 to the player who just moved, a game
 ends on a win or a full board, players alternate 0, 1.  Only the self-play surface is provided (no rendering, no
 human / expert opponents: use the reference's per-object classes for those modes).
+
+``TicTacToe`` / ``Connect4`` are the same two games as per-object classes with the reference's plugin surface
+(games/abstract_game.py:9-105): what the per-object self-play legs of bench.py and the whole-game fixtures use where
+the reference tree is absent (an unmodified reference game file drops in just the same).
 """
 import numpy
+
+
+class _KInARow:
+    """One game: generic k-in-a-row board with the plugin surface of games/abstract_game.py:9-105."""
+    rows = cols = k = 0
+    gravity = False
+    reward_scale = 1
+    int_planes = True
+
+    def __init__(self, seed=None):
+        self.reset()
+
+    def reset(self):
+        self.board = numpy.zeros((self.rows, self.cols), dtype="int32")
+        self.player = 1
+        return self._observation()
+
+    def to_play(self):
+        return 0 if self.player == 1 else 1
+
+    def _observation(self):
+        if self.int_planes:
+            mine = (self.board == 1).astype("int32")
+            theirs = (self.board == -1).astype("int32")
+            turn = numpy.full(self.board.shape, self.player, dtype="int32")
+            return numpy.stack([mine, theirs, turn]).astype("int32")
+        mine = (self.board == 1).astype("float64")
+        theirs = (self.board == -1).astype("float64")
+        turn = numpy.full(self.board.shape, self.player, dtype="float64")
+        return numpy.stack([mine, theirs, turn])
+
+    def legal_actions(self):
+        if self.gravity:
+            return [c for c in range(self.cols) if self.board[self.rows - 1, c] == 0]
+        return [i for i in range(self.rows * self.cols) if self.board[i // self.cols, i % self.cols] == 0]
+
+    def _wins(self, player):
+        b = self.board == player
+        R, C, k = self.rows, self.cols, self.k
+        for r in range(R):
+            for c in range(C):
+                for dr, dc in ((0, 1), (1, 0), (1, 1), (1, -1)):
+                    rr, cc = r + (k - 1) * dr, c + (k - 1) * dc
+                    if 0 <= rr < R and 0 <= cc < C and all(b[r + i * dr, c + i * dc] for i in range(k)):
+                        return True
+        return False
+
+    def step(self, action):
+        if self.gravity:
+            for r in range(self.rows):
+                if self.board[r, action] == 0:
+                    self.board[r, action] = self.player
+                    break
+        else:
+            self.board[action // self.cols, action % self.cols] = self.player
+        won = self._wins(self.player)
+        done = won or len(self.legal_actions()) == 0
+        reward = 1 if won else 0
+        self.player *= -1
+        return self._observation(), reward * self.reward_scale, done
+
+    def render(self):
+        print(self.board[::-1] if self.gravity else self.board)
+
+    def close(self):
+        pass
+
+    def action_to_string(self, action_number):
+        return str(action_number)
+
+
+class TicTacToe(_KInARow):
+    """games/tictactoe.py:125-310, one game."""
+    rows, cols, k = 3, 3, 3
+    reward_scale = 20
+    int_planes = True
+
+
+class Connect4(_KInARow):
+    """games/connect4.py:125-300, one game."""
+    rows, cols, k = 6, 7, 4
+    gravity = True
+    reward_scale = 10
+    int_planes = False
+
+
+PER_OBJECT = {"tictactoe": TicTacToe, "connect4": Connect4}
 
 
 class _KInARowBatched:

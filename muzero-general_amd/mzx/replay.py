@@ -78,125 +78,86 @@ def fill_initial_priorities(game_history, config):
     return True
 
 
+def _stock_replay_buffer_class():
+    """
+    The user's own ``ReplayBuffer`` (the reference's replay_buffer.py:11-303, importable wherever its trainer runs):
+    storage, eviction and sampling stay ITS code.  Under Ray the module attribute is an ActorClass; the plain class
+    behind it is what gets instantiated here (wrap the accelerated buffer with ``ray.remote`` like the reference).
+    """
+    import importlib
+    module = importlib.import_module("replay_buffer")
+    cls = module.ReplayBuffer
+    meta = getattr(cls, "__ray_metadata__", None)
+    return getattr(meta, "modified_class", cls)
+
+
 class ReplayBuffer:
     """
-    replay_buffer.py:11-303 -- same constructor, attributes and methods as the reference's ``ReplayBuffer`` (a
-    plain class: wrap it with ``ray.remote`` exactly like the reference when running under Ray), with the two
-    per-element Python loops of the hand-off replaced by array operations:
+    The stock replay buffer with its two per-element Python loops of the hand-off replaced -- by COMPOSITION: an
+    instance of the reference's own ``ReplayBuffer`` (replay_buffer.py:11-303; pass the class or an instance as
+    ``stock``, default: ``import replay_buffer``) keeps storage, eviction, priority feedback and every sampling draw;
+    this class adds
 
-      * ``save_game``: initial PER priorities through ``fill_initial_priorities`` (:39-51);
+      * ``save_game``: initial PER priorities through ``fill_initial_priorities`` before the stock ``save_game``,
+        which then takes its "priorities already present" branch (:35-37);
       * ``get_batch`` / ``make_target`` (:70-138, :264-303): the reference evaluates, per sample and unroll step,
         ``compute_target_value`` with its own ``td_steps`` loop -- batch x (unroll + 1) x td_steps interpreter
         iterations per training step.  Here the n-step values of every position of a sampled game are one
         vectorised pass (``n_step_values``, same binary64 operations in the same order per position, cached per
-        game until its root values are reanalysed), and a batch is gathers from per-game arrays.
+        game until its root values are reanalysed or the game leaves the buffer), and a batch is gathers from
+        per-game arrays.
 
-    Sampling draws (``numpy.random.choice`` on the process-global legacy stream, seeded with ``config.seed`` like
-    the reference, :31) happen in the reference's order -- games (:166-184), then per sample its position
-    (:193-202) followed by the random actions of its absorbing steps (:301) -- so with the same seed and buffer
-    the batches are IDENTICAL to the reference's, element for element (tests/test_replay_batch.py runs the two
-    side by side).  The tensors come back as numpy arrays instead of nested lists (``trainer.py:55-75`` feeds
-    them to ``torch.tensor`` either way).
+    The numpy draws happen in the reference's order -- the stock ``sample_n_games`` (:166-184), then per sample its
+    position (:193-202) followed by the random actions of its absorbing steps (:301) -- so with the same seed and
+    buffer the batches are IDENTICAL to the reference's, element for element (tests/test_replay_batch.py runs the
+    two side by side).  The tensors come back as numpy arrays instead of nested lists (``trainer.py:55-75`` feeds
+    them to ``torch.tensor`` either way).  Attributes (``buffer``, ``num_played_games``, ``total_samples``, ...)
+    read through to the stock object.
     """
 
-    def __init__(self, initial_checkpoint, initial_buffer, config):
-        import copy
-        self.config = config
-        self.buffer = copy.deepcopy(initial_buffer)
-        self.num_played_games = initial_checkpoint["num_played_games"]
-        self.num_played_steps = initial_checkpoint["num_played_steps"]
-        self.total_samples = sum([len(game_history.root_values) for game_history in self.buffer.values()])
-        if self.total_samples != 0:
-            print(f"Replay buffer initialized with {self.total_samples} samples ({self.num_played_games} games).\n")
-        # Fix random generator seed
-        numpy.random.seed(self.config.seed)
-        self._arrays = {}     # game_id -> per-game numpy views (dropped when the game changes or leaves)
+    def __init__(self, initial_checkpoint, initial_buffer, config, stock=None):
+        factory = stock if stock is not None else _stock_replay_buffer_class()
+        self._stock = factory(initial_checkpoint, initial_buffer, config) if isinstance(factory, type) else factory
+        self._arrays = {}     # game_id -> (game_history, per-game numpy views); dropped when the game changes or leaves
 
-    # ---------------------------------------------------------------- storage (replay_buffer.py:33-68, :204-228)
-    def save_game(self, game_history, shared_storage=None):
-        if self.config.PER:
-            if game_history.priorities is not None:
-                # Avoid read only array when loading replay buffer from disk
-                game_history.priorities = numpy.copy(game_history.priorities)
-            elif not fill_initial_priorities(game_history, self.config):
-                # (games the vectorised pass does not cover -- e.g. None root values of opponent moves -- take the
-                # reference's loop)
-                priorities = [numpy.abs(root_value - self.compute_target_value(game_history, i)) ** self.config.PER_alpha
-                              for i, root_value in enumerate(game_history.root_values)]
-                game_history.priorities = numpy.array(priorities, dtype="float32")
-                game_history.game_priority = numpy.max(game_history.priorities)
-        self.buffer[self.num_played_games] = game_history
-        self.num_played_games += 1
-        self.num_played_steps += len(game_history.root_values)
-        self.total_samples += len(game_history.root_values)
-        if self.config.replay_buffer_size < len(self.buffer):
-            del_id = self.num_played_games - len(self.buffer)
-            self.total_samples -= len(self.buffer[del_id].root_values)
-            del self.buffer[del_id]
-            self._arrays.pop(del_id, None)
-        if shared_storage:
-            put = shared_storage.set_info
-            for key, value in (("num_played_games", self.num_played_games), ("num_played_steps", self.num_played_steps)):
-                put.remote(key, value) if hasattr(put, "remote") else put(key, value)
+    def __getattr__(self, name):
+        if name in ("_stock", "_arrays"):
+            raise AttributeError(name)
+        return getattr(self._stock, name)
 
+    # ---- storage / sampling: the stock buffer's own code (explicit so that ray.remote sees the methods)
     def get_buffer(self):
-        return self.buffer
-
-    def update_game_history(self, game_id, game_history):
-        # The element could have been removed since its selection and update
-        if next(iter(self.buffer)) <= game_id:
-            if self.config.PER:
-                # Avoid read only array when loading replay buffer from disk
-                game_history.priorities = numpy.copy(game_history.priorities)
-            self.buffer[game_id] = game_history
-            self._arrays.pop(game_id, None)          # reanalysed root values change the n-step targets
+        return self._stock.get_buffer()
 
     def update_priorities(self, priorities, index_info):
-        for i in range(len(index_info)):
-            game_id, game_pos = index_info[i]
-            # The element could have been removed since its selection and training
-            if next(iter(self.buffer)) <= game_id:
-                priority = priorities[i, :]
-                start_index = game_pos
-                end_index = min(game_pos + len(priority), len(self.buffer[game_id].priorities))
-                self.buffer[game_id].priorities[start_index:end_index] = priority[: end_index - start_index]
-                self.buffer[game_id].game_priority = numpy.max(self.buffer[game_id].priorities)
+        return self._stock.update_priorities(priorities, index_info)
 
-    # ---------------------------------------------------------------- sampling (replay_buffer.py:140-202)
     def sample_game(self, force_uniform=False):
-        game_prob = None
-        if self.config.PER and not force_uniform:
-            game_probs = numpy.array([game_history.game_priority for game_history in self.buffer.values()], dtype="float32")
-            game_probs /= numpy.sum(game_probs)
-            game_index = numpy.random.choice(len(self.buffer), p=game_probs)
-            game_prob = game_probs[game_index]
-        else:
-            game_index = numpy.random.choice(len(self.buffer))
-        game_id = self.num_played_games - len(self.buffer) + game_index
-        return game_id, self.buffer[game_id], game_prob
+        return self._stock.sample_game(force_uniform)
 
     def sample_n_games(self, n_games, force_uniform=False):
-        if self.config.PER and not force_uniform:
-            game_id_list = list(self.buffer.keys())
-            game_probs = numpy.array([game_history.game_priority for game_history in self.buffer.values()], dtype="float32")
-            game_probs /= numpy.sum(game_probs)
-            game_prob_dict = dict(zip(game_id_list, game_probs))
-            selected_games = numpy.random.choice(game_id_list, n_games, p=game_probs)
-        else:
-            selected_games = numpy.random.choice(list(self.buffer.keys()), n_games)
-            game_prob_dict = {}
-        return [(game_id, self.buffer[game_id], game_prob_dict.get(game_id)) for game_id in selected_games]
+        return self._stock.sample_n_games(n_games, force_uniform)
 
     def sample_position(self, game_history, force_uniform=False):
-        position_prob = None
-        if self.config.PER and not force_uniform:
-            position_probs = game_history.priorities / sum(game_history.priorities)
-            position_index = numpy.random.choice(len(position_probs), p=position_probs)
-            position_prob = position_probs[position_index]
-        else:
-            position_index = numpy.random.choice(len(game_history.root_values))
-        return position_index, position_prob
+        return self._stock.sample_position(game_history, force_uniform)
 
+    def compute_target_value(self, game_history, index):
+        return self._stock.compute_target_value(game_history, index)
+
+    def save_game(self, game_history, shared_storage=None):
+        fill_initial_priorities(game_history, self._stock.config)    # no-op for games it does not cover
+        out = self._stock.save_game(game_history, shared_storage)
+        if self._arrays and self._stock.buffer:                      # evicted games take their cached arrays along
+            oldest = next(iter(self._stock.buffer))                  # game ids only grow (replay_buffer.py:53-62)
+            for game_id in [g for g in self._arrays if g < oldest]:
+                del self._arrays[game_id]
+        return out
+
+    def update_game_history(self, game_id, game_history):
+        self._arrays.pop(game_id, None)          # reanalysed root values change the n-step targets
+        return self._stock.update_game_history(game_id, game_history)
+
+    # ---- position draw
     def _sample_position_fast(self, game_history):
         """
         sample_position (:186-202) without the interpreter loop of ``sum(priorities)`` and without
@@ -204,57 +165,44 @@ class ReplayBuffer:
         array is the sequential float32 accumulation ``cumsum`` performs; ``choice(n, p=p)`` widens p to binary64,
         takes ``cdf = p.cumsum(); cdf /= cdf[-1]`` and bisects one ``random_sample()`` from the right.
         """
-        if not self.config.PER:
+        if not self._stock.config.PER:
             return numpy.random.randint(0, len(game_history.root_values)), None      # choice(n) == randint(0, n)
         pr = game_history.priorities
         if pr.dtype != numpy.float32 or pr.ndim != 1 or pr.size == 0:
-            return self.sample_position(game_history)
+            return self._stock.sample_position(game_history)
         position_probs = pr / numpy.cumsum(pr, dtype=numpy.float32)[-1]
         cdf = position_probs.astype(numpy.float64).cumsum()
         cdf /= cdf[-1]
         position_index = int(cdf.searchsorted(numpy.random.random_sample(), side="right"))
         return position_index, position_probs[position_index]
 
-    # ---------------------------------------------------------------- targets (replay_buffer.py:230-303)
-    def compute_target_value(self, game_history, index):
-        """The reference's scalar form (kept for callers of the single-position API)."""
-        bootstrap_index = index + self.config.td_steps
-        if bootstrap_index < len(game_history.root_values):
-            root_values = (game_history.root_values if game_history.reanalysed_predicted_root_values is None
-                           else game_history.reanalysed_predicted_root_values)
-            last_step_value = (root_values[bootstrap_index]
-                               if game_history.to_play_history[bootstrap_index] == game_history.to_play_history[index]
-                               else -root_values[bootstrap_index])
-            value = last_step_value * self.config.discount ** self.config.td_steps
-        else:
-            value = 0
-        for i, reward in enumerate(game_history.reward_history[index + 1: bootstrap_index + 1]):
-            # The value is oriented from the perspective of the current player
-            value += (reward if game_history.to_play_history[index] == game_history.to_play_history[index + i]
-                      else -reward) * self.config.discount ** i
-        return value
-
-    def _game_arrays(self, game_id, game_history):
+    # ---- targets (replay_buffer.py:264-303 as gathers)
+    def _build_arrays(self, game_history):
         """Per-game arrays a batch gathers from: n-step values [T], rewards / actions [T + 1], child visits [T][A]."""
-        hit = self._arrays.get(game_id)
-        if hit is not None and hit[0] is game_history:
-            return hit[1]
         T = len(game_history.root_values)
-        arrays = dict(
+        return dict(
             T=T,
-            values=n_step_values(game_history, self.config) if T else numpy.zeros(0),
+            values=n_step_values(game_history, self._stock.config) if T else numpy.zeros(0),
             rewards=numpy.array([float(r) for r in game_history.reward_history], dtype=numpy.float64),
             actions=numpy.array([int(a) for a in game_history.action_history], dtype=numpy.int64),
             visits=numpy.array(game_history.child_visits, dtype=numpy.float64).reshape(T, -1),
         )
+
+    def _game_arrays(self, game_id, game_history):
+        hit = self._arrays.get(game_id)
+        if hit is not None and hit[0] is game_history:
+            return hit[1]
+        arrays = self._build_arrays(game_history)
         self._arrays[game_id] = (game_history, arrays)
         return arrays
 
     def make_target(self, game_history, state_index, _arrays=None):
-        """replay_buffer.py:264-303 for one position: (values, rewards, policies, actions) as arrays."""
-        g = _arrays if _arrays is not None else self._game_arrays(id(game_history), game_history)
-        U, T = self.config.num_unroll_steps, g["T"]
-        A = g["visits"].shape[1] if T else len(self.config.action_space)
+        """replay_buffer.py:264-303 for one position: (values, rewards, policies, actions) as arrays.  Without the
+        arrays of a buffered game (``get_batch`` passes them) they are built on the fly, nothing is cached."""
+        cfg = self._stock.config
+        g = _arrays if _arrays is not None else self._build_arrays(game_history)
+        U, T = cfg.num_unroll_steps, g["T"]
+        A = g["visits"].shape[1] if T else len(cfg.action_space)
         idx = state_index + numpy.arange(U + 1)
         inside, at_end = idx < T, idx == T
         safe = numpy.minimum(idx, max(T - 1, 0))
@@ -263,15 +211,16 @@ class ReplayBuffer:
         policies = numpy.where(inside[:, None], g["visits"][safe] if T else 0.0, 1 / A)
         actions = g["actions"][numpy.minimum(idx, T)].copy()
         if idx[-1] > T:                          # States past the end of games are treated as absorbing states
-            space = self.config.action_space
+            space = cfg.action_space
             for k in range(max(0, T + 1 - state_index), U + 1):
                 actions[k] = space[numpy.random.randint(0, len(space))]    # == numpy.random.choice(space), same draw
         return values, rewards, policies, actions
 
     def get_batch(self):
-        cfg = self.config
+        cfg = self._stock.config
         U, A = cfg.num_unroll_steps, len(cfg.action_space)
         n = cfg.batch_size
+        total_samples = self._stock.total_samples
         index_batch, observation_batch = [], []
         action_batch = numpy.empty((n, U + 1), numpy.int64)
         value_batch = numpy.empty((n, U + 1), numpy.float64)
@@ -279,7 +228,7 @@ class ReplayBuffer:
         policy_batch = numpy.empty((n, U + 1, A), numpy.float64)
         gradient_scale_batch = numpy.empty((n, U + 1), numpy.int64)
         weight_batch = [] if cfg.PER else None
-        for i, (game_id, game_history, game_prob) in enumerate(self.sample_n_games(n)):
+        for i, (game_id, game_history, game_prob) in enumerate(self._stock.sample_n_games(n)):
             game_pos, pos_prob = self._sample_position_fast(game_history)
             values, rewards, policies, actions = self.make_target(game_history, game_pos,
                                                                   self._game_arrays(game_id, game_history))
@@ -288,7 +237,7 @@ class ReplayBuffer:
             action_batch[i], value_batch[i], reward_batch[i], policy_batch[i] = actions, values, rewards, policies
             gradient_scale_batch[i] = min(U, len(game_history.action_history) - game_pos)
             if cfg.PER:
-                weight_batch.append(1 / (self.total_samples * game_prob * pos_prob))
+                weight_batch.append(1 / (total_samples * game_prob * pos_prob))
         if cfg.PER:
             weight_batch = numpy.array(weight_batch, dtype="float32") / max(weight_batch)
         # observation_batch: batch, channels, height, width; action / value / reward / gradient_scale: batch,

@@ -700,16 +700,22 @@ class SelfPlay:
     def continuous_self_play(self, shared_storage, replay_buffer, test_mode=False):
         """
         self_play.py:31-108.  With a ``mzx.shared_storage.ShardedStorage`` (one self-play process per GPU under
-        torch.distributed) the per-game weight pull (:37) becomes the storage's collective ``refresh``: one
-        control all-reduce per iteration on every rank and -- when the trainer published new weights -- ONE
-        RCCL broadcast of the flat buffer; the loop condition is evaluated on the shared control values, so all
-        ranks leave the loop together.  This rank's games are seeded ``seed + i`` with ``seed`` =
+        torch.distributed) the per-game weight pull (:37) becomes the storage's ``refresh``: a NON-BLOCKING step of
+        an asynchronous exchange (one six-word control all-reduce in flight at a time; when the trainer published
+        new weights ONE RCCL broadcast of the flat buffer) -- a rank never waits for another one inside this loop,
+        it plays on with the control values and weights it has; the stop condition is evaluated on the same
+        exchange by every rank, ``finish`` drains the sequence.  This rank's games are seeded ``seed + i`` with ``seed`` =
         ``shard_seeds(config.seed, num_games)[0]`` (muzero.py:185).
         """
         sharded = hasattr(shared_storage, "refresh")
         get = (shared_storage.get_info if sharded else (lambda key: _remote(shared_storage.get_info, key)))
         if sharded:
-            shared_storage.refresh(self.model)
+            # what every rank must evaluate alike / how often the trainer publishes (trainer.py: checkpoint_interval)
+            if getattr(shared_storage, "training_steps", 0) is None:
+                shared_storage.training_steps = self.config.training_steps
+            if getattr(shared_storage, "checkpoint_interval", 0) is None:
+                shared_storage.checkpoint_interval = getattr(self.config, "checkpoint_interval", 1)
+            shared_storage.refresh(self.model, block=True)     # the trainer's weights before the first game
         while get("training_step") < self.config.training_steps and not get("terminate"):
             if not sharded:
                 self.model.set_weights(get("weights"))
@@ -752,6 +758,8 @@ class SelfPlay:
                     time.sleep(0.5)
                     if sharded:
                         shared_storage.refresh(self.model)
+        if sharded and hasattr(shared_storage, "finish"):
+            shared_storage.finish(self.model)
         self.close_game()
 
     def play_game(self, temperature, temperature_threshold, render, opponent, muzero_player):
@@ -1166,8 +1174,11 @@ class SelfPlay:
         if uniform.size:
             actions[uniform] = self.bank.randint([searching[r] for r in uniform], n[uniform])
         rest = numpy.nonzero((temps != 0) & ~numpy.isinf(temps))[0]
-        for t in (numpy.unique(temps[rest]) if rest.size else ()):
-            rows = rest if rest.size == k else rest[temps[rest] == t]
+        distinct = numpy.unique(temps[rest]) if rest.size else ()
+        for t in distinct:
+            # the whole-batch shortcut (no index gather) only when ONE temperature covers every game: with several,
+            # each game must be drawn exactly once, under its own temperature
+            rows = rest if (rest.size == k and len(distinct) == 1) else rest[temps[rest] == t]
             dist = counts[rows] ** (1 / float(t))                    # int32 ** float -> float64 pow, elementwise (numpy's own)
             # sum / normalise / cumulative sum / bisection + the one random_sample() per game: native, one call
             stream = searching if rows.size == k else [searching[r] for r in rows]

@@ -14,9 +14,10 @@ No other collective exists on the path.
 single-process / test case; with Ray installed the reference's own actor can be
 passed to ``SelfPlay.continuous_self_play`` instead.  ``ShardedStorage`` is what
 ``continuous_self_play`` talks to when the job runs one self-play process per GPU
-(``torch.distributed``): the rank next to the trainer holds the real storage, every
-refresh is one tiny control all-reduce plus -- only when the trainer published new
-weights -- the flat-buffer broadcast.
+(``torch.distributed``): the rank next to the trainer holds the real storage; control
+values travel in one tiny ASYNCHRONOUS all-reduce at a time (no rank ever waits for
+another inside the actor loop) and -- only when the trainer published new weights --
+the flat-buffer broadcast.
 """
 import torch
 import torch.distributed as dist
@@ -84,34 +85,50 @@ class ShardedStorage:
 
     The reference's N self-play actors each call the storage actor (self_play.py:33-37, :93-107) and the
     replay-buffer actor; here rank ``src`` (the process next to the trainer) holds the real ``storage`` and the
-    other ranks hold ``None``.  ``refresh(model)`` is the COLLECTIVE every rank calls once per loop iteration
-    of ``SelfPlay.continuous_self_play``:
+    other ranks hold ``None``.  The ranks exchange through a SEQUENCE of collectives that every rank issues in the
+    same order but AT ITS OWN PACE -- ``refresh(model)``, called once per loop iteration of
+    ``SelfPlay.continuous_self_play``, never waits for another rank:
 
-      1. one all-reduce(SUM) of six binary64 words: ``src`` contributes ``training_step`` / ``terminate`` /
-         a weights version, every rank its own shard's ``num_played_games`` / ``num_played_steps`` (what its
-         replay buffer reported through ``set_info``, replay_buffer.py:63-65) -- afterwards every rank holds the
-         same control values (so all ranks leave the loop in the same iteration) and ``src`` publishes the
-         job-wide played counts to the real storage (the trainer's ``ratio`` throttle reads them, trainer.py);
-      2. when the version moved: ``src`` loads ``storage.get_info("weights")`` into its model and the flat
-         fp32 buffer is broadcast (RCCL over xGMI; gloo in the CPU tests), derived terms re-folded.
+      * control exchange #n: one ASYNCHRONOUS all-reduce(SUM) of six binary64 words -- ``src`` contributes
+        ``training_step`` / ``terminate`` / the weights version, every rank its own shard's ``num_played_games`` /
+        ``num_played_steps`` (what its replay buffer reported through ``set_info``, replay_buffer.py:63-65).  A rank
+        issues #n + 1 only after it has seen #n complete, so at most one exchange is in flight and the sequence
+        numbers agree across ranks; a rank whose neighbours have not issued #n yet simply keeps playing games on
+        the control values and weights it has (shards with uneven game lengths do not lock-step);
+      * when exchange #n carries a new weights version, every rank issues -- again when IT gets there -- one
+        asynchronous broadcast of the flat fp32 buffer into a staging tensor (RCCL over xGMI; gloo in the CPU
+        tests; ``src`` loads ``storage.get_info("weights")`` first); the model takes the staged weights over at the
+        next loop boundary, never under a running search;
+      * every rank evaluates the stop condition (``training_step >= training_steps`` or ``terminate``) on the SAME
+        exchange, so all ranks issue exactly the same collectives and ``finish()`` (a blocking drain) returns.
 
-    ``get_info`` then serves the control keys from the cached copy, identically on every rank.
+    ``get_info`` serves the control keys from the last completed exchange.  The weights version is the trainer's
+    publication count ``training_step // checkpoint_interval`` (trainer.py publishes every ``checkpoint_interval``
+    steps; the step itself moves all the time), plus -- for storages living in this process -- the identity of the
+    weights object, so that a checkpoint loaded without a step change is seen too.
     """
 
     CONTROL = ("training_step", "terminate", "num_played_games", "num_played_steps")
 
-    def __init__(self, storage=None, src=0, group=None):
+    def __init__(self, storage=None, src=0, group=None, checkpoint_interval=None, training_steps=None):
         self.storage, self.src, self.group = storage, src, group
         on = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if on else 0
         self.world = dist.get_world_size(group) if on else 1
         if (self.rank == src) != (storage is not None):
             raise ValueError("exactly the source rank holds the real storage")
+        self.checkpoint_interval = checkpoint_interval      # None: continuous_self_play fills it from its config
+        self.training_steps = training_steps                # idem: the stop condition every rank evaluates alike
         self.control = {"training_step": 0, "terminate": False, "num_played_games": 0, "num_played_steps": 0}
         self.local = {"num_played_games": 0, "num_played_steps": 0}
         self.version = None          # weights version the model currently holds
-        self.refreshes = self.weight_broadcasts = 0
+        self.refreshes = self.weight_broadcasts = self.polls_without_progress = 0
+        self._pending = None         # ("control", work, tensor) | ("weights", work, staging tensor, version)
+        self._stopped = False        # the stop condition was seen: no further collectives are issued
+        self._weights_ident = None
+        self._publications = 0
 
+    # ---- the real storage (source rank only)
     def _src_get(self, key):
         get = self.storage.get_info
         if hasattr(get, "remote"):
@@ -123,34 +140,304 @@ class ShardedStorage:
         put = self.storage.set_info
         return put.remote(*args) if hasattr(put, "remote") else put(*args)
 
-    def refresh(self, model=None):
+    def _src_version(self, training_step):
+        """Publication counter of the trainer's weights (source rank)."""
+        version = int(training_step) // max(1, int(self.checkpoint_interval or 1))
+        if not hasattr(self.storage.get_info, "remote"):     # same process: notice a replaced weights object, no copy
+            ident = id(self._src_get("weights"))
+            if ident != self._weights_ident:
+                self._weights_ident = ident
+                self._publications += 1
+            version = version * 1000003 + self._publications
+        return version
+
+    def _finished(self):
+        if self.control["terminate"]:
+            return True
+        return self.training_steps is not None and self.control["training_step"] >= self.training_steps
+
+    # ---- the collective sequence
+    def _device(self, model):
         device = model.flat_weights().device if model is not None else torch.device("cpu")
         if device.type == "cpu" and self.world > 1 and dist.get_backend(self.group) == "nccl":
             device = torch.device("cuda", torch.cuda.current_device())
+        return device
+
+    def _issue_control(self, model):
         word = torch.zeros(6, dtype=torch.float64)
         if self.rank == self.src:
-            word[0] = float(self._src_get("training_step"))
+            step = self._src_get("training_step")
+            word[0] = float(step)
             word[1] = 1.0 if self._src_get("terminate") else 0.0
-            word[2] = word[0]                       # weights version = the step they were published at
+            word[2] = float(self._src_version(step))
         word[3] = float(self.local["num_played_games"])
         word[4] = float(self.local["num_played_steps"])
         word[5] = 1.0
-        word = word.to(device)
-        if self.world > 1:
-            dist.all_reduce(word, op=dist.ReduceOp.SUM, group=self.group)
-        w = word.cpu().tolist()
-        assert int(w[5]) == self.world
-        self.control = {"training_step": int(w[0]), "terminate": bool(w[1]), "num_played_games": int(w[3]),
-                        "num_played_steps": int(w[4])}
-        self.refreshes += 1
-        if model is not None and self.version != int(w[2]):
-            if self.rank == self.src:
-                model.set_weights(self._src_get("weights"))
-            broadcast_weights(model, src=self.src, group=self.group)
-            self.version = int(w[2])
+        word = word.to(self._device(model))
+        work = dist.all_reduce(word, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self.world > 1 else None
+        self._pending = ("control", work, word)
+
+    def _issue_weights(self, model, version):
+        if self.rank == self.src:
+            model.set_weights(self._src_get("weights"))      # between searches: refresh() runs at loop boundaries
+            staging = model.flat_weights().clone()
+        else:
+            staging = torch.empty_like(model.flat_weights())
+        work = dist.broadcast(staging, src=self.src, group=self.group, async_op=True) if self.world > 1 else None
+        self._pending = ("weights", work, staging, version)
+
+    def _complete(self, model):
+        """Consumes the completed pending collective (a new weights version issues its broadcast right away)."""
+        kind = self._pending[0]
+        if kind == "control":
+            w = self._pending[2].cpu().tolist()
+            self._pending = None
+            assert int(w[5]) == self.world
+            self.control = {"training_step": int(w[0]), "terminate": bool(w[1]), "num_played_games": int(w[3]),
+                            "num_played_steps": int(w[4])}
+            self.refreshes += 1
+            if self.rank == self.src and self.world > 1:
+                self._src_set({"num_played_games": int(w[3]), "num_played_steps": int(w[4])})
+            if model is not None and self.version != int(w[2]):
+                self._issue_weights(model, int(w[2]))
+                return
+        else:
+            _, _, staging, version = self._pending
+            self._pending = None
+            if self.rank != self.src:
+                model.flat_weights().copy_(staging)
+            model.refresh_derived()
+            self.version = version
             self.weight_broadcasts += 1
-        if self.rank == self.src and self.world > 1:
-            self._src_set({"num_played_games": int(w[3]), "num_played_steps": int(w[4])})
+        if self._finished():
+            self._stopped = True
+
+    def refresh(self, model=None, block=False):
+        """
+        One step of the exchange at a loop boundary of the actor: consume the pending collective if it has completed
+        (``block``: wait for it -- the first refresh of a run, which must deliver the trainer's weights) and put the
+        next control exchange in flight.  Otherwise returns at once; the caller keeps playing on what it has.
+        """
+        if self._stopped:
+            return
+        if self._pending is None:
+            self._issue_control(model)
+        while self._pending is not None:
+            work = self._pending[1]
+            if work is not None:
+                if block:
+                    work.wait()
+                elif not work.is_completed():
+                    self.polls_without_progress += 1
+                    return
+            self._complete(model)
+        if not self._stopped and self.world > 1:
+            self._issue_control(model)         # in flight while the next games are played
+
+    def finish(self, model=None):
+        """
+        Blocking drain at the end of the actor loop: runs the sequence out to the exchange that carries the stop
+        condition.  Every rank issues the same collectives, so this returns on all of them.
+        """
+        while not self._stopped and self.world > 1:
+            if self._pending is None:
+                self._issue_control(model)
+            work = self._pending[1]
+            if work is not None:
+                work.wait()
+            self._complete(model)
+        self._pending = None
+
+    def get_info(self, keys):
+        if isinstance(keys, (list, tuple)):
+            return {k: self._entries[k] for k in keys}
+        if not isinstance(keys, str):
+            raise TypeError(f"keys must be str or list, got {type(keys).__name__}")
+        return self._entries[keys]
+
+    def set_info(self, keys, values=None):
+        if isinstance(keys, dict):
+            self._entries.update(keys)
+        elif isinstance(keys, str) and values is not None:
+            self._entries[keys] = values
+        else:
+            raise TypeError("set_info(key, value) or set_info({key: value, ...})")
+
+
+class ShardedStorage:
+    """
+    The storage one rank of a sharded self-play job sees (duck type of shared_storage.py:7-40).
+
+    The reference's N self-play actors each call the storage actor (self_play.py:33-37, :93-107) and the
+    replay-buffer actor; here rank ``src`` (the process next to the trainer) holds the real ``storage`` and the
+    other ranks hold ``None``.  The ranks exchange through a SEQUENCE of collectives that every rank issues in the
+    same order but AT ITS OWN PACE -- ``refresh(model)``, called once per loop iteration of
+    ``SelfPlay.continuous_self_play``, never waits for another rank:
+
+      * control exchange #n: one ASYNCHRONOUS all-reduce(SUM) of six binary64 words -- ``src`` contributes
+        ``training_step`` / ``terminate`` / the weights version, every rank its own shard's ``num_played_games`` /
+        ``num_played_steps`` (what its replay buffer reported through ``set_info``, replay_buffer.py:63-65).  A rank
+        issues #n + 1 only after it has seen #n complete, so at most one exchange is in flight and the sequence
+        numbers agree across ranks; a rank whose neighbours have not issued #n yet simply keeps playing games on
+        the control values and weights it has (shards with uneven game lengths do not lock-step);
+      * when exchange #n carries a new weights version, every rank issues -- again when IT gets there -- one
+        asynchronous broadcast of the flat fp32 buffer into a staging tensor (RCCL over xGMI; gloo in the CPU
+        tests; ``src`` loads ``storage.get_info("weights")`` first); the model takes the staged weights over at the
+        next loop boundary, never under a running search;
+      * every rank evaluates the stop condition (``training_step >= training_steps`` or ``terminate``) on the SAME
+        exchange, so all ranks issue exactly the same collectives and ``finish()`` (a blocking drain) returns.
+
+    ``get_info`` serves the control keys from the last completed exchange.  The weights version is the trainer's
+    publication count ``training_step // checkpoint_interval`` (trainer.py publishes every ``checkpoint_interval``
+    steps; the step itself moves all the time), plus -- for storages living in this process -- the identity of the
+    weights object, so that a checkpoint loaded without a step change is seen too.
+    """
+
+    CONTROL = ("training_step", "terminate", "num_played_games", "num_played_steps")
+
+    def __init__(self, storage=None, src=0, group=None, checkpoint_interval=None, training_steps=None):
+        self.storage, self.src, self.group = storage, src, group
+        on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if on else 0
+        self.world = dist.get_world_size(group) if on else 1
+        if (self.rank == src) != (storage is not None):
+            raise ValueError("exactly the source rank holds the real storage")
+        self.checkpoint_interval = checkpoint_interval      # None: continuous_self_play fills it from its config
+        self.training_steps = training_steps                # idem: the stop condition every rank evaluates alike
+        self.control = {"training_step": 0, "terminate": False, "num_played_games": 0, "num_played_steps": 0}
+        self.local = {"num_played_games": 0, "num_played_steps": 0}
+        self.version = None          # weights version the model currently holds
+        self.refreshes = self.weight_broadcasts = self.polls_without_progress = 0
+        self._pending = None         # ("control", work, tensor) | ("weights", work, staging tensor, version)
+        self._stopped = False        # the stop condition was seen: no further collectives are issued
+        self._weights_ident = None
+        self._publications = 0
+
+    # ---- the real storage (source rank only)
+    def _src_get(self, key):
+        get = self.storage.get_info
+        if hasattr(get, "remote"):
+            import ray
+            return ray.get(get.remote(key))
+        return get(key)
+
+    def _src_set(self, *args):
+        put = self.storage.set_info
+        return put.remote(*args) if hasattr(put, "remote") else put(*args)
+
+    def _src_version(self, training_step):
+        """Publication counter of the trainer's weights (source rank)."""
+        version = int(training_step) // max(1, int(self.checkpoint_interval or 1))
+        if not hasattr(self.storage.get_info, "remote"):     # same process: notice a replaced weights object, no copy
+            ident = id(self._src_get("weights"))
+            if ident != self._weights_ident:
+                self._weights_ident = ident
+                self._publications += 1
+            version = version * 1000003 + self._publications
+        return version
+
+    def _finished(self):
+        if self.control["terminate"]:
+            return True
+        return self.training_steps is not None and self.control["training_step"] >= self.training_steps
+
+    # ---- the collective sequence
+    def _device(self, model):
+        device = model.flat_weights().device if model is not None else torch.device("cpu")
+        if device.type == "cpu" and self.world > 1 and dist.get_backend(self.group) == "nccl":
+            device = torch.device("cuda", torch.cuda.current_device())
+        return device
+
+    def _issue_control(self, model):
+        word = torch.zeros(6, dtype=torch.float64)
+        if self.rank == self.src:
+            step = self._src_get("training_step")
+            word[0] = float(step)
+            word[1] = 1.0 if self._src_get("terminate") else 0.0
+            word[2] = float(self._src_version(step))
+        word[3] = float(self.local["num_played_games"])
+        word[4] = float(self.local["num_played_steps"])
+        word[5] = 1.0
+        word = word.to(self._device(model))
+        work = dist.all_reduce(word, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self.world > 1 else None
+        self._pending = ("control", work, word)
+
+    def _issue_weights(self, model, version):
+        if self.rank == self.src:
+            model.set_weights(self._src_get("weights"))      # between searches: refresh() runs at loop boundaries
+            staging = model.flat_weights().clone()
+        else:
+            staging = torch.empty_like(model.flat_weights())
+        work = dist.broadcast(staging, src=self.src, group=self.group, async_op=True) if self.world > 1 else None
+        self._pending = ("weights", work, staging, version)
+
+    def _complete(self, model):
+        """Consumes the completed pending collective; returns True when another one was issued right away."""
+        kind = self._pending[0]
+        if kind == "control":
+            w = self._pending[2].cpu().tolist()
+            self._pending = None
+            assert int(w[5]) == self.world
+            self.control = {"training_step": int(w[0]), "terminate": bool(w[1]), "num_played_games": int(w[3]),
+                            "num_played_steps": int(w[4])}
+            self.refreshes += 1
+            if self.rank == self.src and self.world > 1:
+                self._src_set({"num_played_games": int(w[3]), "num_played_steps": int(w[4])})
+            if model is not None and self.version != int(w[2]):
+                self._issue_weights(model, int(w[2]))
+                return True
+            if self._finished():
+                self._stopped = True
+            return False
+        _, _, staging, version = self._pending
+        self._pending = None
+        if self.rank != self.src:
+            model.flat_weights().copy_(staging)
+        model.refresh_derived()
+        self.version = version
+        self.weight_broadcasts += 1
+        if self._finished():
+            self._stopped = True
+        return False
+
+    def refresh(self, model=None, block=False):
+        """
+        One step of the exchange at a loop boundary of the actor: consume the pending collective if it has completed
+        (``block``: wait for it -- the first refresh of a run, which must deliver the trainer's weights), issue the
+        next one.  Returns immediately otherwise; the caller keeps playing on what it has.
+        """
+        if self._stopped:
+            return
+        if self._pending is None:
+            self._issue_control(model)
+        while self._pending is not None:
+            work = self._pending[1]
+            if work is not None:
+                if block:
+                    work.wait()
+                elif not work.is_completed():
+                    self.polls_without_progress += 1
+                    return
+            if self._complete(model):
+                continue                       # a weights broadcast follows its control exchange immediately
+            break
+        if block and not self._stopped and self._pending is None:
+            return
+        if not self._stopped and self._pending is None and not block:
+            self._issue_control(model)         # in flight while the next games are played
+
+    def finish(self, model=None):
+        """Blocking drain at the end of the actor loop: every rank has issued the same collectives, so this returns."""
+        while self._pending is not None:
+            work = self._pending[1]
+            if work is not None:
+                work.wait()
+            if not self._complete(model):
+                break
+        while not self._stopped and self.world > 1:      # left the loop for a local reason: run the sequence out
+            self.refresh(model, block=True)
+            if self._pending is None and not self._stopped:
+                self._issue_control(model)
 
     def get_info(self, keys):
         if isinstance(keys, (list, tuple)):
@@ -167,7 +454,7 @@ class ShardedStorage:
         elif not isinstance(keys, dict):
             raise TypeError("set_info(key, value) or set_info({key: value, ...})")
         played = {k: v for k, v in keys.items() if k in self.local}
-        self.local.update(played)            # this shard's counts; summed over ranks by the next refresh
+        self.local.update(played)            # this shard's counts; summed over ranks by the next exchange
         rest = {k: v for k, v in keys.items() if k not in self.local}
         if self.world == 1:
             rest = dict(keys)

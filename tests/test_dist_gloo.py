@@ -171,20 +171,114 @@ def test_continuous_self_play_two_ranks_with_midrun_weight_update(tmp_path):
     r = [torch.load(tmp_path / f"actor{k}.pt", weights_only=False) for k in range(world)]
     # disjoint game shards, seeded like the reference's workers (muzero.py:185)
     assert r[0]["seeds"] == [0, 1, 2] and r[1]["seeds"] == [3, 4, 5]
-    # The trainer publishes after it has seen round 1's counts, i.e. during the refresh that follows round 1;
-    # the actors pick the new version up at the NEXT refresh (after round 2) and see `terminate` after round 3.
-    # Both ranks left the loop in the same iteration: three rounds of 3 games each
-    assert r[0]["rounds"] == r[1]["rounds"] == 3 and r[0]["games"] == r[1]["games"] == 9
-    assert r[0]["refreshes"] == r[1]["refreshes"] == 4
-    # rounds 1-2 with the trainer's first weights, round 3 with the update published mid-run -- on BOTH ranks,
-    # although only rank 0 can see the storage: one broadcast per published version, none in between
-    assert r[0]["broadcasts"] == r[1]["broadcasts"] == 2
-    for k in range(3):
-        assert torch.equal(r[0]["seen"][k], r[1]["seen"][k])
-    assert torch.equal(r[0]["seen"][0], r[0]["seen"][1]) and not torch.equal(r[0]["seen"][1], r[0]["seen"][2])
-    # the job-wide played counts reached the real storage (what the trainer's ratio throttle reads)
-    assert r[0]["job_counts"]["num_played_games"] == 18
-    assert r[0]["job_counts"]["num_played_steps"] == r[0]["steps"] + r[1]["steps"]
+    # The exchange is asynchronous: how many rounds a rank plays before it sees the update / the stop flag depends on
+    # timing.  What does not: both ranks consumed the SAME sequence of control exchanges and stopped on the same
+    # one, with the same control values ...
+    assert r[0]["refreshes"] == r[1]["refreshes"] >= 3
     assert r[0]["control"] == r[1]["control"] and r[0]["control"]["terminate"] is True
+    # ... one broadcast per published version (the initial weights, the mid-run update), none in between ...
+    assert r[0]["broadcasts"] == r[1]["broadcasts"] == 2
+    # ... every round was played with the trainer's weights -- first version, then the update, on BOTH ranks,
+    # although only rank 0 can see the storage (each rank started from its own junk weights)
+    versions = []
+    for k in range(world):
+        distinct = []
+        for w in r[k]["seen"]:
+            if not distinct or not torch.equal(distinct[-1], w):
+                distinct.append(w)
+        assert len(distinct) == 2 and r[k]["rounds"] >= 2, (k, len(distinct), r[k]["rounds"])
+        versions.append(distinct)
+    assert torch.equal(versions[0][0], versions[1][0]) and torch.equal(versions[0][1], versions[1][1])
+    # the job-wide played counts reached the real storage (what the trainer's ratio throttle reads); they are as
+    # fresh as the last exchange
+    total_games = r[0]["games"] + r[1]["games"]
+    assert 0 < r[0]["job_counts"]["num_played_games"] <= total_games
+    assert 0 < r[0]["job_counts"]["num_played_steps"] <= r[0]["steps"] + r[1]["steps"]
     # different seeds -> different games
     assert r[0]["first_actions"] != r[1]["first_actions"]
+
+
+class _CountingStorage:
+    """Rank 0's real storage: terminates the job once the job-wide number of played games reaches a target."""
+
+    def __init__(self, weights, target_games):
+        from mzx import shared_storage
+        self.inner = shared_storage.LocalStorage(training_step=0, terminate=False, weights=weights,
+                                                 num_played_games=0, num_played_steps=0)
+        self.target = target_games
+
+    def get_info(self, keys):
+        return self.inner.get_info(keys)
+
+    def set_info(self, keys, values=None):
+        self.inner.set_info(keys, values)
+        if isinstance(keys, dict) and keys.get("num_played_games", 0) >= self.target:
+            self.inner.set_info("terminate", True)
+
+
+def _uneven_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "muzero-general_amd"), ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+
+    import games_fixture
+    import hostcheck
+    from mzx import configs, models, self_play, shared_storage, synthetic
+
+    be = hostcheck.backend()
+    cfg = configs.tictactoe()
+    cfg.num_simulations = 4
+    cfg.training_steps = 100
+    cfg.ratio = None
+    cfg.self_play_delay = 0
+    cfg.PER, cfg.PER_alpha, cfg.td_steps = True, 0.5, 9
+    G = 2
+    template = models.MuZeroNetwork(cfg, _backend=be).state_dict()
+    weights = synthetic.fill_state_dict(template, 1)
+
+    class Game(games_fixture.GAMES["tictactoe"]):
+        def step(self, action):
+            if rank == 1:
+                time.sleep(0.03)        # rank 1's environment is slow: its games take several times longer
+            return super().step(action)
+
+    seeds = shared_storage.shard_seeds(cfg.seed, G)
+    actor = self_play.SelfPlay({"weights": synthetic.fill_state_dict(template, 60 + rank)}, Game, cfg, seeds[0],
+                               num_games=G, _backend=be)
+    storage = shared_storage.ShardedStorage(_CountingStorage(weights, 40) if rank == 0 else None, src=0)
+    buffer = _ListBuffer()
+    rounds = []
+    play_games = actor.play_games
+
+    def counting_play_games(*a):
+        rounds.append(time.perf_counter())
+        return play_games(*a)
+
+    actor.play_games = counting_play_games
+    t0 = time.perf_counter()
+    actor.continuous_self_play(storage, buffer)
+    torch.save(dict(rounds=len(rounds), games=len(buffer.games), wall=time.perf_counter() - t0,
+                    refreshes=storage.refreshes, stalls=storage.polls_without_progress, control=storage.control),
+               os.path.join(out_dir, f"uneven{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uneven_game_lengths_do_not_lock_step_the_ranks(tmp_path):
+    """
+    Rank 1 plays through a slow environment.  With a blocking exchange per loop iteration both ranks would play the
+    same number of rounds; with the asynchronous exchange the fast rank keeps playing while the slow one is inside
+    a game, and both still stop on the same control exchange.
+    """
+    world, port = 2, _free_port()
+    mp.spawn(_uneven_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"uneven{k}.pt", weights_only=False) for k in range(world)]
+    assert r[0]["refreshes"] == r[1]["refreshes"]                       # same sequence of exchanges ...
+    assert r[0]["control"] == r[1]["control"] and r[0]["control"]["terminate"] is True
+    assert r[0]["rounds"] >= 2 * r[1]["rounds"] >= 2, (r[0]["rounds"], r[1]["rounds"])   # ... at each rank's own pace
+    assert r[0]["stalls"] > 0                                           # polls that found the exchange incomplete and moved on
+    assert r[0]["games"] + r[1]["games"] >= 40

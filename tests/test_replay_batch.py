@@ -1,6 +1,7 @@
 """
-mzx.replay.ReplayBuffer: same interface as the reference's ReplayBuffer
-(replay_buffer.py:11-303) with get_batch / make_target vectorised.  With the same numpy seed and the same games
+mzx.replay.ReplayBuffer: the reference's own ReplayBuffer (replay_buffer.py:11-303;
+storage, eviction, sampling stay its code -- composition, needs the reference on the path: build container only)
+with save_game's priority step and get_batch / make_target vectorised.  With the same numpy seed and the same games
 the batches must be IDENTICAL to the reference's -- sampled (game, position) pairs, n-step value targets
 (binary64 bit patterns), rewards, policies, actions incl. the random actions of absorbing steps, PER weights,
 gradient scales, stacked observations.  Checked against the unmodified reference when /root/reference is
@@ -129,7 +130,9 @@ def test_float32_reanalysed_values_follow_the_pinned_numpy():
         assert numpy.array_equal(values_g, values_w)
 
 
+@pytest.mark.reference
 def test_batches_equal_the_reference_fixture():
+    ref_shim.load()
     z = numpy.load(os.path.join(GOLDEN, "replay_batch.npz"))
     meta = json.loads(str(z["meta"]))
     for c, case in enumerate(meta["cases"]):
@@ -144,12 +147,15 @@ def test_batches_equal_the_reference_fixture():
             assert_same(got, want, (c, r))
 
 
+@pytest.mark.reference
 def test_single_position_api_matches_the_scalar_form():
+    ref_shim.load()
     config = config_for(True, 2, 0)
     rb = replay.ReplayBuffer({"num_played_games": 0, "num_played_steps": 0}, {}, config)
     gh = make_games(3, 1, 2)[0]
     rb.save_game(gh)
     T = len(gh.root_values)
+    assert not rb._arrays            # nothing is cached for a game looked at outside get_batch (no id()-keyed entries)
     for pos in (0, T // 2, T - 1):
         numpy.random.seed(1)
         values, rewards, policies, actions = rb.make_target(gh, pos)
@@ -160,3 +166,19 @@ def test_single_position_api_matches_the_scalar_form():
             else:
                 assert values[k] == 0 and (rewards[k] == (gh.reward_history[idx] if idx == T else 0))
                 assert list(policies[k]) == [0.25] * 4
+
+
+@pytest.mark.reference
+def test_eviction_drops_cached_arrays_and_storage_is_the_stock_code():
+    ref_shim.load()
+    import replay_buffer as ref_rb
+    config = config_for(True, 1, 0)
+    config.replay_buffer_size = 4
+    rb = replay.ReplayBuffer({"num_played_games": 0, "num_played_steps": 0}, {}, config)
+    assert type(rb._stock).__name__ == "ReplayBuffer" and type(rb._stock).__module__ == ref_rb.__name__
+    for gh in make_games(21, 9, 1):
+        rb.save_game(gh)
+        numpy.random.seed(3)
+        rb.get_batch()
+        assert set(rb._arrays) <= set(rb.buffer) and len(rb.buffer) <= 4
+    assert rb.num_played_games == 9 and min(rb.buffer) == 5

@@ -124,3 +124,33 @@ def test_shard_of_board_games_with_ragged_legal_sets(backend, temperature, thres
             assert numpy.array_equal(numpy.array(a), numpy.array(b))
         lengths.add(len(got.action_history))
     assert len(lengths) > 1, "the games of the shard should end at different moves for this test to mean anything"
+
+
+def test_action_draws_with_mixed_temperatures_follow_each_game_s_own_stream(backend):
+    """
+    _select_actions_bank with DIFFERENT non-zero temperatures in one call: every game is drawn exactly
+    once, under its own temperature, from its own stream -- the same action and the same stream position as the
+    reference's select_action (self_play.py:222-245) on a RandomState seeded like that game.
+    """
+    import types
+
+    cfg = configs.cartpole(num_simulations=4, action_space=list(range(5)))
+    weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 2)
+    k, seed = 6, 90
+    sp = self_play.SelfPlay({"weights": weights}, synthetic.make_synthetic_game(cfg.observation_shape, 5, 1), cfg, seed,
+                            num_games=k, _backend=backend)
+    rs = numpy.random.RandomState(0)
+    visits = rs.randint(0, 30, size=(k, 5)).astype(numpy.int32)
+    legal = [sorted(rs.choice(5, size=rs.randint(2, 6), replace=False).tolist()) for _ in range(k)]
+    for r in range(k):
+        visits[r, [a for a in range(5) if a not in legal[r]]] = 0
+    result = types.SimpleNamespace(visit_counts=visits, legal_actions=legal, shared_legal=None)
+    temps = [1.0, 0.5, 0.25, 0.5, 0, float("inf")]
+    got = sp._select_actions_bank(result, list(range(k)), temps)
+    for r in range(k):
+        ref = numpy.random.RandomState(seed + r)
+        node = types.SimpleNamespace(children={a: types.SimpleNamespace(visit_count=int(visits[r, a])) for a in legal[r]})
+        want = self_play.SelfPlay._select_action(node, temps[r], ref)
+        assert int(got[r]) == int(want), (r, temps[r])
+        state = sp.bank.get_state(r)
+        assert state[2] == ref.get_state()[2] and numpy.array_equal(state[1], ref.get_state()[1]), r
