@@ -30,8 +30,10 @@ namespace mzx {
 // v_exp_f32(x * log2 e) -- two instructions instead of libm's fifteen; relative error <= ~|x| * 2^-24
 // (1e-6 at x = -16), far inside the 1e-4 contract on the heads.  The generic operators and the
 // whole-search kernels share it, so they stay bit-identical to each other on the device.
+// -DMZX_IEEE_MATH (A/B builds only, tools/build_ieee_variant.sh): libm expf and the IEEE division instead, to measure
+// what the fast forms cost in parity (profiles/r03_ieee_math_ab.txt).
 MZX_HD inline float mzx_expf(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MZX_IEEE_MATH)
   return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
 #else
   return expf(x);
@@ -40,7 +42,7 @@ MZX_HD inline float mzx_expf(float x) {
 // a / b where one ulp does not matter (soft-max normalisation, min-max scaling): device v_rcp_f32 + multiply
 // instead of the ten-instruction IEEE expansion.  NOT used by support_inverse_transform (cancellation).
 MZX_HD inline float mzx_div(float a, float b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MZX_IEEE_MATH)
   return a * __builtin_amdgcn_rcpf(b);
 #else
   return a / b;

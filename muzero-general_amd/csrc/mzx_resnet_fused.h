@@ -615,8 +615,11 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        if (ALT && (j & 1)) acc_odd[ALT ? i : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][j], bv[j], acc_odd[ALT ? i : 0], 0, 0, 0);
-        else acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][j], bv[j], acc[i], 0, 0, 0);
+        // weight fragment FIRST: the MFMA then leaves D transposed -- lane l holds row l & 15 of the tile and the four
+        // consecutive output channels 4 (l >> 4) .. + 3 (same products, same k order: the same bits), which is what
+        // the position-major LDS layout wants: one 16-byte residual read and one 16-byte store per lane and tile
+        if (ALT && (j & 1)) acc_odd[ALT ? i : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i][j], acc_odd[ALT ? i : 0], 0, 0, 0);
+        else acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i][j], acc[i], 0, 0, 0);
       }
   };
   auto load_a = [&](int off, f32x4 (&av)[MT]) {
@@ -639,28 +642,28 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
   // an odd chunk count is stored with one trailing zero chunk; prefetches beyond it re-read the last chunk
   const int wlast = op.wchunks - 1;
   auto load_b = [&](int c, f32x4& bv) { bv = wp[(size_t)(c < wlast ? c : wlast) * 64]; };
-  // Small tile counts (latency-bound layers of small networks): fetch everything the epilogue needs that
-  // does not depend on the accumulators -- row addresses and the residual -- BEFORE the K loop, so that
-  // these LDS round trips hide under the MFMAs instead of following them.
-  constexpr bool EARLY = (MT <= 2);
-  const int n = nt * 16 + (lane & 15);
+  // Fetch everything the epilogue needs that does not depend on the accumulators -- the lane's row address and its
+  // residual quad -- BEFORE the K loop, so that these LDS round trips hide under the MFMAs instead of following them
+  // (six registers per tile: up to four row tiles in the 4-wave kernels; the 8-wave kernels sit at the 256-register
+  // limit of two waves per SIMD and prefetch for at most two).
+  constexpr bool EARLY = TBL ? (MT <= 4) : (MT <= 2);
+  const int m_lane = lane & 15;
+  const int n0 = nt * 16 + 4 * (lane >> 4);          // this lane's four output channels n0 .. n0 + 3
   const int* rowo = cx.rowout ? cx.rowout : cx.rowaddr;
   const bool padded = (op.out_layout == RZ_OUT_PADDED);
   const bool need_tp = pos_rows && (!padded || op.asum_off >= 0);
-  const float* res = (op.res_off >= 0) ? cx.reg + T * op.res_off : nullptr;
-  i32x4 e_ra[EARLY ? MT : 1], e_tp[EARLY ? MT : 1];
-  float e_rs[EARLY ? MT : 1][4];
+  const float* res = (op.res_off >= 0) ? cx.reg + T * op.res_off : nullptr;   // padded layout: row address + channel
+  int e_ra[EARLY ? MT : 1], e_tp[EARLY ? MT : 1];
+  f32x4 e_rs[EARLY ? MT : 1];
   if (EARLY) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int m0 = (mt0 + i * mt_step) * 16 + (lane >> 4) * 4;
-      e_ra[i] = pos_rows ? *(const i32x4*)(rowo + m0) : i32x4{0, 0, 0, 0};
-      e_tp[i] = need_tp ? *(const i32x4*)(cx.rowtp + m0) : i32x4{0, 0, 0, 0};
+      const int m = (mt0 + i * mt_step) * 16 + m_lane;
+      e_ra[i] = pos_rows ? rowo[m] : 0;
+      e_tp[i] = need_tp ? cx.rowtp[m] : 0;
     }
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) e_rs[i][r] = res ? res[e_ra[i][r] + n] : 0.f;
+    for (int i = 0; i < MT; ++i) e_rs[i] = res ? *(const f32x4*)(res + e_ra[i] + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   RZ_FINE(2)
   if (!RZ_DBG(a, 1)) {
@@ -736,67 +739,66 @@ __device__ __forceinline__ void rz_gemm_tiles(const RzOp& op, const RzArgs& a, c
   }
   RZ_FINE(3)
   if (RZ_DBG(a, 2)) return;
-  // ---- epilogue: every per-layer variation (BatchNorm or not, bias or not, residual or not, ReLU or not,
-  // output layout) is turned into DATA before the element loop (identity scale / zero bias / -inf floor /
-  // base + stride addressing), so the loop body is straight-line code: no branch per element
-  const bool nv = n < op.cout;
-  float al = 1.f, be = 0.f, bi = 0.f;
-  if (op.alpha_off >= 0) { al = cx.simg[op.alpha_off + n]; be = cx.simg[op.beta_off + n]; }   // padded to whole tiles
-  if (op.bias_off >= 0) bi = cx.simg[op.bias_off + n];
+  // ---- epilogue: every per-layer variation (BatchNorm or not, bias or not, residual or not, ReLU or not) is turned
+  // into DATA before the element loop (identity scale / zero bias / -inf floor), so the loop body is straight-line
+  // code.  Lane l owns row m_lane of every tile and channels n0 .. n0 + 3 (the epilogue parameters are padded to
+  // whole column tiles, channel rows of an activation slot to Cs >= 16 c + 8 floats: the quads are always readable).
+  __builtin_amdgcn_sched_barrier(0);   // the parameter reads stay behind the K loop (its registers are all in use)
+  float al[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+  if (op.alpha_off >= 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { al[u] = cx.simg[op.alpha_off + n0 + u]; be[u] = cx.simg[op.beta_off + n0 + u]; }
+  }
+  if (op.bias_off >= 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bi[u] = cx.simg[op.bias_off + n0 + u];
+  }
   const float floor_v = (op.act == RZ_ACT_RELU) ? 0.f : -MZX_INF;
   float* out = cx.reg + T * op.out_off;
   const float* actval = cx.scratch + 2 * T * a.Cs;
   const int nstride = (!padded && pos_rows) ? a.HW : 1;       // address step per output channel
+  const bool quad_ok = n0 + 3 < op.cout;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    // this lane's four rows are consecutive and 4-aligned: one 16-byte read per table (tables are padded
-    // to whole tiles; rows beyond the matrix hold a valid dummy address and are masked at the store)
-    const int m0 = (mt0 + i * mt_step) * 16 + (lane >> 4) * 4;
-    i32x4 ra4 = i32x4{0, 0, 0, 0}, tp4 = i32x4{0, 0, 0, 0};
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    const int m = (mt0 + i * mt_step) * 16 + m_lane;
+    int ra = 0, tp = 0;
+    f32x4 rs = f32x4{0.f, 0.f, 0.f, 0.f};
     if (EARLY) {
-      ra4 = e_ra[i]; tp4 = e_tp[i];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) rs[r] = e_rs[i][r];
+      ra = e_ra[i]; tp = e_tp[i]; rs = e_rs[i];
     } else {
-      if (pos_rows) ra4 = *(const i32x4*)(rowo + m0);
-      if (need_tp) tp4 = *(const i32x4*)(cx.rowtp + m0);
+      if (pos_rows) ra = rowo[m];
+      if (need_tp) tp = cx.rowtp[m];
+      if (res) rs = *(const f32x4*)(res + ra + n0);
     }
-    int base[4];
-    if (padded) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) base[r] = ra4[r];
-    } else if (pos_rows) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) base[r] = (tp4[r] >> 16) * op.out_tstride + (tp4[r] & 0xFFFF);
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) base[r] = (m0 + r) * op.out_tstride;
-    }
-    if (!EARLY && res) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) rs[r] = res[ra4[r] + n];
-    }
+    int base;
+    if (padded) base = ra;
+    else if (pos_rows) base = (tp >> 16) * op.out_tstride + (tp & 0xFFFF);
+    else base = m * op.out_tstride;
     if (op.asum_off >= 0) {   // action plane of the dynamics input (first layer only)
+      const float av = actval[tp >> 16];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[i][r] += actval[tp4[r] >> 16] * cx.simg[op.asum_off + n * a.HW + (tp4[r] & 0xFFFF)];
+      for (int u = 0; u < 4; ++u) acc[i][u] += av * cx.simg[op.asum_off + (n0 + u) * a.HW + (tp & 0xFFFF)];
     }
-    float v[4];
+    f32x4 v;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float x = acc[i][r] * al + be;
-      x = x + bi;
-      x = x + rs[r];
-      v[r] = fmaxf(x, floor_v);
+    for (int u = 0; u < 4; ++u) {
+      float x = acc[i][u] * al[u] + be[u];
+      x = x + bi[u];
+      x = x + rs[u];
+      v[u] = fmaxf(x, floor_v);
     }
     if (op.act == RZ_ACT_ELU) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = mzx_elu(v[r]);
+      for (int u = 0; u < 4; ++u) v[u] = mzx_elu(v[u]);
     }
+    if (m < rows) {
+      if (padded && quad_ok) *(f32x4*)(out + base + n0) = v;
+      else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (m0 + r < rows && nv) out[base[r] + n * nstride] = v[r];
+        for (int u = 0; u < 4; ++u)
+          if (n0 + u < op.cout) out[base + (n0 + u) * nstride] = v[u];
+      }
+    }
   }
   RZ_FINE(4)
 #undef RZ_FINE

@@ -19,7 +19,7 @@ import lockstep
 import test_hostcheck_search as common
 from conftest import GOLDEN
 from mzx import _lib, configs, models, self_play, synthetic
-from oracle import mcts_oracle, net_oracle
+from oracle import mcts_oracle, net_oracle, parallel
 
 pytestmark = pytest.mark.gpu
 
@@ -146,42 +146,34 @@ def _compare_sample_with_oracle(cfg, sd, res, obs, legal, to_play, seeds, sample
     comfortable margin is a bug, not noise.  Trees whose every simulation agrees must also agree on root
     value (tolerance) and maximum depth.  Returns the number of trees identical in every simulation.
     """
-    onet = net_oracle.make_oracle_network(cfg, sd)
     traces = _device_trace(engine_factory, cfg, [obs[i] for i in sample], [legal[i] for i in sample],
                            [to_play[i] for i in sample], [seeds[i] for i in sample])
+    # the oracle searches run in a pool of single-thread worker processes (oracle/parallel.py): hundreds of trees
+    # in seconds on the GPU box's host cores
+    summaries = parallel.run_searches(cfg, sd, [(obs[i], legal[i], to_play[i], seeds[i]) for i in sample])
     identical = roots_equal = 0
-    # batch-1 inferences of small convolutions: one torch thread is an order of magnitude faster than a 64-core
-    # box's default pool (325 s -> tens of seconds for the connect4 sample)
-    threads = torch.get_num_threads()
-    torch.set_num_threads(1)
-    try:
-        return _compare_loop(cfg, res, obs, legal, to_play, seeds, sample, traces, onet, value_tol, label)
-    finally:
-        torch.set_num_threads(threads)
-
-
-def _compare_loop(cfg, res, obs, legal, to_play, seeds, sample, traces, onet, value_tol, label):
-    identical = roots_equal = 0
-    for i, got in zip(sample, traces):
-        ev = net_oracle.NetworkEvaluator(onet, cfg.support_size)
-        tree = mcts_oracle.run_search(cfg, ev, obs[i], legal[i], to_play[i], True, numpy.random.RandomState(seeds[i]))
-        want = [(p, a) for p, a, _ in tree.trace]
-        roots_equal += int(tree.root_visit_counts(cfg.action_space) == list(res.visit_counts[i]))
+    for i, got, tree in zip(sample, traces, summaries):
+        want = tree["trace"]
+        roots_equal += int(tree["root_visit_counts"] == list(res.visit_counts[i]))
         k = next((k for k in range(len(want)) if k >= len(got) or got[k] != want[k]), None)
         if k is None:
             identical += 1
-            assert tree.root_visit_counts(cfg.action_space) == list(res.visit_counts[i]), (label, i)
-            rv = tree.node_value(0)
+            assert tree["root_visit_counts"] == list(res.visit_counts[i]), (label, i)
+            rv = tree["root_value"]
             assert abs(res.root_values[i] - rv) < value_tol * max(1.0, abs(rv)), (label, i)
-            assert res.max_tree_depth[i] == tree.max_depth, (label, i)
+            assert res.max_tree_depth[i] == tree["max_depth"], (label, i)
             continue
-        gap, depth = tree.margins[k]
+        gap, depth = tree["margins"][k]
         print(f"{label}: tree {i} diverges at simulation {k} of {len(want)} (oracle {want[k]}, device "
               f"{got[k] if k < len(got) else None}); oracle UCB top-2 margin on that walk {gap:.3e} at depth {depth}")
-        assert gap < 2e-3, (label, i, k, gap, "divergence with a comfortable UCB margin: not fp32 noise")
+        # observed margins of diverging trees: <= 8e-5 (profiles/r02_pytest_gpu_full_v2.log); the gate leaves 6x
+        assert gap < MARGIN_GATE, (label, i, k, gap, "divergence with a comfortable UCB margin: not fp32 noise")
     print(f"{label}: {identical}/{len(sample)} sampled trees identical to the oracle in EVERY simulation; "
           f"root visit counts equal on {roots_equal}/{len(sample)}")
     return identical
+
+
+MARGIN_GATE = 5e-4
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -204,9 +196,9 @@ def test_full_size_c2_cartpole(backend, mode):
     res2 = engine.run(list(obs), legal, [0] * B, True, [numpy.random.RandomState(1000 + i) for i in range(B)])
     assert numpy.array_equal(res.visit_counts, res2.visit_counts)
     assert numpy.array_equal(res.root_values.view(numpy.int64), res2.root_values.view(numpy.int64))
-    # 256 sampled trees (whole-search kernel; 64 on the generic path) against the CPU oracle (reference
-    # network arithmetic on the host)
-    sample = list(range(0, B, 16 if mode == 1 else 64))
+    # 1024 sampled trees (whole-search kernel; 256 on the generic path) against the CPU oracle (reference
+    # network arithmetic on the host, oracle searches in a process pool)
+    sample = list(range(0, B, 4 if mode == 1 else 16))
     seeds = [1000 + i for i in range(B)]
     factory = lambda n: self_play.BatchedMCTS(cfg, net, n, mode=0 if mode == 0 else 3)
     same = _compare_sample_with_oracle(cfg, sd, res, obs, legal, [0] * B, seeds, sample, factory, TOL, f"C2 mode {mode}")
@@ -339,10 +331,10 @@ def _check_loose_samples_against_oracle(cfg, sd, net, obs, hidden_in, act, outs_
     front of the per-plane min-max scaling (models.py:541-549), where fp32 round-off is divided by the plane's
     range: NO fp32 implementation reproduces the others there -- the reference's own torch arithmetic included.
     So the yardstick is the oracle evaluated in binary64: on every output the fused engine's error against it
-    must stay within 1e-4 (north_star) or within a bounded multiple (32x: two independent round-off
-    realisations of one ill-conditioned quotient spread that far) of the error the reference's fp32 arithmetic
-    itself makes on that very sample -- measured 2.5e-5 ... 7e-3 on these samples against ~1e-7 elsewhere.  A
-    genuine fused-engine defect shows up as an error the fp32 oracle does not have.
+    must stay within 1e-4 (north_star) or within a bounded multiple (32x for a single output, 4x in geometric mean
+    over the outputs of the sample set) of the error the reference's fp32 arithmetic itself makes on that very
+    sample -- measured 2.5e-5 ... 7e-3 on these samples against ~1e-7 elsewhere.  A genuine fused-engine defect
+    shows up as an error the fp32 oracle does not have.
     """
     if not len(loose):
         return
@@ -354,6 +346,7 @@ def _check_loose_samples_against_oracle(cfg, sd, net, obs, hidden_in, act, outs_
     with torch.no_grad():
         w32 = o32.initial_inference(obs[idx]) + o32.recurrent_inference(h_in, a)
         w64 = o64.initial_inference(obs[idx].double()) + o64.recurrent_inference(h_in.double(), a)
+    ratios = []
     for k in range(8):
         got = outs_fused[k][loose].astype(numpy.float64)
         ref64 = w64[k].numpy().reshape(len(loose), -1)
@@ -367,6 +360,15 @@ def _check_loose_samples_against_oracle(cfg, sd, net, obs, hidden_in, act, outs_
         print(f"{label}: output {k}: {len(loose)} loose samples, fused-vs-f64 {err_fused.max():.2e}, "
               f"torch-fp32-vs-f64 {err_ref32.max():.2e}")
         assert not bad.any(), (label, k, err_fused[bad].tolist(), err_ref32[bad].tolist())
+        ratios += [f / r for f, r in zip(err_fused.tolist(), err_ref32.tolist()) if r > 1e-7 and f > 1e-7]
+    # Any single output may sit in the tail (two round-off realisations of one ill-conditioned quotient: the ratio of
+    # their errors is heavy-tailed -- measured 1/30 ... 14 on these samples, and UNCHANGED by IEEE division / libm expf,
+    # profiles/r03_ieee_math_ab.txt), but a SYSTEMATIC loss of accuracy would move all of a sample's outputs: their
+    # geometric-mean ratio must stay below 4
+    if ratios:
+        gmean = float(numpy.exp(numpy.mean(numpy.log(ratios))))
+        print(f"{label}: geometric mean of fused / torch-fp32 error over {len(ratios)} ill-conditioned outputs: {gmean:.2f}")
+        assert gmean < 4.0, (label, gmean, ratios)
 
 
 @pytest.mark.parametrize("batch", [1, 37, 1024])
@@ -649,7 +651,7 @@ def test_zero_simulations(backend):
         assert (res.visit_counts == 0).all() and (res.root_values == 0).all() and (res.max_tree_depth == 0).all()
 
 
-@pytest.mark.parametrize("name,B,n_sample", [("tictactoe", 1024, 64), ("connect4", 1024, 64), ("breakout", 64, 32)])
+@pytest.mark.parametrize("name,B,n_sample", [("tictactoe", 1024, 256), ("connect4", 1024, 256), ("breakout", 64, 32)])
 def test_full_size_residual_configs(backend, name, B, n_sample):
     """
     BASELINE configs C3 (tic-tac-toe, 1024 trees x 25 simulations), C4 (connect4, 1024 x 200) and C5 (breakout
@@ -681,9 +683,10 @@ def test_full_size_residual_configs(backend, name, B, n_sample):
     factory = lambda n: self_play.BatchedMCTS(cfg, net, n, mode=1)   # residual kernel: trees live in the arena
     same = _compare_sample_with_oracle(cfg, sd, res, obs, legal, to_play, seeds, sample, factory, 10 * TOL, name)
     # fp32 summation order differs between implementations; with 200 simulations of a 64-channel network a
-    # near-tie flips somewhere in a fair share of the trees.  Every divergence is printed with its UCB margin and
-    # bounded in the helper (the real gate); the share of trees identical in EVERY simulation is reported
-    assert same >= len(sample) // 2
+    # near-tie flips somewhere in some trees.  Every divergence is printed with its UCB margin and bounded in the
+    # helper (MARGIN_GATE); the share of trees identical in EVERY simulation is reported and must stay above 80 %
+    # (round 2 observed 57/64, 64/64, 32/32)
+    assert same >= (len(sample) * 4) // 5
 
 
 # ---- observation pipeline + Reanalyse: device twins of tests/test_observations.py
