@@ -21,8 +21,8 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   "roofline"      algorithmic tree bytes (SURVEY.md section 8d formula, with the measured mean leaf depth) /
                   HIP-event time of the search launch, vs the HBM peak (residual networks: network FLOPs vs the
                   dense FP32-input MFMA peak)
-  "workloads"     the other BASELINE configurations (C3, C4 = the Connect4 half of the metric, C5) measured in this
-                  invocation, same fields
+  "workloads"     the other BASELINE configurations (C3, C4 = the Connect4 half of the metric, C5) and the reference's
+                  games/gomoku.py as shipped (streamed MFMA engine) measured in this invocation, same fields
   "per_rank" / "single_gpu_reference"   N > 1: every rank's own rate, and rank 0 timed alone just before
   "selfplay_end_to_end*"  self-play steps/s through the plugin surface (N = 1)
   "observation_stacker"   the path's HBM-bound kernel (mzx_obs_stack, atari geometry) against the HBM peak
@@ -500,12 +500,14 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     try:  # PMC-measured HBM bytes per launch of this kernel (collected by a separate rocprofv3 --pmc run)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             key = "fused-lds" if fused else ("residual-whole-search" if fused_kind == 2 else "generic-per-op")
+            if streamed:
+                key = "streamed"
             if fused_kind == 2 and ran == "mzx::rz_wave_search_kernel":
                 key = "residual-wave-per-tree"
             if fused_kind == 2 and ran == "mzx::rz_tile_search_kernel":
                 key = "residual-tile-per-wave"
             entry = json.load(f).get(f"{workload}:{key}")
-        if not fused and fused_kind != 2 and net_fused:
+        if not fused and fused_kind != 2 and net_fused and not streamed:
             entry = None
         if entry and B == default_trees:
             traffic, traffic_src = entry["bytes"], entry["source"]
@@ -581,7 +583,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env.world}")
     also = args.also
     if also is None:
-        also = "c3,c4,c5" if (args.workload == "c2" and not args.dry_run and args.trees is None) else "none"
+        also = "c3,c4,c5,gomoku" if (args.workload == "c2" and not args.dry_run and args.trees is None) else "none"
     also = [w for w in also.split(",") if w and w != "none"]
 
     line, cfg, net = run_search_workload(env, args, args.workload, args.steps, args.warmup, args.trees,
@@ -591,7 +593,8 @@ def main():
     for w in also:
         if w not in WORKLOADS:
             raise SystemExit(f"unknown workload {w}")
-        r, c2_, n2 = run_search_workload(env, args, w, args.also_steps, 1)
+        # one step of games/gomoku.py as shipped is 512 x 400 simulations of a 128-channel network (~1.9 s)
+        r, c2_, n2 = run_search_workload(env, args, w, 1 if w in ("gomoku", "atari") else args.also_steps, 1)
         if w == "c4":
             c4_net = (c2_, n2)
         else:

@@ -97,6 +97,8 @@ rb_gemm_kernel(const RbGemmArgs a) {
   const int thw = a.th * a.tw, phw = a.PH * a.PW, cells = a.T * phw;
   const int HWo = a.hout * a.wout;
   RB_STAMP(0);
+  if (a.stamps && blockIdx.y == 0 && blockIdx.x < RB_STAMP_WGS && (tid & 63) == 0)   // 100 MHz reference clock beside it
+    a.stamps[((size_t)blockIdx.x * 8 + (tid >> 6)) * RB_STAMP_SLOTS + RB_STAMP_SLOTS - 2] = __builtin_amdgcn_s_memrealtime();
 
   // ---- row tables, per-sample offsets
   for (int m = tid; m < mpad; m += RB_THREADS) {
@@ -337,6 +339,8 @@ rb_gemm_kernel(const RbGemmArgs a) {
     }
   }
   RB_STAMP(1 + 2 * a.phases);
+  if (a.stamps && blockIdx.y == 0 && blockIdx.x < RB_STAMP_WGS && (tid & 63) == 0)
+    a.stamps[((size_t)blockIdx.x * 8 + (tid >> 6)) * RB_STAMP_SLOTS + RB_STAMP_SLOTS - 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // Per-plane min-max scaling of the hidden state (models.py:527-553, :574-599; MinMaxScaleOp's arithmetic): one
@@ -494,6 +498,12 @@ int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
     fprintf(stderr, "  mean over %d workgroups (wave 0):", nw);
     for (int k = 1; k < slots; ++k) fprintf(stderr, " %.0f", mean[k]);
     fprintf(stderr, "\n");
+    {   // effective shader clock: shader cycles (s_memtime) per tick of the 100 MHz reference (s_memrealtime), wave 4 of workgroup 0
+      const unsigned long long* r = h.data() + (size_t)4 * RB_STAMP_SLOTS;
+      const double cycles = (double)(r[slots - 1] - r[0]), ticks = (double)(r[RB_STAMP_SLOTS - 1] - r[RB_STAMP_SLOTS - 2]);
+      if (ticks > 0) fprintf(stderr, "  workgroup 0 wave 4: %.0f shader cycles in %.2f us -> %.0f MHz effective shader clock\n", cycles,
+                             ticks / 100.0, cycles / ticks * 100.0);
+    }
   }
   return MZX_OK;
 }
