@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(256) rb_scale_kernel(const RbScaleArgs a) {
 struct RbPoolOp {
   const float* x;
   float* y;
-  int32_t batch, C, hin, win, hout, wout;
+  int32_t batch, C, hin, win, hout, wout, out_nchw;
   MZX_HD size_t size() const { return (size_t)batch * hout * wout * C; }
   MZX_HD void operator()(size_t i) const {
     const int c = (int)(i % C);
@@ -403,7 +403,9 @@ struct RbPoolOp {
         acc += xb[((int64_t)iy * win + ix) * C];
       }
     }
-    y[i] = acc / 9.0f;
+    const float v = acc / 9.0f;
+    if (out_nchw) y[((b * C + c) * hout + oy) * wout + ox] = v;
+    else y[i] = v;
   }
 };
 
@@ -439,17 +441,67 @@ RbGemmFn rb_pick_mt(int mt) {
   }
 }
 
+// Launch shape of one GEMM operator for THIS batch.  The plan fixes the largest tile (T samples, all column tiles in
+// one workgroup); a small batch would leave most of the chip idle with it, so fewer samples per workgroup and / or a
+// split of the column tiles over more workgroups are considered, by a cost model in units of "accumulator tiles on the
+// busiest wave": rounds of co-resident workgroups x (row tiles x column tiles of that wave), plus a small charge per
+// workgroup for staging its patch again.  Large batches keep the planned tile (fewer, larger workgroups win ties).
+struct RbShape { int T, rows, mtiles, lds, ntiles_wg, nsplit, NT, WN, WM, MT, groups, cpg, phases, Cs; };
+
+RbShape rb_choose_shape(const RbOp& o, int batch) {
+  static const int fixed = getenv("MZX_RB_SHAPE") ? atoi(getenv("MZX_RB_SHAPE")) : 0;   // 1: always the planned tile (A/B)
+  RbShape best{};
+  double best_cost = 1e30;
+  const int spatial = o.tiles_x * o.tiles_y;
+  const int t_lo = (spatial == 1 && !fixed) ? 1 : o.T;
+  for (int T = o.T; T >= t_lo; --T) {
+    RbShape c;
+    c.T = T;
+    c.rows = T * o.th * o.tw;
+    c.mtiles = (c.rows + 15) / 16;
+    c.lds = (int)rb_lds_bytes(T, c.mtiles, T * o.PH * o.PW, o.Cs);
+    c.groups = ((batch + T - 1) / T) * spatial;
+    for (int ntiles_wg = std::min(o.ntiles, 16);; ntiles_wg = (ntiles_wg + 1) / 2) {
+      c.ntiles_wg = ntiles_wg;
+      c.nsplit = (o.ntiles + ntiles_wg - 1) / ntiles_wg;
+      c.NT = ntiles_wg > 8 ? 2 : 1;
+      c.WN = std::min(8, (ntiles_wg + c.NT - 1) / c.NT);
+      c.WM = std::max(1, std::min(8 / c.WN, c.mtiles));
+      c.MT = (c.mtiles + c.WM - 1) / c.WM;
+      const int per_cu = (c.lds <= RB_LDS_BUDGET && c.MT * c.NT <= 9) ? 2 : 1;
+      const int64_t wgs = (int64_t)c.groups * c.nsplit, cap = 256 * per_cu;
+      // a full round of co-resident workgroups shares the matrix pipes per_cu ways; the last, partial round as
+      // many ways as it has workgroups per CU
+      const int64_t rem = wgs % cap;
+      const double ways = (double)(wgs / cap) * per_cu + (rem ? (double)std::min<int64_t>(per_cu, (rem + 255) / 256) : 0.0);
+      const double cost = ways * (c.MT * c.NT) * (1.0 + 0.02 * (c.nsplit - 1)) + 1e-4 * (double)wgs;
+      if (cost < best_cost) { best_cost = cost; best = c; }
+      if (ntiles_wg == 1 || fixed) break;
+    }
+  }
+  // Channel phases: the plan splits the patch so that TWO workgroups fit a CU.  A launch with at most one workgroup
+  // per CU has no partner to overlap its staging with: it takes the whole LDS and as few phases as fit.
+  best.cpg = o.cpg; best.phases = o.phases; best.Cs = o.Cs;
+  if (!fixed && (int64_t)best.groups * best.nsplit <= 256 && o.phases > 1) {
+    const int cells = best.T * o.PH * o.PW;
+    int cpg = o.cchunks;
+    while (cpg > o.cpg && rb_lds_bytes(best.T, best.mtiles, cells, 16 * cpg + 8) > RB_LDS_MAX) --cpg;
+    const int phases = (o.cchunks + cpg - 1) / cpg;
+    cpg = (o.cchunks + phases - 1) / phases;
+    if (phases < o.phases) {
+      best.cpg = cpg; best.phases = phases; best.Cs = 16 * cpg + 8;
+      best.lds = (int)rb_lds_bytes(best.T, best.mtiles, cells, best.Cs);
+    }
+  }
+  return best;
+}
+
 int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
-  // column tiles per workgroup: up to 16 (two per wave); split further while the grid would leave CUs idle
-  const int groups_m = ((batch + o.T - 1) / o.T) * o.tiles_x * o.tiles_y;
-  int ntiles_wg = std::min(o.ntiles, 16);
-  while (ntiles_wg > 1 && (int64_t)groups_m * ((o.ntiles + ntiles_wg - 1) / ntiles_wg) < 256) ntiles_wg = (ntiles_wg + 1) / 2;
-  const int nsplit = (o.ntiles + ntiles_wg - 1) / ntiles_wg;
-  const int NT = ntiles_wg > 8 ? 2 : 1;
-  const int WN = std::min(8, (ntiles_wg + NT - 1) / NT);
-  const int WM = std::max(1, std::min(8 / WN, o.mtiles));
-  const int MT = (o.mtiles + WM - 1) / WM;
-  a.ntiles_wg = ntiles_wg; a.WN = WN; a.WM = WM;
+  const RbShape sh = rb_choose_shape(o, batch);
+  const int groups_m = sh.groups, nsplit = sh.nsplit, NT = sh.NT, WN = sh.WN, WM = sh.WM, MT = sh.MT;
+  a.T = sh.T; a.rows = sh.rows; a.mtiles = sh.mtiles;
+  a.cpg = sh.cpg; a.phases = sh.phases; a.Cs = sh.Cs;
+  a.ntiles_wg = sh.ntiles_wg; a.WN = WN; a.WM = WM;
   static const int dbg = getenv("MZX_RB_DBG") ? atoi(getenv("MZX_RB_DBG")) : 0;
   a.dbg = dbg;
   // MZX_RB_STAMPS=<launch number>: phase clocks of that GEMM launch (counted from the first one of the process),
@@ -472,15 +524,15 @@ int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
   }
   hipError_t e;
   void* params[] = {(void*)&a};
-  e = hipLaunchKernel((const void*)fn, dim3(groups_m, nsplit), dim3(RB_THREADS), params, (size_t)o.lds_bytes, stream);
+  e = hipLaunchKernel((const void*)fn, dim3(groups_m, nsplit), dim3(RB_THREADS), params, (size_t)sh.lds, stream);
   if (e != hipSuccess) { set_error("streamed GEMM launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
   if (stamp && d_stamps) {
     std::vector<unsigned long long> h(stamp_words);
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpy(h.data(), d_stamps, stamp_words * 8, hipMemcpyDeviceToHost);
-    const int slots = 2 + 2 * o.phases;
+    const int slots = 2 + 2 * sh.phases;
     fprintf(stderr, "rb stamps: launch %d, MT %d NT %d WN %d WM %d, grid %d x %d, lds %d, phases %d, rows %d\n", stamp_launch, MT, NT,
-            WN, WM, groups_m, nsplit, o.lds_bytes, o.phases, o.rows);
+            WN, WM, groups_m, nsplit, sh.lds, sh.phases, sh.rows);
     for (int wg = 0; wg < std::min(groups_m, 8); ++wg)
       for (int w = 0; w < 8; w += 4) {
         const unsigned long long* r = h.data() + ((size_t)wg * 8 + w) * RB_STAMP_SLOTS;
@@ -527,7 +579,7 @@ int rb_refresh_derived(const mzx_net* net, const float* d_flat, float* d_derived
 }
 
 int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int batch, stream_t stream,
-                   const NetIndex* ix, int n_ops, float* dump) {
+                   const NetIndex* ix, int n_ops, float* dump, bool last_nchw) {
   const std::vector<OpDesc>& prog = recurrent ? net->prog_recurrent : net->prog_initial;
   const RbProgram& R = recurrent ? net->rb.recurrent : net->rb.initial;
   const float* flat = net->d_flat;
@@ -585,6 +637,7 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
       RbPoolOp op;
       op.x = resolve(net, nb, d.in, batch); op.y = resolve(net, nb, d.out, batch);
       op.batch = batch; op.C = d.cin; op.hin = d.hin; op.win = d.win; op.hout = d.hout; op.wout = d.wout;
+      op.out_nchw = (last_nchw && k == count - 1) ? 1 : 0;
       rc = launch<256>(op, stream);
     } else {
       if (ix && ((d.in == BUF_IN && ix->in_nodes != 1) ||

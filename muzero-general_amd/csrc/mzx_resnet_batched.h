@@ -196,8 +196,10 @@ inline bool rb_enabled(const mzx_net* net, bool recurrent) {
 #ifndef MZX_HOSTCHECK
 // Defined in mzx_batched.hip.  Runs operators [0, n_ops) of the program (n_ops < 0: all of it).  With `ix`, sample b
 // reads hidden-state node ix->in_node[b] of nb.in and writes node ix->out_node[b] of nb.hidden.
+// `last_nchw`: when the last operator run is a pooling whose output would be position-major, it writes NCHW instead
+// (the down-sampling stem in front of the LDS-resident engine, which gathers NCHW).
 int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int batch, stream_t stream,
-                   const NetIndex* ix, int n_ops = -1, float* dump = nullptr);
+                   const NetIndex* ix, int n_ops = -1, float* dump = nullptr, bool last_nchw = false);
 // Packs the B fragments / action tap sums of the plan into the derived buffer (mzx_net_set_weights).
 int rb_refresh_derived(const mzx_net* net, const float* d_flat, float* d_derived, stream_t stream);
 #endif

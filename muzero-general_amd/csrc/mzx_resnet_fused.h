@@ -1529,6 +1529,17 @@ inline int rz_stem_launch(const mzx_net* net, const RzStemConv& sc, const OpDesc
 // stem kernel, everything else (average pooling) on the per-operator kernels.
 inline int rz_run_stem(const mzx_net* net, const std::vector<OpDesc>& prog, int count, const NetBuffers& nb, int batch,
                        stream_t stream) {
+  // Round 3: the stem's convolutions run on the streamed engine's implicit-GEMM kernel (position-major activations,
+  // 16-byte staging and stores, no residual / write-back phases behind barriers) when the whole stem is planned
+  // there and ends in a pooling, which then writes the NCHW tensor the LDS-resident engine gathers (MZX_RZ_STEM=rz:
+  // the round-1 stem kernel, A/B).
+  static const bool rb_stem = !(getenv("MZX_RZ_STEM") && !strcmp(getenv("MZX_RZ_STEM"), "rz"));
+  if (rb_stem && net->rz_mode == 1 && &prog == &net->prog_initial && net->rb.ok && net->rb.initial.ok && count > 0 &&
+      prog[count - 1].kind == OP_POOL) {
+    bool all = true;
+    for (int i = 0; i < count; ++i) all = all && net->rb.initial.ops[i].kind != RB_FUNCTOR;
+    if (all) return rb_run_program(net, false, nb, batch, stream, nullptr, count, nullptr, true);
+  }
   for (int i = 0; i < count; ++i) {
     const OpDesc& d = prog[i];
     const RzStemConv* sc = nullptr;

@@ -119,7 +119,8 @@ inline int row_search_apply(const RowSearchArgs& a, stream_t stream) {
 // MCTS.run for B roots with a network that runs layer by layer on an engine taking indexed hidden states (the
 // streamed MFMA engine): root by the generic kernels, then per simulation row-select, recurrent_inference straight
 // from / into the arena's node store, row-expand + back-propagate.
-inline int search_run_rows(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream) {
+inline int search_run_rows(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream,
+                   const RootOverride* ov = nullptr) {
   const ArenaView v = arena_view(s, d_arena);
   mzx_net* net = s->net;
   const int B = s->p.num_trees;
@@ -131,17 +132,22 @@ inline int search_run_rows(mzx_search* s, const mzx_search_io* io, void* d_arena
   NetBuffers nb;
   nb.in = io->d_observation; nb.action = nullptr; nb.hidden = ix_init ? v.arena.hidden : v.dense_out;
   nb.value = v.value; nb.reward = v.reward; nb.policy = v.policy; nb.workspace = v.ws;
-  rc = run_network(net, false, nb, B, stream, ix_init ? &ix : nullptr);
-  if (rc) return rc;
+  if (!ov) {
+    rc = run_network(net, false, nb, B, stream, ix_init ? &ix : nullptr);
+    if (rc) return rc;
+  }
+  // roots the caller expanded itself (MCTS.run(..., override_root_with=root), self_play.py:275-277): their priors /
+  // reward / hidden state replace initial_inference, the simulations run on the same kernel
   RootInitOp ri;
-  ri.arena = v.arena; ri.p = v.p; ri.value_logits = v.value; ri.policy_logits = v.policy; ri.ext_priors = nullptr; ri.ext_root_reward = nullptr;
+  ri.arena = v.arena; ri.p = v.p; ri.value_logits = v.value; ri.policy_logits = v.policy;
+  ri.ext_priors = ov ? ov->priors : nullptr; ri.ext_root_reward = ov ? ov->reward : nullptr;
   ri.legal = io->d_legal_actions; ri.to_play = io->d_to_play; ri.noise = io->d_noise;
   ri.root_predicted_value = io->d_root_predicted_value;
   MZX_TRY_LAUNCH(launch<64>(ri, stream));
-  if (!ix_init) {
+  if (ov || !ix_init) {
     HiddenMoveOp mv;
     mv.arena = v.arena; mv.num_trees = B; mv.num_nodes = s->p.num_nodes; mv.hidden_size = s->p.hidden_size;
-    mv.dense = v.dense_out; mv.node = nullptr; mv.to_arena = 1;
+    mv.dense = ov ? const_cast<float*>(ov->hidden) : v.dense_out; mv.node = nullptr; mv.to_arena = 1;
     MZX_TRY_LAUNCH(launch<256>(mv, stream));
   }
   RowSearchArgs a;
