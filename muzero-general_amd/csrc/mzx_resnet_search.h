@@ -56,6 +56,10 @@ __device__ __forceinline__ void load_state(const TreeRef& t, RowState& st) {
 // winner's link / visit count are re-read from the tree (one broadcast load) instead of permuted.
 constexpr int WIDE_MAX_CHUNKS = 16;   // up to 256 actions
 
+// NCH: 16-slot chunks a lane can hold (8 covers up to 128 actions).  The slot statistics of ALL chunks of a level are
+// requested before the first one is used -- the trees live in HBM in the per-simulation path (1.2 MB per gomoku tree),
+// where a level costs one memory round trip this way instead of one per chunk.
+template <int NCH = WIDE_MAX_CHUNKS>
 __device__ __forceinline__ RowSel row_select_wide(const TreeRef& t, const SearchParams& p, const uint32_t* tape, int sub,
                                                   int row_in_wave, int sim, RowState& st) {
   RowSel r;
@@ -67,28 +71,30 @@ __device__ __forceinline__ RowSel row_select_wide(const TreeRef& t, const Search
   for (;;) {
     const int d1 = depth + 1;
     const int nc = (node == 0) ? st.root_n : p.num_actions;
-    const int nch = (nc + FUSED_ROW - 1) / FUSED_ROW;
     const double pbc = p.pbc_table[N], sq = p.sqrt_table[N];
-    double sc[WIDE_MAX_CHUNKS];
+    int nv[NCH];
+    double pv[NCH], qv[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {   // slots beyond the node's children re-read slot 0 (masked below)
+      const int s = ch * FUSED_ROW + sub;
+      const int ss = s < nc ? s : 0;
+      nv[ch] = t.slot_visit(node, ss); pv[ch] = t.prior(node, ss); qv[ch] = t.slot_q(node, ss);
+    }
+    double sc[NCH];
     double mine = -MZX_INF;
 #pragma unroll
-    for (int ch = 0; ch < WIDE_MAX_CHUNKS; ++ch) {
-      sc[ch] = -MZX_INF;
-      if (ch < nch) {   // wave-uniform per row set; rows of a wave may differ (root vs inner node): plain select
-        const int s = ch * FUSED_ROW + sub;
-        const bool valid = s < nc;
-        const int ss = valid ? s : 0;
-        const double u = ucb_from(pbc, sq, t.slot_visit(node, ss), t.prior(node, ss), t.slot_q(node, ss), st.mn, st.mx);
-        sc[ch] = valid ? u : -MZX_INF;
-        mine = (sc[ch] > mine) ? sc[ch] : mine;
-      }
+    for (int ch = 0; ch < NCH; ++ch) {
+      const bool valid = ch * FUSED_ROW + sub < nc;
+      const double u = ucb_from(pbc, sq, nv[ch], pv[ch], qv[ch], st.mn, st.mx);
+      sc[ch] = valid ? u : -MZX_INF;
+      mine = (sc[ch] > mine) ? sc[ch] : mine;
     }
     const double best = row_max_d<16>(mine);
     // maximisers, chunk by chunk in slot order
     int nbest = 0, sl = 0;
-    unsigned bits[WIDE_MAX_CHUNKS];
+    unsigned bits[NCH];
 #pragma unroll
-    for (int ch = 0; ch < WIDE_MAX_CHUNKS; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
       bits[ch] = row_bits(__ballot(sc[ch] == best && ch * FUSED_ROW + sub < nc), row_in_wave);
       if (nbest == 0 && bits[ch]) sl = ch * FUSED_ROW + (__ffs(bits[ch]) - 1);
       nbest += __popc(bits[ch]);
@@ -97,7 +103,7 @@ __device__ __forceinline__ RowSel row_select_wide(const TreeRef& t, const Search
       ++st.ties;
       int k = tape_draw(tape, p.tape_words, st.tape_pos, st.flags, nbest);
 #pragma unroll
-      for (int ch = 0; ch < WIDE_MAX_CHUNKS; ++ch) {
+      for (int ch = 0; ch < NCH; ++ch) {
         const int cnt = __popc(bits[ch]);
         if (k >= 0 && k < cnt) {
           unsigned b = bits[ch];
@@ -293,7 +299,10 @@ rz_search_kernel(const RzSearchArgs sa) {
         wave_sync();
         lane_ops = fc2_load_lane<RW>(FT, wk, wk.levels >> 4, sub);   // hides behind the network
       } else {
-        if constexpr (AW == 0) sel = row_select_wide(t, p, tape, sub, row_in_wave, sa.sim0 + sim, st);
+        if constexpr (AW == 0) {
+          if (p.num_actions <= 8 * FUSED_ROW) sel = row_select_wide<8>(t, p, tape, sub, row_in_wave, sa.sim0 + sim, st);
+          else sel = row_select_wide<WIDE_MAX_CHUNKS>(t, p, tape, sub, row_in_wave, sa.sim0 + sim, st);
+        }
         else sel = row_select<AW>(t, p, tape, sub, row_in_wave, sa.sim0 + sim, st);
         if (sub == 0) { sel_parent[row] = sel.c.parent; sel_action[row] = sel.action; sel_leaf[row] = sel.c.leaf; }
       }

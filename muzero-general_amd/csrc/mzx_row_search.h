@@ -47,7 +47,10 @@ __global__ void __launch_bounds__(64) row_select_kernel(const RowSearchArgs a) {
   load_state(t, st);
   const uint32_t* tape = a.tape + (size_t)tree * a.p.tape_words;
   RowSel sel;
-  if constexpr (AW == 0) sel = row_select_wide(t, a.p, tape, sub, row, a.sim, st);
+  if constexpr (AW == 0) {
+    if (a.p.num_actions <= 8 * FUSED_ROW) sel = row_select_wide<8>(t, a.p, tape, sub, row, a.sim, st);
+    else sel = row_select_wide<WIDE_MAX_CHUNKS>(t, a.p, tape, sub, row, a.sim, st);
+  }
   else sel = row_select<AW>(t, a.p, tape, sub, row, a.sim, st);
   int32_t* rs = a.rowsel + (size_t)tree * ROWSEL_INTS;
   rs[16 + 3 * sub] = sel.my_node; rs[17 + 3 * sub] = sel.my_parent; rs[18 + 3 * sub] = sel.my_pslot;
