@@ -116,6 +116,11 @@ int mzx_net_set_mode(mzx_net* net, int32_t mode);
  * tw, tiles_x, tiles_y, PH, PW, chunks per phase, phases, rows, row tiles, LDS bytes}. */
 int mzx_net_streamed_supported(const mzx_net* net);
 int mzx_net_streamed_plan(const mzx_net* net, int32_t recurrent, int32_t op, int32_t out[24]);
+/* The launch shape the streamed engine picks for GEMM operator `op` at `batch` samples (small batches take fewer samples
+ * per workgroup, split the column tiles over more workgroups and use fewer channel phases): {T, rows, row tiles, LDS
+ * bytes, column tiles per workgroup, column splits, column tiles per wave, waves along N, waves along M, row tiles per
+ * wave, row groups (grid.x), chunks per phase, phases, LDS floats per cell, column tiles, 16-channel chunks per tap}. */
+int mzx_net_streamed_shape(const mzx_net* net, int32_t recurrent, int32_t op, int32_t batch, int32_t out[16]);
 
 /* initial_inference(observation) (models.py:172-190 / :601-618).
  * d_observation [batch][input_size]; outputs value_logits [batch][2s+1],

@@ -170,6 +170,20 @@ int mzx_net_streamed_plan(const mzx_net* net, int32_t recurrent, int32_t op, int
   return MZX_OK;
 }
 
+int mzx_net_streamed_shape(const mzx_net* net, int32_t recurrent, int32_t op, int32_t batch, int32_t out[16]) {
+  if (!net || !out || batch < 1) { set_error("null argument / batch < 1"); return MZX_ERR_INVALID; }
+  const RbProgram& R = recurrent ? net->rb.recurrent : net->rb.initial;
+  if (!net->rb.ok || !R.ok || op < 0 || op >= (int32_t)R.ops.size() || R.ops[op].kind != RB_GEMM) {
+    set_error("operator %d has no streamed GEMM plan", op);
+    return MZX_ERR_INVALID;
+  }
+  const RbShape sh = rb_choose_shape(R.ops[op], batch);
+  const int32_t v[16] = {sh.T, sh.rows, sh.mtiles, sh.lds, sh.ntiles_wg, sh.nsplit, sh.NT, sh.WN, sh.WM, sh.MT, sh.groups,
+                         sh.cpg, sh.phases, sh.Cs, R.ops[op].ntiles, R.ops[op].cchunks};
+  for (int k = 0; k < 16; ++k) out[k] = v[k];
+  return MZX_OK;
+}
+
 int mzx_net_set_mode(mzx_net* net, int32_t mode) {
   if (!net) { set_error("null network handle"); return MZX_ERR_INVALID; }
   if (mode < 0 || mode > 3) { set_error("network mode is 0 (one kernel per operator), 1 (fused engine, streamed engine for what it cannot hold), 2 (fused, 4-wave workgroups) or 3 (streamed engine for everything)"); return MZX_ERR_INVALID; }

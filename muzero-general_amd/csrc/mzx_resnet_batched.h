@@ -81,6 +81,61 @@ inline bool rb_choose_tile(RbOp& o) {
   return true;
 }
 
+// Launch shape of one GEMM operator for THIS batch.  The plan fixes the largest tile (T samples, all column tiles in
+// one workgroup); a small batch would leave most of the chip idle with it, so fewer samples per workgroup and / or a
+// split of the column tiles over more workgroups are considered, by a cost model in units of "accumulator tiles on the
+// busiest wave": rounds of co-resident workgroups x (row tiles x column tiles of that wave), plus a small charge per
+// workgroup for staging its patch again.  Large batches keep the planned tile (fewer, larger workgroups win ties).
+struct RbShape { int T, rows, mtiles, lds, ntiles_wg, nsplit, NT, WN, WM, MT, groups, cpg, phases, Cs; };
+
+inline RbShape rb_choose_shape(const RbOp& o, int batch) {
+  static const int fixed = getenv("MZX_RB_SHAPE") ? atoi(getenv("MZX_RB_SHAPE")) : 0;   // 1: always the planned tile (A/B)
+  RbShape best{};
+  double best_cost = 1e30;
+  const int spatial = o.tiles_x * o.tiles_y;
+  const int t_lo = (spatial == 1 && !fixed) ? 1 : o.T;
+  for (int T = o.T; T >= t_lo; --T) {
+    RbShape c;
+    c.T = T;
+    c.rows = T * o.th * o.tw;
+    c.mtiles = (c.rows + 15) / 16;
+    c.lds = (int)rb_lds_bytes(T, c.mtiles, T * o.PH * o.PW, o.Cs);
+    c.groups = ((batch + T - 1) / T) * spatial;
+    for (int ntiles_wg = std::min(o.ntiles, 16);; ntiles_wg = (ntiles_wg + 1) / 2) {
+      c.ntiles_wg = ntiles_wg;
+      c.nsplit = (o.ntiles + ntiles_wg - 1) / ntiles_wg;
+      c.NT = ntiles_wg > 8 ? 2 : 1;
+      c.WN = std::min(8, (ntiles_wg + c.NT - 1) / c.NT);
+      c.WM = std::max(1, std::min(8 / c.WN, c.mtiles));
+      c.MT = (c.mtiles + c.WM - 1) / c.WM;
+      const int per_cu = (c.lds <= RB_LDS_BUDGET && c.MT * c.NT <= 9) ? 2 : 1;
+      const int64_t wgs = (int64_t)c.groups * c.nsplit, cap = 256 * per_cu;
+      // a full round of co-resident workgroups shares the matrix pipes per_cu ways; the last, partial round as
+      // many ways as it has workgroups per CU
+      const int64_t rem = wgs % cap;
+      const double ways = (double)(wgs / cap) * per_cu + (rem ? (double)std::min<int64_t>(per_cu, (rem + 255) / 256) : 0.0);
+      const double cost = ways * (c.MT * c.NT) * (1.0 + 0.02 * (c.nsplit - 1)) + 1e-4 * (double)wgs;
+      if (cost < best_cost) { best_cost = cost; best = c; }
+      if (ntiles_wg == 1 || fixed) break;
+    }
+  }
+  // Channel phases: the plan splits the patch so that TWO workgroups fit a CU.  A launch with at most one workgroup
+  // per CU has no partner to overlap its staging with: it takes the whole LDS and as few phases as fit.
+  best.cpg = o.cpg; best.phases = o.phases; best.Cs = o.Cs;
+  if (!fixed && (int64_t)best.groups * best.nsplit <= 256 && o.phases > 1) {
+    const int cells = best.T * o.PH * o.PW;
+    int cpg = o.cchunks;
+    while (cpg > o.cpg && rb_lds_bytes(best.T, best.mtiles, cells, 16 * cpg + 8) > RB_LDS_MAX) --cpg;
+    const int phases = (o.cchunks + cpg - 1) / cpg;
+    cpg = (o.cchunks + phases - 1) / phases;
+    if (phases < o.phases) {
+      best.cpg = cpg; best.phases = phases; best.Cs = 16 * cpg + 8;
+      best.lds = (int)rb_lds_bytes(best.T, best.mtiles, cells, best.Cs);
+    }
+  }
+  return best;
+}
+
 // Plans one program; `layout` carries the layout of every logical buffer written so far.
 inline bool rb_build_program(mzx_net* net, const std::vector<OpDesc>& prog, RbPlan& P, RbProgram& R, int64_t& cursor,
                              std::map<std::tuple<int64_t, int, int>, int64_t>& packed) {

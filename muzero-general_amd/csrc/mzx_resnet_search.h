@@ -284,7 +284,8 @@ rz_search_kernel(const RzSearchArgs sa) {
   uint32_t pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = 0;
   const bool prof = sa.prof != nullptr && tid == 0;
-  if (prof) t_last = __builtin_readcyclecounter();
+  unsigned long long rt0 = 0;     // 100 MHz reference clock: shader cycles / reference ticks = the effective shader clock
+  if (prof) { t_last = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 #define RZS_PROF(k) if (prof) { const unsigned long long _t = __builtin_readcyclecounter(); pc[k] += (uint32_t)(_t - t_last); t_last = _t; }
 
   for (int sim = 0; sim < sa.num_sims; ++sim) {
@@ -367,7 +368,10 @@ rz_search_kernel(const RzSearchArgs sa) {
     RZS_PROF(5)
   }
 #undef RZS_PROF
-  if (prof) for (int k = 0; k < 8; ++k) sa.prof[blockIdx.x * 8 + k] = pc[k];
+  if (prof) {
+    pc[7] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rt0);
+    for (int k = 0; k < 8; ++k) sa.prof[blockIdx.x * 8 + k] = pc[k];
+  }
   if constexpr (TREC) {
     if (row_valid) { wave_sync(); fc2_to_arena<RW>(FT, rst, t, sub); }
     return;

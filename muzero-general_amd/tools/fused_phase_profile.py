@@ -64,7 +64,7 @@ def residual(args):
     off = engine.arena_offsets(B)
     raw = engine.arena(B)[off["workspace"]: off["workspace"] + 256 * 8 * 4].view(torch.int32).cpu().numpy().reshape(-1, 8)
     raw = raw[((raw[:, [0, 2, 3, 4]] > 0) & (raw < 2 ** 29).all(1, keepdims=True)).all(1)]   # workgroups that wrote counters (the region is shared with the stem's workspace)
-    if (raw[:, 6:] > 0).any():   # wave-per-tree kernel (mzx_resnet_wave.h): the network by operator class, no barriers
+    if (raw[:, 6] > 0).any():   # wave-per-tree kernel (mzx_resnet_wave.h): the network by operator class, no barriers
         S = cfg.num_simulations
         mean = raw.mean(0)
         names8 = ["select + fetch of the path", "9-chunk GEMMs, weights in LDS", "gather parent state -> LDS", "descriptor fetches + fence",
@@ -82,6 +82,11 @@ def residual(args):
     for k, nm in enumerate(names):
         print(f"  {nm:38s} {mean[k] / S:10.0f} cycles per simulation  ({100 * mean[k] / mean.sum():5.1f}%)")
     print(f"  total                                  {mean.sum() / S:10.0f} cycles per simulation = {mean.sum() / S / 2.4e3:.2f} us at 2.4 GHz")
+    ticks = raw[:, 7].astype(numpy.float64)
+    if (ticks > 0).all():   # s_memrealtime (100 MHz) beside s_memtime: the clock the kernel actually ran at
+        mhz = raw[:, :6].sum(1) / ticks * 100.0
+        print(f"  effective shader clock over the launch: {mhz.mean():.0f} MHz (min {mhz.min():.0f}, max {mhz.max():.0f}); "
+              f"launch {ticks.mean() / 100.0:.0f} us per workgroup")
 
 
 if __name__ == "__main__":

@@ -98,3 +98,37 @@ def test_gomoku_and_atari_tiles_as_designed(lib):
     s = _plan(lib, h, 0, 0)                                # stem: 131 -> 128 channels, stride 2, 96 x 96 -> 48 x 48
     assert (s["stride"], s["cin"], s["cout"], s["hout"], s["wout"]) == (2, 131, 128, 48, 48) and s["T"] == 1
     lib.mzx_net_destroy(h)
+
+
+SHAPE = ("T", "rows", "mtiles", "lds", "ntiles_wg", "nsplit", "NT", "WN", "WM", "MT", "groups", "cpg", "phases", "Cs",
+         "ntiles", "cchunks")
+
+
+@pytest.mark.parametrize("name", ["gomoku", "atari"])
+def test_launch_shapes_cover_the_batch_and_fit_the_kernel(lib, name):
+    """rb_choose_shape at batches from 1 to 4096: every sample / column tile / channel chunk is covered, the tiling
+    fits the kernel's limits, small batches spread over more workgroups, large ones keep the planned tile."""
+    h = _create(lib, configs.BY_NAME[name]())
+    for recurrent in (0, 1):
+        for op in range(lib.mzx_net_num_operators(h, recurrent)):
+            p = _plan(lib, h, recurrent, op)
+            if p["kind"] != 0:
+                continue
+            grids = {}
+            for batch in (1, 3, 16, 64, 200, 512, 4096):
+                out = (ctypes.c_int32 * 16)()
+                lib.check(lib.mzx_net_streamed_shape(h, recurrent, op, batch, ctypes.byref(out)))
+                s = dict(zip(SHAPE, list(out)))
+                spatial = p["tiles_x"] * p["tiles_y"]
+                assert 1 <= s["T"] <= p["T"] and s["rows"] == s["T"] * p["th"] * p["tw"] and s["mtiles"] == (s["rows"] + 15) // 16
+                assert s["groups"] == -(-batch // s["T"]) * spatial
+                assert s["nsplit"] * s["ntiles_wg"] >= s["ntiles"] > (s["nsplit"] - 1) * s["ntiles_wg"]
+                assert s["WN"] * s["WM"] <= 8 and s["WN"] * s["NT"] >= s["ntiles_wg"] and s["WM"] * s["MT"] >= s["mtiles"]
+                assert 1 <= s["MT"] <= 9 and s["NT"] in (1, 2)
+                assert s["cpg"] * s["phases"] >= s["cchunks"] and s["Cs"] == 16 * s["cpg"] + 8 and s["lds"] <= 156 * 1024
+                assert s["phases"] <= p["phases"]
+                grids[batch] = s["groups"] * s["nsplit"]
+                if batch >= 4096 and p["taps"] == 9 and -(-batch // p["T"]) * spatial >= 512:
+                    assert s["T"] == p["T"]            # trunk layers at large batches: the planned tile
+            assert grids[1] >= 1 and grids[4096] >= grids[64] >= grids[1]
+    lib.mzx_net_destroy(h)
