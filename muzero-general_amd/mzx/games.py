@@ -1,5 +1,5 @@
 """
-Batched-protocol versions of two reference games: a whole self-play shard stepped by ONE object with array
+Batched-protocol versions of three reference games (tic-tac-toe, connect4, gomoku): a whole self-play shard stepped by ONE object with array
 arithmetic, so that real environments stop being the host bottleneck of the batched search (SURVEY.md section 8f
 row 3).  ``mzx.self_play.SelfPlay`` drives a class with ``batched = True`` through
 
@@ -10,8 +10,9 @@ row 3).  ``mzx.self_play.SelfPlay`` drives a class with ``batched = True`` throu
     legal_actions()    -> int32 [B][A], each row the legal actions in increasing order, padded with -1
     to_play()          -> [B]
 
-Game i of ``TicTacToeBatched`` / ``Connect4Batched`` emits, observation for observation (values AND dtype), reward
-for reward, what ``Game(seed)`` of the reference's games/tictactoe.py:125-351 / games/connect4.py:125-346 emits for
+Game i of ``TicTacToeBatched`` / ``Connect4Batched`` / ``GomokuBatched`` emits, observation for observation (values AND
+dtype), reward for reward, what ``Game(seed)`` of the reference's games/tictactoe.py:125-351 / games/connect4.py:125-346 /
+games/gomoku.py:130-300 emits for
 the same actions (tests/test_batched_games.py runs both side by side against the live files): boards as planes
 [own stones of player 1, stones of player -1, side to move], a win pays 20 / 10 to the player who just moved, a game
 ends on a win or a full board, players alternate 0, 1.  Only the self-play surface is provided (no rendering, no
@@ -30,6 +31,7 @@ class _KInARow:
     gravity = False
     reward_scale = 1
     int_planes = True
+    end_pays = False        # gomoku: the reward is paid whenever the game ends, a full board included (gomoku.py:243)
 
     def __init__(self, seed=None):
         self.reset()
@@ -79,7 +81,7 @@ class _KInARow:
             self.board[action // self.cols, action % self.cols] = self.player
         won = self._wins(self.player)
         done = won or len(self.legal_actions()) == 0
-        reward = 1 if won else 0
+        reward = 1 if (won or (self.end_pays and done)) else 0
         self.player *= -1
         return self._observation(), reward * self.reward_scale, done
 
@@ -108,7 +110,15 @@ class Connect4(_KInARow):
     int_planes = False
 
 
-PER_OBJECT = {"tictactoe": TicTacToe, "connect4": Connect4}
+class Gomoku(_KInARow):
+    """games/gomoku.py:130-300, one game: 11 x 11, five in a row, float64 planes, reward 1 when the game ends."""
+    rows, cols, k = 11, 11, 5
+    reward_scale = 1
+    int_planes = False
+    end_pays = True
+
+
+PER_OBJECT = {"tictactoe": TicTacToe, "connect4": Connect4, "gomoku": Gomoku}
 
 
 class _KInARowBatched:
@@ -117,6 +127,7 @@ class _KInARowBatched:
     gravity = False         # connect4: a stone falls to the lowest empty cell of its column
     reward_scale = 1
     obs_dtype = "int32"
+    end_pays = False        # gomoku: the reward is paid whenever the game ends (win or full board)
 
     def __init__(self, seeds):
         self.num_games = len(seeds)
@@ -174,7 +185,7 @@ class _KInARowBatched:
         else:
             no_move = (self.board != 0).all(1)
         done = (won | no_move) & act
-        reward = numpy.where(won, self.reward_scale, 0).astype(numpy.int64)
+        reward = numpy.where(done if self.end_pays else won, self.reward_scale, 0).astype(numpy.int64)
         self.player = numpy.where(act, -self.player, self.player).astype(numpy.int32)
         return self._observation(), reward, done
 
@@ -206,4 +217,12 @@ class Connect4Batched(_KInARowBatched):
     obs_dtype = "float64"
 
 
-BATCHED = {"tictactoe": TicTacToeBatched, "connect4": Connect4Batched}
+class GomokuBatched(_KInARowBatched):
+    """games/gomoku.py:130-300 for a shard: 11 x 11, five in a row, float64 planes, reward 1 when a game ends."""
+    rows, cols, k = 11, 11, 5
+    reward_scale = 1
+    obs_dtype = "float64"
+    end_pays = True
+
+
+BATCHED = {"tictactoe": TicTacToeBatched, "connect4": Connect4Batched, "gomoku": GomokuBatched}

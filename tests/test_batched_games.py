@@ -50,20 +50,38 @@ def _random_playout(Batched, make_single, B, seed):
     return lengths
 
 
-@pytest.mark.parametrize("name", ["tictactoe", "connect4"])
+@pytest.mark.parametrize("name", ["tictactoe", "connect4", "gomoku"])
 def test_batched_games_equal_the_test_doubles(name):
-    lengths = _random_playout(games.BATCHED[name], lambda i: games_fixture.GAMES[name](i), 40, 5)
+    lengths = _random_playout(games.BATCHED[name], lambda i: games.PER_OBJECT[name](i), 40 if name != "gomoku" else 12, 5)
     assert len(set(lengths.tolist())) > 2      # games of the shard end at different moves
 
 
 @pytest.mark.reference
-@pytest.mark.parametrize("name", ["tictactoe", "connect4"])
+@pytest.mark.parametrize("name", ["tictactoe", "connect4", "gomoku"])
 def test_batched_games_equal_the_reference_game_files(name):
     from oracle import ref_shim
     Ref = ref_shim.game_module(name).Game
-    for seed in range(3):
-        lengths = _random_playout(games.BATCHED[name], lambda i: Ref(i), 48, 100 + seed)
+    for seed in range(3 if name != "gomoku" else 1):
+        lengths = _random_playout(games.BATCHED[name], lambda i: Ref(i), 48 if name != "gomoku" else 10, 100 + seed)
         assert len(set(lengths.tolist())) > 2
+
+
+@pytest.mark.reference
+def test_per_object_gomoku_equals_the_reference_game_file():
+    from oracle import ref_shim
+    Ref = ref_shim.game_module("gomoku").Game
+    rs = numpy.random.RandomState(3)
+    for episode in range(4):
+        a, b = Ref(episode), games.Gomoku(episode)
+        oa, ob = a.reset(), b.reset()
+        done = False
+        while not done:
+            assert numpy.asarray(oa).dtype == numpy.asarray(ob).dtype and numpy.array_equal(oa, ob)
+            assert a.legal_actions() == b.legal_actions() and a.to_play() == b.to_play()
+            act = int(rs.choice(a.legal_actions()))
+            (oa, ra, done), (ob, rb, db) = a.step(act), b.step(act)
+            assert ra == rb and done == db
+        assert numpy.array_equal(oa, ob)
 
 
 @pytest.mark.parametrize("name,temperature,threshold", [("tictactoe", 1.0, None), ("tictactoe", 0.5, 3), ("connect4", 1.0, None)])

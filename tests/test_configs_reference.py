@@ -30,3 +30,18 @@ def test_restated_configs_equal_the_reference_game_files(name):
     for steps in (0, 1, 4999, 5000, 7499, 7500, 10 ** 5, 499999, 500000, 749999, 750000, 10 ** 6):
         ours.training_steps = ref.training_steps
         assert ours.visit_softmax_temperature_fn(trained_steps=steps) == ref.visit_softmax_temperature_fn(trained_steps=steps), (name, steps)
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("name", ["gridworld", "simple_grid", "twentyone"])
+def test_restated_shapes_of_the_other_shipped_games(name):
+    """tests/shipped_shapes.py (used by the GPU routing test) against the live game files."""
+    import shipped_shapes
+    ref = ref_shim.muzero_config(name)
+    ours = shipped_shapes.shapes()[name]
+    for a in shipped_shapes.NETWORK_ATTRS:
+        want, got = getattr(ref, a), getattr(ours, a)
+        if isinstance(want, (list, tuple)):
+            assert list(got) == list(want), (name, a)
+        else:
+            assert got == want, (name, a, got, want)

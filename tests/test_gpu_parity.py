@@ -16,6 +16,7 @@ import pytest
 import torch
 
 import lockstep
+import shipped_shapes
 import test_hostcheck_search as common
 from conftest import GOLDEN
 from mzx import _lib, configs, models, self_play, synthetic
@@ -585,6 +586,36 @@ def test_baseline_configurations_are_routed_to_their_kernels(backend):
         obs = synthetic.observations(B, net.input_shape, seed=1)
         engine.run(list(obs), [list(cfg.action_space)] * B, [0] * B, True, [numpy.random.RandomState(i) for i in range(B)])
         assert _kernel_name(backend, engine, B) == kernel, name
+
+
+def test_every_shipped_game_architecture_runs_on_a_tuned_kernel(backend):
+    """
+    The network / search shapes of EVERY game file the reference ships (games/*.py, restated here where mzx.configs
+    does not carry them: the GPU box has no reference tree) must reach a tuned path -- a whole-search kernel or, for
+    the two large residual networks, the streamed MFMA engine between the row-per-tree kernels -- never the
+    one-thread-per-tree / one-thread-per-output element kernels.  Searches are checked against the CPU oracle.
+    """
+    shapes = shipped_shapes.shapes()
+    tuned = ("mzx::fc2_search_kernel", "mzx::rz_wave_search_kernel", "mzx::rz_tile_search_kernel", "mzx::rz_search_kernel",
+             "mzx::rb_gemm_kernel")
+    for name, cfg in shapes.items():
+        cfg.num_simulations = 6
+        net = models.MuZeroNetwork(cfg)
+        sd = synthetic.fill_state_dict(net.state_dict(), 2)
+        net.set_weights(sd)
+        B = 4
+        engine = self_play.BatchedMCTS(cfg, net, B)
+        obs = synthetic.observations(B, net.input_shape, seed=1)
+        legal = [list(cfg.action_space)] * B
+        res = engine.run(list(obs), legal, [0] * B, True, [numpy.random.RandomState(i) for i in range(B)])
+        kernel = _kernel_name(backend, engine, B)
+        assert kernel.startswith(tuned), (name, kernel)
+        if kernel.startswith("mzx::rb_gemm_kernel"):
+            assert "row_select_kernel" in kernel, (name, kernel)
+        onet = net_oracle.make_oracle_network(cfg, sd)
+        tree = mcts_oracle.run_search(cfg, net_oracle.NetworkEvaluator(onet, cfg.support_size), obs[0], legal[0], 0, True,
+                                      numpy.random.RandomState(0))
+        assert tree.root_visit_counts(cfg.action_space) == list(res.visit_counts[0]), name
 
 
 @pytest.mark.parametrize("name", ["tictactoe", "breakout"])
