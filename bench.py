@@ -61,7 +61,7 @@ WORKLOADS = {
     "c4": ("connect4", {}, 1024, "C4 Connect4 ResNet, 1024 trees x 200 sims per GPU"),
     "c5": ("breakout", {"num_simulations": 50}, 64, "C5 Breakout ResNet (resnet stem), 64 trees x 50 sims per GPU"),
     # the reference's large residual configurations as shipped (streamed MFMA engine, csrc/mzx_batched.hip)
-    "gomoku": ("gomoku", {}, 512, "games/gomoku.py as shipped: 128 ch x 6 blocks, 11 x 11, 512 trees x 400 sims per GPU"),
+    "gomoku": ("gomoku", {}, 1024, "games/gomoku.py as shipped: 128 ch x 6 blocks, 11 x 11, 1024 trees x 400 sims per GPU"),
     "atari": ("atari", {}, 256, "games/atari.py as shipped: 256 ch x 16 blocks, 96 x 96 x 131 input, 256 trees x 50 sims per GPU"),
 }
 
@@ -593,7 +593,7 @@ def main():
     for w in also:
         if w not in WORKLOADS:
             raise SystemExit(f"unknown workload {w}")
-        # one step of games/gomoku.py as shipped is 512 x 400 simulations of a 128-channel network (~1.9 s)
+        # one step of games/gomoku.py as shipped is 1024 x 400 simulations of a 128-channel network (~3.5 s)
         r, c2_, n2 = run_search_workload(env, args, w, 1 if w in ("gomoku", "atari") else args.also_steps, 1)
         if w == "c4":
             c4_net = (c2_, n2)

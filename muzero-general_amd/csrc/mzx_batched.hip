@@ -68,7 +68,7 @@ __device__ __forceinline__ int rb_div(int x, int d, uint32_t magic) {
 // Two workgroups share a CU (their LDS tiles are planned for it, RB_LDS_BUDGET): one stages its patch or writes its
 // outputs while the other keeps the matrix pipes busy.  Four waves per SIMD = 128 registers per lane, which the
 // tilings with at most nine accumulator tiles per wave fit; the 2 x 9 tilings (wide layers) run one workgroup per CU.
-constexpr int RB_STAMP_WGS = 64, RB_STAMP_SLOTS = 24;
+constexpr int RB_STAMP_WGS = 1024, RB_STAMP_SLOTS = 24;
 #define RB_STAMP(slot)                                                                                   \
   do {                                                                                                   \
     if (a.stamps && blockIdx.y == 0 && blockIdx.x < RB_STAMP_WGS && (tid & 63) == 0 && (slot) < RB_STAMP_SLOTS)  \
@@ -495,6 +495,24 @@ int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
     fprintf(stderr, "  mean over %d workgroups (wave 0):", nw);
     for (int k = 1; k < slots; ++k) fprintf(stderr, " %.0f", mean[k]);
     fprintf(stderr, "\n");
+    {   // when workgroups start and end on the 100 MHz reference clock (comparable across XCDs), every wave 0 / wave 4
+      std::vector<double> t0, t1;
+      const int nall = std::min(groups_m, RB_STAMP_WGS);
+      for (int wg = 0; wg < nall; ++wg)
+        for (int w = 0; w < 8; w += 4) {
+          const unsigned long long* r = h.data() + ((size_t)wg * 8 + w) * RB_STAMP_SLOTS;
+          if (r[RB_STAMP_SLOTS - 1] > r[RB_STAMP_SLOTS - 2]) { t0.push_back((double)r[RB_STAMP_SLOTS - 2]); t1.push_back((double)r[RB_STAMP_SLOTS - 1]); }
+        }
+      if (!t0.empty()) {
+        const double base = *std::min_element(t0.begin(), t0.end());
+        std::vector<double> start(t0), end(t1), dur(t0.size());
+        for (size_t i = 0; i < t0.size(); ++i) { start[i] = (t0[i] - base) / 100.0; end[i] = (t1[i] - base) / 100.0; dur[i] = end[i] - start[i]; }
+        auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+        fprintf(stderr, "  %zu waves of %d workgroups: start (us) p50 %.1f p99 %.1f max %.1f | duration p1 %.1f p50 %.1f p99 %.1f max %.1f | "
+                        "end p1 %.1f p50 %.1f max %.1f\n", t0.size(), nall, pct(start, .5), pct(start, .99), pct(start, 1.0), pct(dur, .01),
+                pct(dur, .5), pct(dur, .99), pct(dur, 1.0), pct(end, .01), pct(end, .5), pct(end, 1.0));
+      }
+    }
     {   // effective shader clock: shader cycles (s_memtime) per tick of the 100 MHz reference (s_memrealtime), wave 4 of workgroup 0
       const unsigned long long* r = h.data() + (size_t)4 * RB_STAMP_SLOTS;
       const double cycles = (double)(r[slots - 1] - r[0]), ticks = (double)(r[RB_STAMP_SLOTS - 1] - r[RB_STAMP_SLOTS - 2]);

@@ -115,6 +115,8 @@ inline RbShape rb_choose_shape(const RbOp& o, int batch) {
       const int64_t rem = wgs % cap;
       const double ways = (double)(wgs / cap) * per_cu + (rem ? (double)std::min<int64_t>(per_cu, (rem + 255) / 256) : 0.0);
       const double cost = ways * (c.MT * c.NT) * (1.0 + 0.02 * (c.nsplit - 1)) + 1e-4 * (double)wgs;
+      static const int force_ntw = getenv("MZX_RB_NTILES_WG") ? atoi(getenv("MZX_RB_NTILES_WG")) : 0;   // experiment knob
+      if (force_ntw > 0 && T == o.T && ntiles_wg == std::min(force_ntw, std::min(o.ntiles, 16))) { best_cost = -1.0; best = c; }
       if (cost < best_cost) { best_cost = cost; best = c; }
       if (ntiles_wg == 1 || fixed) break;
     }
