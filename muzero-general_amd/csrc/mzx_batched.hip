@@ -56,6 +56,8 @@ struct RbGemmArgs {
   int32_t cin, cout, hin, win, hout, wout, stride, taps;
   int32_t T, th, tw, tiles_x, tiles_y, PH, PW, Cs, cpg, phases, cchunks, wchunks, rows, mtiles;
   int32_t ntiles, ntiles_wg, WN, WM, y_layout, act, x_vec, y_vec, r_vec;   // *_vec: 16-byte accesses are aligned
+  int32_t rowsplit;      // > 0: ROW-RANGE tiles -- workgroup sp of a sample owns its row tiles [sp * rowsplit, (sp + 1) * rowsplit)
+                         // (positions in raster order; stride-1 operators, T = 1); the patch is the board rows they touch
   unsigned long long* stamps;   // diagnostics (env MZX_RB_STAMPS): s_memtime of the phases, wave 0 of the first 64 workgroups
   int32_t dbg;           // latency experiments (env MZX_RB_DBG): 1 skip the K loops, 2 skip the epilogue, 4 skip the staging
   uint32_t magic_thw, magic_tw, magic_phw, magic_pw;   // ceil(2^32 / d)
@@ -91,9 +93,12 @@ rb_gemm_kernel(const RbGemmArgs a) {
   const int nsp = a.tiles_x * a.tiles_y;
   const int sg = blockIdx.x / nsp, sp = blockIdx.x - sg * nsp;
   const int tyi = sp / a.tiles_x, txi = sp - tyi * a.tiles_x;
-  const int ty0 = tyi * a.th, tx0 = txi * a.tw;
   const int b0 = sg * a.T;
   const int pad = a.taps == 9 ? 1 : 0;
+  // row-range tiles: first position of the range and the board row it lies in
+  const int p_first = a.rowsplit > 0 ? sp * a.rowsplit * 16 : 0;
+  const int y_first = a.rowsplit > 0 ? p_first / a.wout : 0;
+  const int ty0 = a.rowsplit > 0 ? y_first : tyi * a.th, tx0 = a.rowsplit > 0 ? 0 : txi * a.tw;
   const int thw = a.th * a.tw, phw = a.PH * a.PW, cells = a.T * phw;
   const int HWo = a.hout * a.wout;
   RB_STAMP(0);
@@ -102,6 +107,15 @@ rb_gemm_kernel(const RbGemmArgs a) {
 
   // ---- row tables, per-sample offsets
   for (int m = tid; m < mpad; m += RB_THREADS) {
+    if (a.rowsplit > 0) {   // position p of the sample in raster order, patch rows y_first - pad ...
+      const int p = p_first + m;
+      const bool ok = p < HWo && b0 < a.batch;
+      const int y = rb_div(p < HWo ? p : 0, a.wout, a.magic_tw), x = (p < HWo ? p : 0) - y * a.wout;
+      rowaddr[m] = ok ? ((y - y_first + pad) * a.PW + x + pad) * a.Cs : 0;
+      rowt[m] = 0;
+      rowpos[m] = ok ? p : -1;
+      continue;
+    }
     const int t = rb_div(m, thw, a.magic_thw), r = m - t * thw;
     const int ty = rb_div(r, a.tw, a.magic_tw), tx = r - ty * a.tw;
     const int oy = ty0 + ty, ox = tx0 + tx;
@@ -446,6 +460,11 @@ int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
   const int groups_m = sh.groups, nsplit = sh.nsplit, NT = sh.NT, WN = sh.WN, WM = sh.WM, MT = sh.MT;
   a.T = sh.T; a.rows = sh.rows; a.mtiles = sh.mtiles;
   a.cpg = sh.cpg; a.phases = sh.phases; a.Cs = sh.Cs;
+  a.rowsplit = sh.rowsplit;
+  if (sh.rowsplit > 0) {   // row-range tiles: tiles_y workgroups per sample, patch = the board rows a range touches
+    a.tiles_x = 1; a.tiles_y = sh.splits; a.PH = sh.PH;
+    a.magic_tw = rb_magic(o.wout); a.magic_phw = rb_magic(sh.PH * o.PW);
+  }
   a.ntiles_wg = sh.ntiles_wg; a.WN = WN; a.WM = WM;
   static const int dbg = getenv("MZX_RB_DBG") ? atoi(getenv("MZX_RB_DBG")) : 0;
   a.dbg = dbg;

@@ -86,7 +86,7 @@ inline bool rb_choose_tile(RbOp& o) {
 // split of the column tiles over more workgroups are considered, by a cost model in units of "accumulator tiles on the
 // busiest wave": rounds of co-resident workgroups x (row tiles x column tiles of that wave), plus a small charge per
 // workgroup for staging its patch again.  Large batches keep the planned tile (fewer, larger workgroups win ties).
-struct RbShape { int T, rows, mtiles, lds, ntiles_wg, nsplit, NT, WN, WM, MT, groups, cpg, phases, Cs; };
+struct RbShape { int T, rows, mtiles, lds, ntiles_wg, nsplit, NT, WN, WM, MT, groups, cpg, phases, Cs, rowsplit, splits, PH; };
 
 inline RbShape rb_choose_shape(const RbOp& o, int batch) {
   static const int fixed = getenv("MZX_RB_SHAPE") ? atoi(getenv("MZX_RB_SHAPE")) : 0;   // 1: always the planned tile (A/B)
@@ -121,11 +121,33 @@ inline RbShape rb_choose_shape(const RbOp& o, int batch) {
       if (ntiles_wg == 1 || fixed) break;
     }
   }
+  // Row-range tiles (stride-1 operators on whole samples, one sample per workgroup): a sample's row tiles are dealt to
+  // `splits` workgroups, each staging only the board rows its positions touch.  More, shorter-lived workgroups per CU
+  // keep two of them overlapping to the end of the launch (with ONE round of two the younger one, which loses the
+  // matrix pipes to the older by age, runs alone for the last quarter: measured 115 / 165 us for the two of a CU).
+  best.rowsplit = 0; best.splits = 1; best.PH = o.PH;
+  static const int want_splits = getenv("MZX_RB_ROWSPLIT") ? atoi(getenv("MZX_RB_ROWSPLIT")) : 0;
+  if (!fixed && want_splits > 1 && o.tiles_x * o.tiles_y == 1 && best.T == 1 && o.stride == 1 && best.mtiles >= 2 * want_splits) {
+    const int per = (best.mtiles + want_splits - 1) / want_splits;
+    const int splits = (best.mtiles + per - 1) / per;
+    const int pad = o.taps == 9 ? 1 : 0, HWo = o.hout * o.wout;
+    int PH = 1;
+    for (int sp = 0; sp < splits; ++sp) {
+      const int p0 = sp * per * 16, p1 = std::min(p0 + per * 16, HWo) - 1;
+      PH = std::max(PH, p1 / o.wout - p0 / o.wout + 1 + 2 * pad);
+    }
+    best.rowsplit = per; best.splits = splits; best.PH = PH;
+    best.mtiles = per; best.rows = per * 16;
+    best.groups *= splits;
+    best.WM = std::max(1, std::min(8 / best.WN, best.mtiles));
+    best.MT = (best.mtiles + best.WM - 1) / best.WM;
+    best.lds = (int)rb_lds_bytes(1, best.mtiles, PH * o.PW, o.Cs);
+  }
   // Channel phases: the plan splits the patch so that TWO workgroups fit a CU.  A launch with at most one workgroup
   // per CU has no partner to overlap its staging with: it takes the whole LDS and as few phases as fit.
   best.cpg = o.cpg; best.phases = o.phases; best.Cs = o.Cs;
   if (!fixed && (int64_t)best.groups * best.nsplit <= 256 && o.phases > 1) {
-    const int cells = best.T * o.PH * o.PW;
+    const int cells = best.T * best.PH * o.PW;
     int cpg = o.cchunks;
     while (cpg > o.cpg && rb_lds_bytes(best.T, best.mtiles, cells, 16 * cpg + 8) > RB_LDS_MAX) --cpg;
     const int phases = (o.cchunks + cpg - 1) / cpg;
