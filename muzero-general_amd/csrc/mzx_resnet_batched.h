@@ -104,7 +104,10 @@ inline RbShape rb_choose_shape(const RbOp& o, int batch) {
     for (int ntiles_wg = std::min(o.ntiles, 16);; ntiles_wg = (ntiles_wg + 1) / 2) {
       c.ntiles_wg = ntiles_wg;
       c.nsplit = (o.ntiles + ntiles_wg - 1) / ntiles_wg;
-      c.NT = ntiles_wg > 8 ? 2 : 1;
+      // two column tiles per wave when the workgroup has more than eight -- or, MZX_RB_NT=2 (experiment), whenever it has
+      // an even number: half the A-fragment LDS reads per MFMA, the waves split the row tiles instead
+      static const int want_nt = getenv("MZX_RB_NT") ? atoi(getenv("MZX_RB_NT")) : 0;
+      c.NT = (ntiles_wg > 8 || (want_nt == 2 && ntiles_wg >= 2 && ntiles_wg % 2 == 0)) ? 2 : 1;
       c.WN = std::min(8, (ntiles_wg + c.NT - 1) / c.NT);
       c.WM = std::max(1, std::min(8 / c.WN, c.mtiles));
       c.MT = (c.mtiles + c.WM - 1) / c.WM;
