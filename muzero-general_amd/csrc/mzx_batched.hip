@@ -53,7 +53,7 @@ struct RbGemmArgs {
   const float* asum;     // [cout][hout * wout] tap sums of the action plane (null: none)
   const int32_t* action;
   int32_t num_actions, batch;
-  int32_t cin, cout, hin, win, hout, wout, stride, taps;
+  int32_t cin, cout, hin, win, hout, wout, stride, taps, ksize, pad;
   int32_t T, th, tw, tiles_x, tiles_y, PH, PW, Cs, cpg, phases, cchunks, wchunks, rows, mtiles;
   int32_t ntiles, ntiles_wg, WN, WM, y_layout, act, x_vec, y_vec, r_vec;   // *_vec: 16-byte accesses are aligned
   int32_t rowsplit;      // > 0: ROW-RANGE tiles -- workgroup sp of a sample owns its row tiles [sp * rowsplit, (sp + 1) * rowsplit)
@@ -94,7 +94,7 @@ rb_gemm_kernel(const RbGemmArgs a) {
   const int sg = blockIdx.x / nsp, sp = blockIdx.x - sg * nsp;
   const int tyi = sp / a.tiles_x, txi = sp - tyi * a.tiles_x;
   const int b0 = sg * a.T;
-  const int pad = a.taps == 9 ? 1 : 0;
+  const int pad = a.pad;
   // row-range tiles: first position of the range and the board row it lies in
   const int p_first = a.rowsplit > 0 ? sp * a.rowsplit * 16 : 0;
   const int y_first = a.rowsplit > 0 ? p_first / a.wout : 0;
@@ -111,7 +111,7 @@ rb_gemm_kernel(const RbGemmArgs a) {
       const int p = p_first + m;
       const bool ok = p < HWo && b0 < a.batch;
       const int y = rb_div(p < HWo ? p : 0, a.wout, a.magic_tw), x = (p < HWo ? p : 0) - y * a.wout;
-      rowaddr[m] = ok ? ((y - y_first + pad) * a.PW + x + pad) * a.Cs : 0;
+      rowaddr[m] = ok ? ((y - y_first) * a.PW + x) * a.Cs : 0;     // top-left cell of the position's window
       rowt[m] = 0;
       rowpos[m] = ok ? p : -1;
       continue;
@@ -121,7 +121,7 @@ rb_gemm_kernel(const RbGemmArgs a) {
     const int oy = ty0 + ty, ox = tx0 + tx;
     const bool valid = m < a.rows;
     const bool ok = valid && (b0 + t) < a.batch && oy < a.hout && ox < a.wout;
-    rowaddr[m] = valid ? ((t * a.PH + ty * a.stride + pad) * a.PW + tx * a.stride + pad) * a.Cs : 0;
+    rowaddr[m] = valid ? ((t * a.PH + ty * a.stride) * a.PW + tx * a.stride) * a.Cs : 0;   // top-left cell of the window
     rowt[m] = valid ? t : 0;
     rowpos[m] = ok ? oy * a.wout + ox : -1;
   }
@@ -240,17 +240,19 @@ rb_gemm_kernel(const RbGemmArgs a) {
     if (active && !(a.dbg & 1)) {
       const int cpg_g = cw >> 4;
       const int n_it = a.taps * cpg_g;
-      int tap = 0, cc = 0;
+      int tap = 0, cc = 0, ky = 0, kx = 0;      // tap = ky * ksize + kx of the square kernel
       f32x4 fa0[MT], fa1[MT], fb0[NT], fb1[NT];
       auto load = [&](f32x4 (&fa)[MT], f32x4 (&fb)[NT]) {
-        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-        const int aoff = (a.taps == 9 ? ((ky - 1) * a.PW + (kx - 1)) * a.Cs : 0) + cc * 16;
+        const int aoff = (ky * a.PW + kx) * a.Cs + cc * 16;
         const size_t widx = (size_t)(tap * a.cchunks + g * a.cpg + cc) * 256;
 #pragma unroll
         for (int j = 0; j < NT; ++j) fb[j] = *(const f32x4*)(wp[j] + widx);
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa[i] = *(const f32x4*)(tile + ra[i] + aoff);
-        if (++cc == cpg_g) { cc = 0; ++tap; }
+        if (++cc == cpg_g) {
+          cc = 0; ++tap;
+          if (++kx == a.ksize) { kx = 0; ++ky; }
+        }
       };
       auto mma = [&](const f32x4 (&fa)[MT], const f32x4 (&fb)[NT]) {
 #pragma unroll
@@ -423,6 +425,44 @@ struct RbPoolOp {
   }
 };
 
+// torch.nn.MaxPool2d(kernel_size=3, stride=2) (models.py:286, :289: no padding, floor mode), position-major tensors.
+struct RbMaxPoolOp {
+  const float* x;
+  float* y;
+  int32_t batch, C, hin, win, hout, wout;
+  MZX_HD size_t size() const { return (size_t)batch * hout * wout * C; }
+  MZX_HD void operator()(size_t i) const {
+    const int c = (int)(i % C);
+    const int ox = (int)((i / C) % wout), oy = (int)((i / ((size_t)C * wout)) % hout);
+    const int64_t b = (int64_t)(i / ((size_t)C * wout * hout));
+    const float* xb = x + b * hin * win * C + c;
+    float m = xb[((int64_t)(oy * 2) * win + ox * 2) * C];
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) m = fmaxf(m, xb[((int64_t)(oy * 2 + ky) * win + ox * 2 + kx) * C]);
+    y[i] = m;
+  }
+};
+
+// torch.nn.AdaptiveAvgPool2d((hout, wout)) (models.py:291; AdaptiveAvgPoolOp's windows and order), position-major.
+struct RbAdaptivePoolOp {
+  const float* x;
+  float* y;
+  int32_t batch, C, hin, win, hout, wout;
+  MZX_HD size_t size() const { return (size_t)batch * hout * wout * C; }
+  MZX_HD void operator()(size_t i) const {
+    const int c = (int)(i % C);
+    const int ox = (int)((i / C) % wout), oy = (int)((i / ((size_t)C * wout)) % hout);
+    const int64_t b = (int64_t)(i / ((size_t)C * wout * hout));
+    const float* xb = x + b * hin * win * C + c;
+    const int y0 = (oy * hin) / hout, y1 = ((oy + 1) * hin + hout - 1) / hout;
+    const int x0 = (ox * win) / wout, x1 = ((ox + 1) * win + wout - 1) / wout;
+    float acc = 0.f;
+    for (int iy = y0; iy < y1; ++iy)
+      for (int ix = x0; ix < x1; ++ix) acc += xb[((int64_t)iy * win + ix) * C];
+    y[i] = acc / (float)((y1 - y0) * (x1 - x0));
+  }
+};
+
 // [batch][HW][C] -> [batch][C][HW] (diagnostic dumps: the per-operator kernels' layout)
 struct RbToNchwOp {
   const float* x;
@@ -590,11 +630,11 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
       a.y_layout = o.out_layout;
       a.wpack = der + o.w_off;
       if (d.kind == OP_CONV3 && d.bn.channels) { a.alpha = der + d.bn.alpha; a.beta = der + d.bn.beta; }
-      if (d.kind != OP_CONV3) a.bias = flat + d.b;
+      if (d.kind != OP_CONV3) a.bias = flat + d.b;   // 1x1 heads, Linear, DownsampleCNN convolutions
       if (o.asum_off >= 0) { a.asum = der + o.asum_off; a.action = nb.action; a.num_actions = net->cfg.action_space_size; }
       a.batch = batch;
       a.cin = o.cin; a.cout = o.cout; a.hin = o.hin; a.win = o.win; a.hout = o.hout; a.wout = o.wout;
-      a.stride = o.stride; a.taps = o.taps;
+      a.stride = o.stride; a.taps = o.taps; a.ksize = o.ksize; a.pad = o.pad;
       a.T = o.T; a.th = o.th; a.tw = o.tw; a.tiles_x = o.tiles_x; a.tiles_y = o.tiles_y; a.PH = o.PH; a.PW = o.PW;
       a.Cs = o.Cs; a.cpg = o.cpg; a.phases = o.phases; a.cchunks = o.cchunks; a.wchunks = o.wchunks;
       a.rows = o.rows; a.mtiles = o.mtiles; a.ntiles = o.ntiles; a.act = o.act;
@@ -621,6 +661,16 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
       op.batch = batch; op.C = d.cin; op.hin = d.hin; op.win = d.win; op.hout = d.hout; op.wout = d.wout;
       op.out_nchw = (last_nchw && k == count - 1) ? 1 : 0;
       rc = launch<256>(op, stream);
+    } else if (o.kind == RB_MAXPOOL) {
+      RbMaxPoolOp op;
+      op.x = resolve(net, nb, d.in, batch); op.y = resolve(net, nb, d.out, batch);
+      op.batch = batch; op.C = d.cin; op.hin = d.hin; op.win = d.win; op.hout = d.hout; op.wout = d.wout;
+      rc = launch<256>(op, stream);
+    } else if (o.kind == RB_ADAPTIVE_POOL) {
+      RbAdaptivePoolOp op;
+      op.x = resolve(net, nb, d.in, batch); op.y = resolve(net, nb, d.out, batch);
+      op.batch = batch; op.C = d.cin; op.hin = d.hin; op.win = d.win; op.hout = d.hout; op.wout = d.wout;
+      rc = launch<256>(op, stream);
     } else {
       if (ix && ((d.in == BUF_IN && ix->in_nodes != 1) ||
                  ((d.in == BUF_HIDDEN || d.out == BUF_HIDDEN) && ix->out_nodes != 1))) {
@@ -638,7 +688,7 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
     const RbOp& o = R.ops[count - 1];
     const float* src = resolve(net, nb, d.out, batch);
     int rc = 0;
-    const bool spatial = d.kind == OP_CONV3 || d.kind == OP_POOL;
+    const bool spatial = d.kind == OP_CONV3 || d.kind == OP_POOL || d.kind == OP_CONVK || d.kind == OP_MAXPOOL || d.kind == OP_ADAPTIVE_POOL;
     if (spatial && o.out_layout == RB_NHWC) {
       RbToNchwOp op;
       op.x = src; op.y = dump; op.batch = batch; op.C = d.cout; op.HW = d.hout * d.wout;

@@ -24,7 +24,7 @@ constexpr int RB_LDS_BUDGET = 78 * 1024;      // what the planner asks for: TWO 
                                               // patch / writes its outputs while the other feeds the matrix pipes
 
 enum RbLayout { RB_NHWC = 0, RB_NCHW = 1 };   // [sample][position][channel] / [sample][channel][position]
-enum RbKind { RB_GEMM = 0, RB_SCALE = 1, RB_POOL = 2, RB_FUNCTOR = 3 };
+enum RbKind { RB_GEMM = 0, RB_SCALE = 1, RB_POOL = 2, RB_FUNCTOR = 3, RB_MAXPOOL = 4, RB_ADAPTIVE_POOL = 5 };
 
 // One operator of a program (index-aligned with mzx_net::prog_initial / prog_recurrent).
 struct RbOp {
@@ -32,6 +32,7 @@ struct RbOp {
   int32_t in_layout = RB_NCHW, out_layout = RB_NCHW, res_layout = RB_NCHW;
   // ---- RB_GEMM: D[rows x cout] = A[rows x taps*cin] . B, rows = (sample, output position)
   int32_t taps = 1, stride = 1, cin = 0, cin_total = 0, cout = 0, hin = 1, win = 1, hout = 1, wout = 1;
+  int32_t ksize = 1, pad = 0;   // square kernel: taps = ksize * ksize (3 / 1: the residual trunk; 5, 2 ceil(H / 16): DownsampleCNN)
   int32_t cchunks = 0;     // 16-channel K chunks per tap (cin padded to a multiple of 16)
   int32_t nchunks = 0, wchunks = 0, ntiles = 0;
   // workgroup tile: T whole samples (small maps) or one th x tw patch of output positions of one sample

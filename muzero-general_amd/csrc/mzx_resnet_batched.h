@@ -6,8 +6,9 @@
 // the program built by mzx_net.h becomes one launch over the whole batch:
 //   conv3x3 (:206-209, stride 1 | 2, folded BatchNorm, residual, ReLU, action plane)   rb_gemm_kernel, 9 taps
 //   conv1x1 head (:369-389, :404-433), Linear (:630-642)                               rb_gemm_kernel, 1 tap
+//   DownsampleCNN convolutions (:281-290: K x K stride 4 / 5 x 5, bias, ReLU)          rb_gemm_kernel, K * K taps
 //   per-plane min-max scaling (:527-553, :574-599)                                     rb_scale_kernel
-//   AvgPool2d of the stem (:233-275)                                                   element kernel, NHWC
+//   AvgPool2d of the stem (:233-275), MaxPool2d / AdaptiveAvgPool2d (:286-291)         element kernels, NHWC
 // Activations between operators are position-major ([sample][y][x][channel]) so that a workgroup's input patch is
 // staged into LDS with 16-byte copies; observations and hidden states keep the reference's NCHW layout at the
 // boundary (the first convolution gathers, the scaling operator writes NCHW -- straight into / out of the search
@@ -44,12 +45,11 @@ inline int rb_lds_budget() {   // MZX_RB_LDS: A/B knob (bytes), e.g. 159744 = on
 }
 
 inline bool rb_choose_tile(RbOp& o) {
-  const int pad = o.taps == 9 ? 1 : 0;
   const int HWo = o.hout * o.wout;
   double best = -1.0;
   RbOp pick = o;
   auto consider = [&](int T, int th, int tw) {
-    const int PH = (th - 1) * o.stride + 1 + 2 * pad, PW = (tw - 1) * o.stride + 1 + 2 * pad;
+    const int PH = (th - 1) * o.stride + o.ksize, PW = (tw - 1) * o.stride + o.ksize;   // the windows' extent
     const int cells = T * PH * PW;
     const int rows = T * th * tw, mtiles = (rows + 15) / 16;
     if (rows > RB_MAX_ROWS) return;
@@ -130,10 +130,11 @@ inline RbShape rb_choose_shape(const RbOp& o, int batch) {
   // matrix pipes to the older by age, runs alone for the last quarter: measured 115 / 165 us for the two of a CU).
   best.rowsplit = 0; best.splits = 1; best.PH = o.PH;
   static const int want_splits = getenv("MZX_RB_ROWSPLIT") ? atoi(getenv("MZX_RB_ROWSPLIT")) : 0;
-  if (!fixed && want_splits > 1 && o.tiles_x * o.tiles_y == 1 && best.T == 1 && o.stride == 1 && best.mtiles >= 2 * want_splits) {
+  if (!fixed && want_splits > 1 && o.tiles_x * o.tiles_y == 1 && best.T == 1 && o.stride == 1 && o.ksize == 2 * o.pad + 1 &&
+      best.mtiles >= 2 * want_splits) {
     const int per = (best.mtiles + want_splits - 1) / want_splits;
     const int splits = (best.mtiles + per - 1) / per;
-    const int pad = o.taps == 9 ? 1 : 0, HWo = o.hout * o.wout;
+    const int pad = o.pad, HWo = o.hout * o.wout;
     int PH = 1;
     for (int sp = 0; sp < splits; ++sp) {
       const int p0 = sp * per * 16, p1 = std::min(p0 + per * 16, HWo) - 1;
@@ -193,7 +194,7 @@ inline bool rb_build_program(mzx_net* net, const std::vector<OpDesc>& prog, RbPl
     o.res_layout = (d.res == -100) ? (int)RB_NCHW : layout_of(d.res);
     switch (d.kind) {
       case OP_CONV3: {
-        o.kind = RB_GEMM; o.taps = 9; o.stride = d.stride;
+        o.kind = RB_GEMM; o.taps = 9; o.ksize = 3; o.pad = 1; o.stride = d.stride;
         o.cin_total = d.cin; o.cin = d.use_action ? d.cin - 1 : d.cin; o.cout = d.cout;
         o.hin = d.hin; o.win = d.win; o.hout = d.hout; o.wout = d.wout;
         o.act = d.relu ? RZ_ACT_RELU : RZ_ACT_NONE;
@@ -226,7 +227,17 @@ inline bool rb_build_program(mzx_net* net, const std::vector<OpDesc>& prog, RbPl
       }
       case OP_SCALE: o.kind = RB_SCALE; o.out_layout = RB_NCHW; break;
       case OP_POOL: o.kind = RB_POOL; o.out_layout = o.in_layout; break;
-      default:   // DownsampleCNN pieces (models.py:278-297): per-operator kernels, NCHW in and out
+      case OP_CONVK: {   // DownsampleCNN.features.0 / .3 (models.py:281-290): K x K, stride, padding, bias, ReLU
+        o.kind = RB_GEMM; o.taps = d.ksize * d.ksize; o.ksize = d.ksize; o.pad = d.pad; o.stride = d.stride;
+        o.cin_total = o.cin = d.cin; o.cout = d.cout;
+        o.hin = d.hin; o.win = d.win; o.hout = d.hout; o.wout = d.wout;
+        o.act = d.relu ? RZ_ACT_RELU : RZ_ACT_NONE;
+        o.out_layout = RB_NHWC;
+        break;
+      }
+      case OP_MAXPOOL: o.kind = (o.in_layout == RB_NHWC) ? RB_MAXPOOL : RB_FUNCTOR; o.out_layout = o.in_layout; break;
+      case OP_ADAPTIVE_POOL: o.kind = (o.in_layout == RB_NHWC) ? RB_ADAPTIVE_POOL : RB_FUNCTOR; o.out_layout = o.in_layout; break;
+      default:
         if (o.in_layout != RB_NCHW) return false;
         o.kind = RB_FUNCTOR; o.out_layout = RB_NCHW;
         break;

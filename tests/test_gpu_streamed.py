@@ -88,6 +88,10 @@ STREAMED_CASES = {
     "tictactoe": (lambda: configs.tictactoe(), 37),
     "connect4": (lambda: configs.connect4(), 37),
     "breakout": (lambda: configs.breakout(), 3),
+    # DownsampleCNN stems (models.py:278-297): K x K stride-4 and 5 x 5 convolutions with bias, max / adaptive pooling
+    "breakout_cnn": (lambda: configs.breakout(downsample="CNN"), 3),
+    "cnn_small": (lambda: configs.breakout(downsample="CNN", observation_shape=(2, 40, 56), stacked_observations=1,
+                                           channels=8, blocks=1), 5),
 }
 
 

@@ -44,7 +44,7 @@ def test_which_networks_are_streamed(lib):
     lib.mzx_net_destroy(h)
 
 
-@pytest.mark.parametrize("name", ["gomoku", "atari", "go19", "wide_heads", "odd_channels"])
+@pytest.mark.parametrize("name", ["gomoku", "atari", "go19", "wide_heads", "odd_channels", "breakout_cnn"])
 def test_streamed_tiles_fit_the_kernel(lib, name):
     cfg = {
         "gomoku": configs.gomoku, "atari": configs.atari,
@@ -53,9 +53,11 @@ def test_streamed_tiles_fit_the_kernel(lib, name):
                                              resnet_fc_value_layers=[200, 77]),
         "odd_channels": lambda: configs.gomoku(channels=70, observation_shape=(5, 13, 9), action_space=list(range(117)),
                                                stacked_observations=2),
+        # DownsampleCNN (models.py:278-297): 12 x 12 stride-4 and 5 x 5 convolutions, max / adaptive pooling
+        "breakout_cnn": lambda: configs.breakout(downsample="CNN"),
     }[name]()
     h = _create(lib, cfg)
-    assert lib.mzx_net_streamed_supported(h) == 3
+    assert lib.mzx_net_streamed_supported(h) == (0 if name == "breakout_cnn" else 3)   # (the small trunk fits the LDS engine)
     derived = lib.mzx_net_derived_floats(h)
     gemm_weights = 0
     for recurrent in (0, 1):
@@ -66,10 +68,11 @@ def test_streamed_tiles_fit_the_kernel(lib, name):
             kinds.append(p["kind"])
             if p["kind"] != 0:
                 continue
-            pad = 1 if p["taps"] == 9 else 0
+            ksize = int(round(p["taps"] ** 0.5))     # square kernels: 1, 3 (trunk), 5 / 2 ceil(H / 16) (DownsampleCNN)
+            assert ksize * ksize == p["taps"]
             assert p["lds_bytes"] <= 78 * 1024
             assert p["rows"] == p["T"] * p["th"] * p["tw"] <= 144 and p["mtiles"] == (p["rows"] + 15) // 16 <= 9
-            assert p["PH"] == (p["th"] - 1) * p["stride"] + 1 + 2 * pad and p["PW"] == (p["tw"] - 1) * p["stride"] + 1 + 2 * pad
+            assert p["PH"] == (p["th"] - 1) * p["stride"] + ksize and p["PW"] == (p["tw"] - 1) * p["stride"] + ksize
             assert p["tiles_x"] * p["tw"] >= p["wout"] and p["tiles_y"] * p["th"] >= p["hout"]
             assert (p["tiles_x"] - 1) * p["tw"] < p["wout"] and (p["tiles_y"] - 1) * p["th"] < p["hout"]
             if p["T"] > 1:
@@ -78,6 +81,7 @@ def test_streamed_tiles_fit_the_kernel(lib, name):
             assert p["cpg"] * p["phases"] >= cchunks and p["cpg"] * (p["phases"] - 1) < cchunks
             gemm_weights += p["taps"] * cchunks * 16 * ((p["cout"] + 15) // 16) * 16
         assert kinds.count(0) >= 10 and kinds.count(1) == 1      # GEMM layers, one scaling operator
+        assert 3 not in kinds                                     # nothing is left on the per-operator element kernels
     assert derived * 2 >= gemm_weights // 2       # the packed images exist (prediction weights shared by both programs)
     lib.mzx_net_destroy(h)
 
