@@ -26,6 +26,9 @@
 #include "mzx_pack.h"
 #include "mzx_resnet_batched.h"
 
+#ifndef MZX_RB_RING_MAX
+#define MZX_RB_RING_MAX 4   // accumulator tiles per wave up to which the K loop keeps four chunks in flight
+#endif
 namespace mzx {
 
 namespace {
@@ -54,6 +57,7 @@ struct RbGemmArgs {
   const int32_t* action;
   int32_t num_actions, batch;
   int32_t cin, cout, hin, win, hout, wout, stride, taps, ksize, pad;
+  int32_t kmagic, rowskip;   // ceil(2^16 / ksize): tap / ksize by multiply-shift (taps <= 64); (PW - ksize) * Cs
   int32_t T, th, tw, tiles_x, tiles_y, PH, PW, Cs, cpg, phases, cchunks, wchunks, rows, mtiles;
   int32_t ntiles, ntiles_wg, WN, WM, y_layout, act, x_vec, y_vec, r_vec;   // *_vec: 16-byte accesses are aligned
   int32_t rowsplit;      // > 0: ROW-RANGE tiles -- workgroup sp of a sample owns its row tiles [sp * rowsplit, (sp + 1) * rowsplit)
@@ -81,7 +85,8 @@ template <int MT, int NT>
 __global__ void __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(MT * NT <= 9 ? 4 : 2, MT * NT <= 9 ? 4 : 2)))
 rb_gemm_kernel(const RbGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float rb_lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform, and the compiler is told so: tile indices in SGPRs
   const int mpad = a.mtiles * 16, Tpad = (a.T + 1) & ~1;
   int* rowaddr = (int*)rb_lds;
   int* rowt = rowaddr + mpad;
@@ -149,8 +154,9 @@ rb_gemm_kernel(const RbGemmArgs a) {
   for (int j = 0; j < NT; ++j) {
     const int nt = blockIdx.y * a.ntiles_wg + nt_first + j;
     nvalid[j] = active && (nt_first + j) < a.ntiles_wg && nt < a.ntiles;
-    wp[j] = a.wpack + ((size_t)(nvalid[j] ? nt : 0) * a.wchunks) * 256 + lane * 4;
+    wp[j] = a.wpack + ((size_t)(nvalid[j] ? nt : 0) * a.wchunks) * 256;    // scalar base: the lane's 16 bytes are added per load
   }
+  const unsigned lane4 = (unsigned)lane * 4;
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -240,19 +246,18 @@ rb_gemm_kernel(const RbGemmArgs a) {
     if (active && !(a.dbg & 1)) {
       const int cpg_g = cw >> 4;
       const int n_it = a.taps * cpg_g;
-      int tap = 0, cc = 0, ky = 0, kx = 0;      // tap = ky * ksize + kx of the square kernel
+      int tap = 0, cc = 0;                      // tap = ky * ksize + kx of the square kernel
       f32x4 fa0[MT], fa1[MT], fb0[NT], fb1[NT];
       auto load = [&](f32x4 (&fa)[MT], f32x4 (&fb)[NT]) {
-        const int aoff = (ky * a.PW + kx) * a.Cs + cc * 16;
+        // cell (ky, kx) of the window = tap cells on, plus the rest of a patch row per kernel row: few scalar
+        // registers live across the loop (a (ky, kx) cursor pushed the 9-tile kernel's fragments to scratch)
+        const int aoff = tap * a.Cs + ((tap * a.kmagic) >> 16) * a.rowskip + cc * 16;
         const size_t widx = (size_t)(tap * a.cchunks + g * a.cpg + cc) * 256;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fb[j] = *(const f32x4*)(wp[j] + widx);
+        for (int j = 0; j < NT; ++j) fb[j] = *(const f32x4*)(wp[j] + widx + lane4);
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa[i] = *(const f32x4*)(tile + ra[i] + aoff);
-        if (++cc == cpg_g) {
-          cc = 0; ++tap;
-          if (++kx == a.ksize) { kx = 0; ++ky; }
-        }
+        if (++cc == cpg_g) { cc = 0; ++tap; }
       };
       auto mma = [&](const f32x4 (&fa)[MT], const f32x4 (&fb)[NT]) {
 #pragma unroll
@@ -263,21 +268,93 @@ rb_gemm_kernel(const RbGemmArgs a) {
             for (int j = 0; j < NT; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][k], fa[i][k], acc[i][j], 0, 0, 0);
       };
-      // branch-free steady state (the wait counters of the next chunk's loads stay exact), one- or two-chunk tail
-      load(fa0, fb0);
-      int it = 0;
-      for (; it + 2 < n_it; it += 2) {
-        load(fa1, fb1);
-        mma(fa0, fb0);
+      if constexpr ((MT - 1) * NT >= 5) {
+        // ONE set of position fragments, refilled IN PLACE: tile i's fragment is dead after its last k = 3 MFMA, its
+        // read for the next chunk goes out right there and is first needed (MT - 1) NT MFMAs (>= 160 cycles, the LDS
+        // latency) later.  Two full sets (2 x 4 MT registers) plus the accumulators leave the 128-register kernels
+        // (four waves per SIMD) NO slack, and whether that loop compiles without scratch traffic, or with each
+        // chunk's LDS reads sunk next to their first use, changed with every edit nearby (0.68 <-> 0.62 of the peak).
+        // Weight fragments (L2 latency) stay double-buffered, one chunk ahead.
+        auto step = [&](const f32x4 (&fbc)[NT], f32x4 (&fbn)[NT]) {
+          const int aoff = tap * a.Cs + ((tap * a.kmagic) >> 16) * a.rowskip + cc * 16;
+          const size_t widx = (size_t)(tap * a.cchunks + g * a.cpg + cc) * 256;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) fbn[j] = *(const f32x4*)(wp[j] + widx + lane4);
+          // pinned only where registers are plentiful (two waves per SIMD): in the 128-register kernels the extra
+          // barriers cost a fragment spill inside the loop, and the scheduler keeps this order there by itself
+          constexpr bool PIN = MT * NT > 9;
+          if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);   // a whole chunk of MFMAs between the request and its use
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {           // k = 0 in tile order: the order the refills were requested in
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fbc[j][0], fa0[i][0], acc[i][j], 0, 0, 0);
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int k = 1; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fbc[j][k], fa0[i][k], acc[i][j], 0, 0, 0);
+          if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fbc[j][3], fa0[i][3], acc[i][j], 0, 0, 0);
+            fa0[i] = *(const f32x4*)(tile + ra[i] + aoff);
+            __builtin_amdgcn_sched_barrier(0);     // the read goes out HERE, not next to its first use
+          }
+          if (++cc == cpg_g) { cc = 0; ++tap; }
+        };
+        load(fa0, fb0);                           // chunk 0; the cursor now names chunk 1
+        int it = 0;
+        for (; it + 2 < n_it; it += 2) { step(fb0, fb1); step(fb1, fb0); }
+        if (it + 1 < n_it) { step(fb0, fb1); mma(fa0, fb1); }
+        else mma(fa0, fb0);
+      } else if constexpr (MT * NT <= MZX_RB_RING_MAX) {
+        // Few accumulator tiles per wave (small launches, head layers): a chunk is at most 16 MFMAs = 512 cycles, less
+        // than the L2 round trip of its weight fragment -- a ring of FOUR chunks in flight instead of two.
+        f32x4 fa2[MT], fa3[MT], fb2[NT], fb3[NT];
         load(fa0, fb0);
-        mma(fa1, fb1);
-      }
-      if (it + 1 < n_it) {
-        load(fa1, fb1);
-        mma(fa0, fb0);
-        mma(fa1, fb1);
+        if (n_it > 1) load(fa1, fb1);
+        if (n_it > 2) load(fa2, fb2);
+        if (n_it > 3) load(fa3, fb3);
+        int it = 0;
+        for (; it + 8 <= n_it; it += 4) {      // branch-free: every slot has a successor four chunks ahead
+          mma(fa0, fb0); load(fa0, fb0);
+          mma(fa1, fb1); load(fa1, fb1);
+          mma(fa2, fb2); load(fa2, fb2);
+          mma(fa3, fb3); load(fa3, fb3);
+        }
+        // it .. it + 3 are in flight; up to four more chunks follow
+        mma(fa0, fb0); if (it + 4 < n_it) load(fa0, fb0);
+        if (it + 1 < n_it) { mma(fa1, fb1); if (it + 5 < n_it) load(fa1, fb1); }
+        if (it + 2 < n_it) { mma(fa2, fb2); if (it + 6 < n_it) load(fa2, fb2); }
+        if (it + 3 < n_it) { mma(fa3, fb3); if (it + 7 < n_it) load(fa3, fb3); }
+        if (it + 4 < n_it) mma(fa0, fb0);
+        if (it + 5 < n_it) mma(fa1, fb1);
+        if (it + 6 < n_it) mma(fa2, fb2);
+        if (it + 7 < n_it) mma(fa3, fb3);
       } else {
-        mma(fa0, fb0);
+        // branch-free steady state (the wait counters of the next chunk's loads stay exact), one- or two-chunk tail
+        load(fa0, fb0);
+        int it = 0;
+        for (; it + 2 < n_it; it += 2) {
+          load(fa1, fb1);
+          mma(fa0, fb0);
+          load(fa0, fb0);
+          mma(fa1, fb1);
+        }
+        if (it + 1 < n_it) {
+          load(fa1, fb1);
+          mma(fa0, fb0);
+          mma(fa1, fb1);
+        } else {
+          mma(fa0, fb0);
+        }
       }
     }
     RB_STAMP(2 + 2 * g);
@@ -500,6 +577,7 @@ int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
   const int groups_m = sh.groups, nsplit = sh.nsplit, NT = sh.NT, WN = sh.WN, WM = sh.WM, MT = sh.MT;
   a.T = sh.T; a.rows = sh.rows; a.mtiles = sh.mtiles;
   a.cpg = sh.cpg; a.phases = sh.phases; a.Cs = sh.Cs;
+  a.kmagic = (65536 + o.ksize - 1) / o.ksize; a.rowskip = (o.PW - o.ksize) * sh.Cs;   // the launch's Cs, not the plan's
   a.rowsplit = sh.rowsplit;
   if (sh.rowsplit > 0) {   // row-range tiles: tiles_y workgroups per sample, patch = the board rows a range touches
     a.tiles_x = 1; a.tiles_y = sh.splits; a.PH = sh.PH;
