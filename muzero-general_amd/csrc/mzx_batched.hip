@@ -82,7 +82,7 @@ constexpr int RB_STAMP_WGS = 1024, RB_STAMP_SLOTS = 24;
   } while (0)
 
 template <int MT, int NT>
-__global__ void __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(MT * NT <= 9 ? 4 : 2, MT * NT <= 9 ? 4 : 2)))
+__global__ void __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(MT * NT <= 8 ? 4 : 2, MT * NT <= 8 ? 4 : 2)))
 rb_gemm_kernel(const RbGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float rb_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -170,17 +170,23 @@ rb_gemm_kernel(const RbGemmArgs a) {
     const int c0 = g * a.cpg * 16;
     const int cw = min(a.cpg * 16, a.cchunks * 16 - c0);   // channels of this phase (padded to whole chunks)
     const int q = cw >> 2;
-    if (g > 0) __syncthreads();                            // every wave is done reading the previous group
     // ---- stage the input patch: tile[cell][c - c0], zero outside the image / beyond cin
     if (a.dbg & 4) {
+      if (g > 0) __syncthreads();
     } else if (a.x.layout == RB_NHWC) {
+      // SU 16-byte requests per thread before the first LDS write (eight where the kernel has the registers: a patch of
+      // up to 4096 quads -- every shipped trunk layer -- is then one round trip to memory), and the requests of the next
+      // channel group go out BEFORE the barrier that waits for the slowest wave's K loop: they land in registers, not
+      // in LDS, so they need not wait for it.
+      constexpr int SU = MT * NT >= 6 ? 8 : 4;
       const uint32_t magic_q = (uint32_t)((0x100000000ull + (uint64_t)q - 1) / (uint64_t)q);
       const int total = cells * q;
-      for (int i0 = tid; i0 < total; i0 += 4 * RB_THREADS) {
-        f32x4 v[4];
-        int at[4];
+      bool synced = g == 0;
+      for (int i0 = tid; i0 < total || !synced; i0 += SU * RB_THREADS) {
+        f32x4 v[SU];
+        int at[SU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SU; ++u) {
           const int idx = i0 + u * RB_THREADS;
           at[u] = -1;
           v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -202,11 +208,13 @@ rb_gemm_kernel(const RbGemmArgs a) {
             }
           }
         }
+        if (!synced) { __syncthreads(); synced = true; }     // every wave is done reading the previous group
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < SU; ++u)
           if (at[u] >= 0) *(f32x4*)(tile + at[u]) = v[u];
       }
     } else {
+      if (g > 0) __syncthreads();                          // every wave is done reading the previous group
       // NCHW source: consecutive threads take consecutive cells of one channel quad (coalesced along x)
       const uint32_t magic_cells = (uint32_t)((0x100000000ull + (uint64_t)cells - 1) / (uint64_t)cells);
       const long long plane = (long long)a.hin * a.win;
@@ -282,7 +290,7 @@ rb_gemm_kernel(const RbGemmArgs a) {
           for (int j = 0; j < NT; ++j) fbn[j] = *(const f32x4*)(wp[j] + widx + lane4);
           // pinned only where registers are plentiful (two waves per SIMD): in the 128-register kernels the extra
           // barriers cost a fragment spill inside the loop, and the scheduler keeps this order there by itself
-          constexpr bool PIN = MT * NT > 9;
+          constexpr bool PIN = MT * NT > 8;
           if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);   // a whole chunk of MFMAs between the request and its use
 #pragma unroll
           for (int i = 0; i < MT; ++i) {           // k = 0 in tile order: the order the refills were requested in

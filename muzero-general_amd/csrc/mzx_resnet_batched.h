@@ -111,7 +111,7 @@ inline RbShape rb_choose_shape(const RbOp& o, int batch) {
       c.WN = std::min(8, (ntiles_wg + c.NT - 1) / c.NT);
       c.WM = std::max(1, std::min(8 / c.WN, c.mtiles));
       c.MT = (c.mtiles + c.WM - 1) / c.WM;
-      const int per_cu = (c.lds <= RB_LDS_BUDGET && c.MT * c.NT <= 9) ? 2 : 1;
+      const int per_cu = (c.lds <= RB_LDS_BUDGET && c.MT * c.NT <= 8) ? 2 : 1;   // 128-register instantiations
       const int64_t wgs = (int64_t)c.groups * c.nsplit, cap = 256 * per_cu;
       // a full round of co-resident workgroups shares the matrix pipes per_cu ways; the last, partial round as
       // many ways as it has workgroups per CU
