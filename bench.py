@@ -54,11 +54,18 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense FP32-input MFMA peak (= FP32 vector peak), same guide
 
+# workloads that choose their network engine themselves (unless --net-mode says otherwise)
+WORKLOAD_NET_MODE = {"c4-large": "streamed"}
+
 WORKLOADS = {
     # name: (config factory name, overrides, trees per GPU, description)
     "c2": ("cartpole", {}, 4096, "C2 CartPole FullyConnectedNetwork, 4096 trees x 50 sims per GPU"),
     "c3": ("tictactoe", {}, 1024, "C3 Tic-tac-toe MuZeroResidualNetwork, 1024 trees x 25 sims per GPU"),
     "c4": ("connect4", {}, 1024, "C4 Connect4 ResNet, 1024 trees x 200 sims per GPU"),
+    # the same network and search at a shard large enough for layer-by-layer launches: from ~3000 trees per GPU the
+    # streamed MFMA engine + row-per-tree kernels overtake the LDS-resident whole-search kernel (0.60 against 0.53 of
+    # the FP32 MFMA peak, profiles/r03_streamed_experiments.txt section 10)
+    "c4-large": ("connect4", {}, 9216, "C4 Connect4 ResNet at a large shard, 9216 trees x 200 sims per GPU"),
     "c5": ("breakout", {"num_simulations": 50}, 64, "C5 Breakout ResNet (resnet stem), 64 trees x 50 sims per GPU"),
     # the reference's large residual configurations as shipped (streamed MFMA engine, csrc/mzx_batched.hip)
     "gomoku": ("gomoku", {}, 1024, "games/gomoku.py as shipped: 128 ch x 6 blocks, 11 x 11, 1024 trees x 400 sims per GPU"),
@@ -385,6 +392,8 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     name, overrides, default_trees, description = WORKLOADS[workload]
     cfg = configs.BY_NAME[name](**overrides)
     B = trees or default_trees
+    if B != default_trees:       # --trees: the label follows what ran
+        description = description.replace(f"{default_trees} trees", f"{B} trees")
     S, A = cfg.num_simulations, len(cfg.action_space)
     rank, world = env.rank, env.world
 
@@ -398,15 +407,16 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     env.sync()
     broadcast_ms = (time.perf_counter() - t_b0) * 1e3
 
-    if args.net_mode == "per-operator":
+    net_mode = WORKLOAD_NET_MODE.get(workload, "fused") if args.net_mode == "fused" else args.net_mode
+    if net_mode == "per-operator":
         net.set_mode(0)
-    elif args.net_mode == "fused-4wave" and net.fused_supported():
+    elif net_mode == "fused-4wave" and net.fused_supported():
         net.set_mode(2)
-    elif args.net_mode == "streamed" and cfg.network == "resnet":
+    elif net_mode == "streamed" and cfg.network == "resnet":
         net.set_mode(3)          # every layer on the streamed MFMA engine (A/B against the LDS-resident engine)
-    streamed = cfg.network == "resnet" and args.net_mode != "per-operator" and (
-        args.net_mode == "streamed" or bool(net.streamed_supported()))
-    net_fused = bool(net.fused_supported()) and args.net_mode not in ("per-operator", "streamed")
+    streamed = cfg.network == "resnet" and net_mode != "per-operator" and (
+        net_mode == "streamed" or bool(net.streamed_supported()))
+    net_fused = bool(net.fused_supported()) and net_mode not in ("per-operator", "streamed")
     mode = {"auto": None, "generic": 0, "fused": 1, "fused-v1": 17}[args.mode]
     engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
     handle = engine.handle(B)
@@ -513,7 +523,8 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
             traffic, traffic_src = entry["bytes"], entry["source"]
     except (OSError, ValueError):
         pass
-    kernel_name = ("per-sim launches + streamed MFMA layers (rb_gemm_kernel)" if streamed else
+    kernel_name = ("per-sim launches + streamed MFMA layers (rb_gemm_kernel)" +
+                   (", two half-shards on two HIP streams" if "two half-shards" in ran else "") if streamed else
                    "fused-lds" if fused else
                    "residual whole-search kernel (arena trees, fused MFMA network)" if fused_kind == 2 else
                    "per-sim launches + fused-mfma network" if net_fused else "generic-per-op")
@@ -583,7 +594,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env.world}")
     also = args.also
     if also is None:
-        also = "c3,c4,c5,gomoku" if (args.workload == "c2" and not args.dry_run and args.trees is None) else "none"
+        also = "c3,c4,c4-large,c5,gomoku" if (args.workload == "c2" and not args.dry_run and args.trees is None) else "none"
     also = [w for w in also.split(",") if w and w != "none"]
 
     line, cfg, net = run_search_workload(env, args, args.workload, args.steps, args.warmup, args.trees,

@@ -331,6 +331,14 @@ int mzx_search_create(const mzx_search_config* cfg, mzx_net* net, mzx_search** o
 
 void mzx_search_destroy(mzx_search* s) {
   if (s && s->d_tables) device_free(s->d_tables);
+#ifndef MZX_HOSTCHECK
+  if (s && s->side_stream) {      // the row-per-tree path's second stream (joined at the end of every run)
+    (void)hipStreamSynchronize((hipStream_t)s->side_stream);
+    if (s->ev_fork) (void)hipEventDestroy((hipEvent_t)s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy((hipEvent_t)s->ev_join);
+    (void)hipStreamDestroy((hipStream_t)s->side_stream);
+  }
+#endif
   delete s;
 }
 
@@ -389,7 +397,7 @@ int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_
   if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) return rz_search_run(s, io, d_arena, (stream_t)stream);
   if ((s->mode & 1) && rb_enabled(s->net, true) && row_search_supported(s->p)) {
     s->last_kernel = "mzx::rb_gemm_kernel (streamed FP32-MFMA layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
-    return search_run_rows(s, io, d_arena, (stream_t)stream);
+    return search_run_rows(s, io, d_arena, (stream_t)stream);   // (renames last_kernel when it runs two half-shards)
   }
 #endif
   s->last_kernel = "one kernel per step of a simulation (select / network / expand + back-propagate)";

@@ -9,7 +9,8 @@
 // slots s, s + 16, ..., binary64 DPP arg-max + wave ballot, tie draws from the tape, lane d back-propagates path
 // node d; bit-identical to the generic operators, asserted on the device) run as two small kernels per simulation,
 // four trees per wavefront, the trees staying in the arena (HBM / L2).  What one kernel hands to the other -- the
-// path's nodes per lane -- goes through 64 ints per tree in the arena.
+// path's nodes per lane -- goes through 64 ints per tree in the arena.  Shards of 1024 trees and more run as two
+// half-shards on two HIP streams (search_run_rows).
 #pragma once
 #include "mzx_resnet_search.h"
 
@@ -153,21 +154,91 @@ inline int search_run_rows(mzx_search* s, const mzx_search_io* io, void* d_arena
     mv.dense = ov ? const_cast<float*>(ov->hidden) : v.dense_out; mv.node = nullptr; mv.to_arena = 1;
     MZX_TRY_LAUNCH(launch<256>(mv, stream));
   }
-  RowSearchArgs a;
-  a.p = v.p; a.L = s->L; a.trees = v.arena.trees; a.tape = io->d_tape;
-  a.sel_parent = v.sel_parent; a.sel_action = v.sel_action; a.sel_leaf = v.sel_leaf;
-  a.rowsel = (int32_t*)((char*)d_arena + s->off_rowsel);
-  a.value = v.value; a.reward = v.reward; a.policy = v.policy;
+  // ---- the simulations.  Large shards run as TWO HALF-SHARDS on two HIP streams: the layers of one half start under
+  // the tail of the other's (a launch ends with a few workgroups on a mostly idle chip, and ~6 us pass before a
+  // dependent launch starts), and the small per-simulation kernels (select, expand, heads, scaling) of one half hide
+  // under the trunk layers of the other.  Trees are independent and a sample's arithmetic does not depend on the
+  // batch it runs in (the halves keep the planned launch shape), so the trees are the ones of the undivided run.
+  const char* split_env = getenv("MZX_ROW_SPLIT_MIN");       // read per run: the tests run both ways in one process
+  const int split_min = split_env ? atoi(split_env) : 1024;  // 0: never
+  int parts = 1;
+  const int first = ((B / 2 + 15) / 16) * 16;                // 16 trees: every per-tree array stays 16-byte aligned
+  // The summation order of a layer depends on the launch shape only through its channel groups (phases x chunks per
+  // group): split only when both halves run every layer with the groups of the undivided launch (true of every shipped
+  // configuration from 512 trees per half on: the planned tile).
+  auto same_arithmetic = [&]() {
+    for (const RbOp& o : net->rb.recurrent.ops) {
+      if (o.kind != RB_GEMM) continue;
+      const RbShape w = rb_choose_shape(o, B), h0 = rb_choose_shape(o, first), h1 = rb_choose_shape(o, B - first);
+      if (h0.phases != w.phases || h0.cpg != w.cpg || h1.phases != w.phases || h1.cpg != w.cpg) return false;
+    }
+    return true;
+  };
+  if (split_min > 0 && B >= split_min && B >= 32 && same_arithmetic()) {
+    if (!s->side_stream) {
+      hipStream_t st = nullptr;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+          hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess &&
+          hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess) {
+        s->side_stream = st; s->ev_fork = e0; s->ev_join = e1;
+      } else {
+        if (e0) (void)hipEventDestroy(e0);
+        if (st) (void)hipStreamDestroy(st);
+        (void)hipGetLastError();
+      }
+    }
+    if (s->side_stream) parts = 2;
+  }
+  if (parts == 2)
+    s->last_kernel = "mzx::rb_gemm_kernel (streamed FP32-MFMA layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel, two half-shards on two streams";
   const bool wide = s->p.num_actions > FUSED_ROW || 2 * s->p.support_size + 1 > 2 * FUSED_ROW;
   const int aw = wide ? 0 : (s->p.num_actions <= 4 ? 4 : 16);
-  nb.in = v.arena.hidden; nb.hidden = v.arena.hidden; nb.action = v.sel_action;
-  ix.in_node = v.sel_parent; ix.out_node = v.sel_leaf; ix.in_nodes = s->p.num_nodes; ix.out_nodes = s->p.num_nodes;
+  const int F = 2 * s->p.support_size + 1, A = s->p.num_actions;
+  const int64_t node_floats = (int64_t)s->p.num_nodes * s->p.hidden_size;
+  RowSearchArgs as[2];
+  NetBuffers nbs[2];
+  NetIndex ixs[2];
+  int count[2] = {parts == 2 ? first : B, B - first};
+  stream_t streams[2] = {stream, (stream_t)s->side_stream};
+  for (int h = 0; h < parts; ++h) {
+    const int64_t o = h ? first : 0;      // (h = 1 only when split)
+    RowSearchArgs& a = as[h];
+    a.p = v.p; a.p.num_trees = count[h]; a.L = s->L;
+    a.trees = v.arena.trees + o * s->L.tree_bytes; a.tape = io->d_tape + o * s->p.tape_words;
+    a.sel_parent = v.sel_parent + o; a.sel_action = v.sel_action + o; a.sel_leaf = v.sel_leaf + o;
+    a.rowsel = (int32_t*)((char*)d_arena + s->off_rowsel) + o * ROWSEL_INTS;
+    a.value = v.value + o * F; a.reward = v.reward + o * F; a.policy = v.policy + o * A;
+    NetBuffers& n = nbs[h];
+    n.in = v.arena.hidden + o * node_floats; n.hidden = v.arena.hidden + o * node_floats; n.action = a.sel_action;
+    n.value = v.value + o * F; n.reward = v.reward + o * F; n.policy = v.policy + o * A;
+    n.workspace = v.ws + o * net->act_floats * net->n_temp;      // the workspace is linear in the batch
+    ixs[h].in_node = a.sel_parent; ixs[h].out_node = a.sel_leaf;
+    ixs[h].in_nodes = s->p.num_nodes; ixs[h].out_nodes = s->p.num_nodes;
+  }
+  if (parts == 2) {
+    if (hipEventRecord((hipEvent_t)s->ev_fork, stream) != hipSuccess ||
+        hipStreamWaitEvent((hipStream_t)s->side_stream, (hipEvent_t)s->ev_fork, 0) != hipSuccess) {
+      set_error("row search: fork onto the second stream failed: %s", hipGetErrorString(hipGetLastError()));
+      return MZX_ERR_RUNTIME;
+    }
+  }
   for (int k = 0; k < s->p.num_sims; ++k) {
-    a.sim = k;
-    MZX_TRY_LAUNCH(aw == 0 ? row_search_step<0>(a, stream) : aw == 4 ? row_search_step<4>(a, stream) : row_search_step<16>(a, stream));
-    rc = run_network(net, true, nb, B, stream, &ix);
-    if (rc) return rc;
-    MZX_TRY_LAUNCH(aw == 0 ? row_search_apply<0>(a, stream) : aw == 4 ? row_search_apply<4>(a, stream) : row_search_apply<16>(a, stream));
+    for (int h = 0; h < parts; ++h) {
+      RowSearchArgs& a = as[h];
+      a.sim = k;
+      MZX_TRY_LAUNCH(aw == 0 ? row_search_step<0>(a, streams[h]) : aw == 4 ? row_search_step<4>(a, streams[h]) : row_search_step<16>(a, streams[h]));
+      rc = run_network(net, true, nbs[h], count[h], streams[h], &ixs[h]);
+      if (rc) return rc;
+      MZX_TRY_LAUNCH(aw == 0 ? row_search_apply<0>(a, streams[h]) : aw == 4 ? row_search_apply<4>(a, streams[h]) : row_search_apply<16>(a, streams[h]));
+    }
+  }
+  if (parts == 2) {
+    if (hipEventRecord((hipEvent_t)s->ev_join, (hipStream_t)s->side_stream) != hipSuccess ||
+        hipStreamWaitEvent(stream, (hipEvent_t)s->ev_join, 0) != hipSuccess) {
+      set_error("row search: join of the second stream failed: %s", hipGetErrorString(hipGetLastError()));
+      return MZX_ERR_RUNTIME;
+    }
   }
   return search_finish(s, io, d_arena, stream);
 }

@@ -27,6 +27,11 @@ struct mzx_search {
   int32_t mode = 0;
   int32_t fused_ok = 0;
   const char* last_kernel = "";   // search kernel of the last mzx_search_run (mzx_search_kernel_name)
+  // second HIP stream + fork / join events of the row-per-tree path (mzx_row_search.h: two half-shards in flight
+  // together); created on first use, owned by the handle
+  void* side_stream = nullptr;
+  void* ev_fork = nullptr;
+  void* ev_join = nullptr;
 };
 
 namespace mzx {

@@ -285,3 +285,47 @@ def test_row_kernels_bit_identical_to_one_thread_per_tree(backend, name, B, S):
         if a.dtype == numpy.float64:
             a, b = a.view(numpy.int64), b.view(numpy.int64)
         assert numpy.array_equal(a, b), (name, key)
+
+
+@pytest.mark.parametrize("name,B,S,split", [("gomoku", 77, 24, False), ("gomoku", 64, 16, True), ("connect4", 130, 30, True)])
+def test_two_half_shards_on_two_streams_build_the_same_trees(backend, name, B, S, split, monkeypatch):
+    """
+    search_run_rows splits large shards into two halves on two HIP streams (default: from 1024 trees).  With the
+    threshold lowered (MZX_ROW_SPLIT_MIN, read per run) the halves -- 16-tree aligned, the second one ragged -- must
+    build bit for bit the trees of the undivided run, and a second run on the same handle (stream and events reused) too.
+    Halves whose layers would run with other channel groups than the undivided launch (another summation order:
+    gomoku at 48 + 29 trees) are not split.
+    """
+    make = STREAMED_CASES[name][0]
+    cfg = make()
+    cfg.num_simulations = S
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 12))
+    net.set_mode(3)
+    A = len(cfg.action_space)
+    obs = synthetic.observations(B, net.input_shape, seed=6)
+    rs = numpy.random.RandomState(4)
+    legal = [sorted(rs.choice(A, size=rs.randint(1, A + 1), replace=False).tolist()) for _ in range(B)]
+    to_play = [int(i % len(cfg.players)) for i in range(B)]
+    out = []
+    for split_min in ("0", "32", "32"):
+        monkeypatch.setenv("MZX_ROW_SPLIT_MIN", split_min)
+        engine = self_play.BatchedMCTS(cfg, net, B, mode=1) if split_min == "0" or len(out) == 1 else engine
+        res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(500 + i) for i in range(B)])
+        kernel = engine.kernel_name(B)
+        assert "row_select_kernel" in kernel
+        if split_min == "0":
+            assert "two half-shards" not in kernel
+        elif split:      # halves whose layers keep the channel groups of the undivided launch
+            assert "two half-shards" in kernel
+        out.append((res, engine.export_trees(B)))
+    (r0, t0) = out[0]
+    for r1, t1 in out[1:]:
+        assert numpy.array_equal(r0.visit_counts, r1.visit_counts)
+        assert numpy.array_equal(r0.root_values.view(numpy.int64), r1.root_values.view(numpy.int64))
+        assert numpy.array_equal(r0.max_tree_depth, r1.max_tree_depth) and numpy.array_equal(r0.tape_used, r1.tape_used)
+        for key in ("visit", "value_sum", "reward", "prior", "child", "parent", "to_play", "minmax", "n_nodes"):
+            a, b = t0[key], t1[key]
+            if a.dtype == numpy.float64:
+                a, b = a.view(numpy.int64), b.view(numpy.int64)
+            assert numpy.array_equal(a, b), (name, key)
