@@ -223,23 +223,29 @@ inline int search_run_rows(mzx_search* s, const mzx_search_io* io, void* d_arena
       return MZX_ERR_RUNTIME;
     }
   }
-  for (int k = 0; k < s->p.num_sims; ++k) {
-    for (int h = 0; h < parts; ++h) {
-      RowSearchArgs& a = as[h];
-      a.sim = k;
-      MZX_TRY_LAUNCH(aw == 0 ? row_search_step<0>(a, streams[h]) : aw == 4 ? row_search_step<4>(a, streams[h]) : row_search_step<16>(a, streams[h]));
-      rc = run_network(net, true, nbs[h], count[h], streams[h], &ixs[h]);
-      if (rc) return rc;
-      MZX_TRY_LAUNCH(aw == 0 ? row_search_apply<0>(a, streams[h]) : aw == 4 ? row_search_apply<4>(a, streams[h]) : row_search_apply<16>(a, streams[h]));
+  // the simulations of every part; whatever happens, the caller's stream is joined with the second one afterwards
+  auto simulations = [&]() -> int {
+    for (int k = 0; k < s->p.num_sims; ++k) {
+      for (int h = 0; h < parts; ++h) {
+        RowSearchArgs& a = as[h];
+        a.sim = k;
+        MZX_TRY_LAUNCH(aw == 0 ? row_search_step<0>(a, streams[h]) : aw == 4 ? row_search_step<4>(a, streams[h]) : row_search_step<16>(a, streams[h]));
+        const int nrc = run_network(net, true, nbs[h], count[h], streams[h], &ixs[h]);
+        if (nrc) return nrc;
+        MZX_TRY_LAUNCH(aw == 0 ? row_search_apply<0>(a, streams[h]) : aw == 4 ? row_search_apply<4>(a, streams[h]) : row_search_apply<16>(a, streams[h]));
+      }
     }
-  }
+    return 0;
+  };
+  rc = simulations();
   if (parts == 2) {
     if (hipEventRecord((hipEvent_t)s->ev_join, (hipStream_t)s->side_stream) != hipSuccess ||
         hipStreamWaitEvent(stream, (hipEvent_t)s->ev_join, 0) != hipSuccess) {
-      set_error("row search: join of the second stream failed: %s", hipGetErrorString(hipGetLastError()));
-      return MZX_ERR_RUNTIME;
+      if (!rc) set_error("row search: join of the second stream failed: %s", hipGetErrorString(hipGetLastError()));
+      return rc ? rc : MZX_ERR_RUNTIME;
     }
   }
+  if (rc) return rc;
   return search_finish(s, io, d_arena, stream);
 }
 
