@@ -136,3 +136,28 @@ def test_launch_shapes_cover_the_batch_and_fit_the_kernel(lib, name):
                     assert s["T"] == p["T"]            # trunk layers at large batches: the planned tile
             assert grids[1] >= 1 and grids[4096] >= grids[64] >= grids[1]
     lib.mzx_net_destroy(h)
+
+
+@pytest.mark.parametrize("name,B", [("gomoku", 1024), ("connect4", 9216), ("atari", 1024), ("gomoku", 4096), ("connect4", 1024)])
+def test_half_shards_keep_the_channel_groups_of_the_whole_shard(lib, name, B):
+    """
+    search_run_rows (csrc/mzx_row_search.h) runs shards of >= 1024 trees as two halves on two streams -- but only when every
+    layer of both halves keeps the channel groups (phases x chunks per group: the one launch-shape property that changes a
+    summation order) of the undivided launch.  For the shipped configurations that holds from 512 trees per half on, so
+    the split engages for the bench workloads (gomoku 1024, c4-large 9216, atari 1024).
+    """
+    h = _create(lib, configs.BY_NAME[name]())
+    first = ((B // 2 + 15) // 16) * 16
+    gemms = 0
+    for op in range(lib.mzx_net_num_operators(h, 1)):
+        if _plan(lib, h, 1, op)["kind"] != 0:
+            continue
+        gemms += 1
+        shapes = []
+        for batch in (B, first, B - first):
+            out = (ctypes.c_int32 * 16)()
+            lib.check(lib.mzx_net_streamed_shape(h, 1, op, batch, ctypes.byref(out)))
+            shapes.append(dict(zip(SHAPE, list(out))))
+        assert {(s["phases"], s["cpg"]) for s in shapes} == {(shapes[0]["phases"], shapes[0]["cpg"])}, (name, op, shapes)
+    assert gemms >= 10
+    lib.mzx_net_destroy(h)
