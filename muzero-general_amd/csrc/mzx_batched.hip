@@ -4,14 +4,16 @@
 // BatchNorm / residual / ReLU / action plane, 1x1 head convolution, Linear (+ ELU) -- as an FP32-MFMA implicit GEMM
 // over the whole batch.  A 512-thread workgroup (8 waves, two per SIMD) owns a tile of up to 144 GEMM rows =
 // (sample, output position) pairs and up to 16 column tiles of 16 output channels:
-//   * the tile's input patch (with the 3x3 halo, out-of-image cells zero) is staged ONCE into LDS, position-major
-//     [cell][Cs] with Cs = 8 mod 16 floats -- a 3x3 tap is a constant LDS offset, no bounds tests in the K loop;
+//   * the tile's input patch (with the K x K halo, out-of-image cells zero) is staged ONCE into LDS, position-major
+//     [cell][Cs] with Cs = 8 mod 16 floats -- a tap is a constant LDS offset, no bounds tests in the K loop;
 //     patches that do not fit are staged in channel groups (phases), accumulators live across phases;
 //   * K runs over (tap, 16-channel chunk): lane (row l & 15, group g = l >> 4) reads channels 4g..4g+3 of its row
 //     with one ds_read_b128 = the A operands of four v_mfma_f32_16x16x4_f32 K-steps; B fragments come pre-packed
 //     in the same lane order (RzPackOp), 16 bytes per lane per chunk, straight from L2 (every workgroup streams the
-//     layer's weights once; all workgroups read the same image, so it stays L2-resident); both operand sets are
-//     double-buffered in registers one chunk ahead;
+//     layer's weights once; all workgroups read the same image, so it stays L2-resident).  Weight fragments are
+//     double-buffered one chunk ahead; the position fragments of the larger tilings are ONE set refilled in place
+//     (tile i's read for the next chunk is issued right after its last MFMA of this one), the smaller tilings keep two
+//     sets or a four-chunk ring;
 //   * waves take column tiles first (each wave streams a disjoint slice of the weights), row tiles next; a wave
 //     owns up to 9 x 2 accumulator tiles, one B fragment feeds up to nine MFMAs;
 //   * epilogue in registers in the per-operator kernels' order (mzx_ops.h): action term, alpha * acc + beta, bias,
