@@ -44,15 +44,28 @@ inline int rb_lds_budget() {   // MZX_RB_LDS: A/B knob (bytes), e.g. 159744 = on
   return v;
 }
 
+// Rows a workgroup can own: nine row tiles per wave, and the waves the column tiles leave over split the rows -- a
+// 64-channel layer has four column tiles -> two waves deep in rows -> 288 rows (connect4: six boards per workgroup
+// instead of three, in two channel groups: the per-workgroup costs -- tables, first weight fetch, barriers, pipeline
+// fill -- are paid half as often; 0.615 -> 0.65 of the MFMA peak for the whole step at 9216 trees).
+// MZX_RB_ROWS_WIDE=0: nine row tiles per workgroup whatever the width (A/B).
+inline int rb_max_rows(const RbOp& o) {
+  static const int wide = getenv("MZX_RB_ROWS_WIDE") ? atoi(getenv("MZX_RB_ROWS_WIDE")) : 1;
+  if (!wide || o.taps == 1 || o.ntiles < 2) return RB_MAX_ROWS;      // trunk convolutions only: head layers are tiny
+  const int nt = o.ntiles > 8 ? 2 : 1, wn = std::min(8, (std::min(o.ntiles, 16) + nt - 1) / nt);
+  return RB_MAX_ROWS * std::min(4, std::max(1, 8 / wn));
+}
+
 inline bool rb_choose_tile(RbOp& o) {
   const int HWo = o.hout * o.wout;
+  const int max_rows = rb_max_rows(o);
   double best = -1.0;
   RbOp pick = o;
   auto consider = [&](int T, int th, int tw) {
     const int PH = (th - 1) * o.stride + o.ksize, PW = (tw - 1) * o.stride + o.ksize;   // the windows' extent
     const int cells = T * PH * PW;
     const int rows = T * th * tw, mtiles = (rows + 15) / 16;
-    if (rows > RB_MAX_ROWS) return;
+    if (rows > max_rows) return;
     int cpg = o.cchunks;
     while (cpg >= 1 && rb_lds_bytes(T, mtiles, cells, 16 * cpg + 8) > rb_lds_budget()) --cpg;
     if (cpg < 1) return;
@@ -70,11 +83,11 @@ inline bool rb_choose_tile(RbOp& o) {
       pick.lds_bytes = (int32_t)rb_lds_bytes(T, mtiles, cells, pick.Cs);
     }
   };
-  if (HWo <= RB_MAX_ROWS) {
-    for (int T = 1; T * HWo <= RB_MAX_ROWS; ++T) consider(T, o.hout, o.wout);
+  if (HWo <= max_rows) {
+    for (int T = 1; T * HWo <= max_rows; ++T) consider(T, o.hout, o.wout);
   } else {
-    for (int tw = 1; tw <= std::min(o.wout, RB_MAX_ROWS); ++tw)
-      for (int th = 1; th <= o.hout && th * tw <= RB_MAX_ROWS; ++th) consider(1, th, tw);
+    for (int tw = 1; tw <= std::min(o.wout, max_rows); ++tw)
+      for (int th = 1; th <= o.hout && th * tw <= max_rows; ++th) consider(1, th, tw);
   }
   if (best < 0.0) return false;
   o = pick;
