@@ -70,3 +70,13 @@ def test_cpu_baseline_workers_reference_and_port():
         assert searches >= 1 and sims == 50 * searches and wall > 0
     finally:
         torch.set_num_threads(threads)
+
+
+def test_bench_large_shard_workload_labels_what_ran():
+    """`c4-large` chooses the layer-by-layer engine itself, and a `--trees` override shows in the line's label."""
+    line = _run(["--dry-run", "--workload", "c4-large", "--trees", "4", "--steps", "1", "--warmup", "0",
+                 "--selfplay-moves", "0", "--also", "none"])
+    cfg = line["config"]
+    assert cfg["trees_per_gpu"] == 4 and "4 trees x 200 sims" in cfg["workload"] and "9216" not in cfg["workload"]
+    assert "streamed MFMA layers" in cfg["search_kernel"]
+    assert line["roofline"]["bound"] == "mfma" and line["roofline"]["traffic"] is None     # PMC entry is for the default shard
