@@ -69,7 +69,8 @@ WORKLOADS = {
     "c5": ("breakout", {"num_simulations": 50}, 64, "C5 Breakout ResNet (resnet stem), 64 trees x 50 sims per GPU"),
     # the reference's large residual configurations as shipped (streamed MFMA engine, csrc/mzx_batched.hip)
     "gomoku": ("gomoku", {}, 1024, "games/gomoku.py as shipped: 128 ch x 6 blocks, 11 x 11, 1024 trees x 400 sims per GPU"),
-    "atari": ("atari", {}, 256, "games/atari.py as shipped: 256 ch x 16 blocks, 96 x 96 x 131 input, 256 trees x 50 sims per GPU"),
+    # (1024 trees: two half-shards of 512 on two streams, 0.75 of the MFMA peak for the whole step; --trees 256: 0.61)
+    "atari": ("atari", {}, 1024, "games/atari.py as shipped: 256 ch x 16 blocks, 96 x 96 x 131 input, 1024 trees x 50 sims per GPU"),
 }
 
 
