@@ -48,6 +48,11 @@ sys.path.insert(0, ROOT)
 # dmabuf IPC is the only mode the host driver supports: RCCL between the ranks of a node needs it
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+if os.environ.get("MZX_BENCH_CPU_WORKER"):
+    # a spawned CPU-baseline worker re-imports this module: keep its import-time chatter (libdrm's "amdgpu.ids: No such
+    # file" line, once per process) out of the parent's output -- the driver reads the JSON line from the tail of it
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 2)
+
 import numpy  # noqa: E402
 import torch  # noqa: E402
 
@@ -56,6 +61,10 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # dense FP32-input MFMA peak (= FP32 vector peak),
 
 # workloads that choose their network engine themselves (unless --net-mode says otherwise)
 WORKLOAD_NET_MODE = {"c4-large": "streamed"}
+DEFAULT_WORKLOAD = "c2"
+# measured in the same invocation and reported under "workloads" when the main workload is the default one.  Every
+# launch the streamed ones make (c4-large, gomoku, atari) is parity-tested at size: tests/test_streamed_coverage.py
+DEFAULT_ALSO = "c3,c4,c4-large,c5,gomoku,atari"
 
 WORKLOADS = {
     # name: (config factory name, overrides, trees per GPU, description)
@@ -79,7 +88,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--also", default=None,
                     help="comma list of further workloads measured in the same invocation and reported under "
                          "'workloads' (default: c4 when the main workload is c2; 'none' = skip)")
@@ -284,7 +293,8 @@ def cpu_baseline(workload, seconds, cores, kind):
     # CPU baseline: the workers must not see the GPU (the reference wraps its networks in
     # torch.nn.DataParallel, models.py:98-126, which would route batch-1 inferences through cuda:0)
     hidden = {k: os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")}
-    os.environ.update({"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+    hidden["MZX_BENCH_CPU_WORKER"] = os.environ.get("MZX_BENCH_CPU_WORKER")
+    os.environ.update({"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": "", "MZX_BENCH_CPU_WORKER": "1"})
     try:
         with ctx.Pool(cores) as pool:
             res = pool.map(worker, [(workload, w, seconds) for w in range(cores)])
@@ -296,6 +306,7 @@ def cpu_baseline(workload, seconds, cores, kind):
                 os.environ[k] = v
     sims = sum(r[0] for r in res)
     wall = max(r[2] for r in res)
+    rates = [r[0] / r[2] for r in res]
     what = ("unmodified reference self_play.MCTS(config).run + models.py (oracle/_ref bytecode of /root/reference)"
             if kind == "reference" else "CPU oracle (oracle/mcts_oracle.py + net_oracle.py)")
     return {
@@ -303,6 +314,9 @@ def cpu_baseline(workload, seconds, cores, kind):
         "sample": f"{sum(r[1] for r in res)} searches x {sims // max(1, sum(r[1] for r in res))} sims of the same "
                   f"workload, {cores} processes x {seconds:.0f} s, torch.set_num_threads(1) each; {what}",
         "per_core": res[0][0] / res[0][2],
+        # spread over the worker processes (each one's own sims / wall): one aggregate number hides a slow socket / a
+        # busy host; the aggregate above is sum(sims) / max(wall)
+        "per_core_min_median_max": [float(numpy.min(rates)), float(numpy.median(rates)), float(numpy.max(rates))],
     }
 
 
@@ -377,13 +391,11 @@ def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic"):
         "materialize_all_histories_s": materialize if batched else 0.0,
         "steps_per_sec_with_all_histories_as_lists": steps / (wall + (materialize if batched else 0.0)),
         "game_protocol": "batched (one object steps the shard)" if batched else "reference plugin surface (B Game objects)",
-        "note": "one host process: plugin game stepping + host bookkeeping + batched search "
-                "(search_share = fraction of the wall spent inside BatchedMCTS.run incl. uploads/downloads)",
     }
 
 
 # ----------------------------------------------------------------------------- the search workload
-def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_reference=False):
+def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_reference=False, compact=False):
     """
     Times `steps` passes of the hot path of `workload` on every rank (contract bracket: barrier +
     synchronize on both sides, MAX over ranks).  Returns (rank-0 result dict, cfg, net).
@@ -429,10 +441,20 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
 
     # synthetic inputs, resident in HBM: a few distinct input sets rotated over the steps
     c_in = cfg.observation_shape[0] * (cfg.stacked_observations + 1) + cfg.stacked_observations
-    n_sets = 4
+    obs_shape = (c_in,) + tuple(cfg.observation_shape[1:])
+    obs_bytes = 4 * B * int(numpy.prod(obs_shape))
+    # large inputs (games/atari.py: 131 x 96 x 96 floats per tree, 4.9 GB at 1024 trees): uniform [0, 1) observations drawn
+    # ON the device from a seeded generator instead of 10 GB of host doubles per set, and as many sets as steps are run
+    big = obs_bytes > (1 << 30) and not env.dry
+    n_sets = min(4, max(1, steps, warmup)) if big else 4
     sets = []
     for k in range(n_sets):
-        obs = synthetic.observations(B, (c_in,) + tuple(cfg.observation_shape[1:]), seed=123 + 7919 * k + rank)
+        if big:
+            gen = torch.Generator(device="cuda")
+            gen.manual_seed(123 + 7919 * k + rank)
+            obs = torch.rand((B, int(numpy.prod(obs_shape))), device="cuda", generator=gen)
+        else:
+            obs = synthetic.observations(B, obs_shape, seed=123 + 7919 * k + rank)
         legal = numpy.tile(numpy.arange(A, dtype=numpy.int32), (B, 1))
         noise = numpy.zeros((B, A))
         tape = numpy.zeros((B, self_play.TAPE_WORDS), numpy.uint32)
@@ -507,7 +529,7 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     achieved = bytes_per_sim * B * S / (launch_ms * 1e-3) / 1e9
     ran = lib.mzx_search_kernel_name(handle)      # the search kernel the last step launched
     ran = ran.decode() if ran else ""
-    traffic, traffic_src = None, None
+    traffic = None
     try:  # PMC-measured HBM bytes per launch of this kernel (collected by a separate rocprofv3 --pmc run)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             key = "fused-lds" if fused else ("residual-whole-search" if fused_kind == 2 else "generic-per-op")
@@ -521,7 +543,7 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         if not fused and fused_kind != 2 and net_fused and not streamed:
             entry = None
         if entry and B == default_trees:
-            traffic, traffic_src = entry["bytes"], entry["source"]
+            traffic = entry["bytes"]      # (its provenance: profiles/pmc_traffic.json "source")
     except (OSError, ValueError):
         pass
     kernel_name = ("per-sim launches + streamed MFMA layers (rb_gemm_kernel)" +
@@ -529,14 +551,14 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
                    "fused-lds" if fused else
                    "residual whole-search kernel (arena trees, fused MFMA network)" if fused_kind == 2 else
                    "per-sim launches + fused-mfma network" if net_fused else "generic-per-op")
+    # (what the fields mean: module docstring / DESIGN.md section 5; prose is kept out of the line so that the driver's
+    # stdout tail holds the whole JSON)
     roofline = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "algorithmic_bytes_per_launch": bytes_per_sim * B * S,
         "kernel": ran if fused else "whole step (one kernel per operator)",
         "launch_ms": launch_ms, "algorithmic_bytes_per_sim": bytes_per_sim,
-        "note": "tree bytes per simulation x B x S / HIP-event time of one search launch; trees live in "
-                "LDS in the fused kernel, so this is algorithmic traffic, not HBM traffic (DESIGN.md)",
     }
     if cfg.network == "resnet":  # dense contractions: FP32 MFMA roofline
         f_init = int(lib.mzx_net_flops(net.handle, 0))
@@ -545,16 +567,21 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         tf = flops / (launch_ms * 1e-3) / 1e12
         roofline = {
             "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "whole step: select / one mzx::rb_gemm_kernel launch per layer / expand+backprop per simulation" if streamed
-                      else ("whole step: root kernels + " + ran + " (all simulations, one launch)") if fused_kind == 2
-                      else "whole step: select / rz_network_kernel (fused MFMA network) / expand+backprop per simulation"
+            "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+            "kernel": "whole step: select / mzx::rb_gemm_kernel per layer / expand+backprop per simulation" if streamed
+                      else ("whole step: root kernels + " + ran) if fused_kind == 2
+                      else "whole step: select / rz_network_kernel / expand+backprop per simulation"
                       if net_fused else "whole step (one kernel per operator)",
             "launch_ms": launch_ms, "flops_per_simulation": f_rec, "flops_initial_inference": f_init,
-            "flops_per_step": flops, "tree_bytes_per_sim": bytes_per_sim,
-            "note": "network FLOPs (2 x MAC of every conv / linear layer, as the reference's modules count) of one "
-                    "step / HIP-event time of the step, vs the dense FP32-input MFMA peak",
+            "flops_per_step": flops,
         }
+    instantiations = None
+    if streamed:     # WHICH rb_gemm_kernel<MT, NT> / channel phases / K loop this workload launched (host-side planner)
+        first, second = net.streamed_split(B) if "two half-shards" in ran else (B, 0)
+        launches = net.streamed_launches(0, B)
+        for b in sorted({first, second} - {0}):
+            launches += net.streamed_launches(1, b)
+        instantiations = {"half_shards": [first, second], "rb_gemm_kernel": models.summarize_launches(launches)}
     result = {
         "metric": "mcts_simulations_per_sec", "value": value, "unit": "sims/s", "n_gpus": world,
         "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
@@ -567,21 +594,32 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
             "mean_leaf_depth": L,
         },
         "repeats": {"n": len(blocks), "steps_per_block": steps, "median": sorted(block_rates)[len(block_rates) // 2],
-                    "min": min(block_rates), "max": max(block_rates), "unit": "sims/s",
-                    "note": "each block = exactly `steps` steps between barrier + synchronize brackets; value / ms_per_step are the median block's"},
+                    "min": min(block_rates), "max": max(block_rates), "unit": "sims/s"},
         "search_steps_per_sec": world * B * steps / elapsed,
         "weight_broadcast_ms": broadcast_ms,
         "collective_world_size": (torch.distributed.get_world_size() if world > 1 else 1),
         "collective_backend": (torch.distributed.get_backend() if world > 1 else None),
         "roofline": roofline,
     }
+    if instantiations:
+        result["config"]["instantiations"] = instantiations
+    if compact:      # an entry of "workloads": the same measurement, the fields that are not constant across entries
+        result = {
+            "workload": workload, "value": value, "unit": "sims/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "config": {"workload": description, "trees_per_gpu": B, "num_simulations": S, "search_kernel": kernel_name,
+                       "mean_leaf_depth": round(L, 3)},
+            "repeats": {"n": len(blocks), "min": min(block_rates), "max": max(block_rates)},
+            "roofline": {k: roofline[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms") if k in roofline},
+        }
+        if "flops_per_step" in roofline:
+            result["roofline"]["flops_per_step"] = roofline["flops_per_step"]
+        if instantiations:
+            result["config"]["instantiations"] = instantiations
     if world > 1:
         result["per_rank"] = {"sims_per_sec": per_rank, "min": min(per_rank), "max": max(per_rank)}
         if solo is not None:
             result["single_gpu_reference"] = {
-                "sims_per_sec": solo, "weak_scaling_efficiency": value / (world * solo),
-                "note": "rank 0 timed alone (other ranks idle at a barrier) on the same box, same steps; the driver "
-                        "computes the official efficiency from its own N = 1 run",
+                "sims_per_sec": solo, "weak_scaling_efficiency": value / (world * solo),   # rank 0 timed alone on the same box
             }
     return result, cfg, net
 
@@ -595,7 +633,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env.world}")
     also = args.also
     if also is None:
-        also = "c3,c4,c4-large,c5,gomoku" if (args.workload == "c2" and not args.dry_run and args.trees is None) else "none"
+        also = DEFAULT_ALSO if (args.workload == DEFAULT_WORKLOAD and not args.dry_run and args.trees is None) else "none"
     also = [w for w in also.split(",") if w and w != "none"]
 
     line, cfg, net = run_search_workload(env, args, args.workload, args.steps, args.warmup, args.trees,
@@ -606,7 +644,7 @@ def main():
         if w not in WORKLOADS:
             raise SystemExit(f"unknown workload {w}")
         # one step of games/gomoku.py as shipped is 1024 x 400 simulations of a 128-channel network (~3.5 s)
-        r, c2_, n2 = run_search_workload(env, args, w, 1 if w in ("gomoku", "atari") else args.also_steps, 1)
+        r, c2_, n2 = run_search_workload(env, args, w, 1 if w in ("gomoku", "atari") else args.also_steps, 1, compact=True)
         if w == "c4":
             c4_net = (c2_, n2)
         else:

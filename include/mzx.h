@@ -121,6 +121,15 @@ int mzx_net_streamed_plan(const mzx_net* net, int32_t recurrent, int32_t op, int
  * bytes, column tiles per workgroup, column splits, column tiles per wave, waves along N, waves along M, row tiles per
  * wave, row groups (grid.x), chunks per phase, phases, LDS floats per cell, column tiles, 16-channel chunks per tap}. */
 int mzx_net_streamed_shape(const mzx_net* net, int32_t recurrent, int32_t op, int32_t batch, int32_t out[16]);
+/* The row-per-tree search runs large shards as two half-shards on two HIP streams (csrc/mzx_row_search.h; from 1024
+ * trees, and only when both halves keep the channel groups -- the summation order -- of the undivided launch):
+ * out = {trees of the first half, trees of the second half}; {batch, 0} when a shard of `batch` trees runs undivided.
+ * recurrent_inference is then launched at THESE batch sizes (tests / bench.py derive the kernel instantiations a
+ * workload launches from it, host-side). */
+int mzx_net_streamed_split(const mzx_net* net, int32_t batch, int32_t out[2]);
+/* Floats per sample of the output tensor of operator `op` (what mzx_net_debug_prefix copies out for a prefix ending
+ * there); 0 for an unknown operator. */
+int64_t mzx_net_operator_out_floats(const mzx_net* net, int32_t recurrent, int32_t op);
 
 /* initial_inference(observation) (models.py:172-190 / :601-618).
  * d_observation [batch][input_size]; outputs value_logits [batch][2s+1],

@@ -599,9 +599,9 @@ int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
   // MZX_RB_STAMPS=<launch number>: phase clocks of that GEMM launch (counted from the first one of the process),
   // printed to stderr after a blocking copy -- a diagnostic, never set in production
   static const int stamp_launch = getenv("MZX_RB_STAMPS") ? atoi(getenv("MZX_RB_STAMPS")) : -1;
-  static int launch_no = 0;
-  static unsigned long long* d_stamps = nullptr;
-  const bool stamp = stamp_launch >= 0 && launch_no++ == stamp_launch;
+  static std::atomic<int> launch_no{0};      // (two streams / host threads launch through here)
+  static unsigned long long* d_stamps = nullptr;   // touched by the one stamped launch only
+  const bool stamp = stamp_launch >= 0 && launch_no.fetch_add(1) == stamp_launch;
   const size_t stamp_words = (size_t)RB_STAMP_WGS * 8 * RB_STAMP_SLOTS;
   if (stamp) {
     if (!d_stamps && hipMalloc((void**)&d_stamps, stamp_words * 8) != hipSuccess) d_stamps = nullptr;

@@ -184,6 +184,27 @@ int mzx_net_streamed_shape(const mzx_net* net, int32_t recurrent, int32_t op, in
   return MZX_OK;
 }
 
+int mzx_net_streamed_split(const mzx_net* net, int32_t batch, int32_t out[2]) {
+  if (!net || !out || batch < 1) { set_error("null argument / batch < 1"); return MZX_ERR_INVALID; }
+  const int first = rb_split_first(net, batch);
+  out[0] = first > 0 ? first : batch;
+  out[1] = first > 0 ? batch - first : 0;
+  return MZX_OK;
+}
+
+int64_t mzx_net_operator_out_floats(const mzx_net* net, int32_t recurrent, int32_t op) {
+  if (!net) return 0;
+  const std::vector<OpDesc>& prog = recurrent ? net->prog_recurrent : net->prog_initial;
+  if (op < 0 || op >= (int32_t)prog.size()) return 0;
+  const OpDesc& d = prog[op];
+  switch (d.kind) {      // (the sizes run_network_prefix copies out)
+    case OP_LINEAR: return d.out_features;
+    case OP_CONV3: case OP_POOL: case OP_CONVK: case OP_MAXPOOL: case OP_ADAPTIVE_POOL: return (int64_t)d.cout * d.hout * d.wout;
+    case OP_CONV1: return (int64_t)d.cout * d.hin;
+    default: return (int64_t)d.groups_per_sample * d.len;
+  }
+}
+
 int mzx_net_set_mode(mzx_net* net, int32_t mode) {
   if (!net) { set_error("null network handle"); return MZX_ERR_INVALID; }
   if (mode < 0 || mode > 3) { set_error("network mode is 0 (one kernel per operator), 1 (fused engine, streamed engine for what it cannot hold), 2 (fused, 4-wave workgroups) or 3 (streamed engine for everything)"); return MZX_ERR_INVALID; }

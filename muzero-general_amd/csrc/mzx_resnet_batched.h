@@ -177,6 +177,25 @@ inline RbShape rb_choose_shape(const RbOp& o, int batch) {
   return best;
 }
 
+// Two half-shards on two streams (mzx_row_search.h): size of the FIRST half for a shard of `batch` trees, 0 = the shard
+// runs undivided.  16-tree aligned (every per-tree array of the second half stays 16-byte aligned).  The summation
+// order of a layer depends on the launch shape only through its channel groups (phases x chunks per group): a shard is
+// split only when both halves run every layer with the groups of the undivided launch (true of every shipped
+// configuration from 512 trees per half on: the planned tile), so the halves build the trees of the undivided run.
+constexpr int RB_SPLIT_MIN_DEFAULT = 1024;
+inline int rb_split_first(const mzx_net* net, int batch, int split_min = RB_SPLIT_MIN_DEFAULT) {
+  if (!net || !net->rb.ok || !net->rb.recurrent.ok) return 0;
+  if (split_min <= 0 || batch < split_min || batch < 32) return 0;
+  const int first = ((batch / 2 + 15) / 16) * 16;
+  if (first <= 0 || first >= batch) return 0;
+  for (const RbOp& o : net->rb.recurrent.ops) {
+    if (o.kind != RB_GEMM) continue;
+    const RbShape w = rb_choose_shape(o, batch), h0 = rb_choose_shape(o, first), h1 = rb_choose_shape(o, batch - first);
+    if (h0.phases != w.phases || h0.cpg != w.cpg || h1.phases != w.phases || h1.cpg != w.cpg) return 0;
+  }
+  return first;
+}
+
 // Plans one program; `layout` carries the layout of every logical buffer written so far.
 inline bool rb_build_program(mzx_net* net, const std::vector<OpDesc>& prog, RbPlan& P, RbProgram& R, int64_t& cursor,
                              std::map<std::tuple<int64_t, int, int>, int64_t>& packed) {

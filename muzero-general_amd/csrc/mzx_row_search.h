@@ -160,21 +160,12 @@ inline int search_run_rows(mzx_search* s, const mzx_search_io* io, void* d_arena
   // under the trunk layers of the other.  Trees are independent and a sample's arithmetic does not depend on the
   // batch it runs in (the halves keep the planned launch shape), so the trees are the ones of the undivided run.
   const char* split_env = getenv("MZX_ROW_SPLIT_MIN");       // read per run: the tests run both ways in one process
-  const int split_min = split_env ? atoi(split_env) : 1024;  // 0: never
+  const int split_min = split_env ? atoi(split_env) : RB_SPLIT_MIN_DEFAULT;  // 0: never
   int parts = 1;
-  const int first = ((B / 2 + 15) / 16) * 16;                // 16 trees: every per-tree array stays 16-byte aligned
-  // The summation order of a layer depends on the launch shape only through its channel groups (phases x chunks per
-  // group): split only when both halves run every layer with the groups of the undivided launch (true of every shipped
-  // configuration from 512 trees per half on: the planned tile).
-  auto same_arithmetic = [&]() {
-    for (const RbOp& o : net->rb.recurrent.ops) {
-      if (o.kind != RB_GEMM) continue;
-      const RbShape w = rb_choose_shape(o, B), h0 = rb_choose_shape(o, first), h1 = rb_choose_shape(o, B - first);
-      if (h0.phases != w.phases || h0.cpg != w.cpg || h1.phases != w.phases || h1.cpg != w.cpg) return false;
-    }
-    return true;
-  };
-  if (split_min > 0 && B >= split_min && B >= 32 && same_arithmetic()) {
+  // the decision (rb_split_first: three launch-shape evaluations per layer) is made once per handle and threshold
+  if (s->split_for != split_min) { s->split_first = rb_split_first(net, B, split_min); s->split_for = split_min; }
+  const int first = s->split_first > 0 ? s->split_first : B;
+  if (s->split_first > 0) {
     if (!s->side_stream) {
       hipStream_t st = nullptr;
       hipEvent_t e0 = nullptr, e1 = nullptr;

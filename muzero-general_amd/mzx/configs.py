@@ -43,6 +43,7 @@ class HotPathConfig:
         self.fc_value_layers = [16]
         self.fc_policy_layers = [16]
         self.training_steps = 10000
+        self.checkpoint_interval = 10      # trainer.py:87 publishes weights every checkpoint_interval steps (games/*.py: 10 ... 1000)
         self.self_play_delay = 0
         self.ratio = None
         self.use_last_model_value = True   # every BASELINE game file but breakout (games/breakout.py:109)
@@ -122,7 +123,7 @@ def breakout(**kw):
         reduced_channels_reward=4, reduced_channels_value=4, reduced_channels_policy=4,
         resnet_fc_reward_layers=[16], resnet_fc_value_layers=[16], resnet_fc_policy_layers=[16],
         encoding_size=10, fc_value_layers=[], fc_policy_layers=[], training_steps=int(1000e3),
-        temperature_schedule="breakout", use_last_model_value=False,
+        temperature_schedule="breakout", use_last_model_value=False, checkpoint_interval=500,
     )
     base.update(kw)
     return HotPathConfig(**base)
@@ -157,7 +158,7 @@ def gomoku(**kw):
         resnet_fc_reward_layers=[64], resnet_fc_value_layers=[64], resnet_fc_policy_layers=[64],
         encoding_size=32, fc_dynamics_layers=[64], fc_reward_layers=[64],
         fc_value_layers=[], fc_policy_layers=[], training_steps=10000,
-        use_last_model_value=False, ratio=1,   # temperature: the fractions schedule (games/gomoku.py:115-128)
+        use_last_model_value=False, ratio=1, checkpoint_interval=50,   # temperature: the fractions schedule (games/gomoku.py:115-128)
     )
     base.update(kw)
     return HotPathConfig(**base)
@@ -174,7 +175,7 @@ def atari(**kw):
         reduced_channels_reward=256, reduced_channels_value=256, reduced_channels_policy=256,
         resnet_fc_reward_layers=[256, 256], resnet_fc_value_layers=[256, 256], resnet_fc_policy_layers=[256, 256],
         encoding_size=10, fc_dynamics_layers=[16], fc_reward_layers=[16], fc_value_layers=[], fc_policy_layers=[],
-        training_steps=int(1000e3), temperature_schedule="breakout",
+        training_steps=int(1000e3), temperature_schedule="breakout", checkpoint_interval=1000,
     )
     base.update(kw)
     return HotPathConfig(**base)

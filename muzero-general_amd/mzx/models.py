@@ -96,6 +96,66 @@ def net_config_from(config):
     return c
 
 
+STREAMED_SHAPE_FIELDS = ("T", "rows", "mtiles", "lds", "ntiles_wg", "nsplit", "NT", "WN", "WM", "MT", "groups", "cpg",
+                         "phases", "Cs", "ntiles", "cchunks")
+
+
+def streamed_k_loop(MT, NT):
+    """Which K loop ``rb_gemm_kernel<MT, NT>`` compiles (csrc/mzx_batched.hip): one set of position fragments refilled in
+    place, the four-chunk ring of the small tilings, or two alternating fragment sets."""
+    if (MT - 1) * NT >= 5:
+        return "in-place"
+    return "ring" if MT * NT <= 4 else "two-sets"
+
+
+def streamed_launches(lib, handle, recurrent, batch):
+    """
+    Host-side (no GPU): the launch of every GEMM operator of a residual program on the streamed engine at ``batch``
+    samples -- [{op, MT, NT, phases, k_loop, WM, WN, T, nsplit, cpg, taps, stride, in_layout, res}] -- i.e. WHICH
+    ``rb_gemm_kernel<MT, NT>`` instantiation runs, with how many channel phases and which K loop.  The at-size parity
+    tests assert these, bench.py prints them, and tests/test_streamed_coverage.py checks that every launch a bench
+    workload makes is one a -m gpu parity test makes too.
+    """
+    out = []
+    plan = (ctypes.c_int32 * 24)()
+    shape = (ctypes.c_int32 * 16)()
+    for op in range(lib.mzx_net_num_operators(handle, int(bool(recurrent)))):
+        lib.check(lib.mzx_net_streamed_plan(handle, int(bool(recurrent)), op, ctypes.byref(plan)))
+        p = dict(zip(HipNetwork.STREAMED_PLAN_FIELDS, list(plan)))
+        if p["kind"] != 0:
+            continue
+        lib.check(lib.mzx_net_streamed_shape(handle, int(bool(recurrent)), op, int(batch), ctypes.byref(shape)))
+        s = dict(zip(STREAMED_SHAPE_FIELDS, list(shape)))
+        out.append(dict(op=op, MT=s["MT"], NT=s["NT"], phases=s["phases"], k_loop=streamed_k_loop(s["MT"], s["NT"]),
+                        WM=s["WM"], WN=s["WN"], T=s["T"], nsplit=s["nsplit"], cpg=s["cpg"], taps=p["taps"],
+                        stride=p["stride"], in_layout=p["in_layout"], cin=p["cin"], cout=p["cout"]))
+    return out
+
+
+def streamed_split(lib, handle, batch):
+    """(first half, second half) the row-per-tree search runs a shard of ``batch`` trees as; (batch, 0) = undivided."""
+    out = (ctypes.c_int32 * 2)()
+    lib.check(lib.mzx_net_streamed_split(handle, int(batch), ctypes.byref(out)))
+    return int(out[0]), int(out[1])
+
+
+def instantiation_key(launch):
+    """What identifies the compiled code path of a launch: (MT, NT, channel phases > 1, K loop)."""
+    return (launch["MT"], launch["NT"], launch["phases"], launch["k_loop"])
+
+
+def launch_key(launch):
+    """The instantiation plus everything else that selects a branch inside it (wave grid, samples per workgroup, column
+    split, kernel size / stride, gather layout)."""
+    return instantiation_key(launch) + (launch["WM"], launch["WN"], launch["T"], launch["nsplit"], launch["cpg"],
+                                        launch["taps"], launch["stride"], launch["in_layout"])
+
+
+def summarize_launches(launches):
+    """Compact, sorted labels '<MT,NT> phases K-loop' of a launch list (bench.py reports these per workload)."""
+    return [f"<{mt},{nt}> {ph}ph {kl}" for mt, nt, ph, kl in sorted({instantiation_key(l) for l in launches})]
+
+
 class MuZeroNetwork:
     """models.py:7-41: ``MuZeroNetwork(config)`` returns the network object."""
 
@@ -259,6 +319,16 @@ class HipNetwork:
                                                                       ctypes.byref(out)))
         return dict(zip(self.STREAMED_PLAN_FIELDS, list(out)))
 
+    def streamed_launches(self, recurrent, batch):
+        """``streamed_launches`` of this network (module function above)."""
+        return streamed_launches(self.backend.lib, self.handle, recurrent, batch)
+
+    def streamed_split(self, batch):
+        return streamed_split(self.backend.lib, self.handle, batch)
+
+    def operator_out_floats(self, recurrent, op):
+        return int(self.backend.lib.mzx_net_operator_out_floats(self.handle, int(bool(recurrent)), int(op)))
+
     def set_mode(self, mode):
         """0 = one kernel per operator, 1 = fused engine where available (default)."""
         self.backend.lib.check(self.backend.lib.mzx_net_set_mode(self.handle, int(mode)))
@@ -272,7 +342,9 @@ class HipNetwork:
         x = self._prepare(x, self.hidden_size if recurrent else self.input_size)
         n = x.shape[0]
         act = None if action is None else action.to(b.device).reshape(-1).to(torch.int32).contiguous()
-        cap = max(self.hidden_size, self.input_size, 4096) * 64
+        cap = self.operator_out_floats(recurrent, n_ops - 1) if fused != 2 else 0   # (fused == 2: cycle stamps, not a tensor)
+        if cap <= 0:
+            cap = max(self.hidden_size, self.input_size, 4096) * 64
         out = b.zeros((n, cap), torch.float32)
         scratch = b.empty(((self.hidden_size + 2 * self.full_support_size + self.action_space_size) * n,), torch.float32)
         ws = self._ws(n)

@@ -85,8 +85,18 @@ def _stock_replay_buffer_class():
     behind it is what gets instantiated here (wrap the accelerated buffer with ``ray.remote`` like the reference).
     """
     import importlib
-    module = importlib.import_module("replay_buffer")
-    cls = module.ReplayBuffer
+    try:
+        module = importlib.import_module("replay_buffer")
+    except ModuleNotFoundError as e:
+        raise ModuleNotFoundError(
+            "mzx.replay.ReplayBuffer wraps the reference's own buffer: module 'replay_buffer' (replay_buffer.py of "
+            "muzero-general) must be importable -- put the reference checkout on sys.path, or pass the class / an "
+            "instance as ReplayBuffer(..., stock=...)") from e
+    return _plain_class(module.ReplayBuffer)
+
+
+def _plain_class(cls):
+    """The class behind a ``ray.remote`` wrapper (``ActorClass.__ray_metadata__.modified_class``), else ``cls`` itself."""
     meta = getattr(cls, "__ray_metadata__", None)
     return getattr(meta, "modified_class", cls)
 
@@ -116,14 +126,25 @@ class ReplayBuffer:
     """
 
     def __init__(self, initial_checkpoint, initial_buffer, config, stock=None):
-        factory = stock if stock is not None else _stock_replay_buffer_class()
-        self._stock = factory(initial_checkpoint, initial_buffer, config) if isinstance(factory, type) else factory
-        self._arrays = {}     # game_id -> (game_history, per-game numpy views); dropped when the game changes or leaves
+        factory = _plain_class(stock) if stock is not None else _stock_replay_buffer_class()
+        # a class (also the one behind a ray.remote ActorClass) is instantiated; anything that already has the buffer's
+        # methods is taken as the instance to wrap
+        built = factory(initial_checkpoint, initial_buffer, config) if isinstance(factory, type) else factory
+        object.__setattr__(self, "_stock", built)
+        object.__setattr__(self, "_arrays", {})   # game_id -> (game_history, per-game numpy views); dropped when the game changes or leaves
 
     def __getattr__(self, name):
         if name in ("_stock", "_arrays"):
             raise AttributeError(name)
         return getattr(self._stock, name)
+
+    def __setattr__(self, name, value):
+        # the buffer's state lives in the stock object: writes to its public attributes (buffer, num_played_games, ...)
+        # land there, like the reads above
+        if name.startswith("_"):
+            object.__setattr__(self, name, value)
+        else:
+            setattr(self._stock, name, value)
 
     # ---- storage / sampling: the stock buffer's own code (explicit so that ray.remote sees the methods)
     def get_buffer(self):

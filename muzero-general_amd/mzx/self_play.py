@@ -714,7 +714,7 @@ class SelfPlay:
             if getattr(shared_storage, "training_steps", 0) is None:
                 shared_storage.training_steps = self.config.training_steps
             if getattr(shared_storage, "checkpoint_interval", 0) is None:
-                shared_storage.checkpoint_interval = getattr(self.config, "checkpoint_interval", 1)
+                shared_storage.checkpoint_interval = getattr(self.config, "checkpoint_interval", 10)
             shared_storage.refresh(self.model, block=True)     # the trainer's weights before the first game
         while get("training_step") < self.config.training_steps and not get("terminate"):
             if not sharded:

@@ -250,7 +250,9 @@ class NetworkEvaluator:
 
     def initial(self, observation, actions):
         with torch.no_grad():
-            obs = torch.tensor(observation).float().unsqueeze(0)
+            # (the reference feeds float32, self_play.py:280-285; a binary64 yardstick network takes the observation in
+            # its own precision)
+            obs = torch.tensor(observation).float().to(getattr(self.net, "dtype", torch.float32)).unsqueeze(0)
             return self._finish(*self.net.initial_inference(obs), actions)
 
     def recurrent(self, hidden, action, actions):

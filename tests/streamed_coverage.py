@@ -1,0 +1,96 @@
+"""
+Which launches of the streamed MFMA engine (csrc/mzx_batched.hip: rb_gemm_kernel<MT, NT>, channel phases, K loop) the
+AT-SIZE GPU parity tests make, and which ones bench.py's workloads make -- both derived host-side through the C ABI
+(mzx_net_streamed_shape / mzx_net_streamed_split; no GPU), from the same tables the tests and the bench run on:
+
+  AT_SIZE           the (configuration, network mode, batch) cases tests/test_gpu_streamed_at_size.py runs operator by
+                    operator and against the oracle network -- both programs at `batch`;
+  AT_SIZE_SEARCHES  the whole searches the same file runs against the CPU oracle (initial_inference at the shard size,
+                    recurrent_inference at the half-shard sizes AND at the undivided shard: the test runs both ways);
+  bench_launches()  what every streamed workload of bench.py launches at its default shard.
+
+tests/test_streamed_coverage.py (CPU) fails when a bench launch is not among the GPU-tested ones, so the roofline
+fractions the bench reports always have device parity evidence behind the very instantiation that was timed.
+"""
+import ctypes
+
+from mzx import configs, models
+
+# name -> (configs factory, network mode for set_mode (None: the default routing), batch)
+AT_SIZE = {
+    "gomoku-512": ("gomoku", None, 512),
+    "gomoku-1024": ("gomoku", None, 1024),
+    "connect4-4608": ("connect4", 3, 4608),
+    "connect4-9216": ("connect4", 3, 9216),
+    "atari-256": ("atari", None, 256),
+    "atari-512": ("atari", None, 512),
+    "atari-1024": ("atari", None, 1024),
+}
+
+# name -> (configs factory, network mode, trees, simulations (None: as shipped), trees compared with the oracle)
+AT_SIZE_SEARCHES = {
+    "gomoku-1024": ("gomoku", None, 1024, None, 16),
+    "connect4-9216": ("connect4", 3, 9216, None, 64),
+    "atari-1024": ("atari", None, 1024, None, 8),
+    "atari-256": ("atari", None, 256, None, 4),
+}
+
+
+def _create(lib, cfg):
+    c = models.net_config_from(cfg)
+    h = ctypes.c_void_p()
+    lib.check(lib.mzx_net_create(ctypes.byref(c), ctypes.byref(h)))
+    return h
+
+
+def inference_launches(lib, game, batch, recurrent, overrides=None):
+    h = _create(lib, configs.BY_NAME[game](**(overrides or {})))
+    try:
+        return models.streamed_launches(lib, h, recurrent, batch)
+    finally:
+        lib.mzx_net_destroy(h)
+
+
+def search_launches(lib, game, trees, overrides=None, both_ways=False):
+    """
+    The GEMM launches of one search over `trees` roots on the row-per-tree path: initial_inference at the shard size,
+    recurrent_inference at the sizes of the two half-shards (or the shard, when it runs undivided); `both_ways` adds the
+    undivided shard (the parity test runs the search split AND unsplit).  Returns (launch dicts, (first, second)).
+    """
+    h = _create(lib, configs.BY_NAME[game](**(overrides or {})))
+    try:
+        parts = models.streamed_split(lib, h, trees)
+        out = [dict(l, program="initial", batch=trees) for l in models.streamed_launches(lib, h, 0, trees)]
+        sizes = {p for p in parts if p > 0}
+        if both_ways:
+            sizes.add(trees)
+        for b in sorted(sizes):
+            out += [dict(l, program="recurrent", batch=b) for l in models.streamed_launches(lib, h, 1, b)]
+        return out, parts
+    finally:
+        lib.mzx_net_destroy(h)
+
+
+def gpu_tested_launches(lib):
+    """Every launch the at-size GPU parity tests make."""
+    out = []
+    for game, _, batch in AT_SIZE.values():
+        for recurrent in (0, 1):
+            out += inference_launches(lib, game, batch, recurrent)
+    for game, _, trees, _, _ in AT_SIZE_SEARCHES.values():
+        out += search_launches(lib, game, trees, both_ways=True)[0]
+    return out
+
+
+def bench_streamed_workloads(bench):
+    """bench.py's default workloads that run on the streamed engine: {name: (game, overrides, trees)}."""
+    names = [bench.DEFAULT_WORKLOAD] + [w for w in bench.DEFAULT_ALSO.split(",") if w]
+    out = {}
+    for w in names:
+        game, overrides, trees, _ = bench.WORKLOADS[w]
+        if bench.WORKLOAD_NET_MODE.get(w) == "streamed" or game in ("gomoku", "atari"):
+            out[w] = (game, overrides, trees)
+    return out
+
+
+summarize = models.summarize_launches

@@ -47,7 +47,8 @@ def test_bench_single_rank_dry_run_with_second_workload():
     line = _run(["--dry-run", "--trees", "4", "--steps", "1", "--warmup", "0", "--selfplay-moves", "2",
                  "--also", "c3", "--also-steps", "1"])
     assert line["n_gpus"] == 1 and "per_rank" not in line
-    assert [w["config"]["network"] for w in line["workloads"]] == ["resnet"]
+    assert [w["workload"] for w in line["workloads"]] == ["c3"]      # compact entries: name, value, config, repeats, roofline
+    assert set(line["workloads"][0]) == {"workload", "value", "unit", "ms_per_step", "steps", "config", "repeats", "roofline"}
     assert line["workloads"][0]["roofline"]["bound"] == "mfma"
     assert line["selfplay_end_to_end"]["steps_per_sec"] > 0
     assert line["selfplay_end_to_end_batched_game"]["steps_per_sec"] > 0

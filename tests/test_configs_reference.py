@@ -13,7 +13,8 @@ ATTRS = ["observation_shape", "action_space", "players", "stacked_observations",
          "downsample", "blocks", "channels", "reduced_channels_reward", "reduced_channels_value",
          "reduced_channels_policy", "resnet_fc_reward_layers", "resnet_fc_value_layers", "resnet_fc_policy_layers",
          "encoding_size", "fc_representation_layers", "fc_dynamics_layers", "fc_reward_layers", "fc_value_layers",
-         "fc_policy_layers", "max_moves", "temperature_threshold", "muzero_player", "opponent", "use_last_model_value"]
+         "fc_policy_layers", "max_moves", "temperature_threshold", "muzero_player", "opponent", "use_last_model_value",
+         "checkpoint_interval"]
 
 
 @pytest.mark.reference
