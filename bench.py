@@ -350,13 +350,16 @@ def observation_stacker_leg(backend, games=64, stacked=32, iters=20):
             "algorithmic_bytes_per_launch": nbytes, "launch_ms": ms, "games": games, "stacked_observations": stacked}
 
 
-def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic"):
+def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=False):
     """
-    SelfPlay(num_games=B).play_games: what a user of the drop-in engine sees per process -- game stepping, per-game
-    numpy-compatible streams (native bank), temperature sampling and GameHistory records around one batched search
-    per move.  game = "synthetic": the fixed-shape synthetic game, `moves` moves per game; game = "connect4" /
-    "tictactoe": the real rules (mzx.games: per-object classes with the reference plugin surface, or the batched
-    protocol), whole games to their natural end.
+    What a user of the drop-in engine sees per process -- game stepping, per-game numpy-compatible streams (native
+    bank), temperature sampling and GameHistory records around one batched search per move.  Default:
+    SelfPlay(num_games=B).play_rounds -- every slot of the shard is one reference actor whose next game starts the
+    moment one ends (self_play.py:31-52), so every search runs at full width; `rounds` rounds = B x rounds self-play
+    steps.  lockstep=True: play_games, one whole shard of games searched as a thinning batch until its longest game ends
+    (rounds 1-3's number, kept as the A/B).  game = "synthetic": the fixed-shape synthetic game, `moves` moves per game;
+    game = "connect4" / "tictactoe": the real rules (mzx.games: per-object classes with the reference plugin surface, or
+    the batched protocol), whole games to their natural end.
     """
     import copy
 
@@ -368,29 +371,38 @@ def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic"):
         c.max_moves = moves
         make = synthetic.make_synthetic_batched_game if batched else synthetic.make_synthetic_game
         Game = make(c.observation_shape, len(c.action_space), len(c.players))
+        rounds = moves
     else:
         Game = (board_games.BATCHED if batched else board_games.PER_OBJECT)[game]
+        rounds = c.max_moves          # as many rounds as the longest possible game (connect4: 42)
     sp = self_play.SelfPlay({"weights": net.get_weights()}, Game, c, 0, num_games=B, _backend=net.backend)
-    sp.play_games(1.0, None, False, "self", 0)          # warm-up (allocations, kernel attributes)
+    if lockstep:
+        sp.play_games(1.0, None, False, "self", 0)          # warm-up (allocations, kernel attributes)
+    else:
+        sp.play_rounds(1.0, None, min_games=1 << 60, max_rounds=2)
     sp.stats = {"searches": 0, "simulations": 0, "search_seconds": 0.0}
     t0 = time.perf_counter()
-    histories = sp.play_games(1.0, None, False, "self", 0)
+    if lockstep:
+        histories = sp.play_games(1.0, None, False, "self", 0)
+    else:
+        histories = sp.play_rounds(1.0, None, min_games=1 << 60, max_rounds=rounds)
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     t1 = time.perf_counter()
-    steps = sum(len(h.action_history) - 1 for h in histories)
+    steps = sp.stats["searches"]     # one search = one self-play step of one game (lock-step: finished games are not searched)
     for h in histories:       # batched protocol: per-game records are views until touched; time touching ALL of them
         if hasattr(h, "materialize"):
             h.materialize()
     materialize = time.perf_counter() - t1
     return {
         "steps_per_sec": steps / wall, "sims_per_sec": steps * c.num_simulations / wall, "games": B,
-        "moves_per_game": steps / B, "game": game,
+        "games_finished": len(histories), "moves_per_finished_game": (sum(len(h.action_history) - 1 for h in histories) /
+                                                                      max(1, len(histories))),
+        "game": game, "mode": "lock-step shards (play_games)" if lockstep else "finished slots refilled (play_rounds)",
         "wall_s": wall, "search_share": sp.stats["search_seconds"] / wall,
-        "materialize_all_histories_s": materialize if batched else 0.0,
         "steps_per_sec_with_all_histories_as_lists": steps / (wall + (materialize if batched else 0.0)),
-        "game_protocol": "batched (one object steps the shard)" if batched else "reference plugin surface (B Game objects)",
+        "game_protocol": "batched" if batched else "reference plugin surface (B Game objects)",
     }
 
 
@@ -670,6 +682,9 @@ def main():
                 line["selfplay_end_to_end_connect4"] = selfplay_leg(c4_cfg, c4_model, WORKLOADS["c4"][2], 0, game="connect4")
                 line["selfplay_end_to_end_connect4_batched_game"] = selfplay_leg(c4_cfg, c4_model, WORKLOADS["c4"][2], 0,
                                                                                  batched=True, game="connect4")
+                # rounds 1-3 played whole shards in lock-step (the batch thins out while the longest game ends): the A/B
+                line["selfplay_end_to_end_connect4_batched_game"]["lockstep_steps_per_sec"] = selfplay_leg(
+                    c4_cfg, c4_model, WORKLOADS["c4"][2], 0, batched=True, game="connect4", lockstep=True)["steps_per_sec"]
             if not args.dry_run:
                 line["observation_stacker"] = observation_stacker_leg(net.backend)
         line["cpu_baseline"] = None

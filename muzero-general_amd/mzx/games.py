@@ -9,6 +9,8 @@ row 3).  ``mzx.self_play.SelfPlay`` drives a class with ``batched = True`` throu
                                         (finished earlier) are left untouched
     legal_actions()    -> int32 [B][A], each row the legal actions in increasing order, padded with -1
     to_play()          -> [B]
+    reset_games(idx)   -> observations [len(idx), ...]   (optional: restarts only those games; SelfPlay.play_rounds
+                                        refills finished slots through it so that every search runs at full width)
 
 Game i of ``TicTacToeBatched`` / ``Connect4Batched`` / ``GomokuBatched`` emits, observation for observation (values AND
 dtype), reward for reward, what ``Game(seed)`` of the reference's games/tictactoe.py:125-351 / games/connect4.py:125-346 /
@@ -151,6 +153,15 @@ class _KInARowBatched:
         self.player = numpy.ones(self.num_games, numpy.int32)
         self.height = numpy.zeros((self.num_games, self.cols), numpy.int64)   # stones per column (gravity games)
         return self._observation()
+
+    def reset_games(self, games):
+        """Optional refill hook of the batched protocol: restart ONLY the given games (a finished game hands its slot to
+        the next one at once, like the reference actor's loop self_play.py:31-52); returns their first observations."""
+        g = numpy.asarray(games, numpy.int64)
+        self.board[g] = 0
+        self.player[g] = 1
+        self.height[g] = 0
+        return self._observation()[g]
 
     def to_play(self):
         return numpy.where(self.player == 1, 0, 1)

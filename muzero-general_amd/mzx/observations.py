@@ -114,6 +114,22 @@ class FrameStore:
             act = numpy.ascontiguousarray(numpy.asarray(actions).reshape(self.G), dtype=numpy.int32)
             self.actions[slot].copy_(torch.as_tensor(act).to(self.backend.device, non_blocking=True))
 
+    def clear_history(self, games):
+        """
+        The given games start over (a finished game's slot is refilled, SelfPlay.play_rounds): every frame and action the
+        ring holds for them becomes zero -- exactly what get_stacked_observations emits for positions before the start
+        of a game (zero frames, zero action planes: self_play.py:541-548) -- while the shard's common history index
+        keeps counting.  The next ``push`` writes their first frame (with action 0, the leading entry of action_history).
+        """
+        idx = numpy.ascontiguousarray(games, dtype=numpy.int64)
+        if idx.size == 0:
+            return
+        if idx.min() < 0 or idx.max() >= self.G:
+            raise ValueError("game index out of range")
+        d = torch.as_tensor(idx).to(self.backend.device)
+        self.frames.index_fill_(1, d, 0.0)
+        self.actions.index_fill_(1, d, 0)
+
     def stacked(self, games=None):
         """get_stacked_observations(-1, k, A) of the given games (default all): device tensor [n, C', H, W]."""
         if self.time < 0:

@@ -695,6 +695,7 @@ class SelfPlay:
         if self.num_games > 1 or self.batched_game is not None:
             self.bank = _rng.StreamBank(self.model.backend.lib, [(seed + i) & 0xFFFFFFFF for i in range(self.num_games)])
         self.stats = {"searches": 0, "simulations": 0, "search_seconds": 0.0}
+        self._live = None       # state of the games in progress under play_rounds
 
     # ------------------------------------------------------------------ loops
     def continuous_self_play(self, shared_storage, replay_buffer, test_mode=False):
@@ -720,10 +721,12 @@ class SelfPlay:
             if not sharded:
                 self.model.set_weights(get("weights"))
             if not test_mode:
-                histories = self.play_games(
-                    self.config.visit_softmax_temperature_fn(trained_steps=get("training_step")),
-                    self.config.temperature_threshold, False, "self", 0,
-                )
+                # every slot of the shard is one reference actor: its next game starts the moment one ends (:31-52), so
+                # every search runs at full width (``refill_finished_games = False``: whole shards in lock-step)
+                play = self.play_rounds if getattr(self.config, "refill_finished_games", True) else (
+                    lambda t, th: self.play_games(t, th, False, "self", 0))
+                histories = play(self.config.visit_softmax_temperature_fn(trained_steps=get("training_step")),
+                                 self.config.temperature_threshold)
                 for game_history in histories:
                     # initial PER priorities, vectorised (replay_buffer.py:39-51 would loop in Python);
                     # save_game then takes its "priorities already present" branch
@@ -768,6 +771,7 @@ class SelfPlay:
 
     def play_games(self, temperature, temperature_threshold, render, opponent, muzero_player):
         """All ``num_games`` games of this shard in lock-step; returns their GameHistory list."""
+        self._live = None       # (games in progress under play_rounds end here: every game object is reset)
         if self.batched_game is not None:
             if opponent != "self" or render:
                 raise NotImplementedError("the batched game protocol covers self-play without rendering")
@@ -1084,6 +1088,230 @@ class SelfPlay:
                 plain &= legal_mask.all(2)
             record = _ShardRecord(A, obs_all, acts, rews, tps, vis, vals, totals, ratios, plain.all(1), legal_mask)
         return [ShardGameHistory(record, i, n) for i, n in enumerate(length.tolist())]
+
+    # ------------------------------------------------------------------ continuous play: finished slots are refilled
+    def play_rounds(self, temperature, temperature_threshold, min_games=None, max_rounds=None):
+        """
+        Self-play of the shard WITHOUT lock-step game boundaries: the reference actor starts its next game the moment
+        one ends (self_play.py:31-52) -- here every slot s of the shard is such an actor (its ``Game`` object and its
+        numpy stream ``RandomState(seed + s)`` live on from game to game, exactly the sequence a lone reference-style
+        actor seeded ``seed + s`` produces, tests/test_selfplay_refill.py), and ALL slots are searched together in every
+        round: when the game of slot s ends its GameHistory is handed out and the slot restarts at once, so every
+        search launch runs at the full shard width (``play_games`` searches a thinning batch until the longest game of
+        the shard ends: connect4 games average 21 moves and last up to 42).
+
+        Plays rounds (one move of every slot) until at least ``min_games`` games have finished (default: one shard's
+        worth) or ``max_rounds`` rounds were played; returns the games that finished, in the order they did.  Games in
+        progress stay in the shard and continue with the next call.  ``temperature`` applies to the games that START
+        during this call (the reference reads it once per game, self_play.py:39-41); weights may be refreshed between
+        calls, i.e. between two searches -- a game can straddle a refresh (deliberate: the alternative is lock-step).
+        Batched games need the optional ``reset_games(idx)`` hook; without it, and for a single-game actor, this falls
+        back to ``play_games``.
+        """
+        if self.bank is None or (self.batched_game is not None and not hasattr(self.batched_game, "reset_games")):
+            self.finished_slots = list(range(self.num_games))
+            return self.play_games(temperature, temperature_threshold, False, "self", 0)
+        min_games = self.num_games if min_games is None else int(min_games)
+        self.finished_slots = []      # slot of every returned game, in the same order (slot s = the actor seeded seed + s)
+        if self.batched_game is not None:
+            return self._rounds_batched(temperature, temperature_threshold, min_games, max_rounds)
+        return self._rounds_shard(temperature, temperature_threshold, min_games, max_rounds)
+
+    def _rounds_shard(self, temperature, temperature_threshold, min_games, max_rounds):
+        """``play_rounds`` through the reference plugin surface (B ``Game`` objects); bookkeeping as ``_play_shard``."""
+        cfg, games = self.config, self.games
+        A, G = len(cfg.action_space), len(self.games)
+        shape = tuple(cfg.observation_shape)
+        cfg_shape_is_tuple = cfg.observation_shape if isinstance(cfg.observation_shape, tuple) else shape
+        live = self._live
+
+        def start(s):
+            gh = GameHistory()
+            observation = games[s].reset()
+            gh.action_history.append(0)
+            gh.observation_history.append(observation)
+            gh.reward_history.append(0)
+            gh.to_play_history.append(games[s].to_play())
+            self._check_observation(observation)
+            live["batch"][s] = observation
+            live["histories"][s] = gh
+            live["temps"][s] = temperature
+
+        if live is None:
+            live = self._live = dict(batch=numpy.empty((G,) + shape, numpy.float32), histories=[None] * G,
+                                     temps=[temperature] * G, store=None, everyone=list(range(G)))
+            for s in range(G):
+                start(s)
+            if cfg.stacked_observations > 0:
+                live["store"] = self._frame_store(G)
+                live["store"].push(live["batch"], None)
+        batch, histories, store, everyone = live["batch"], live["histories"], live["store"], live["everyone"]
+        max_moves = cfg.max_moves
+        moved = numpy.zeros(G, numpy.int32)
+        finished, rounds = [], 0
+        while len(finished) < min_games and (max_rounds is None or rounds < max_rounds):
+            legal = [game.legal_actions() for game in games]
+            to_play = [game.to_play() for game in games]
+            stacked = store.stacked(None) if store is not None else batch
+            t0 = time.perf_counter()
+            result = self.engine.run(stacked, legal, to_play, True, (self.bank, everyone))
+            self.stats["search_seconds"] += time.perf_counter() - t0
+            self.stats["searches"] += G
+            self.stats["simulations"] += G * self.engine.num_simulations
+            slot_temps = live["temps"]
+            if temperature_threshold:
+                temps = [slot_temps[s] if len(histories[s].action_history) < temperature_threshold else 0 for s in everyone]
+            elif slot_temps.count(slot_temps[0]) == G:
+                temps = slot_temps[0]
+            else:
+                temps = list(slot_temps)
+            actions = self._select_actions_bank(result, everyone, temps)
+            vis = result.visit_counts
+            totals = vis.sum(1)
+            rows = (vis / numpy.maximum(totals, 1)[:, None]).tolist()     # int / int true division, as Python's
+            values = result.root_values.tolist()
+            plain = bool((totals > 0).all()) and all(len(l) == A for l in result.legal_actions)
+            restarted = []
+            for s in everyone:
+                game, gh, action = games[s], histories[s], actions[s]
+                observation, reward, done = game.step(action)
+                if plain:
+                    gh.child_visits.append(rows[s])
+                    gh.root_values.append(values[s])
+                else:      # illegal actions get 0, an unvisited root reports value 0 (self_play.py:496-511, :446-449)
+                    total, legal_set = int(totals[s]), set(result.legal_actions[s])
+                    gh.child_visits.append([int(vis[s][a]) / total if a in legal_set else 0 for a in cfg.action_space])
+                    gh.root_values.append(values[s] if total else 0)
+                gh.action_history.append(action)
+                gh.observation_history.append(observation)
+                gh.reward_history.append(reward)
+                gh.to_play_history.append(game.to_play())
+                if getattr(observation, "shape", None) != cfg_shape_is_tuple:
+                    self._check_observation(observation)
+                batch[s] = observation
+                moved[s] = action
+                if done or len(gh.action_history) > max_moves:     # self_play.py:129: the game is over
+                    finished.append(gh)
+                    self.finished_slots.append(s)
+                    start(s)                                       # ... and the slot's next game begins (:31-52)
+                    moved[s] = 0
+                    restarted.append(s)
+            if store is not None:
+                store.clear_history(restarted)
+                store.push(batch, moved)
+            rounds += 1
+        return finished
+
+    def _rounds_batched(self, temperature, temperature_threshold, min_games, max_rounds):
+        """
+        ``play_rounds`` behind the batched plugin protocol: per round ONE game call, ONE search, ONE action draw for
+        the whole shard.  A round is logged as a handful of arrays over all slots; a finished game is the column of its
+        slot over the rounds it lasted, handed out as a ``ShardGameHistory`` view (games that started and ended together
+        share one game-major record).
+        """
+        cfg, g, B = self.config, self.batched_game, self.num_games
+        A, k = len(cfg.action_space), int(cfg.stacked_observations)
+        live = self._live
+        if live is None:
+            obs = numpy.asarray(g.reset())
+            assert obs.shape == (B,) + tuple(cfg.observation_shape), \
+                f"Observation should match the observation_shape defined in MuZeroConfig. Expected {(B,) + tuple(cfg.observation_shape)} but got {obs.shape}."
+            live = self._live = dict(obs=obs, tp=numpy.asarray(g.to_play()).astype(numpy.int64), start=numpy.zeros(B, numpy.int64),
+                                     temps=numpy.full(B, float(temperature)), log=[], base=0, round=0, store=None,
+                                     everyone=numpy.arange(B))
+            if k > 0:   # frames stay in HBM; the stacked inputs are assembled there (csrc/mzx_obs.h)
+                live["store"] = self._frame_store(B)
+                live["store"].push(obs, None)
+        store, everyone, start, log = live["store"], live["everyone"], live["start"], live["log"]
+        finished, rounds = [], 0
+        while len(finished) < min_games and (max_rounds is None or rounds < max_rounds):
+            r = live["round"]
+            legal = g.legal_actions()
+            stacked = store.stacked(None) if store is not None else live["obs"]
+            t0 = time.perf_counter()
+            result = self.engine.run(stacked, legal, live["tp"], True, (self.bank, everyone))
+            self.stats["search_seconds"] += time.perf_counter() - t0
+            self.stats["searches"] += B
+            self.stats["simulations"] += B * self.engine.num_simulations
+            moves_before = r - start                      # len(action_history) - 1 of every slot's game
+            temps = live["temps"]
+            if temperature_threshold:                     # self_play.py:151-157
+                temps = numpy.where(moves_before + 1 < temperature_threshold, temps, 0.0)
+            t = float(temps[0]) if (temps == temps[0]).all() else temps
+            actions = numpy.asarray(self._select_actions_bank(result, everyone, t), numpy.int64)
+            obs2, reward, done = g.step(actions, None)
+            obs2 = numpy.asarray(obs2)
+            if isinstance(legal, numpy.ndarray) and (legal >= 0).all():
+                mask = None                               # every action legal for every game
+            else:
+                mask = numpy.zeros((B, A), bool)
+                if isinstance(legal, numpy.ndarray):
+                    mask[numpy.repeat(everyone, (legal >= 0).sum(1)), legal[legal >= 0]] = True
+                else:
+                    for i, acts in enumerate(legal):
+                        mask[i, acts] = True
+            log.append(dict(obs=live["obs"], tp=live["tp"], act=actions, rew=numpy.asarray(reward), vis=result.visit_counts,
+                            val=result.root_values, mask=mask))
+            tp2 = numpy.asarray(g.to_play()).astype(numpy.int64)
+            over = numpy.asarray(done, bool) | (moves_before + 2 > cfg.max_moves)     # len(action_history) <= max_moves, :129
+            pushed = actions
+            if over.any():
+                idx = numpy.nonzero(over)[0]
+                finished += self._harvest(live, idx, r, obs2[idx], tp2[idx])
+                self.finished_slots += idx.tolist()
+                if not obs2.flags.writeable or obs2 is live["obs"]:
+                    obs2 = obs2.copy()
+                obs2[idx] = numpy.asarray(g.reset_games(idx))       # the slots' next games begin (self_play.py:31-52)
+                tp2 = numpy.asarray(g.to_play()).astype(numpy.int64)
+                start[idx] = r + 1
+                live["temps"][idx] = float(temperature)
+                pushed = actions.copy()
+                pushed[idx] = 0
+                if store is not None:
+                    store.clear_history(idx)
+                keep = int(start.min()) - live["base"]              # rounds no running game reaches back to
+                if keep > 0:
+                    del log[:keep]
+                    live["base"] += keep
+            if store is not None:
+                store.push(obs2, pushed)
+            live["obs"], live["tp"] = obs2, tp2
+            live["round"] = r + 1
+            rounds += 1
+        return finished
+
+    def _harvest(self, live, idx, r, final_obs, final_tp):
+        """GameHistory views of the games of slots ``idx`` that ended with round ``r`` (self_play.py:479-511)."""
+        A = len(self.config.action_space)
+        log, base, start = live["log"], live["base"], live["start"]
+        out = [None] * len(idx)
+        starts = start[idx]
+        for st in numpy.unique(starts):
+            where = numpy.nonzero(starts == st)[0]
+            slots = idx[where]
+            entries = log[int(st) - base: r - base + 1]
+            n = len(entries)
+            whole = slots.size == self.num_games
+            col = (lambda a: a) if whole else (lambda a: a[slots])
+            by_game = lambda seq: numpy.ascontiguousarray(numpy.swapaxes(numpy.stack(seq), 0, 1))
+            zeros = numpy.zeros(slots.size, numpy.int64)
+            obs_all = by_game([col(e["obs"]) for e in entries] + [final_obs[where]])
+            acts = by_game([zeros] + [col(e["act"]) for e in entries])
+            rews = by_game([zeros.astype(entries[0]["rew"].dtype)] + [col(e["rew"]) for e in entries])
+            tps = by_game([col(e["tp"]) for e in entries] + [final_tp[where]])
+            vis = by_game([col(e["vis"]) for e in entries])          # [games][n][A]
+            vals = by_game([col(e["val"]) for e in entries])
+            totals = vis.sum(2)
+            ratios = vis / numpy.maximum(totals, 1)[:, :, None]       # true division of small integers == Python's int / int
+            plain = totals > 0
+            legal_mask = None
+            if any(e["mask"] is not None for e in entries):
+                legal_mask = by_game([numpy.ones((slots.size, A), bool) if e["mask"] is None else col(e["mask"]) for e in entries])
+                plain = plain & legal_mask.all(2)
+            record = _ShardRecord(A, obs_all, acts, rews, tps, vis, vals, totals, ratios, plain.all(1), legal_mask)
+            for j, w in enumerate(where):
+                out[w] = ShardGameHistory(record, j, n)
+        return out
 
     @staticmethod
     def _stacked_batch(obs_hist, act_hist, k, A):

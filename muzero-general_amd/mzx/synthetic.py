@@ -155,30 +155,39 @@ def make_synthetic_batched_game(observation_shape, num_actions, num_players=1):
             self.seeds = numpy.asarray([0 if s is None else int(s) for s in seeds], dtype=numpy.uint64)
             self.num_games = int(self.seeds.size)
             self._legal = numpy.tile(numpy.arange(num_actions, dtype=numpy.int32), (self.num_games, 1))
-            self.t = 0
-            self.player = 0
+            self.t = numpy.zeros(self.num_games, numpy.uint64)       # per game: refilled slots restart at 0
+            self.player = numpy.zeros(self.num_games, numpy.int64)
             self.key = self.seeds & numpy.uint64(0xFFFFFFFF)
 
-        def _observation(self):
-            h = _hash_u32(lane[None, :] + self.key[:, None])
-            return (h.astype(numpy.float64) / 4294967296.0).astype(numpy.float32).reshape((self.num_games,) + shape)
+        def _observation(self, key=None):
+            key = self.key if key is None else key
+            h = _hash_u32(lane[None, :] + key[:, None])
+            return (h.astype(numpy.float64) / 4294967296.0).astype(numpy.float32).reshape((key.size,) + shape)
 
         def reset(self):
-            self.t = 0
-            self.player = 0
+            self.t[:] = 0
+            self.player[:] = 0
             self.key = _hash_u32(self.seeds * numpy.uint64(7919) + numpy.uint64(17))
             return self._observation()
 
+        def reset_games(self, games):
+            """Restart only the given games (refill hook of the batched protocol); their first observations."""
+            g = numpy.asarray(games, numpy.int64)
+            self.t[g] = 0
+            self.player[g] = 0
+            self.key[g] = _hash_u32(self.seeds[g] * numpy.uint64(7919) + numpy.uint64(17))
+            return self._observation(self.key[g])
+
         def step(self, actions, active=None):
-            self.t += 1
+            self.t += numpy.uint64(1)
             a = numpy.asarray(actions).astype(numpy.uint64)
-            self.key = _hash_u32(self.key * numpy.uint64(31) + a * numpy.uint64(131) + numpy.uint64(self.t))
+            self.key = _hash_u32(self.key * numpy.uint64(31) + a * numpy.uint64(131) + self.t)
             self.player = (self.player + 1) % num_players
             reward = (self.key & numpy.uint64(1)).astype(numpy.int64)
             return self._observation(), reward, numpy.zeros(self.num_games, bool)
 
         def to_play(self):
-            return numpy.full(self.num_games, self.player, numpy.int64)
+            return self.player
 
         def legal_actions(self):
             return self._legal

@@ -1,0 +1,144 @@
+"""
+SelfPlay.play_rounds: finished games hand their slot to the next game at once, so every search runs at the full shard
+width -- the reference actor's own loop (self_play.py:31-52: play_game, save, play the next game on the SAME numpy
+stream and the SAME Game object), per slot.  The contract: the k-th game slot s hands out equals the k-th game of a
+lone reference-style actor seeded ``seed + s`` (muzero.py:185 seeds actor s so) that plays its games one after the
+other -- for the per-object plugin surface and for the batched protocol, with ragged game lengths, temperature
+thresholds and stacked observations.  CPU test through tests/hostcheck (the host logic is what is under test).
+"""
+import numpy
+import pytest
+
+import games_fixture
+import hostcheck
+from mzx import configs, games, models, self_play, synthetic
+
+
+@pytest.fixture(scope="module")
+def backend():
+    return hostcheck.backend()
+
+
+def _same(got, want, where):
+    assert [int(a) for a in got.action_history] == [int(a) for a in want.action_history], where
+    assert [float(x) for x in got.reward_history] == [float(x) for x in want.reward_history], where
+    assert [int(x) for x in got.to_play_history] == [int(x) for x in want.to_play_history], where
+    assert got.child_visits == want.child_visits, where
+    assert numpy.array_equal(numpy.array(got.root_values, numpy.float64).view(numpy.int64),
+                             numpy.array(want.root_values, numpy.float64).view(numpy.int64)), where
+    assert len(got.observation_history) == len(want.observation_history), where
+    for a, b in zip(got.observation_history, want.observation_history):
+        assert numpy.array_equal(numpy.array(a), numpy.array(b)), where
+
+
+def _lone_actor_games(weights, Game, cfg, seed, temperature, count, backend):
+    actor = self_play.SelfPlay({"weights": weights}, Game, cfg, seed, _backend=backend)
+    return [actor.play_game(temperature, cfg.temperature_threshold, False, "self", 0) for _ in range(count)]
+
+
+CASES = {
+    # name: (config, per-object Game, batched Game (or None), temperature)
+    "tictactoe": (lambda: configs.tictactoe(num_simulations=8), lambda: games_fixture.GAMES["tictactoe"],
+                  lambda: games.TicTacToeBatched, 1.0),
+    "tictactoe-threshold": (lambda: configs.tictactoe(num_simulations=8, temperature_threshold=3),
+                            lambda: games.TicTacToe, lambda: games.TicTacToeBatched, 0.5),
+    "connect4": (lambda: configs.connect4(num_simulations=6, blocks=1, channels=8), lambda: games.Connect4,
+                 lambda: games.Connect4Batched, 1.0),
+}
+
+
+@pytest.mark.parametrize("protocol", ["per-object", "batched"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_slot_games_equal_a_lone_actor_s_sequence(backend, name, protocol):
+    make_cfg, make_game, make_batched, temperature = CASES[name]
+    cfg = make_cfg()
+    Game = make_game()
+    weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 21)
+    B, seed, per_slot = 5, 70, 3
+    shard = self_play.SelfPlay({"weights": weights}, make_batched() if protocol == "batched" else Game, cfg, seed,
+                               num_games=B, _backend=backend)
+    by_slot = {s: [] for s in range(B)}
+    rounds_played = 0
+    searches0 = shard.stats["searches"]
+    while min(len(v) for v in by_slot.values()) < per_slot:
+        before = shard.stats["searches"]
+        out = shard.play_rounds(temperature, cfg.temperature_threshold, min_games=2)
+        assert len(out) >= 2
+        rounds_played += (shard.stats["searches"] - before) // B
+        assert len(shard.finished_slots) == len(out)
+        for gh, slot in zip(out, shard.finished_slots):
+            by_slot[slot].append(gh)
+    assert shard.stats["searches"] - searches0 == rounds_played * B      # every round searched ALL slots
+    lengths = set()
+    for s in range(B):
+        want = _lone_actor_games(weights, Game, cfg, seed + s, temperature, per_slot, backend)
+        for k in range(per_slot):
+            _same(by_slot[s][k], want[k], (name, protocol, s, k))
+            lengths.add(len(want[k].action_history))
+    assert len(lengths) > 1, "games should end at different moves for this test to mean anything"
+
+
+@pytest.mark.parametrize("protocol", ["per-object", "batched"])
+def test_refill_with_stacked_observations_and_fixed_length_games(backend, protocol):
+    """Synthetic game (never ends on its own: max_moves does), stacked observations through the device frame store:
+    a restarted slot must see zeros in front of its first frame, not the previous game's frames."""
+    cfg = configs.cartpole(num_simulations=7, max_moves=4, action_space=list(range(3)), observation_shape=(2, 1, 3),
+                           players=list(range(2)), stacked_observations=2)
+    Game = synthetic.make_synthetic_game(cfg.observation_shape, 3, 2)
+    Batched = synthetic.make_synthetic_batched_game(cfg.observation_shape, 3, 2)
+    weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 5)
+    B, seed = 4, 11
+    shard = self_play.SelfPlay({"weights": weights}, Batched if protocol == "batched" else Game, cfg, seed, num_games=B,
+                               _backend=backend)
+    first = shard.play_rounds(0.5, None)              # one shard's worth: all four games end with round 4
+    first_slots = list(shard.finished_slots)
+    assert len(first) == B and shard.stats["searches"] == 4 * B
+    second = shard.play_rounds(0.5, None, max_rounds=3)
+    assert second == []                               # three rounds into the next games: nothing finished
+    second = shard.play_rounds(0.5, None)
+    assert len(second) == B and shard.stats["searches"] == 8 * B
+    for s in range(B):
+        want = _lone_actor_games(weights, Game, cfg, seed + s, 0.5, 2, backend)
+        _same(first[first_slots.index(s)], want[0], (protocol, s, 0))
+        _same(second[shard.finished_slots.index(s)], want[1], (protocol, s, 1))
+
+
+def test_play_games_after_play_rounds_starts_over(backend):
+    """play_games (whole shards in lock-step) resets every game: it must not continue play_rounds' games in progress."""
+    cfg = configs.tictactoe(num_simulations=6)
+    weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 2)
+    shard = self_play.SelfPlay({"weights": weights}, games.TicTacToeBatched, cfg, 5, num_games=3, _backend=backend)
+    shard.play_rounds(1.0, None, max_rounds=2)
+    assert shard._live is not None
+    out = shard.play_games(1.0, None, False, "self", 0)
+    assert len(out) == 3 and shard._live is None
+    assert all(len(h.action_history) >= 6 for h in out)       # whole games (a tic-tac-toe game lasts >= 5 moves)
+
+
+def test_continuous_self_play_refills_by_default(backend):
+    """continuous_self_play hands games to the replay buffer as they finish; all slots are searched in every round."""
+    from mzx import shared_storage
+
+    cfg = configs.tictactoe(num_simulations=5, training_steps=10, ratio=None, self_play_delay=0)
+    weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 4)
+    storage = shared_storage.LocalStorage(weights=weights, training_step=0, terminate=False, num_played_games=0,
+                                          num_played_steps=0)
+
+    class Buffer:
+        def __init__(self):
+            self.games = []
+
+        def save_game(self, game_history, shared_storage=None):
+            self.games.append(game_history)
+            if len(self.games) >= 9:
+                storage.set_info("terminate", True)
+
+    buf = Buffer()
+    B = 4
+    actor = self_play.SelfPlay({"weights": weights}, games.TicTacToeBatched, cfg, 1, num_games=B, _backend=backend)
+    actor.continuous_self_play(storage, buf)
+    assert len(buf.games) >= 9
+    assert actor.stats["searches"] % B == 0
+    moves = sum(len(g.action_history) - 1 for g in buf.games)
+    assert actor.stats["searches"] >= moves                   # (games in progress at the stop are not handed out)
+    assert all(g.priorities is not None or not getattr(cfg, "PER", False) for g in buf.games)
