@@ -111,7 +111,8 @@ int mzx_net_set_mode(mzx_net* net, int32_t mode);
  * run on the STREAMED MFMA engine: one FP32-MFMA implicit-GEMM launch per convolution / Linear layer over the
  * whole batch.  mzx_net_streamed_supported: bit 0 = initial_inference, bit 1 = recurrent_inference run there
  * by default (mode 0 still forces one element kernel per operator; mzx_net_set_mode(3) routes EVERY residual
- * program there, fused-capable ones included -- the A/B and parity knob).  mzx_net_streamed_plan: the workgroup tiling of
+ * program there, fused-capable ones included -- the A/B and parity knob; 4 = as 3 and 5 = as 1, but the streamed
+ * engine launches every layer on its own, no towers).  mzx_net_streamed_plan: the workgroup tiling of
  * operator `op`: {kind, in_layout, out_layout, res_layout, taps, stride, cin, cout, hin, win, hout, wout, T, th,
  * tw, tiles_x, tiles_y, PH, PW, chunks per phase, phases, rows, row tiles, LDS bytes}. */
 int mzx_net_streamed_supported(const mzx_net* net);
@@ -121,6 +122,13 @@ int mzx_net_streamed_plan(const mzx_net* net, int32_t recurrent, int32_t op, int
  * bytes, column tiles per workgroup, column splits, column tiles per wave, waves along N, waves along M, row tiles per
  * wave, row groups (grid.x), chunks per phase, phases, LDS floats per cell, column tiles, 16-channel chunks per tap}. */
 int mzx_net_streamed_shape(const mzx_net* net, int32_t recurrent, int32_t op, int32_t batch, int32_t out[16]);
+/* TOWERS: runs of stride-1 3x3 convolutions of one width (the representation / dynamics / prediction trunks,
+ * models.py:300-433) run as ONE launch of rb_tower_kernel with the activations resident in LDS, updated in place
+ * (mzx_net_set_mode(4) / (5): layer by layer instead, the A/B).  Tower `index` of the program at `batch` samples:
+ * {first operator, operators, channels, H, W, samples per workgroup, row tiles per wave, column tiles per wave, waves
+ * along M, waves along N, LDS bytes, workgroups}; an error when the program has no such tower.  The operators of a
+ * tower are not launched one by one (mzx_net_streamed_shape still describes what the layer-by-layer path would do). */
+int mzx_net_streamed_tower(const mzx_net* net, int32_t recurrent, int32_t index, int32_t batch, int32_t out[12]);
 /* The row-per-tree search runs large shards as two half-shards on two HIP streams (csrc/mzx_row_search.h; from 1024
  * trees, and only when both halves keep the channel groups -- the summation order -- of the undivided launch):
  * out = {trees of the first half, trees of the second half}; {batch, 0} when a shard of `batch` trees runs undivided.

@@ -446,6 +446,316 @@ rb_gemm_kernel(const RbGemmArgs a) {
     a.stamps[((size_t)blockIdx.x * 8 + (tid >> 6)) * RB_STAMP_SLOTS + RB_STAMP_SLOTS - 1] = __builtin_amdgcn_s_memrealtime();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// rb_tower_kernel<MT, NT>: a whole TOWER -- conv3x3 + BatchNorm + ReLU followed by residual blocks (ResidualBlock.forward,
+// models.py:213-229), i.e. the representation / dynamics / prediction trunks of MuZeroResidualNetwork -- in ONE launch.
+// A 512-thread workgroup owns T whole samples for all layers of the run:
+//   * the input patch (zero halo, every channel of the tower's width) is staged ONCE into LDS, position-major
+//     [cell][Cs] as in rb_gemm_kernel;
+//   * per layer: the K loop of rb_gemm_kernel over (tap, 16-channel chunk) with the layer's B fragments streamed from L2
+//     -> workgroup barrier (every wave is done reading the tile) -> epilogue in registers (action term, folded
+//     BatchNorm, residual, ReLU) -> the result OVERWRITES the tile's interior cells in place (the zero halo of the
+//     input is the zero padding of every later layer) -> barrier.  One activation tile per sample instead of the three
+//     slots of the LDS-resident engine: connect4 (64 channels, 6 x 7) holds three boards in 62 KB, so TWO workgroups
+//     share a CU and hide each other's barriers and epilogues;
+//   * the residual of a block never exists in memory: before a wave overwrites the interior cells with the output of
+//     the block's first convolution it keeps the elements IT will add two layers later -- its own (row, channel)
+//     footprint, the same lanes -- in registers;
+//   * only the last layer's output goes to memory (position-major, as rb_gemm_kernel writes it).
+// Per residual block this moves 2 x [positions][C] floats (stage, final store: once per TOWER, not per block) instead of
+// five transfers per block of the layer-by-layer path, and pays no launch / staging / epilogue tail per layer.
+// Summation order per output: taps in order, 16-channel chunks in order, the MFMA's k order -- independent of T and of
+// the batch (two half-shards build the trees of the undivided run).
+struct RbTowerLayer {
+  int64_t w_off;       // derived buffer: packed B fragments (RzPackOp) of the layer
+  int64_t bn_alpha;    // derived buffer offsets of the folded BatchNorm terms (-1: none)
+  int64_t bn_beta;
+  int32_t cchunks;     // 16-channel chunks of the layer's input
+  int32_t flags;       // 1: ReLU, 2: the layer's INPUT is the residual of the next layer (keep it), 4: add the kept residual
+};
+
+struct RbTowerArgs {
+  RbTensor x;
+  float* y;
+  int64_t y_sstride;
+  const float* der;
+  const float* asum;       // first layer only: border-aware tap sums of the action plane (null: none)
+  const int32_t* action;
+  int32_t num_actions, batch;
+  int32_t cin0, C, H, W, PH, PW, Cs, cchunks, T, rows, mtiles, ntiles, WN, WM, layers, y_vec, rowskip;
+  uint32_t magic_hw, magic_w, magic_phw, magic_pw;
+  RbTowerLayer layer[RB_TOWER_MAX_LAYERS];
+};
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(MT * NT <= 4 ? 4 : 2, MT * NT <= 4 ? 4 : 2)))
+rb_tower_kernel(const RbTowerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float rb_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mpad = a.mtiles * 16, Tpad = (a.T + 1) & ~1;
+  int* rowaddr = (int*)rb_lds;
+  int* rowt = rowaddr + mpad;
+  int* rowpos = rowt + mpad;
+  long long* soff_x = (long long*)(rowpos + mpad);
+  float* tile = (float*)(soff_x + Tpad);
+  const int b0 = blockIdx.x * a.T;
+  const int HW = a.H * a.W, phw = a.PH * a.PW, cells = a.T * phw;
+
+  // ---- row tables: row m = (sample t, position r); its 3 x 3 window starts at cell (y, x) of the haloed board
+  for (int m = tid; m < mpad; m += RB_THREADS) {
+    const int t = rb_div(m, HW, a.magic_hw), r = m - t * HW;
+    const int y = rb_div(r, a.W, a.magic_w), x = r - y * a.W;
+    const bool valid = m < a.rows;
+    rowaddr[m] = valid ? ((t * a.PH + y) * a.PW + x) * a.Cs : 0;
+    rowt[m] = valid ? t : 0;
+    rowpos[m] = (valid && b0 + t < a.batch) ? r : -1;
+  }
+  for (int t = tid; t < a.T; t += RB_THREADS) {
+    const int b = (b0 + t < a.batch) ? b0 + t : a.batch - 1;
+    soff_x[t] = ((long long)b * a.x.nodes + (a.x.node ? a.x.node[b] : 0)) * a.x.sstride;
+  }
+  __syncthreads();
+
+  // ---- stage the input: EVERY channel of the tile (zero beyond cin0: later layers read all of them), zero halo
+  {
+    const int q = a.cchunks * 4;                      // channel quads per cell
+    const int total = cells * q;
+    const float* xp = a.x.p;
+    if (a.x.layout == RB_NHWC) {
+      const uint32_t magic_q = (uint32_t)((0x100000000ull + (uint64_t)q - 1) / (uint64_t)q);
+      const bool vec = (a.cin0 & 3) == 0 && (a.x.sstride & 3) == 0 && ((uintptr_t)xp & 15) == 0;
+      for (int i0 = tid; i0 < total; i0 += 4 * RB_THREADS) {
+        f32x4 v[4];
+        int at[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = i0 + u * RB_THREADS;
+          at[u] = -1;
+          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (idx < total) {
+            const int cell = rb_div(idx, q, magic_q), k = idx - cell * q;
+            const int t = rb_div(cell, phw, a.magic_phw), rem = cell - t * phw;
+            const int iy = rb_div(rem, a.PW, a.magic_pw), ix = rem - iy * a.PW;
+            const int gy = iy - 1, gx = ix - 1, c = 4 * k;
+            at[u] = cell * a.Cs + 4 * k;
+            if (b0 + t < a.batch && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.cin0) {
+              const float* src = xp + soff_x[t] + ((long long)gy * a.W + gx) * a.cin0 + c;
+              if (vec && c + 3 < a.cin0) v[u] = *(const f32x4*)src;
+              else {
+                v[u][0] = src[0];
+                if (c + 1 < a.cin0) v[u][1] = src[1];
+                if (c + 2 < a.cin0) v[u][2] = src[2];
+                if (c + 3 < a.cin0) v[u][3] = src[3];
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (at[u] >= 0) *(f32x4*)(tile + at[u]) = v[u];
+      }
+    } else {
+      // NCHW source (observations, hidden states of the search arena): consecutive threads take consecutive cells of
+      // one channel quad (coalesced along x)
+      const uint32_t magic_cells = (uint32_t)((0x100000000ull + (uint64_t)cells - 1) / (uint64_t)cells);
+      const long long plane = (long long)HW;
+      for (int i0 = tid; i0 < total; i0 += 2 * RB_THREADS) {
+        f32x4 v[2];
+        int at[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int idx = i0 + u * RB_THREADS;
+          at[u] = -1;
+          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (idx < total) {
+            const int k = rb_div(idx, cells, magic_cells), cell = idx - k * cells;
+            const int t = rb_div(cell, phw, a.magic_phw), rem = cell - t * phw;
+            const int iy = rb_div(rem, a.PW, a.magic_pw), ix = rem - iy * a.PW;
+            const int gy = iy - 1, gx = ix - 1, c = 4 * k;
+            at[u] = cell * a.Cs + 4 * k;
+            if (b0 + t < a.batch && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.cin0) {
+              const float* src = xp + soff_x[t] + (long long)c * plane + (long long)gy * a.W + gx;
+              v[u][0] = src[0];
+              if (c + 1 < a.cin0) v[u][1] = src[plane];
+              if (c + 2 < a.cin0) v[u][2] = src[2 * plane];
+              if (c + 3 < a.cin0) v[u][3] = src[3 * plane];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (at[u] >= 0) *(f32x4*)(tile + at[u]) = v[u];
+      }
+    }
+  }
+
+  // ---- this wave's tiles: column tiles first (a disjoint slice of every layer's weights), row tiles next
+  const int wn = wave % a.WN, wm = wave / a.WN;
+  const bool active = wm < a.WM && wn * NT < a.ntiles && wm * MT < a.mtiles;
+  const int m_lane = lane & 15, g4 = 4 * (lane >> 4);
+  int ra[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int mt = wm * MT + i;
+    const bool ok = active && mt < a.mtiles;
+    ra[i] = (ok ? rowaddr[mt * 16 + m_lane] : 0) + g4;       // A operand: row m_lane of the tile, channels g4 .. g4 + 3 of a chunk
+  }
+  const int ctr = (a.PW + 1) * a.Cs;                         // from a window's top-left cell to its centre = the output cell
+  const unsigned lane4 = (unsigned)lane * 4;
+  f32x4 acc[MT][NT], res[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; res[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __syncthreads();
+
+  for (int l = 0; l < a.layers; ++l) {
+    const RbTowerLayer& L = a.layer[l];
+    const bool last = l + 1 == a.layers;
+    // ---- K loop: (tap, chunk) pairs, operands one chunk ahead in registers
+    if (active) {
+      const int cpl = L.cchunks, n_it = 9 * cpl;
+      const float* wp[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int nt = wn * NT + j;
+        wp[j] = a.der + L.w_off + (size_t)(nt < a.ntiles ? nt : 0) * (size_t)n_it * 256;
+      }
+      int tap = 0, cc = 0;
+      f32x4 fa0[MT], fb0[NT], fb1[NT];
+      auto load = [&](f32x4 (&fa)[MT], f32x4 (&fb)[NT]) {
+        const int aoff = tap * a.Cs + ((tap * 21846) >> 16) * a.rowskip + cc * 16;     // tap / 3 by multiply-shift
+        const size_t widx = (size_t)(tap * cpl + cc) * 256;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j] = *(const f32x4*)(wp[j] + widx + lane4);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i] = *(const f32x4*)(tile + ra[i] + aoff);
+        if (++cc == cpl) { cc = 0; ++tap; }
+      };
+      auto mma = [&](const f32x4 (&fa)[MT], const f32x4 (&fb)[NT]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][k], fa[i][k], acc[i][j], 0, 0, 0);
+      };
+      if constexpr ((MT - 1) * NT >= 5) {
+        // one set of position fragments refilled in place (rb_gemm_kernel's loop for the deep tilings)
+        auto step = [&](const f32x4 (&fbc)[NT], f32x4 (&fbn)[NT]) {
+          const int aoff = tap * a.Cs + ((tap * 21846) >> 16) * a.rowskip + cc * 16;
+          const size_t widx = (size_t)(tap * cpl + cc) * 256;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) fbn[j] = *(const f32x4*)(wp[j] + widx + lane4);
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fbc[j][k], fa0[i][k], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fbc[j][3], fa0[i][3], acc[i][j], 0, 0, 0);
+            fa0[i] = *(const f32x4*)(tile + ra[i] + aoff);
+            __builtin_amdgcn_sched_barrier(0);     // the read goes out HERE, not next to its first use
+          }
+          if (++cc == cpl) { cc = 0; ++tap; }
+        };
+        load(fa0, fb0);
+        int it = 0;
+        for (; it + 2 < n_it; it += 2) { step(fb0, fb1); step(fb1, fb0); }
+        if (it + 1 < n_it) { step(fb0, fb1); mma(fa0, fb1); }
+        else mma(fa0, fb0);
+      } else {
+        // two fragment sets; the requests of chunk n + 1 are pinned IN FRONT of the MFMAs of chunk n (left alone, the
+        // scheduler sinks them behind: the wave then waits out the LDS / L2 latency at the top of every chunk)
+        f32x4 fa1[MT];
+        load(fa0, fb0);
+        int it = 0;
+        for (; it + 2 < n_it; it += 2) {
+          load(fa1, fb1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(fa0, fb0);
+          __builtin_amdgcn_sched_barrier(0);
+          load(fa0, fb0);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(fa1, fb1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (it + 1 < n_it) {
+          load(fa1, fb1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(fa0, fb0);
+          mma(fa1, fb1);
+        } else {
+          mma(fa0, fb0);
+        }
+      }
+    }
+    __syncthreads();                                   // every wave is done reading the layer's input
+    // ---- epilogue: lane = position row m_lane of a tile, four consecutive output channels
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n0 = (wn * NT + j) * 16 + g4;
+        if (n0 >= a.C || (wn * NT + j) >= a.ntiles) continue;
+        float al[4], be[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = n0 + u < a.C;
+          al[u] = (L.bn_alpha >= 0 && ok) ? a.der[L.bn_alpha + n0 + u] : 1.f;
+          be[u] = (L.bn_alpha >= 0 && ok) ? a.der[L.bn_beta + n0 + u] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int mt = wm * MT + i;
+          // (position / sample of the row come from the LDS tables again: two registers per tile less in the K loop)
+          const int pos = mt < a.mtiles ? rowpos[mt * 16 + m_lane] : -1;
+          f32x4 v = acc[i][j];
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (pos < 0) continue;
+          const int b = b0 + rowt[mt * 16 + m_lane];
+          if (l == 0 && a.asum) {
+            const float av = (float)a.action[b] / (float)a.num_actions;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (n0 + u < a.C) v[u] += av * a.asum[(size_t)(n0 + u) * HW + pos];
+          }
+          float* cell = tile + (ra[i] - g4) + ctr + n0;   // the output cell of this row, channels n0 .. n0 + 3
+          f32x4 keep = f32x4{0.f, 0.f, 0.f, 0.f};
+          if ((L.flags & 2) && !last) keep = *(const f32x4*)cell;       // the block input, before it is overwritten
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            float x = v[u];
+            if (L.bn_alpha >= 0) x = x * al[u] + be[u];
+            if (L.flags & 4) x += res[i][j][u];
+            if (L.flags & 1) x = fmaxf(x, 0.f);
+            v[u] = (n0 + u < a.C) ? x : 0.f;
+          }
+          if (L.flags & 2) res[i][j] = keep;
+          if (!last) {
+            *(f32x4*)cell = v;
+          } else {
+            float* yp = a.y + (long long)b * a.y_sstride + (long long)pos * a.C + n0;
+            if (a.y_vec) *(f32x4*)yp = v;
+            else {
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (n0 + u < a.C) yp[u] = v[u];
+            }
+          }
+        }
+      }
+    }
+    if (!last) __syncthreads();                        // the next layer reads what every wave wrote
+  }
+}
+
 // Per-plane min-max scaling of the hidden state (models.py:527-553, :574-599; MinMaxScaleOp's arithmetic): one
 // workgroup per sample, NHWC or NCHW in, NCHW out (into the search arena's node store when `node` is set).
 struct RbScaleArgs {
@@ -670,6 +980,66 @@ int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
   return MZX_OK;
 }
 
+typedef void (*RbTowerFn)(const RbTowerArgs);
+
+template <int NT>
+RbTowerFn rb_pick_tower_mt(int mt) {
+  switch (mt) {
+    case 1: return rb_tower_kernel<1, NT>;
+    case 2: return rb_tower_kernel<2, NT>;
+    case 3: return rb_tower_kernel<3, NT>;
+    case 4: return rb_tower_kernel<4, NT>;
+    case 5: return rb_tower_kernel<5, NT>;
+    case 6: return rb_tower_kernel<6, NT>;
+    case 7: return rb_tower_kernel<7, NT>;
+    case 8: return rb_tower_kernel<8, NT>;
+    default: return rb_tower_kernel<9, NT>;
+  }
+}
+
+// Launches layers [tw.first, tw.first + layers) of a tower (layers < tw.count: a diagnostic prefix; the last layer run
+// writes its output to memory like the whole tower's last layer does).
+int rb_launch_tower(const mzx_net* net, const std::vector<OpDesc>& prog, const RbProgram& R, const RbTower& tw, int layers,
+                    const RbTensor& x, float* y, const int32_t* action, int batch, stream_t stream) {
+  const RbTowerShape sh = rb_tower_shape(tw, batch);
+  if (sh.T < 1) { set_error("tower: no launch shape"); return MZX_ERR_INVALID; }
+  RbTowerArgs a;
+  memset(&a, 0, sizeof(a));
+  const RbOp& o0 = R.ops[tw.first];
+  a.x = x; a.y = y; a.y_sstride = (int64_t)tw.C * tw.H * tw.W;
+  a.der = net->d_derived;
+  if (o0.asum_off >= 0) { a.asum = net->d_derived + o0.asum_off; a.action = action; a.num_actions = net->cfg.action_space_size; }
+  a.batch = batch; a.cin0 = o0.cin; a.C = tw.C; a.H = tw.H; a.W = tw.W; a.PH = tw.H + 2; a.PW = tw.W + 2;
+  a.Cs = sh.Cs; a.cchunks = tw.cchunks; a.T = sh.T; a.rows = sh.rows; a.mtiles = sh.mtiles; a.ntiles = tw.ntiles;
+  a.WN = sh.WN; a.WM = sh.WM; a.layers = layers;
+  a.y_vec = (tw.C % 4 == 0 && a.y_sstride % 4 == 0 && ((uintptr_t)y % 16) == 0) ? 1 : 0;
+  a.rowskip = (a.PW - 3) * sh.Cs;
+  a.magic_hw = rb_magic(tw.H * tw.W); a.magic_w = rb_magic(tw.W);
+  a.magic_phw = rb_magic(a.PH * a.PW); a.magic_pw = rb_magic(a.PW);
+  for (int l = 0; l < layers; ++l) {
+    const OpDesc& d = prog[tw.first + l];
+    const RbOp& o = R.ops[tw.first + l];
+    RbTowerLayer& L = a.layer[l];
+    L.w_off = o.w_off;
+    L.bn_alpha = d.bn.channels ? d.bn.alpha : -1;
+    L.bn_beta = d.bn.channels ? d.bn.beta : -1;
+    L.cchunks = o.cchunks;
+    L.flags = (o.act == RZ_ACT_RELU ? 1 : 0) | (d.res != -100 ? 4 : 0);
+    // the NEXT layer adds this layer's input (the block input): keep it when this layer's output replaces it
+    if (l + 1 < tw.count && prog[tw.first + l + 1].res != -100) L.flags |= 2;
+  }
+  RbTowerFn fn = sh.NT == 2 ? rb_pick_tower_mt<2>(sh.MT) : rb_pick_tower_mt<1>(sh.MT);
+  static std::atomic<uint64_t> lds_attr_done[2][RB_MT + 1];
+  if (const int ae = allow_large_lds((const void*)fn, RB_LDS_MAX, lds_attr_done[sh.NT - 1][sh.MT])) {
+    set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
+    return MZX_ERR_RUNTIME;
+  }
+  void* params[] = {(void*)&a};
+  const hipError_t e = hipLaunchKernel((const void*)fn, dim3(sh.groups), dim3(RB_THREADS), params, (size_t)sh.lds, stream);
+  if (e != hipSuccess) { set_error("tower launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+  return MZX_OK;
+}
+
 }  // namespace
 
 int rb_refresh_derived(const mzx_net* net, const float* d_flat, float* d_derived, stream_t stream) {
@@ -708,6 +1078,17 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
     const OpDesc& d = prog[k];
     const RbOp& o = R.ops[k];
     int rc = 0;
+    if (o.kind == RB_GEMM && o.tower >= 0 && !net->rb_no_towers && R.towers[o.tower].first == k) {
+      // a whole tower (or, for a diagnostic prefix, its first layers) in one launch; inner outputs never reach memory
+      const RbTower& tw = R.towers[o.tower];
+      const int layers = std::min(tw.count, count - k);
+      const OpDesc& dl = prog[k + layers - 1];
+      const RbTensor x = tensor(d.in, (int64_t)o.cin * o.hin * o.win, o.in_layout);
+      rc = rb_launch_tower(net, prog, R, tw, layers, x, resolve(net, nb, dl.out, batch), nb.action, batch, stream);
+      if (rc) return rc;
+      k += layers - 1;
+      continue;
+    }
     if (o.kind == RB_GEMM) {
       RbGemmArgs a;
       memset(&a, 0, sizeof(a));

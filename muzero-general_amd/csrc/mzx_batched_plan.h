@@ -45,11 +45,25 @@ struct RbOp {
   int64_t w_off = -1;      // derived buffer: B fragments in v_mfma_f32_16x16x4_f32 lane order (RzPackOp)
   int64_t asum_off = -1;   // derived buffer: border-aware tap sums of the action plane's weights [cout][H*W]
   int32_t act = 0;         // RzAct
+  int32_t tower = -1;      // index into RbProgram::towers when this operator is a layer of one
+};
+
+// A TOWER: a run of consecutive stride-1 3x3 convolutions of one width on one board size in which every operator reads
+// what the previous one wrote -- the representation / dynamics trunk (conv + residual blocks, models.py:300-389) and the
+// prediction trunk (:392-433).  rb_tower_kernel runs the whole run in ONE launch with the activations resident in LDS,
+// updated IN PLACE (csrc/mzx_batched.hip); `first` / `count` index the program's operators.
+constexpr int RB_TOWER_MAX_LAYERS = 40;
+struct RbTower {
+  int32_t first = 0, count = 0;
+  int32_t C = 0, H = 0, W = 0;          // channels (= cout of every layer), board
+  int32_t cchunks = 0, ntiles = 0;      // ceil(C / 16)
+  int32_t t_max = 1;                    // most samples per workgroup that fit the LDS and the wave grid
 };
 
 struct RbProgram {
   int32_t ok = 0;
   std::vector<RbOp> ops;
+  std::vector<RbTower> towers;
 };
 
 struct RbPlan {

@@ -184,6 +184,20 @@ int mzx_net_streamed_shape(const mzx_net* net, int32_t recurrent, int32_t op, in
   return MZX_OK;
 }
 
+int mzx_net_streamed_tower(const mzx_net* net, int32_t recurrent, int32_t index, int32_t batch, int32_t out[12]) {
+  if (!net || !out || batch < 1) { set_error("null argument / batch < 1"); return MZX_ERR_INVALID; }
+  const RbProgram& R = recurrent ? net->rb.recurrent : net->rb.initial;
+  if (!net->rb.ok || !R.ok || net->rb_no_towers || index < 0 || index >= (int32_t)R.towers.size()) {
+    set_error("no tower %d", index);
+    return MZX_ERR_INVALID;
+  }
+  const RbTower& tw = R.towers[index];
+  const RbTowerShape sh = rb_tower_shape(tw, batch);
+  const int32_t v[12] = {tw.first, tw.count, tw.C, tw.H, tw.W, sh.T, sh.MT, sh.NT, sh.WM, sh.WN, sh.lds, sh.groups};
+  for (int k = 0; k < 12; ++k) out[k] = v[k];
+  return MZX_OK;
+}
+
 int mzx_net_streamed_split(const mzx_net* net, int32_t batch, int32_t out[2]) {
   if (!net || !out || batch < 1) { set_error("null argument / batch < 1"); return MZX_ERR_INVALID; }
   const int first = rb_split_first(net, batch);
@@ -207,11 +221,12 @@ int64_t mzx_net_operator_out_floats(const mzx_net* net, int32_t recurrent, int32
 
 int mzx_net_set_mode(mzx_net* net, int32_t mode) {
   if (!net) { set_error("null network handle"); return MZX_ERR_INVALID; }
-  if (mode < 0 || mode > 3) { set_error("network mode is 0 (one kernel per operator), 1 (fused engine, streamed engine for what it cannot hold), 2 (fused, 4-wave workgroups) or 3 (streamed engine for everything)"); return MZX_ERR_INVALID; }
-  if (mode == 3 && !net->rb.ok) { set_error("the streamed engine runs residual networks only"); return MZX_ERR_INVALID; }
+  if (mode < 0 || mode > 5) { set_error("network mode is 0 (one kernel per operator), 1 (fused engine, streamed engine for what it cannot hold), 2 (fused, 4-wave workgroups), 3 (streamed engine for everything), 4 (as 3, layer by layer: no tower launches) or 5 (as 1, the streamed engine layer by layer)"); return MZX_ERR_INVALID; }
+  if ((mode == 3 || mode == 4) && !net->rb.ok) { set_error("the streamed engine runs residual networks only"); return MZX_ERR_INVALID; }
   net->rz_mode = mode ? 1 : 0;
   net->rz_waves = (mode == 2) ? 4 : 0;
-  net->rb_force = (mode == 3) ? 1 : 0;
+  net->rb_force = (mode == 3 || mode == 4) ? 1 : 0;
+  net->rb_no_towers = (mode == 4 || mode == 5) ? 1 : 0;
   return MZX_OK;
 }
 

@@ -69,7 +69,8 @@ struct mzx_net {
   mzx::RzPlan rz;          // fused residual-network engine (mzx_resnet_fused.h)
   int32_t rz_mode = 1;     // 0: one kernel per operator, 1: fused engine where planned
   int32_t rz_waves = 0;    // 0: automatic, 4: force 256-thread workgroups (A/B measurements)
-  int32_t rb_force = 0;    // 1: every program on the streamed engine (mzx_net_set_mode(3))
+  int32_t rb_force = 0;    // 1: every program on the streamed engine (mzx_net_set_mode(3) / (4))
+  int32_t rb_no_towers = 0;  // 1: the streamed engine runs layer by layer, no tower launches (mzx_net_set_mode(4): A/B)
   mzx::RbPlan rb;          // streamed MFMA engine for residual networks the fused engine cannot hold (mzx_resnet_batched.h)
 };
 

@@ -177,6 +177,123 @@ inline RbShape rb_choose_shape(const RbOp& o, int batch) {
   return best;
 }
 
+// ---- towers (rb_tower_kernel): runs of same-width stride-1 3x3 convolutions, one launch, activations in LDS in place.
+// Wave grid of a tower workgroup (512 threads): column tiles over WN waves (NT = 2 per wave above eight tiles), the
+// remaining 8 / WN waves deep in rows, at most nine row tiles per wave.
+struct RbTowerShape { int T, rows, mtiles, lds, NT, WN, WM, MT, groups, Cs, per_cu; };
+
+inline int64_t rb_tower_lds_bytes(int T, int mtiles, int cells, int Cs) {
+  return (int64_t)3 * 16 * mtiles * 4 + (int64_t)((T + 1) & ~1) * 8 + (int64_t)cells * Cs * 4;
+}
+
+inline bool rb_tower_grid(const RbTower& tw, int T, RbTowerShape& c) {
+  if (tw.ntiles > 16) return false;
+  c.T = T;
+  c.rows = T * tw.H * tw.W;
+  c.mtiles = (c.rows + 15) / 16;
+  c.NT = tw.ntiles > 8 ? 2 : 1;
+  c.WN = std::min(8, (tw.ntiles + c.NT - 1) / c.NT);
+  c.WM = std::max(1, std::min(8 / c.WN, c.mtiles));
+  c.MT = (c.mtiles + c.WM - 1) / c.WM;
+  c.Cs = 16 * tw.cchunks + 8;
+  c.lds = (int)rb_tower_lds_bytes(T, c.mtiles, T * (tw.H + 2) * (tw.W + 2), c.Cs);
+  // two workgroups per CU: half the LDS each and the 128-register instantiations (accumulators + saved residual of at
+  // most four tiles per wave)
+  c.per_cu = (c.lds <= RB_LDS_BUDGET && c.MT * c.NT <= 4) ? 2 : 1;
+  // (the tower kernel keeps a saved residual beside the accumulators: the 2-column tilings compile without scratch up
+  // to six row tiles per wave, ISA checked)
+  return c.MT <= (c.NT == 2 ? 6 : RB_MT) && rb_tower_lds_bytes(T, c.mtiles, T * (tw.H + 2) * (tw.W + 2), c.Cs) <= RB_LDS_MAX;
+}
+
+// Samples per workgroup for THIS batch: the cost model of rb_choose_shape (accumulator tiles on the busiest wave x rounds
+// of co-resident workgroups); two co-resident workgroups hide each other's barriers and epilogues, hence the bonus.
+// MZX_RB_TOWER_T=<n>: force (A/B).
+inline RbTowerShape rb_tower_shape(const RbTower& tw, int batch) {
+  const char* force_env = getenv("MZX_RB_TOWER_T");      // read per call: the tests force several values in one process
+  const int force_t = force_env ? atoi(force_env) : 0;
+  RbTowerShape best{};
+  double best_cost = 1e30;
+  for (int T = tw.t_max; T >= 1; --T) {
+    RbTowerShape c;
+    if (!rb_tower_grid(tw, T, c)) continue;
+    c.groups = (batch + T - 1) / T;
+    const int64_t wgs = c.groups, cap = 256 * c.per_cu;
+    const int64_t rem = wgs % cap;
+    const double ways = (double)(wgs / cap) * c.per_cu + (rem ? (double)std::min<int64_t>(c.per_cu, (rem + 255) / 256) : 0.0);
+    const double cost = ways * (c.MT * c.NT) * (c.per_cu == 2 ? 0.9 : 1.0) + 1e-4 * (double)wgs;
+    if (force_t > 0 && T == std::min(force_t, tw.t_max)) { best = c; break; }
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+// Finds the towers of a planned program.  A layer joins the tower of its predecessor when it is a stride-1 3x3 GEMM of
+// the tower's width on the tower's board that reads the predecessor's output, its residual (if any) is the
+// predecessor's INPUT (the block input: ResidualBlock.forward, models.py:221-229), and the predecessor's output has no
+// reader outside the run (it never reaches memory).  MZX_RB_TOWER=0 plans none (A/B).
+inline void rb_find_towers(const std::vector<OpDesc>& prog, RbProgram& R) {
+  R.towers.clear();
+  for (RbOp& o : R.ops) o.tower = -1;
+  static const int enabled = getenv("MZX_RB_TOWER") ? atoi(getenv("MZX_RB_TOWER")) : 1;
+  if (!enabled) return;
+  const int n = (int)prog.size();
+  auto trunk_conv = [&](int k) {
+    const OpDesc& d = prog[k];
+    const RbOp& o = R.ops[k];
+    return d.kind == OP_CONV3 && o.kind == RB_GEMM && o.stride == 1 && o.taps == 9 && o.hin == o.hout && o.win == o.wout &&
+           o.cout <= 256 && o.out_layout == RB_NHWC;
+  };
+  // readers of the output of operator j before that buffer is written again must all lie in (j, last]
+  auto private_output = [&](int j, int last) {
+    const int id = prog[j].out;
+    for (int m = j + 1; m < n; ++m) {
+      if ((prog[m].in == id || prog[m].res == id) && m > last) return false;
+      if (prog[m].out == id) break;
+    }
+    return true;
+  };
+  int k = 0;
+  while (k < n) {
+    if (!trunk_conv(k) || prog[k].res != -100) { ++k; continue; }   // (a tower starts at a layer without a residual)
+    const RbOp& o0 = R.ops[k];
+    int last = k;
+    while (last + 1 < n && last + 1 - k < RB_TOWER_MAX_LAYERS) {
+      const int j = last + 1;
+      if (!trunk_conv(j)) break;
+      const OpDesc& d = prog[j];
+      const RbOp& o = R.ops[j];
+      if (o.cin != o0.cout || o.cout != o0.cout || o.hin != o0.hin || o.win != o0.win || d.use_action) break;
+      if (d.in != prog[j - 1].out) break;
+      if (d.res != -100 && d.res != prog[j - 1].in) break;
+      if (d.res != -100 && j - 1 == k && R.ops[k].cin != o0.cout) break;   // the first layer's input has another width
+      last = j;
+    }
+    // cut the run where an inner output is needed elsewhere (to a fixed point: a shorter run moves readers outside)
+    for (bool changed = true; changed;) {
+      changed = false;
+      for (int j = k; j < last; ++j)
+        if (!private_output(j, last)) { last = j; changed = true; break; }
+    }
+    if (last - k + 1 >= 2) {
+      RbTower tw;
+      tw.first = k; tw.count = last - k + 1;
+      tw.C = o0.cout; tw.H = o0.hout; tw.W = o0.wout;
+      tw.cchunks = rb_round16(std::max(o0.cout, o0.cin)) / 16; tw.ntiles = (o0.cout + 15) / 16;
+      tw.t_max = 0;
+      for (int T = 1; T <= 64; ++T) {
+        RbTowerShape c;
+        if (rb_tower_grid(tw, T, c)) tw.t_max = T;
+        else if (T * tw.H * tw.W > 16 * RB_MT * 8) break;
+      }
+      if (tw.t_max >= 1) {
+        for (int j = k; j <= last; ++j) R.ops[j].tower = (int)R.towers.size();
+        R.towers.push_back(tw);
+      }
+    }
+    k = last + 1;
+  }
+}
+
 // Two half-shards on two streams (mzx_row_search.h): size of the FIRST half for a shard of `batch` trees, 0 = the shard
 // runs undivided.  16-tree aligned (every per-tree array of the second half stays 16-byte aligned).  The summation
 // order of a layer depends on the launch shape only through its channel groups (phases x chunks per group): a shard is
@@ -284,6 +401,7 @@ inline bool rb_build_program(mzx_net* net, const std::vector<OpDesc>& prog, RbPl
     R.ops.push_back(o);
   }
   R.ok = 1;
+  rb_find_towers(prog, R);
   return true;
 }
 

@@ -100,12 +100,13 @@ STREAMED_SHAPE_FIELDS = ("T", "rows", "mtiles", "lds", "ntiles_wg", "nsplit", "N
                          "phases", "Cs", "ntiles", "cchunks")
 
 
-def streamed_k_loop(MT, NT):
-    """Which K loop ``rb_gemm_kernel<MT, NT>`` compiles (csrc/mzx_batched.hip): one set of position fragments refilled in
-    place, the four-chunk ring of the small tilings, or two alternating fragment sets."""
+def streamed_k_loop(MT, NT, tower=False):
+    """Which K loop ``rb_gemm_kernel<MT, NT>`` / ``rb_tower_kernel<MT, NT>`` compiles (csrc/mzx_batched.hip): one set of
+    position fragments refilled in place, the four-chunk ring of the small tilings (layer kernel only), or two alternating
+    fragment sets."""
     if (MT - 1) * NT >= 5:
         return "in-place"
-    return "ring" if MT * NT <= 4 else "two-sets"
+    return "ring" if (MT * NT <= 4 and not tower) else "two-sets"
 
 
 def streamed_launches(lib, handle, recurrent, batch):
@@ -119,7 +120,20 @@ def streamed_launches(lib, handle, recurrent, batch):
     out = []
     plan = (ctypes.c_int32 * 24)()
     shape = (ctypes.c_int32 * 16)()
+    # towers first: their operators run inside ONE rb_tower_kernel<MT, NT> launch, not one by one
+    in_tower = set()
+    tw = (ctypes.c_int32 * 12)()
+    index = 0
+    while lib.mzx_net_streamed_tower(handle, int(bool(recurrent)), index, int(batch), ctypes.byref(tw)) == 0:
+        t = dict(zip(("first", "count", "C", "H", "W", "T", "MT", "NT", "WM", "WN", "lds", "groups"), list(tw)))
+        in_tower.update(range(t["first"], t["first"] + t["count"]))
+        out.append(dict(op=t["first"], MT=t["MT"], NT=t["NT"], phases=1, k_loop="tower " + streamed_k_loop(t["MT"], t["NT"], tower=True),
+                        WM=t["WM"], WN=t["WN"], T=t["T"], nsplit=1, cpg=(t["C"] + 15) // 16, taps=9, stride=1,
+                        in_layout=-t["count"], cin=t["C"], cout=t["C"]))
+        index += 1
     for op in range(lib.mzx_net_num_operators(handle, int(bool(recurrent)))):
+        if op in in_tower:
+            continue
         lib.check(lib.mzx_net_streamed_plan(handle, int(bool(recurrent)), op, ctypes.byref(plan)))
         p = dict(zip(HipNetwork.STREAMED_PLAN_FIELDS, list(plan)))
         if p["kind"] != 0:
@@ -330,7 +344,9 @@ class HipNetwork:
         return int(self.backend.lib.mzx_net_operator_out_floats(self.handle, int(bool(recurrent)), int(op)))
 
     def set_mode(self, mode):
-        """0 = one kernel per operator, 1 = fused engine where available (default)."""
+        """0 = one kernel per operator, 1 = fused engine where available, streamed engine otherwise (default), 2 = fused with
+        4-wave workgroups, 3 = streamed engine for everything, 4 / 5 = as 3 / 1 with the streamed engine layer by layer
+        (no tower launches: the A/B of csrc/mzx_batched.hip's rb_tower_kernel)."""
         self.backend.lib.check(self.backend.lib.mzx_net_set_mode(self.handle, int(mode)))
 
     def num_operators(self, recurrent):

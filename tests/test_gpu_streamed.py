@@ -92,6 +92,8 @@ STREAMED_CASES = {
     "breakout_cnn": (lambda: configs.breakout(downsample="CNN"), 3),
     "cnn_small": (lambda: configs.breakout(downsample="CNN", observation_shape=(2, 40, 56), stacked_observations=1,
                                            channels=8, blocks=1), 5),
+    # nine column tiles: two per wave (NT = 2) in the layer kernel and in the tower kernel
+    "wide144": (lambda: configs.connect4(channels=144, blocks=2), 5),
 }
 
 
@@ -117,6 +119,62 @@ def test_streamed_operator_by_operator(backend, name):
             worst = max(worst, err / scale)
             assert err < 2e-5 * scale, (name, "recurrent" if recurrent else "initial", n_ops, err)
         print(f"{name} {'recurrent' if recurrent else 'initial'}: worst relative operator error {worst:.2e}")
+
+
+@pytest.mark.parametrize("name,B,T", [("connect4", 50, 1), ("connect4", 50, 2), ("connect4", 50, 3), ("connect4", 47, 4),
+                                      ("connect4", 50, 6), ("tictactoe", 37, 1), ("tictactoe", 200, 29), ("tictactoe", 300, 64),
+                                      ("gomoku", 3, 1), ("odd", 5, 1), ("atari_narrow", 7, 1), ("atari_narrow", 7, 2),
+                                      ("atari_narrow", 9, 4), ("breakout", 9, 3), ("wide144", 5, 1), ("wide144", 7, 2)])
+def test_tower_kernel_layer_by_layer(backend, name, B, T, monkeypatch):
+    """
+    rb_tower_kernel (a whole trunk -- conv + residual blocks -- in one launch, activations in LDS in place, the block
+    input kept in registers as the residual) against the element kernels, LAYER BY LAYER: a prefix that ends inside a
+    tower runs the tower's first layers only, so every layer's output is compared.  Forced samples per workgroup T
+    (MZX_RB_TOWER_T) walk the instantiations <MT, NT> -- one to nine row tiles per wave, one and two column tiles, the
+    in-place and the two-set K loops -- with batches that do not fill the last workgroup.
+    """
+    make, _ = STREAMED_CASES[name]
+    cfg = make()
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 33))
+    net.set_mode(3)
+    monkeypatch.setenv("MZX_RB_TOWER_T", str(T))
+    rs = numpy.random.RandomState(7)
+    obs = torch.tensor(rs.rand(B, *net.input_shape).astype(numpy.float32))
+    hid = torch.tensor(rs.rand(B, *net.hidden_shape).astype(numpy.float32))
+    act = torch.tensor(rs.randint(0, len(cfg.action_space), size=B).astype(numpy.int32))
+    seen = set()
+    for recurrent, x, a in ((0, obs, None), (1, hid, act)):
+        towers = [l for l in net.streamed_launches(recurrent, B) if l["k_loop"].startswith("tower")]
+        assert towers, (name, recurrent)
+        in_tower = set()
+        for t in towers:
+            assert t["T"] <= T
+            seen.add((t["MT"], t["NT"], t["T"]))
+            in_tower.update(range(t["op"], t["op"] - t["in_layout"]))      # (in_layout = -layers for a tower entry)
+        worst = 0.0
+        for n_ops in range(1, net.num_operators(recurrent) + 1):
+            if n_ops - 1 not in in_tower and n_ops % 3:
+                continue          # operators outside towers: test_streamed_operator_by_operator covers them; sample a third
+            got = net.debug_prefix(recurrent, 1, n_ops, x, a).cpu().numpy()
+            want = net.debug_prefix(recurrent, 0, n_ops, x, a).cpu().numpy()
+            err = numpy.abs(got - want).max()
+            scale = 1.0 + numpy.abs(want).max()
+            worst = max(worst, err / scale)
+            assert err < 2e-5 * scale, (name, T, "recurrent" if recurrent else "initial", n_ops, err)
+        print(f"{name} T={T} {'recurrent' if recurrent else 'initial'}: towers {[(t['op'], -t['in_layout'], t['MT'], t['NT'], t['T']) for t in towers]}, "
+              f"worst relative error {worst:.2e}")
+    # and the whole inferences (heads behind the towers) against the layer-by-layer streamed path
+    o1, r1 = net.initial_inference(obs), net.recurrent_inference(hid, act)
+    net.set_mode(4)
+    o0, r0 = net.initial_inference(obs), net.recurrent_inference(hid, act)
+    for got, want in zip(o1 + r1, o0 + r0):
+        g, w = got.cpu().numpy(), want.cpu().numpy()
+        fin = numpy.isfinite(w)
+        assert numpy.array_equal(numpy.isfinite(g), fin)
+        # (a near-flat plane in front of the min-max scaling amplifies the two summation orders: a few samples may differ)
+        err = numpy.abs(numpy.where(fin, g - w, 0.0)).reshape(B, -1).max(axis=1)
+        assert (err < 5e-5 * (1.0 + numpy.abs(w[fin]).max())).sum() >= B - max(1, B // 16), (name, T, err.max())
 
 
 def test_atari_as_shipped_operator_by_operator(backend):

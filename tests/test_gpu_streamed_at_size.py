@@ -247,15 +247,24 @@ def test_at_size_search_two_streams_and_oracle(backend, case, monkeypatch):
     s32 = parallel.run_searches(cfg, sd, jobs, processes=procs)
     s64 = parallel.run_searches(cfg, sd, jobs, processes=procs, dtype_name="float64")
     identical = own_identical = 0
+    failures = []
+    first_diff = lambda a, b: next((k for k in range(max(len(a), len(b))) if k >= len(a) or k >= len(b) or a[k] != b[k]), None)
     for i, g, t32, t64 in zip(sample, got, s32, s64):
         want = t32["trace"]
-        own_identical += int(t64["trace"] == want)
-        k = next((k for k in range(len(want)) if k >= len(g) or g[k] != want[k]), None)
+        k64 = first_diff(t64["trace"], want)          # where the oracle's own fp32 search leaves its binary64 evaluation
+        own_identical += int(k64 is None)
+        k = first_diff(g, want)
         if k is not None:
             gap, depth = t32["margins"][k]
             print(f"{case}: tree {i} diverges at simulation {k} of {len(want)} (oracle {want[k]}, device "
-                  f"{g[k] if k < len(g) else None}); oracle UCB top-2 margin on that walk {gap:.3e} at depth {depth}")
-            assert gap < parity.MARGIN_GATE, (case, i, k, gap, "divergence with a comfortable UCB margin: not fp32 noise")
+                  f"{g[k] if k < len(g) else None}); oracle UCB top-2 margin on that walk {gap:.3e} at depth {depth}; the "
+                  f"oracle's own fp32 search leaves its binary64 evaluation at simulation {k64}")
+            # A divergence must be a near-tie of the oracle's UCB scores (MARGIN_GATE) -- unless the oracle's OWN fp32
+            # arithmetic has already left exact arithmetic on this tree by then: behind that simulation the fp32 trees
+            # of any two implementations are different trees (deep single-line searches compound the round-off of every
+            # recurrent_inference on the path: gomoku's 400 simulations dig 90-ply lines), and a margin says nothing
+            if gap >= parity.MARGIN_GATE and not (k64 is not None and k64 <= k):
+                failures.append((i, k, gap, depth, k64))
             continue
         identical += 1
         assert t32["root_visit_counts"] == list(res.visit_counts[i]), (case, i)
@@ -264,12 +273,14 @@ def test_at_size_search_two_streams_and_oracle(backend, case, monkeypatch):
         # against binary64 on this very tree (the decode cancels ~3 digits; near-flat planes)
         rv32 = t32["root_value"]
         tol, ref = 30 * TOL, rv32
-        if t64["trace"] == want:
+        if k64 is None:
             ref = t64["root_value"]
             tol = max(tol, 8 * abs(rv32 - ref))
-        assert abs(res.root_values[i] - ref) < tol * max(1.0, abs(ref)), (case, i, res.root_values[i], rv32, ref)
+        if not abs(res.root_values[i] - ref) < tol * max(1.0, abs(ref)):
+            failures.append((i, "root value", res.root_values[i], rv32, ref))
     n = len(sample)
     print(f"{case}: {identical}/{n} sampled trees identical to the oracle (fp32) in EVERY simulation; the oracle's own fp32 "
           f"search is identical to its binary64 evaluation on {own_identical}/{n} of the same trees")
+    assert not failures, (case, failures)
     # the device may diverge from the oracle's fp32 about as often as the oracle's fp32 diverges from exact arithmetic
     assert n - identical <= math.ceil(1.5 * (n - own_identical)) + max(2, n // 16), (case, identical, own_identical, n)
