@@ -483,6 +483,7 @@ struct RbTowerArgs {
   const int32_t* action;
   int32_t num_actions, batch;
   int32_t cin0, C, H, W, PH, PW, Cs, cchunks, T, rows, mtiles, ntiles, WN, WM, layers, y_vec, rowskip;
+  int32_t dbg;             // latency experiments (env MZX_RB_DBG, never set in production): 1 skip the K loops, 2 skip the epilogues
   uint32_t magic_hw, magic_w, magic_phw, magic_pw;
   RbTowerLayer layer[RB_TOWER_MAX_LAYERS];
 };
@@ -614,7 +615,7 @@ rb_tower_kernel(const RbTowerArgs a) {
     const RbTowerLayer& L = a.layer[l];
     const bool last = l + 1 == a.layers;
     // ---- K loop: (tap, chunk) pairs, operands one chunk ahead in registers
-    if (active) {
+    if (active && !(a.dbg & 1)) {
       const int cpl = L.cchunks, n_it = 9 * cpl;
       const float* wp[NT];
 #pragma unroll
@@ -699,7 +700,7 @@ rb_tower_kernel(const RbTowerArgs a) {
     }
     __syncthreads();                                   // every wave is done reading the layer's input
     // ---- epilogue: lane = position row m_lane of a tile, four consecutive output channels
-    if (active) {
+    if (active && !(a.dbg & 2)) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n0 = (wn * NT + j) * 16 + g4;
@@ -1012,6 +1013,8 @@ int rb_launch_tower(const mzx_net* net, const std::vector<OpDesc>& prog, const R
   a.batch = batch; a.cin0 = o0.cin; a.C = tw.C; a.H = tw.H; a.W = tw.W; a.PH = tw.H + 2; a.PW = tw.W + 2;
   a.Cs = sh.Cs; a.cchunks = tw.cchunks; a.T = sh.T; a.rows = sh.rows; a.mtiles = sh.mtiles; a.ntiles = tw.ntiles;
   a.WN = sh.WN; a.WM = sh.WM; a.layers = layers;
+  static const int dbg = getenv("MZX_RB_DBG") ? atoi(getenv("MZX_RB_DBG")) : 0;
+  a.dbg = dbg;
   a.y_vec = (tw.C % 4 == 0 && a.y_sstride % 4 == 0 && ((uintptr_t)y % 16) == 0) ? 1 : 0;
   a.rowskip = (a.PW - 3) * sh.Cs;
   a.magic_hw = rb_magic(tw.H * tw.W); a.magic_w = rb_magic(tw.W);

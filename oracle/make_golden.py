@@ -438,17 +438,19 @@ def make_large_residual_fixtures():
         k = rs.randint(2, len(cfg.action_space) + 1)
         return sorted(rs.choice(cfg.action_space, size=k, replace=False).tolist())
 
-    make_net_fixture("resnet_gomoku", "gomoku", 28, 3)
-    make_net_fixture("resnet_atari", "atari", 29, 2, store_obs=False)
-    make_tree_fixture("gomoku", "gomoku", 2, 17, subset, overrides=dict(num_simulations=48),
+    if "--large-trees-only" not in sys.argv:
+        make_net_fixture("resnet_gomoku", "gomoku", 28, 3)
+        make_net_fixture("resnet_atari", "atari", 29, 2, store_obs=False)
+    # round 4: eight gomoku trees (was two), four atari trees x the 50 simulations games/atari.py:42 ships (was one x 12);
+    # ragged legal sets for both (atari: the full action space for the first tree)
+    make_tree_fixture("gomoku", "gomoku", 8, 17, subset, overrides=dict(num_simulations=48),
                       players_fn=lambda c, cfg: c % 2)
-    make_tree_fixture("atari", "atari", 1, 18, lambda c, cfg: list(cfg.action_space),
-                      overrides=dict(num_simulations=12))
+    make_tree_fixture("atari", "atari", 4, 18, lambda c, cfg: list(cfg.action_space) if c == 0 else subset(c, cfg))
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    if "--large-residual" in sys.argv:
+    if "--large-residual" in sys.argv or "--large-trees-only" in sys.argv:
         make_large_residual_fixtures()
         return
     full = lambda c, cfg: list(cfg.action_space)
