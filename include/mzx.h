@@ -126,9 +126,12 @@ int mzx_net_streamed_shape(const mzx_net* net, int32_t recurrent, int32_t op, in
  * models.py:300-433) run as ONE launch of rb_tower_kernel with the activations resident in LDS, updated in place
  * (mzx_net_set_mode(4) / (5): layer by layer instead, the A/B).  Tower `index` of the program at `batch` samples:
  * {first operator, operators, channels, H, W, samples per workgroup, row tiles per wave, column tiles per wave, waves
- * along M, waves along N, LDS bytes, workgroups}; an error when the program has no such tower.  The operators of a
+ * along M, waves along N, LDS bytes, workgroups (0: at this batch the tower's shape would waste more than a fifth of the
+ * MFMA rows and its layers launch one by one), operators directly behind the tower that run INSIDE its launch on the
+ * LDS-resident output (the per-plane min-max scaling, 1x1 head convolutions with few output channels: the tower's
+ * output then never reaches memory), 0, 0, 0}; an error when the program has no such tower.  The operators of a
  * tower are not launched one by one (mzx_net_streamed_shape still describes what the layer-by-layer path would do). */
-int mzx_net_streamed_tower(const mzx_net* net, int32_t recurrent, int32_t index, int32_t batch, int32_t out[12]);
+int mzx_net_streamed_tower(const mzx_net* net, int32_t recurrent, int32_t index, int32_t batch, int32_t out[16]);
 /* The row-per-tree search runs large shards as two half-shards on two HIP streams (csrc/mzx_row_search.h; from 1024
  * trees, and only when both halves keep the channel groups -- the summation order -- of the undivided launch):
  * out = {trees of the first half, trees of the second half}; {batch, 0} when a shard of `batch` trees runs undivided.

@@ -466,6 +466,10 @@ rb_gemm_kernel(const RbGemmArgs a) {
 // five transfers per block of the layer-by-layer path, and pays no launch / staging / epilogue tail per layer.
 // Summation order per output: taps in order, 16-channel chunks in order, the MFMA's k order -- independent of T and of
 // the batch (two half-shards build the trees of the undivided run).
+__device__ __forceinline__ uint32_t rb_magic_dev(int d) {      // ceil(2^32 / d), as rb_magic on the host
+  return d > 1 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u;
+}
+
 struct RbTowerLayer {
   int64_t w_off;       // derived buffer: packed B fragments (RzPackOp) of the layer
   int64_t bn_alpha;    // derived buffer offsets of the folded BatchNorm terms (-1: none)
@@ -484,7 +488,16 @@ struct RbTowerArgs {
   int32_t num_actions, batch;
   int32_t cin0, C, H, W, PH, PW, Cs, cchunks, T, rows, mtiles, ntiles, WN, WM, layers, y_vec, rowskip;
   int32_t dbg;             // latency experiments (env MZX_RB_DBG, never set in production): 1 skip the K loops, 2 skip the epilogues
-  uint32_t magic_hw, magic_w, magic_phw, magic_pw;
+  uint32_t magic_hw, magic_w, magic_phw, magic_pw, magic_chw;
+  // ---- the tower's TAIL: operators that read nothing but the tower's output run on the LDS-resident tile before the
+  // workgroup retires (a workgroup owns whole samples, so a per-plane reduction is an intra-workgroup one)
+  int32_t write_out;       // 0: nobody else reads the tower's output -- it never goes to memory
+  float* scale_y;          // per-plane min-max scaling (models.py:527-553, :574-599; MinMaxScaleOp's arithmetic) of the output,
+  const int32_t* scale_node;   // written NCHW into the search arena's node store (null scale_y: none)
+  int64_t scale_sstride;
+  int32_t scale_nodes;
+  int32_t n_conv;          // 1x1 head convolutions with few output channels (conv1x1_reward / _value / _policy, models.py:369-433)
+  struct { const float* w; const float* b; float* y; int32_t R; int32_t pad; } conv[2];
   RbTowerLayer layer[RB_TOWER_MAX_LAYERS];
 };
 
@@ -611,6 +624,7 @@ rb_tower_kernel(const RbTowerArgs a) {
     for (int j = 0; j < NT; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; res[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   __syncthreads();
 
+  const bool has_tail = a.scale_y != nullptr || a.n_conv > 0;
   for (int l = 0; l < a.layers; ++l) {
     const RbTowerLayer& L = a.layer[l];
     const bool last = l + 1 == a.layers;
@@ -739,9 +753,8 @@ rb_tower_kernel(const RbTowerArgs a) {
             v[u] = (n0 + u < a.C) ? x : 0.f;
           }
           if (L.flags & 2) res[i][j] = keep;
-          if (!last) {
-            *(f32x4*)cell = v;
-          } else {
+          if (!last || has_tail) *(f32x4*)cell = v;
+          if (last && a.write_out) {
             float* yp = a.y + (long long)b * a.y_sstride + (long long)pos * a.C + n0;
             if (a.y_vec) *(f32x4*)yp = v;
             else {
@@ -754,6 +767,65 @@ rb_tower_kernel(const RbTowerArgs a) {
       }
     }
     if (!last) __syncthreads();                        // the next layer reads what every wave wrote
+  }
+  if (!has_tail) return;
+  __syncthreads();                                     // the last layer's output is in the tile's interior cells
+  const int in0 = (a.PW + 1) * a.Cs;                   // cell (0, 0) of a board inside its halo
+  if (a.scale_y) {
+    float* lo = tile + (size_t)cells * a.Cs;
+    float* sc = lo + a.T * a.C;
+    for (int idx = tid; idx < a.T * a.C; idx += RB_THREADS) {
+      const int t = rb_div(idx, a.C, rb_magic_dev(a.C)), c = idx - t * a.C;
+      const float* base = tile + (size_t)t * phw * a.Cs + in0 + c;
+      float l = base[0], h = l;
+      for (int y = 0; y < a.H; ++y)
+        for (int x = 0; x < a.W; ++x) {
+          const float v = base[(y * a.PW + x) * a.Cs];
+          l = fminf(l, v);
+          h = fmaxf(h, v);
+        }
+      float sp = h - l;
+      if (sp < 1e-5f) sp += 1e-5f;
+      lo[idx] = l;
+      sc[idx] = sp;
+    }
+    __syncthreads();
+    const int CHW = a.C * HW, total = a.T * CHW;
+    for (int i = tid; i < total; i += RB_THREADS) {
+      const int t = rb_div(i, CHW, a.magic_chw), r = i - t * CHW;
+      const int c = rb_div(r, HW, a.magic_hw), p = r - c * HW;
+      const int y = rb_div(p, a.W, a.magic_w), x = p - y * a.W;
+      const int b = b0 + t;
+      if (b >= a.batch) continue;
+      const float v = tile[(size_t)t * phw * a.Cs + in0 + (y * a.PW + x) * a.Cs + c];
+      float* yb = a.scale_y + ((long long)b * a.scale_nodes + (a.scale_node ? a.scale_node[b] : 0)) * a.scale_sstride;
+      yb[r] = mzx_div(v - lo[t * a.C + c], sc[t * a.C + c]);
+    }
+  }
+  for (int q = 0; q < a.n_conv; ++q) {
+    // y[b][rc][p] = bias[rc] + sum_c x[b][p][c] w[rc][c], channels in order (one fmaf chain per output)
+    const int R = a.conv[q].R, RHW = R * HW, total = a.T * RHW;
+    const uint32_t magic_rhw = rb_magic_dev(RHW);
+    for (int i = tid; i < total; i += RB_THREADS) {
+      const int t = rb_div(i, RHW, magic_rhw), r = i - t * RHW;
+      const int rc = rb_div(r, HW, a.magic_hw), p = r - rc * HW;
+      const int y = rb_div(p, a.W, a.magic_w), x = p - y * a.W;
+      const int b = b0 + t;
+      if (b >= a.batch) continue;
+      const float* xin = tile + (size_t)t * phw * a.Cs + in0 + (y * a.PW + x) * a.Cs;
+      const float* w = a.conv[q].w + (size_t)rc * a.C;
+      float acc = 0.f;
+      int c = 0;
+      for (; c + 3 < a.C; c += 4) {
+        const f32x4 v = *(const f32x4*)(xin + c);
+        acc = fmaf(v[0], w[c], acc);
+        acc = fmaf(v[1], w[c + 1], acc);
+        acc = fmaf(v[2], w[c + 2], acc);
+        acc = fmaf(v[3], w[c + 3], acc);
+      }
+      for (; c < a.C; ++c) acc = fmaf(xin[c], w[c], acc);
+      a.conv[q].y[(long long)b * RHW + r] = acc + a.conv[q].b[rc];
+    }
   }
 }
 
@@ -1000,12 +1072,25 @@ RbTowerFn rb_pick_tower_mt(int mt) {
 
 // Launches layers [tw.first, tw.first + layers) of a tower (layers < tw.count: a diagnostic prefix; the last layer run
 // writes its output to memory like the whole tower's last layer does).
+struct RbTowerTail {
+  int write_out = 1;
+  RbTensor scale;            // .p null: no scaling operator in the tail
+  int n_conv = 0;
+  struct { const float* w; const float* b; float* y; int R; } conv[2];
+};
+
 int rb_launch_tower(const mzx_net* net, const std::vector<OpDesc>& prog, const RbProgram& R, const RbTower& tw, int layers,
-                    const RbTensor& x, float* y, const int32_t* action, int batch, stream_t stream) {
+                    const RbTensor& x, float* y, const int32_t* action, int batch, stream_t stream, const RbTowerTail& tail) {
   const RbTowerShape sh = rb_tower_shape(tw, batch);
   if (sh.T < 1) { set_error("tower: no launch shape"); return MZX_ERR_INVALID; }
   RbTowerArgs a;
   memset(&a, 0, sizeof(a));
+  a.write_out = tail.write_out;
+  a.scale_y = const_cast<float*>(tail.scale.p); a.scale_node = tail.scale.node; a.scale_sstride = tail.scale.sstride;
+  a.scale_nodes = tail.scale.nodes;
+  a.n_conv = tail.n_conv;
+  for (int q = 0; q < tail.n_conv; ++q) { a.conv[q].w = tail.conv[q].w; a.conv[q].b = tail.conv[q].b; a.conv[q].y = tail.conv[q].y; a.conv[q].R = tail.conv[q].R; }
+  a.magic_chw = rb_magic(tw.C * tw.H * tw.W);
   const RbOp& o0 = R.ops[tw.first];
   a.x = x; a.y = y; a.y_sstride = (int64_t)tw.C * tw.H * tw.W;
   a.der = net->d_derived;
@@ -1081,15 +1166,40 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
     const OpDesc& d = prog[k];
     const RbOp& o = R.ops[k];
     int rc = 0;
-    if (o.kind == RB_GEMM && o.tower >= 0 && !net->rb_no_towers && R.towers[o.tower].first == k) {
+    if (o.kind == RB_GEMM && o.tower >= 0 && !net->rb_no_towers && R.towers[o.tower].first == k &&
+        rb_tower_use(R.towers[o.tower], batch)) {
       // a whole tower (or, for a diagnostic prefix, its first layers) in one launch; inner outputs never reach memory
       const RbTower& tw = R.towers[o.tower];
       const int layers = std::min(tw.count, count - k);
       const OpDesc& dl = prog[k + layers - 1];
       const RbTensor x = tensor(d.in, (int64_t)o.cin * o.hin * o.win, o.in_layout);
-      rc = rb_launch_tower(net, prog, R, tw, layers, x, resolve(net, nb, dl.out, batch), nb.action, batch, stream);
+      // the tail: the scaling operator and the small 1x1 head convolutions that directly follow the whole tower and read
+      // its output run inside the tower launch, on the LDS-resident tile (a diagnostic prefix takes as many as it covers)
+      RbTowerTail tail;
+      int n_tail = 0;
+      const char* tail_env = getenv("MZX_RB_TAIL");       // 0: towers end at their last convolution (A/B; read per call)
+      if (layers == tw.count && !(tail_env && atoi(tail_env) == 0)) {
+        for (int m = k + layers; m < count && m < k + layers + tw.n_tail; ++m) {
+          const OpDesc& dm = prog[m];
+          if (dm.kind == OP_SCALE) {
+            tail.scale = tensor(dm.out, (int64_t)dm.groups_per_sample * dm.len, RB_NCHW);
+          } else {
+            auto& cv = tail.conv[tail.n_conv++];
+            cv.w = flat + dm.w; cv.b = flat + dm.b; cv.y = resolve(net, nb, dm.out, batch); cv.R = dm.cout;
+          }
+          ++n_tail;
+        }
+        // does anything else still read the tower's output?
+        tail.write_out = 0;
+        for (int m = k + layers + n_tail; m < (int)prog.size(); ++m) {
+          if (prog[m].in == dl.out || prog[m].res == dl.out) { tail.write_out = 1; break; }
+          if (prog[m].out == dl.out) break;
+        }
+        if (n_tail < tw.n_tail || n_tail == 0) tail.write_out = 1;   // (a prefix that ends inside the tail: the rest would read it)
+      }
+      rc = rb_launch_tower(net, prog, R, tw, layers, x, resolve(net, nb, dl.out, batch), nb.action, batch, stream, tail);
       if (rc) return rc;
-      k += layers - 1;
+      k += layers + n_tail - 1;
       continue;
     }
     if (o.kind == RB_GEMM) {

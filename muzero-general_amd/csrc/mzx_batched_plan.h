@@ -58,7 +58,10 @@ struct RbTower {
   int32_t C = 0, H = 0, W = 0;          // channels (= cout of every layer), board
   int32_t cchunks = 0, ntiles = 0;      // ceil(C / 16)
   int32_t t_max = 1;                    // most samples per workgroup that fit the LDS and the wave grid
+  int32_t n_tail = 0;                   // operators directly behind the tower that run inside its launch (the per-plane
+                                        // scaling, 1x1 head convolutions with at most RB_TAIL_MAX_R output channels)
 };
+constexpr int RB_TAIL_MAX_R = 8;
 
 struct RbProgram {
   int32_t ok = 0;

@@ -184,7 +184,7 @@ int mzx_net_streamed_shape(const mzx_net* net, int32_t recurrent, int32_t op, in
   return MZX_OK;
 }
 
-int mzx_net_streamed_tower(const mzx_net* net, int32_t recurrent, int32_t index, int32_t batch, int32_t out[12]) {
+int mzx_net_streamed_tower(const mzx_net* net, int32_t recurrent, int32_t index, int32_t batch, int32_t out[16]) {
   if (!net || !out || batch < 1) { set_error("null argument / batch < 1"); return MZX_ERR_INVALID; }
   const RbProgram& R = recurrent ? net->rb.recurrent : net->rb.initial;
   if (!net->rb.ok || !R.ok || net->rb_no_towers || index < 0 || index >= (int32_t)R.towers.size()) {
@@ -193,8 +193,11 @@ int mzx_net_streamed_tower(const mzx_net* net, int32_t recurrent, int32_t index,
   }
   const RbTower& tw = R.towers[index];
   const RbTowerShape sh = rb_tower_shape(tw, batch);
-  const int32_t v[12] = {tw.first, tw.count, tw.C, tw.H, tw.W, sh.T, sh.MT, sh.NT, sh.WM, sh.WN, sh.lds, sh.groups};
-  for (int k = 0; k < 12; ++k) out[k] = v[k];
+  // (groups = 0: at this batch the tower's layers launch one by one, rb_tower_use)
+  const char* tail_env = getenv("MZX_RB_TAIL");
+  const int32_t v[16] = {tw.first, tw.count, tw.C, tw.H, tw.W, sh.T, sh.MT, sh.NT, sh.WM, sh.WN, sh.lds,
+                         rb_tower_use(tw, batch) ? sh.groups : 0, (tail_env && atoi(tail_env) == 0) ? 0 : tw.n_tail, 0, 0, 0};
+  for (int k = 0; k < 16; ++k) out[k] = v[k];
   return MZX_OK;
 }
 
@@ -432,13 +435,13 @@ int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_
   }
   if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) return rz_search_run(s, io, d_arena, (stream_t)stream);
   if ((s->mode & 1) && rb_enabled(s->net, true) && row_search_supported(s->p)) {
-    s->last_kernel = "mzx::rb_gemm_kernel (streamed FP32-MFMA layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
+    s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel (streamed FP32-MFMA trunks and layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
     return search_run_rows(s, io, d_arena, (stream_t)stream);   // (renames last_kernel when it runs two half-shards)
   }
 #endif
   s->last_kernel = "one kernel per step of a simulation (select / network / expand + back-propagate)";
 #ifndef MZX_HOSTCHECK
-  if (rb_enabled(s->net, true)) s->last_kernel = "mzx::rb_gemm_kernel (streamed FP32-MFMA layers) between one-thread-per-tree kernels";
+  if (rb_enabled(s->net, true)) s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel (streamed FP32-MFMA trunks and layers) between one-thread-per-tree kernels";
 #endif
   return search_run_generic(s, io, d_arena, (stream_t)stream);
 }
@@ -461,7 +464,7 @@ int mzx_search_run_from_roots(mzx_search* s, const mzx_search_io* io, const floa
   // the per-operator path here
   if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) return rz_search_run(s, io, d_arena, (stream_t)stream, &ov);
   if ((s->mode & 1) && rb_enabled(s->net, true) && row_search_supported(s->p)) {
-    s->last_kernel = "mzx::rb_gemm_kernel (streamed FP32-MFMA layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
+    s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel (streamed FP32-MFMA trunks and layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
     return search_run_rows(s, io, d_arena, (stream_t)stream, &ov);
   }
 #endif

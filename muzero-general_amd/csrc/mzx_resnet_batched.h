@@ -182,8 +182,9 @@ inline RbShape rb_choose_shape(const RbOp& o, int batch) {
 // remaining 8 / WN waves deep in rows, at most nine row tiles per wave.
 struct RbTowerShape { int T, rows, mtiles, lds, NT, WN, WM, MT, groups, Cs, per_cu; };
 
+// row tables, per-sample offsets, the tile, and the per-plane (min, range) pairs of a scaling operator in the tail
 inline int64_t rb_tower_lds_bytes(int T, int mtiles, int cells, int Cs) {
-  return (int64_t)3 * 16 * mtiles * 4 + (int64_t)((T + 1) & ~1) * 8 + (int64_t)cells * Cs * 4;
+  return (int64_t)3 * 16 * mtiles * 4 + (int64_t)((T + 1) & ~1) * 8 + (int64_t)cells * Cs * 4 + (int64_t)2 * T * (Cs - 8) * 4;
 }
 
 inline bool rb_tower_grid(const RbTower& tw, int T, RbTowerShape& c) {
@@ -206,8 +207,10 @@ inline bool rb_tower_grid(const RbTower& tw, int T, RbTowerShape& c) {
 }
 
 // Samples per workgroup for THIS batch: the cost model of rb_choose_shape (accumulator tiles on the busiest wave x rounds
-// of co-resident workgroups); two co-resident workgroups hide each other's barriers and epilogues, hence the bonus.
-// MZX_RB_TOWER_T=<n>: force (A/B).
+// of co-resident workgroups; ties: fewer, larger workgroups).  Calibrated on connect4 (profiles/r04_tower_experiments.txt:
+// samples per workgroup 2 .. 6 at 1024 / 2048 / 3072 / 4608 trees): the model ranks the measured rates correctly in all
+// four cases -- whole rounds of workgroups matter more than anything else (4608 trees: six boards = 768 workgroups =
+// three rounds of 256 -> 0.663; four boards = 4.5 rounds -> 0.545).  MZX_RB_TOWER_T=<n>: force (A/B).
 inline RbTowerShape rb_tower_shape(const RbTower& tw, int batch) {
   const char* force_env = getenv("MZX_RB_TOWER_T");      // read per call: the tests force several values in one process
   const int force_t = force_env ? atoi(force_env) : 0;
@@ -220,11 +223,20 @@ inline RbTowerShape rb_tower_shape(const RbTower& tw, int batch) {
     const int64_t wgs = c.groups, cap = 256 * c.per_cu;
     const int64_t rem = wgs % cap;
     const double ways = (double)(wgs / cap) * c.per_cu + (rem ? (double)std::min<int64_t>(c.per_cu, (rem + 255) / 256) : 0.0);
-    const double cost = ways * (c.MT * c.NT) * (c.per_cu == 2 ? 0.9 : 1.0) + 1e-4 * (double)wgs;
+    const double cost = ways * (c.MT * c.NT) + 1e-4 * (double)wgs;
     if (force_t > 0 && T == std::min(force_t, tw.t_max)) { best = c; break; }
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;
+}
+
+// Does the tower run as one launch at THIS batch?  Not when the shape the batch leaves it wastes more than a fifth of the
+// MFMA rows (games/atari.py at 256 trees: one 6 x 6 sample per workgroup = 36 rows in three 16-row tiles; the layer
+// kernel packs four samples into nine full tiles and wins, 0.62 against 0.58) -- the layers then launch one by one.
+inline bool rb_tower_use(const RbTower& tw, int batch) {
+  const RbTowerShape sh = rb_tower_shape(tw, batch);
+  if (sh.T < 1) return false;
+  return sh.rows * 5 >= sh.mtiles * 16 * 4;
 }
 
 // Finds the towers of a planned program.  A layer joins the tower of its predecessor when it is a stride-1 3x3 GEMM of
@@ -285,6 +297,19 @@ inline void rb_find_towers(const std::vector<OpDesc>& prog, RbProgram& R) {
         if (rb_tower_grid(tw, T, c)) tw.t_max = T;
         else if (T * tw.H * tw.W > 16 * RB_MT * 8) break;
       }
+      // the tail: operators directly behind the tower that read only its output -- at most one scaling operator and two
+      // small 1x1 head convolutions, in program order
+      for (int m = last + 1, scales = 0, convs = 0; m < n; ++m) {
+        const OpDesc& dm = prog[m];
+        const bool scale = dm.kind == OP_SCALE && R.ops[m].kind == RB_SCALE && dm.in == prog[last].out &&
+                           dm.groups_per_sample == tw.C && dm.len == tw.H * tw.W;
+        const bool conv1 = dm.kind == OP_CONV1 && R.ops[m].kind == RB_GEMM && dm.in == prog[last].out && dm.cin == tw.C &&
+                           dm.hin == tw.H * tw.W && dm.cout <= RB_TAIL_MAX_R;
+        if (scale && scales == 0) ++scales;
+        else if (conv1 && convs < 2) ++convs;
+        else break;
+        ++tw.n_tail;
+      }
       if (tw.t_max >= 1) {
         for (int j = k; j <= last; ++j) R.ops[j].tower = (int)R.towers.size();
         R.towers.push_back(tw);
@@ -310,6 +335,13 @@ inline int rb_split_first(const mzx_net* net, int batch, int split_min = RB_SPLI
     const RbShape w = rb_choose_shape(o, batch), h0 = rb_choose_shape(o, first), h1 = rb_choose_shape(o, batch - first);
     if (h0.phases != w.phases || h0.cpg != w.cpg || h1.phases != w.phases || h1.cpg != w.cpg) return 0;
   }
+  // a tower sums in (tap, chunk) order whatever its shape; the layer kernel in (channel group, tap, chunk) order: the
+  // halves must take the same path as the undivided shard
+  if (!net->rb_no_towers)
+    for (const RbTower& tw : net->rb.recurrent.towers) {
+      const bool w = rb_tower_use(tw, batch);
+      if (rb_tower_use(tw, first) != w || rb_tower_use(tw, batch - first) != w) return 0;
+    }
   return first;
 }
 

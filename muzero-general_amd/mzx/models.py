@@ -122,15 +122,17 @@ def streamed_launches(lib, handle, recurrent, batch):
     shape = (ctypes.c_int32 * 16)()
     # towers first: their operators run inside ONE rb_tower_kernel<MT, NT> launch, not one by one
     in_tower = set()
-    tw = (ctypes.c_int32 * 12)()
+    tw = (ctypes.c_int32 * 16)()
     index = 0
     while lib.mzx_net_streamed_tower(handle, int(bool(recurrent)), index, int(batch), ctypes.byref(tw)) == 0:
-        t = dict(zip(("first", "count", "C", "H", "W", "T", "MT", "NT", "WM", "WN", "lds", "groups"), list(tw)))
-        in_tower.update(range(t["first"], t["first"] + t["count"]))
-        out.append(dict(op=t["first"], MT=t["MT"], NT=t["NT"], phases=1, k_loop="tower " + streamed_k_loop(t["MT"], t["NT"], tower=True),
-                        WM=t["WM"], WN=t["WN"], T=t["T"], nsplit=1, cpg=(t["C"] + 15) // 16, taps=9, stride=1,
-                        in_layout=-t["count"], cin=t["C"], cout=t["C"]))
+        t = dict(zip(("first", "count", "C", "H", "W", "T", "MT", "NT", "WM", "WN", "lds", "groups", "n_tail"), list(tw)))
         index += 1
+        if t["groups"] == 0:     # at this batch the layers of the tower launch one by one
+            continue
+        in_tower.update(range(t["first"], t["first"] + t["count"] + t["n_tail"]))    # (the tail runs inside the launch)
+        out.append(dict(op=t["first"], MT=t["MT"], NT=t["NT"], phases=1, k_loop="tower " + streamed_k_loop(t["MT"], t["NT"], tower=True),
+                        WM=t["WM"], WN=t["WN"], T=t["T"], nsplit=1 + t["n_tail"], cpg=(t["C"] + 15) // 16, taps=9, stride=1,
+                        in_layout=-t["count"], cin=t["C"], cout=t["C"]))
     for op in range(lib.mzx_net_num_operators(handle, int(bool(recurrent)))):
         if op in in_tower:
             continue

@@ -25,6 +25,10 @@ AT_SIZE = {
     "atari-256": ("atari", None, 256),
     "atari-512": ("atari", None, 512),
     "atari-1024": ("atari", None, 1024),
+    # the same trunks LAYER BY LAYER (network modes 4 / 5: no tower launches) -- the path of boards too large for a tower
+    # and the A/B of rb_tower_kernel; keeps rb_gemm_kernel<8,1> with two channel phases covered at size
+    "connect4-4608-layers": ("connect4", 4, 4608),
+    "gomoku-512-layers": ("gomoku", 5, 512),
 }
 
 # name -> (configs factory, network mode, trees, simulations (None: as shipped), trees compared with the oracle)
@@ -43,15 +47,17 @@ def _create(lib, cfg):
     return h
 
 
-def inference_launches(lib, game, batch, recurrent, overrides=None):
+def inference_launches(lib, game, batch, recurrent, overrides=None, mode=None):
     h = _create(lib, configs.BY_NAME[game](**(overrides or {})))
     try:
+        if mode is not None:
+            lib.check(lib.mzx_net_set_mode(h, int(mode)))
         return models.streamed_launches(lib, h, recurrent, batch)
     finally:
         lib.mzx_net_destroy(h)
 
 
-def search_launches(lib, game, trees, overrides=None, both_ways=False):
+def search_launches(lib, game, trees, overrides=None, both_ways=False, mode=None):
     """
     The GEMM launches of one search over `trees` roots on the row-per-tree path: initial_inference at the shard size,
     recurrent_inference at the sizes of the two half-shards (or the shard, when it runs undivided); `both_ways` adds the
@@ -59,6 +65,8 @@ def search_launches(lib, game, trees, overrides=None, both_ways=False):
     """
     h = _create(lib, configs.BY_NAME[game](**(overrides or {})))
     try:
+        if mode is not None:
+            lib.check(lib.mzx_net_set_mode(h, int(mode)))
         parts = models.streamed_split(lib, h, trees)
         out = [dict(l, program="initial", batch=trees) for l in models.streamed_launches(lib, h, 0, trees)]
         sizes = {p for p in parts if p > 0}
@@ -74,22 +82,23 @@ def search_launches(lib, game, trees, overrides=None, both_ways=False):
 def gpu_tested_launches(lib):
     """Every launch the at-size GPU parity tests make."""
     out = []
-    for game, _, batch in AT_SIZE.values():
+    for game, mode, batch in AT_SIZE.values():
         for recurrent in (0, 1):
-            out += inference_launches(lib, game, batch, recurrent)
-    for game, _, trees, _, _ in AT_SIZE_SEARCHES.values():
-        out += search_launches(lib, game, trees, both_ways=True)[0]
+            out += inference_launches(lib, game, batch, recurrent, mode=mode)
+    for game, mode, trees, _, _ in AT_SIZE_SEARCHES.values():
+        out += search_launches(lib, game, trees, both_ways=True, mode=mode)[0]
     return out
 
 
 def bench_streamed_workloads(bench):
-    """bench.py's default workloads that run on the streamed engine: {name: (game, overrides, trees)}."""
+    """bench.py's default workloads that run on the streamed engine: {name: (game, overrides, trees, network mode)}."""
     names = [bench.DEFAULT_WORKLOAD] + [w for w in bench.DEFAULT_ALSO.split(",") if w]
     out = {}
     for w in names:
         game, overrides, trees, _ = bench.WORKLOADS[w]
-        if bench.WORKLOAD_NET_MODE.get(w) == "streamed" or game in ("gomoku", "atari"):
-            out[w] = (game, overrides, trees)
+        forced = bench.WORKLOAD_NET_MODE.get(w) == "streamed"
+        if forced or game in ("gomoku", "atari"):
+            out[w] = (game, overrides, trees, 3 if forced else None)
     return out
 
 

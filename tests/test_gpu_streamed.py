@@ -151,7 +151,8 @@ def test_tower_kernel_layer_by_layer(backend, name, B, T, monkeypatch):
         for t in towers:
             assert t["T"] <= T
             seen.add((t["MT"], t["NT"], t["T"]))
-            in_tower.update(range(t["op"], t["op"] - t["in_layout"]))      # (in_layout = -layers for a tower entry)
+            # (a tower entry: in_layout = -layers, nsplit - 1 = operators of its tail, which run inside the launch too)
+            in_tower.update(range(t["op"], t["op"] - t["in_layout"] + t["nsplit"] - 1))
         worst = 0.0
         for n_ops in range(1, net.num_operators(recurrent) + 1):
             if n_ops - 1 not in in_tower and n_ops % 3:
@@ -164,8 +165,20 @@ def test_tower_kernel_layer_by_layer(backend, name, B, T, monkeypatch):
             assert err < 2e-5 * scale, (name, T, "recurrent" if recurrent else "initial", n_ops, err)
         print(f"{name} T={T} {'recurrent' if recurrent else 'initial'}: towers {[(t['op'], -t['in_layout'], t['MT'], t['NT'], t['T']) for t in towers]}, "
               f"worst relative error {worst:.2e}")
-    # and the whole inferences (heads behind the towers) against the layer-by-layer streamed path
+    # the tail (per-plane scaling, small 1x1 head convolutions on the LDS-resident output) against the same operators
+    # launched on their own: the scaled hidden state bit for bit (same arithmetic on the same values), everything else tightly
     o1, r1 = net.initial_inference(obs), net.recurrent_inference(hid, act)
+    monkeypatch.setenv("MZX_RB_TAIL", "0")
+    assert all(l["nsplit"] == 1 for l in net.streamed_launches(1, B) if l["k_loop"].startswith("tower"))
+    o2, r2 = net.initial_inference(obs), net.recurrent_inference(hid, act)
+    monkeypatch.delenv("MZX_RB_TAIL")
+    assert any(l["nsplit"] > 1 for l in net.streamed_launches(1, B) if l["k_loop"].startswith("tower")), "no tower has a tail"
+    assert torch.equal(o1[3], o2[3]) and torch.equal(r1[3], r2[3])
+    for got, want in zip(o1 + r1, o2 + r2):
+        g, w = got.cpu().numpy(), want.cpu().numpy()
+        fin = numpy.isfinite(w)
+        assert numpy.array_equal(numpy.isfinite(g), fin) and numpy.abs(numpy.where(fin, g - w, 0.0)).max() < 1e-5 * (1.0 + numpy.abs(w[fin]).max())
+    # and the whole inferences (heads behind the towers) against the layer-by-layer streamed path
     net.set_mode(4)
     o0, r0 = net.initial_inference(obs), net.recurrent_inference(hid, act)
     for got, want in zip(o1 + r1, o0 + r0):

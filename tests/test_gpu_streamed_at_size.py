@@ -3,9 +3,9 @@ GPU parity of the streamed MFMA engine AT THE SIZES bench.py TIMES (-m gpu, thro
 
 tests/test_gpu_streamed.py pins the engine on small batches, which launch rb_gemm_kernel<1,1> / <2,1> only.  The
 workloads behind the reported roofline fractions -- games/gomoku.py at 512 / 1024 trees, games/connect4.py forced
-onto this engine at 4608 / 9216 trees, games/atari.py at 256 / 512 / 1024 trees -- launch OTHER instantiations
-(<8,1>, <9,1>, <9,2>, <6,2>, <5,1>, <4,1>: position fragments refilled in place, two to four channel phases staged
-across barriers, six boards per workgroup).  This file runs exactly those launches (tests/streamed_coverage.py is the
+onto this engine at 4608 / 9216 trees, games/atari.py at 256 / 512 / 1024 trees -- launch OTHER code: the trunks as
+rb_tower_kernel<8,1> / <5,2> (a whole conv + residual-block run per launch, round 4) and rb_gemm_kernel<8,1>, <9,1>,
+<9,2>, <6,2>, <5,1>, <4,1> (position fragments refilled in place, two to four channel phases staged across barriers).  This file runs exactly those launches (tests/streamed_coverage.py is the
 table; tests/test_streamed_coverage.py, CPU, keeps bench.py inside it):
 
   (a) every operator of both programs against the one-element-kernel-per-operator engine (mode 0), at size;
@@ -45,16 +45,21 @@ def backend():
 # The instantiations every case must launch (MT, NT, channel phases, K loop): hard-wired, so that a planner change that
 # moves a workload onto other code paths fails HERE and has to be acknowledged (together with streamed_coverage)
 MUST_LAUNCH = {
-    "gomoku-512": {(8, 1, 2, "in-place"), (8, 1, 1, "in-place"), (1, 1, 1, "ring")},
-    "gomoku-1024": {(8, 1, 2, "in-place"), (8, 1, 1, "in-place"), (1, 1, 1, "ring")},
-    "connect4-4608": {(8, 1, 2, "in-place"), (8, 1, 1, "in-place"), (1, 1, 1, "ring")},
-    "connect4-9216": {(8, 1, 2, "in-place"), (8, 1, 1, "in-place"), (2, 1, 1, "ring")},
+    # trunks as towers (rb_tower_kernel): one sample (gomoku) / six boards (connect4) / two samples (atari) per workgroup
+    "gomoku-512": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring")},
+    "gomoku-1024": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring")},
+    "connect4-4608": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring")},
+    "connect4-9216": {(8, 1, 1, "tower in-place"), (2, 1, 1, "ring")},
+    # 256 trees leave a tower three-quarter-empty row tiles: its layers launch one by one
     "atari-256": {(5, 1, 1, "two-sets"), (9, 1, 2, "in-place"), (9, 2, 2, "in-place"), (6, 2, 4, "in-place"),
                   (6, 2, 2, "in-place"), (4, 1, 3, "ring"), (1, 1, 4, "ring")},
-    "atari-512": {(9, 1, 1, "in-place"), (9, 1, 2, "in-place"), (9, 2, 4, "in-place"), (6, 2, 4, "in-place"),
+    "atari-512": {(5, 2, 1, "tower in-place"), (9, 1, 1, "in-place"), (9, 2, 4, "in-place"), (6, 2, 4, "in-place"),
                   (6, 2, 2, "in-place"), (4, 1, 3, "ring"), (1, 1, 4, "ring")},
-    "atari-1024": {(9, 2, 1, "in-place"), (9, 2, 2, "in-place"), (9, 2, 4, "in-place"), (9, 1, 2, "in-place"),
+    "atari-1024": {(5, 2, 1, "tower in-place"), (9, 2, 1, "in-place"), (9, 2, 4, "in-place"), (9, 1, 2, "in-place"),
                    (6, 2, 4, "in-place"), (6, 2, 2, "in-place"), (4, 1, 3, "ring"), (1, 2, 1, "ring")},
+    # layer by layer (modes 4 / 5)
+    "connect4-4608-layers": {(8, 1, 2, "in-place"), (8, 1, 1, "in-place"), (1, 1, 1, "ring")},
+    "gomoku-512-layers": {(8, 1, 2, "in-place"), (8, 1, 1, "in-place"), (1, 1, 1, "ring")},
 }
 
 
@@ -122,13 +127,13 @@ def _rows_against_oracle(cfg, sd, rows, obs, hid, act, outs, label, loose=()):
 def test_at_size_operators_and_heads(backend, case):
     game, mode, B = sc.AT_SIZE[case]
     cfg, net, sd = _network(game, mode, seed=41)
-    if mode is None:
+    if mode in (None, 5):
         assert net.fused_supported() == 0 and net.streamed_supported() == 3
     launched = set()
     for recurrent in (0, 1):
         launches = net.streamed_launches(recurrent, B)
         assert [models.launch_key(l) for l in launches] == [models.launch_key(l) for l in
-                                                            sc.inference_launches(backend.lib, game, B, recurrent)]
+                                                            sc.inference_launches(backend.lib, game, B, recurrent, mode=mode)]
         launched |= {models.instantiation_key(l) for l in launches}
         print(f"{case} {'recurrent' if recurrent else 'initial'}: {models.summarize_launches(launches)}")
     assert MUST_LAUNCH[case] <= launched, (case, sorted(MUST_LAUNCH[case] - launched))
@@ -202,7 +207,7 @@ def test_at_size_search_two_streams_and_oracle(backend, case, monkeypatch):
     if sims is not None:
         cfg.num_simulations = sims
     S, A = cfg.num_simulations, len(cfg.action_space)
-    launches, parts = sc.search_launches(backend.lib, game, B)
+    launches, parts = sc.search_launches(backend.lib, game, B, mode=mode)
     print(f"{case}: half-shards {parts}; launches {sc.summarize(launches)}")
     assert MUST_LAUNCH[f"{game}-{parts[0]}"] & {models.instantiation_key(l) for l in launches if l["program"] == "recurrent"}
     monkeypatch.delenv("MZX_ROW_SPLIT_MIN", raising=False)

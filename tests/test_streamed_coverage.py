@@ -41,8 +41,8 @@ def test_every_bench_launch_is_gpu_parity_tested(lib, bench):
     tested = sc.gpu_tested_launches(lib)
     tested_full = {models.launch_key(l) for l in tested}
     tested_inst = {models.instantiation_key(l) for l in tested}
-    for name, (game, overrides, trees) in sc.bench_streamed_workloads(bench).items():
-        launches, parts = sc.search_launches(lib, game, trees, overrides)
+    for name, (game, overrides, trees, mode) in sc.bench_streamed_workloads(bench).items():
+        launches, parts = sc.search_launches(lib, game, trees, overrides, mode=mode)
         assert launches
         missing = sorted({models.instantiation_key(l) for l in launches} - tested_inst)
         assert not missing, f"bench workload {name} ({trees} trees, half-shards {parts}) launches instantiations no -m gpu parity test runs: {missing}"
@@ -53,13 +53,15 @@ def test_every_bench_launch_is_gpu_parity_tested(lib, bench):
 def test_bench_workloads_run_at_exactly_tested_sizes(lib, bench):
     """Stronger than shape equality: the (configuration, program, batch) triples themselves are in the at-size tables."""
     tested = set()
-    for game, _, batch in sc.AT_SIZE.values():
-        tested |= {(game, "initial", batch), (game, "recurrent", batch)}
-    for game, _, trees, _, _ in sc.AT_SIZE_SEARCHES.values():
-        tested |= {(game, l["program"], l["batch"]) for l in sc.search_launches(lib, game, trees, both_ways=True)[0]}
-    for name, (game, overrides, trees) in sc.bench_streamed_workloads(bench).items():
-        for l in sc.search_launches(lib, game, trees, overrides)[0]:
-            assert (game, l["program"], l["batch"]) in tested, (name, l["program"], l["batch"])
+    towers_on = lambda mode: mode not in (4, 5)
+    for game, mode, batch in sc.AT_SIZE.values():
+        tested |= {(game, towers_on(mode), "initial", batch), (game, towers_on(mode), "recurrent", batch)}
+    for game, mode, trees, _, _ in sc.AT_SIZE_SEARCHES.values():
+        tested |= {(game, towers_on(mode), l["program"], l["batch"])
+                   for l in sc.search_launches(lib, game, trees, both_ways=True, mode=mode)[0]}
+    for name, (game, overrides, trees, mode) in sc.bench_streamed_workloads(bench).items():
+        for l in sc.search_launches(lib, game, trees, overrides, mode=mode)[0]:
+            assert (game, towers_on(mode), l["program"], l["batch"]) in tested, (name, l["program"], l["batch"])
 
 
 def test_split_matches_the_row_search(lib):
