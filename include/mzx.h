@@ -232,9 +232,9 @@ int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_
  * d_root_priors [B][A] (binary64 Node.prior of the root's children in slot order = order of
  * io->d_legal_actions), d_root_reward [B] (Node.reward).  io->d_observation is not read and
  * io->d_root_predicted_value not written (the reference reports None).  Exploration noise, the
- * simulations and the outputs are those of mzx_search_run, on the same kernels for residual networks (whole-search
- * kernels / streamed engine); fully connected networks run the per-operator path here (their whole-search kernel
- * expands the root inside the launch). */
+ * simulations and the outputs are those of mzx_search_run, on the same kernels: the residual whole-search kernels /
+ * streamed engine read the given roots from the arena, the fully connected whole-search kernel (fc2_search_kernel)
+ * takes them as launch arguments in place of its initial_inference. */
 int mzx_search_run_from_roots(mzx_search* s, const mzx_search_io* io, const float* d_root_hidden,
                               const double* d_root_priors, const double* d_root_reward, void* d_arena,
                               int64_t arena_bytes, void* stream);

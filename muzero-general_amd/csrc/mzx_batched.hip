@@ -1074,9 +1074,9 @@ RbTowerFn rb_pick_tower_mt(int mt) {
 // writes its output to memory like the whole tower's last layer does).
 struct RbTowerTail {
   int write_out = 1;
-  RbTensor scale;            // .p null: no scaling operator in the tail
+  RbTensor scale{};          // .p null: no scaling operator in the tail
   int n_conv = 0;
-  struct { const float* w; const float* b; float* y; int R; } conv[2];
+  struct { const float* w; const float* b; float* y; int R; } conv[2] = {};
 };
 
 int rb_launch_tower(const mzx_net* net, const std::vector<OpDesc>& prog, const RbProgram& R, const RbTower& tw, int layers,

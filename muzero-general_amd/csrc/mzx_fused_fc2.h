@@ -38,6 +38,11 @@
 namespace mzx {
 
 struct Fc2Args {
+  // roots the caller expanded itself (MCTS.run(..., override_root_with=root), self_play.py:275-277,
+  // diagnose_model.py:57-74): hidden state / child priors in legal-action order / reward replace initial_inference
+  const float* ov_hidden;    // [B][E]   (null: the kernel runs initial_inference)
+  const double* ov_priors;   // [B][A]
+  const double* ov_reward;   // [B]
   FusedFcArgs f;   // network description, search parameters, io, export pointers (f.L = arena TreeLayout)
   int32_t off_slots, off_nodes, off_path, off_roota, off_mm, off_hidden, off_scratch;  // byte offsets inside a tree's slab
   int32_t tree_stride, lds_inv;                                               // lds_inv: reciprocal table (bytes)
@@ -423,30 +428,35 @@ __global__ void __launch_bounds__(256) fc2_search_kernel(const Fc2Args a) {
   // ---- initial_inference (models.py:172-190) + root expansion (self_play.py:286-314, :467-476)
   {
     NetOut o;
-    net.initial(a.f.io.d_observation + (size_t)tree * a.f.in_size, hidden, scr, sub, o);
+    const bool given = a.ov_hidden != nullptr;       // (launch-uniform) the caller's roots: no initial_inference
+    if (!given) net.initial(a.f.io.d_observation + (size_t)tree * a.f.in_size, hidden, scr, sub, o);
+    else
+      for (int e = sub; e < E; e += FUSED_ROW) hidden[e] = a.ov_hidden[(size_t)tree * E + e];
     const int32_t* lg = a.f.io.d_legal_actions + (size_t)tree * A;
     const double* nz = a.f.io.d_noise ? a.f.io.d_noise + (size_t)tree * A : nullptr;
     while (root_n < A && lg[root_n] >= 0) ++root_n;
-    if (sub < A) scr[sub] = o.policy;
+    if (!given && sub < A) scr[sub] = o.policy;
     wave_sync();
     const bool in = sub < root_n;
-    const float l = in ? scr[lg[sub]] : -MZX_INF;   // logits gathered in the game's legal-action order
+    const float l = (in && !given) ? scr[lg[sub]] : -MZX_INF;   // logits gathered in the game's legal-action order
     const float m = row_max_w<AW>(l);
-    const float e = in ? mzx_expf(l - m) : 0.f;
+    const float e = (in && !given) ? mzx_expf(l - m) : 0.f;
     const float den = row_sum_w<AW>(e);
     root_to_play = a.f.io.d_to_play[tree];
     if (sub == 0) {
       Fc2Node r;
-      r.value_sum = 0.0; r.reward = (double)support_inverse_transform(0.0f); r.visit = 0; r.to_play = root_to_play;
+      r.value_sum = 0.0; r.visit = 0; r.to_play = root_to_play;
+      r.reward = given ? a.ov_reward[tree] : (double)support_inverse_transform(0.0f);
       r.parent = -1; r.parent_slot = -1;
       nodes[0] = r;
       path[0] = make_int2(0, -1);
       mm[0] = MZX_INF; mm[1] = -MZX_INF;      // MinMaxStats (self_play.py:558-560)
-      if (a.f.io.d_root_predicted_value) a.f.io.d_root_predicted_value[tree] = (double)o.value;
+      if (!given && a.f.io.d_root_predicted_value) a.f.io.d_root_predicted_value[tree] = (double)o.value;
     }
     if (sub < AW) {
       Fc2Slot s;
-      s.prior = in ? root_noisy_prior((double)mzx_div(e, den), nz, sub, a.f.p.exploration_fraction) : 0.0;
+      const double pr = !in ? 0.0 : (given ? a.ov_priors[(size_t)tree * A + sub] : (double)mzx_div(e, den));
+      s.prior = in ? root_noisy_prior(pr, nz, sub, a.f.p.exploration_fraction) : 0.0;
       s.q = 0.0; s.n = 0; s.child = -1;
       s.ps = in ? prior_score(pbc[0], sqt[0], 0, inv_y[1], s.prior) : -MZX_INF;   // root visit count 0
       slots[sub] = s;
@@ -606,11 +616,12 @@ inline int fc2_launch_aw(const Fc2Plan& P, unsigned grid, stream_t stream) {
 }
 
 // mode bits: 1 = fused, 2 = export trees to the arena, 4 = force LdsNet, 8 = cycle-profile build
-inline int fc2_run(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream) {
+inline int fc2_run(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream, const RootOverride* ov = nullptr) {
   Fc2Plan P = fc2_plan(s, !(s->mode & 4));
   if (!P.ok) { set_error("fused search kernel does not support this configuration"); return MZX_ERR_INVALID; }
   int rc = ensure_tables(s, d_arena, stream);
   if (rc) return rc;
+  if (ov) { P.args.ov_hidden = ov->hidden; P.args.ov_priors = ov->priors; P.args.ov_reward = ov->reward; }
   P.args.f.flat = s->net->d_flat;
   P.args.f.tables = s->d_tables;
   P.args.f.io = *io;

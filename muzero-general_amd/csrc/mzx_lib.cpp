@@ -459,9 +459,13 @@ int mzx_search_run_from_roots(mzx_search* s, const mzx_search_io* io, const floa
   RootOverride ov;
   ov.hidden = d_root_hidden; ov.priors = d_root_priors; ov.reward = d_root_reward;
 #ifndef MZX_HOSTCHECK
-  // residual networks: the simulations run on the kernel mzx_search_run would use (the whole-search kernels read the
-  // roots from the arena); the fully connected whole-search kernel expands its roots inside the launch and stays on
-  // the per-operator path here
+  // the simulations run on the kernel mzx_search_run would use: the residual whole-search kernels read the roots from
+  // the arena, the fully connected one (second generation) takes them as launch arguments instead of running
+  // initial_inference; the first-generation kernel (flag 16, A/B only) stays on the per-operator path here
+  if ((s->mode & 1) && s->fused_ok == 1 && !(s->mode & 16)) {
+    s->last_kernel = "mzx::fc2_search_kernel";
+    return fc2_run(s, io, d_arena, (stream_t)stream, &ov);
+  }
   if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) return rz_search_run(s, io, d_arena, (stream_t)stream, &ov);
   if ((s->mode & 1) && rb_enabled(s->net, true) && row_search_supported(s->p)) {
     s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel (streamed FP32-MFMA trunks and layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";

@@ -801,6 +801,54 @@ def test_override_root_rejections(backend):
     virtual_common.test_override_root_rejections(backend)
 
 
+@pytest.mark.parametrize("name", ["cartpole", "lunarlander"])
+def test_fc_override_roots_on_the_whole_search_kernel(backend, name):
+    """
+    MCTS.run(..., override_root_with=root) (self_play.py:275-277; diagnose_model.py:57-74) for a batch of roots on the
+    fully connected whole-search kernel: fc2_search_kernel takes the given hidden states / priors / rewards in place of
+    its initial_inference (round 4; rounds 1-3 ran this on the per-operator path).  Every statistic of the finished
+    trees bit for bit against the per-operator path, for both network engines of the kernel (register-resident
+    CartPole shape, LDS weights), ragged legal sets, both noise settings.
+    """
+    cfg = configs.BY_NAME[name](num_simulations=30)
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 17))
+    A, B = len(cfg.action_space), 37
+    rs = numpy.random.RandomState(3)
+    obs = torch.tensor(synthetic.observations(B, net.input_shape, seed=9))
+    hidden0 = net.initial_inference(obs)[3]
+    act = torch.tensor(rs.randint(0, A, size=B).astype(numpy.int32))
+    value, reward, policy, hidden = net.recurrent_inference(hidden0, act)
+    rewards = models.support_to_scalar(reward, cfg.support_size).cpu().numpy().reshape(-1)
+    legal = [sorted(rs.choice(A, size=rs.randint(1, A + 1), replace=False).tolist()) for _ in range(B)]
+
+    def roots():
+        out = []
+        for i in range(B):
+            node = self_play.Node(0)
+            node.expand(legal[i], 0, float(rewards[i]), policy[i:i + 1].cpu(), hidden[i:i + 1])
+            out.append(node)
+        return out
+
+    for noise in (True, False):
+        got = {}
+        for mode in (0, 3):        # 3 = whole-search kernel + export of its LDS trees to the arena
+            engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
+            res = engine.run_from_roots(roots(), [0] * B, noise, [numpy.random.RandomState(700 + i) for i in range(B)])
+            assert ("fc2_search_kernel" in engine.kernel_name(B)) == (mode == 3), engine.kernel_name(B)
+            got[mode] = (res, engine.export_trees(B))
+        (r0, t0), (r1, t1) = got[0], got[3]
+        assert (r0.visit_counts.sum(1) == cfg.num_simulations).all()
+        assert numpy.array_equal(r0.visit_counts, r1.visit_counts)
+        assert numpy.array_equal(r0.root_values.view(numpy.int64), r1.root_values.view(numpy.int64))
+        assert numpy.array_equal(r0.max_tree_depth, r1.max_tree_depth) and numpy.array_equal(r0.tape_used, r1.tape_used)
+        for key in ("visit", "value_sum", "reward", "prior", "child", "parent", "to_play", "minmax", "n_nodes"):
+            a, b = t0[key], t1[key]
+            if a.dtype == numpy.float64:
+                a, b = a.view(numpy.int64), b.view(numpy.int64)
+            assert numpy.array_equal(a, b), (name, noise, key)
+
+
 # ---- randomised configurations (tests/test_random_configs.py) on the device, every engine
 
 import test_random_configs as random_common  # noqa: E402
