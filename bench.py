@@ -593,7 +593,7 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         launches = net.streamed_launches(0, B)
         for b in sorted({first, second} - {0}):
             launches += net.streamed_launches(1, b)
-        instantiations = {"half_shards": [first, second], "rb_gemm_kernel": models.summarize_launches(launches)}
+        instantiations = {"half_shards": [first, second], "kernels": models.summarize_launches(launches)}
     result = {
         "metric": "mcts_simulations_per_sec", "value": value, "unit": "sims/s", "n_gpus": world,
         "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,

@@ -147,13 +147,13 @@ def _actor_worker(rank, world, port, out_dir):
     storage = shared_storage.ShardedStorage(_ScriptedStorage(wa, wb) if rank == 0 else None, src=0)
     buffer = _ListBuffer()
     seen = []
-    play_games = actor.play_games
+    play_rounds = actor.play_rounds      # (continuous_self_play plays rounds: finished slots are refilled at once)
 
-    def recording_play_games(*a):
-        seen.append(actor.model.flat_weights().clone())      # the weights each round is played with
-        return play_games(*a)
+    def recording_play_rounds(*a, **kw):
+        seen.append(actor.model.flat_weights().clone())      # the weights each call is played with
+        return play_rounds(*a, **kw)
 
-    actor.play_games = recording_play_games
+    actor.play_rounds = recording_play_rounds
     actor.continuous_self_play(storage, buffer)
     job_counts = storage.storage.inner.get_info(["num_played_games", "num_played_steps"]) if rank == 0 else None
     torch.save(dict(seeds=made, rounds=len(seen), seen=seen, games=len(buffer.games), steps=buffer.steps,
@@ -252,13 +252,13 @@ def _uneven_worker(rank, world, port, out_dir):
     storage = shared_storage.ShardedStorage(_CountingStorage(weights, 40) if rank == 0 else None, src=0)
     buffer = _ListBuffer()
     rounds = []
-    play_games = actor.play_games
+    play_rounds = actor.play_rounds
 
-    def counting_play_games(*a):
+    def counting_play_rounds(*a, **kw):
         rounds.append(time.perf_counter())
-        return play_games(*a)
+        return play_rounds(*a, **kw)
 
-    actor.play_games = counting_play_games
+    actor.play_rounds = counting_play_rounds
     t0 = time.perf_counter()
     actor.continuous_self_play(storage, buffer)
     torch.save(dict(rounds=len(rounds), games=len(buffer.games), wall=time.perf_counter() - t0,

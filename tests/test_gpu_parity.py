@@ -607,7 +607,7 @@ def test_every_shipped_game_architecture_runs_on_a_tuned_kernel(backend):
     """
     shapes = shipped_shapes.shapes()
     tuned = ("mzx::fc2_search_kernel", "mzx::rz_wave_search_kernel", "mzx::rz_tile_search_kernel", "mzx::rz_search_kernel",
-             "mzx::rb_gemm_kernel")
+             "mzx::rb_tower_kernel / mzx::rb_gemm_kernel")
     for name, cfg in shapes.items():
         cfg.num_simulations = 6
         net = models.MuZeroNetwork(cfg)
