@@ -61,16 +61,21 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # dense FP32-input MFMA peak (= FP32 vector peak),
 
 # workloads that choose their network engine themselves (unless --net-mode says otherwise)
 WORKLOAD_NET_MODE = {"c4-large": "streamed"}
+# workloads that run with an environment knob of the library set (A/B legs)
+WORKLOAD_ENV = {"c4-ws": {"MZX_SEARCH_STREAMED_MIN": "0"}}
 DEFAULT_WORKLOAD = "c2"
 # measured in the same invocation and reported under "workloads" when the main workload is the default one.  Every
 # launch the streamed ones make (c4-large, gomoku, atari) is parity-tested at size: tests/test_streamed_coverage.py
-DEFAULT_ALSO = "c3,c4,c4-large,c5,gomoku,atari"
+DEFAULT_ALSO = "c3,c4,c4-ws,c4-large,c5,gomoku,atari"
 
 WORKLOADS = {
     # name: (config factory name, overrides, trees per GPU, description)
     "c2": ("cartpole", {}, 4096, "C2 CartPole FullyConnectedNetwork, 4096 trees x 50 sims per GPU"),
     "c3": ("tictactoe", {}, 1024, "C3 Tic-tac-toe MuZeroResidualNetwork, 1024 trees x 25 sims per GPU"),
+    # (since round 4 the library routes this shard to the streamed engine -- trunks as towers between the row-per-tree
+    # kernels --, which overtook the LDS-resident whole-search kernel; "c4-ws" is the same workload on that kernel)
     "c4": ("connect4", {}, 1024, "C4 Connect4 ResNet, 1024 trees x 200 sims per GPU"),
+    "c4-ws": ("connect4", {}, 1024, "C4 Connect4 ResNet, 1024 trees x 200 sims per GPU, LDS-resident whole-search kernel (A/B)"),
     # the same network and search at a shard large enough for layer-by-layer launches: from ~3000 trees per GPU the
     # streamed MFMA engine + row-per-tree kernels overtake the LDS-resident whole-search kernel (0.60 against 0.53 of
     # the FP32 MFMA peak, profiles/r03_streamed_experiments.txt section 10)
@@ -415,6 +420,8 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     from mzx import configs, models, self_play, shared_storage, synthetic
 
     name, overrides, default_trees, description = WORKLOADS[workload]
+    for k, v in WORKLOAD_ENV.get(workload, {}).items():      # (read by the library per call; removed again below)
+        os.environ[k] = v
     cfg = configs.BY_NAME[name](**overrides)
     B = trees or default_trees
     if B != default_trees:       # --trees: the label follows what ran
@@ -532,6 +539,8 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         assert (visits.sum(1) == S).all(), "a tree did not complete its simulations"
         assert (info[:, 1] == 0).all(), "search flagged an overflow"
     mean_leaf_depth = float(sets[0][1]["info"].cpu().numpy()[:, 3].mean() / S)
+    for k in WORKLOAD_ENV.get(workload, {}):
+        os.environ.pop(k, None)
     if rank != 0:
         return None, cfg, net
 
@@ -541,6 +550,8 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     achieved = bytes_per_sim * B * S / (launch_ms * 1e-3) / 1e9
     ran = lib.mzx_search_kernel_name(handle)      # the search kernel the last step launched
     ran = ran.decode() if ran else ""
+    if "row_select_kernel" in ran:                # (the library routes wide networks at large shards there by itself)
+        streamed = True
     traffic = None
     try:  # PMC-measured HBM bytes per launch of this kernel (collected by a separate rocprofv3 --pmc run)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -558,7 +569,7 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
             traffic = entry["bytes"]      # (its provenance: profiles/pmc_traffic.json "source")
     except (OSError, ValueError):
         pass
-    kernel_name = ("per-sim launches + streamed MFMA layers (rb_gemm_kernel)" +
+    kernel_name = ("per-sim launches + streamed MFMA trunks / layers (rb_tower_kernel, rb_gemm_kernel)" +
                    (", two half-shards on two HIP streams" if "two half-shards" in ran else "") if streamed else
                    "fused-lds" if fused else
                    "residual whole-search kernel (arena trees, fused MFMA network)" if fused_kind == 2 else
@@ -580,7 +591,7 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         roofline = {
             "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-            "kernel": "whole step: select / mzx::rb_gemm_kernel per layer / expand+backprop per simulation" if streamed
+            "kernel": "whole step: select / mzx::rb_tower_kernel per trunk + mzx::rb_gemm_kernel per head layer / expand+backprop per simulation" if streamed
                       else ("whole step: root kernels + " + ran) if fused_kind == 2
                       else "whole step: select / rz_network_kernel / expand+backprop per simulation"
                       if net_fused else "whole step (one kernel per operator)",

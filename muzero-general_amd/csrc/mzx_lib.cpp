@@ -433,7 +433,13 @@ int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_
     s->last_kernel = (s->mode & 16) ? "mzx::fused_fc_search" : "mzx::fc2_search_kernel";
     return (s->mode & 16) ? fused_fc_run(s, io, d_arena, (stream_t)stream) : fc2_run(s, io, d_arena, (stream_t)stream);
   }
-  if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) return rz_search_run(s, io, d_arena, (stream_t)stream);
+  if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) {
+    if (row_search_preferred(s)) {      // a wide network at a large shard: trunks as towers between the row-per-tree kernels
+      s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel (streamed FP32-MFMA trunks and layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
+      return search_run_rows(s, io, d_arena, (stream_t)stream, nullptr, true);
+    }
+    return rz_search_run(s, io, d_arena, (stream_t)stream);
+  }
   if ((s->mode & 1) && rb_enabled(s->net, true) && row_search_supported(s->p)) {
     s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel (streamed FP32-MFMA trunks and layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
     return search_run_rows(s, io, d_arena, (stream_t)stream);   // (renames last_kernel when it runs two half-shards)
@@ -466,7 +472,13 @@ int mzx_search_run_from_roots(mzx_search* s, const mzx_search_io* io, const floa
     s->last_kernel = "mzx::fc2_search_kernel";
     return fc2_run(s, io, d_arena, (stream_t)stream, &ov);
   }
-  if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) return rz_search_run(s, io, d_arena, (stream_t)stream, &ov);
+  if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) {
+    if (row_search_preferred(s)) {
+      s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel (streamed FP32-MFMA trunks and layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
+      return search_run_rows(s, io, d_arena, (stream_t)stream, &ov, true);
+    }
+    return rz_search_run(s, io, d_arena, (stream_t)stream, &ov);
+  }
   if ((s->mode & 1) && rb_enabled(s->net, true) && row_search_supported(s->p)) {
     s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel (streamed FP32-MFMA trunks and layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
     return search_run_rows(s, io, d_arena, (stream_t)stream, &ov);

@@ -331,18 +331,23 @@ inline int rb_split_first(const mzx_net* net, int batch, int split_min = RB_SPLI
   if (split_min <= 0 || batch < split_min || batch < 32) return 0;
   const int first = ((batch / 2 + 15) / 16) * 16;
   if (first <= 0 || first >= batch) return 0;
-  for (const RbOp& o : net->rb.recurrent.ops) {
-    if (o.kind != RB_GEMM) continue;
+  // a tower sums in (tap, chunk) order whatever its shape; the layer kernel in (channel group, tap, chunk) order: the
+  // halves must take the same path as the undivided shard
+  const RbProgram& R = net->rb.recurrent;
+  std::vector<char> in_tower(R.ops.size(), 0);      // operators that run inside a tower launch (layers and tail)
+  if (!net->rb_no_towers)
+    for (const RbTower& tw : R.towers) {
+      const bool w = rb_tower_use(tw, batch);
+      if (rb_tower_use(tw, first) != w || rb_tower_use(tw, batch - first) != w) return 0;
+      if (w)
+        for (int k = tw.first; k < tw.first + tw.count + tw.n_tail && k < (int)R.ops.size(); ++k) in_tower[k] = 1;
+    }
+  for (size_t k = 0; k < R.ops.size(); ++k) {
+    const RbOp& o = R.ops[k];
+    if (o.kind != RB_GEMM || in_tower[k]) continue;    // (only the layers that launch on their own have channel groups)
     const RbShape w = rb_choose_shape(o, batch), h0 = rb_choose_shape(o, first), h1 = rb_choose_shape(o, batch - first);
     if (h0.phases != w.phases || h0.cpg != w.cpg || h1.phases != w.phases || h1.cpg != w.cpg) return 0;
   }
-  // a tower sums in (tap, chunk) order whatever its shape; the layer kernel in (channel group, tap, chunk) order: the
-  // halves must take the same path as the undivided shard
-  if (!net->rb_no_towers)
-    for (const RbTower& tw : net->rb.recurrent.towers) {
-      const bool w = rb_tower_use(tw, batch);
-      if (rb_tower_use(tw, first) != w || rb_tower_use(tw, batch - first) != w) return 0;
-    }
   return first;
 }
 

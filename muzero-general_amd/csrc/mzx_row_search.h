@@ -123,14 +123,39 @@ inline int row_search_apply(const RowSearchArgs& a, stream_t stream) {
 // MCTS.run for B roots with a network that runs layer by layer on an engine taking indexed hidden states (the
 // streamed MFMA engine): root by the generic kernels, then per simulation row-select, recurrent_inference straight
 // from / into the arena's node store, row-expand + back-propagate.
+// Large shards of a WIDE residual network that also fits the LDS-resident whole-search kernel (connect4: 64 channels)
+// are faster on this path since the trunks run as towers (rb_tower_kernel): measured whole steps, connect4 x 200
+// simulations -- 1024 trees 0.563 of the FP32 MFMA peak against 0.528 on rz_search_kernel, 2048 trees 0.59 against 0.53,
+// 3072 trees 0.69 against 0.53 (profiles/r04_c4_by_shard.txt).  MZX_SEARCH_STREAMED_MIN=<trees> moves the threshold
+// (default 1024; 0 = never: the whole-search kernel at every shard size).
+inline bool row_search_preferred(const mzx_search* s) {
+  const mzx_net* net = s->net;
+  if (!net || !net->rb.ok || !net->rb.initial.ok || !net->rb.recurrent.ok || net->rb_no_towers) return false;
+  if (!row_search_supported(s->p)) return false;
+  const char* e = getenv("MZX_SEARCH_STREAMED_MIN");
+  const int min_trees = e ? atoi(e) : 1024;
+  if (min_trees <= 0 || s->p.num_trees < min_trees) return false;
+  if (net->cfg.channels < 48) return false;          // narrow networks: the wave / tile whole-search kernels win by far
+  const int first = rb_split_first(net, s->p.num_trees);
+  const int per_launch = first > 0 ? first : s->p.num_trees;
+  bool any = false;
+  for (const RbTower& tw : net->rb.recurrent.towers) any |= rb_tower_use(tw, per_launch);
+  return any;
+}
+
 inline int search_run_rows(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream,
-                   const RootOverride* ov = nullptr) {
+                   const RootOverride* ov = nullptr, bool force_streamed = false) {
   const ArenaView v = arena_view(s, d_arena);
   mzx_net* net = s->net;
   const int B = s->p.num_trees;
   int rc = ensure_tables(s, d_arena, stream);
   if (rc) return rc;
-  const bool ix_init = rz_enabled(net, false) || rb_enabled(net, false);
+  // (force_streamed: the network would run on the LDS-resident engine by default; this search runs it on the streamed
+  // one -- row_search_preferred -- without touching the network handle's mode)
+  auto run_network = [&](mzx_net* n, bool recurrent, const NetBuffers& b, int batch, stream_t st, const NetIndex* ixp) {
+    return force_streamed ? rb_run_program(n, recurrent, b, batch, st, ixp) : mzx::run_network(n, recurrent, b, batch, st, ixp);
+  };
+  const bool ix_init = force_streamed || rz_enabled(net, false) || rb_enabled(net, false);
   NetIndex ix;
   ix.in_nodes = 1; ix.out_nodes = s->p.num_nodes;
   NetBuffers nb;

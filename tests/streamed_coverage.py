@@ -20,6 +20,8 @@ from mzx import configs, models
 AT_SIZE = {
     "gomoku-512": ("gomoku", None, 512),
     "gomoku-1024": ("gomoku", None, 1024),
+    "connect4-512": ("connect4", 3, 512),
+    "connect4-1024": ("connect4", 3, 1024),
     "connect4-4608": ("connect4", 3, 4608),
     "connect4-9216": ("connect4", 3, 9216),
     "atari-256": ("atari", None, 256),
@@ -35,6 +37,8 @@ AT_SIZE = {
 AT_SIZE_SEARCHES = {
     "gomoku-1024": ("gomoku", None, 1024, None, 16),
     "connect4-9216": ("connect4", 3, 9216, None, 64),
+    # BASELINE config C4 at its 1024-tree shard: the library's own routing (no network mode set) sends it to this engine
+    "connect4-1024": ("connect4", None, 1024, None, 64),
     "atari-1024": ("atari", None, 1024, None, 8),
     "atari-256": ("atari", None, 256, None, 4),
 }
@@ -97,7 +101,9 @@ def bench_streamed_workloads(bench):
     for w in names:
         game, overrides, trees, _ = bench.WORKLOADS[w]
         forced = bench.WORKLOAD_NET_MODE.get(w) == "streamed"
-        if forced or game in ("gomoku", "atari"):
+        # (connect4 from 1024 trees: csrc/mzx_row_search.h row_search_preferred, unless the workload's environment says no)
+        routed = game == "connect4" and trees >= 1024 and "MZX_SEARCH_STREAMED_MIN" not in bench.WORKLOAD_ENV.get(w, {})
+        if forced or routed or game in ("gomoku", "atari"):
             out[w] = (game, overrides, trees, 3 if forced else None)
     return out
 

@@ -79,5 +79,5 @@ def test_bench_large_shard_workload_labels_what_ran():
                  "--selfplay-moves", "0", "--also", "none"])
     cfg = line["config"]
     assert cfg["trees_per_gpu"] == 4 and "4 trees x 200 sims" in cfg["workload"] and "9216" not in cfg["workload"]
-    assert "streamed MFMA layers" in cfg["search_kernel"]
+    assert "streamed MFMA trunks / layers" in cfg["search_kernel"]
     assert line["roofline"]["bound"] == "mfma" and line["roofline"]["traffic"] is None     # PMC entry is for the default shard

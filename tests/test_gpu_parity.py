@@ -136,7 +136,8 @@ def _device_trace(engine_factory, cfg, obs, legal, to_play, seeds):
     return traces
 
 
-def _compare_sample_with_oracle(cfg, sd, res, obs, legal, to_play, seeds, sample, engine_factory, value_tol, label):
+def _compare_sample_with_oracle(cfg, sd, res, obs, legal, to_play, seeds, sample, engine_factory, value_tol, label,
+                                traces=None):
     """
     Tree-by-tree comparison of a sample against the CPU oracle (the reference's algorithm with its torch
     network), SIMULATION BY SIMULATION: the (parent, action) of every expansion, rebuilt from the exported
@@ -147,8 +148,9 @@ def _compare_sample_with_oracle(cfg, sd, res, obs, legal, to_play, seeds, sample
     comfortable margin is a bug, not noise.  Trees whose every simulation agrees must also agree on root
     value (tolerance) and maximum depth.  Returns the number of trees identical in every simulation.
     """
-    traces = _device_trace(engine_factory, cfg, [obs[i] for i in sample], [legal[i] for i in sample],
-                           [to_play[i] for i in sample], [seeds[i] for i in sample])
+    if traces is None:     # (else: the sampled trees of the at-size run itself, exported by the caller)
+        traces = _device_trace(engine_factory, cfg, [obs[i] for i in sample], [legal[i] for i in sample],
+                               [to_play[i] for i in sample], [seeds[i] for i in sample])
     # the oracle searches run in a pool of single-thread worker processes (oracle/parallel.py): hundreds of trees
     # in seconds on the GPU box's host cores
     jobs = [(obs[i], legal[i], to_play[i], seeds[i]) for i in sample]
@@ -721,8 +723,22 @@ def test_full_size_residual_configs(backend, name, B, n_sample):
     assert numpy.array_equal(res.visit_counts, res2.visit_counts)
     assert numpy.array_equal(res.root_values.view(numpy.int64), res2.root_values.view(numpy.int64))
     sample = list(range(0, B, B // n_sample))
-    factory = lambda n: self_play.BatchedMCTS(cfg, net, n, mode=1)   # residual kernel: trees live in the arena
-    same = _compare_sample_with_oracle(cfg, sd, res, obs, legal, to_play, seeds, sample, factory, 10 * TOL, name)
+    # the sampled trees OF THIS RUN (residual kernels keep / write back their trees in the arena): since round 4 the
+    # library routes connect4 at this shard to the streamed engine (towers between the row-per-tree kernels), a re-run of
+    # the sample at another batch size would take another kernel
+    kernel = _kernel_name(backend, engine, B)
+    print(f"{name}: {B} trees on {kernel}")
+    assert kernel.startswith("mzx::rb_tower_kernel" if name == "connect4" else "mzx::rz_")
+    exported = engine.export_trees(B)
+    traces = []
+    for i in sample:
+        tr = []
+        for n in range(1, int(exported["n_nodes"][i])):
+            par = int(exported["parent"][i, n])
+            slot = int(numpy.nonzero(exported["child"][i, par] == n)[0][0])
+            tr.append((par, legal[i][slot] if par == 0 else slot))
+        traces.append(tr)
+    same = _compare_sample_with_oracle(cfg, sd, res, obs, legal, to_play, seeds, sample, None, 10 * TOL, name, traces=traces)
     # fp32 summation order differs between implementations; with 200 simulations of a 64-channel network a
     # near-tie flips somewhere in some trees.  Every divergence is printed with its UCB margin and bounded in the
     # helper (MARGIN_GATE); the share of trees identical in EVERY simulation is reported and must stay above 80 %

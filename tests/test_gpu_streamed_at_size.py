@@ -48,6 +48,8 @@ MUST_LAUNCH = {
     # trunks as towers (rb_tower_kernel): one sample (gomoku) / six boards (connect4) / two samples (atari) per workgroup
     "gomoku-512": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring")},
     "gomoku-1024": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring")},
+    "connect4-512": {(3, 1, 1, "tower two-sets"), (1, 1, 1, "ring")},
+    "connect4-1024": {(6, 1, 1, "tower in-place"), (1, 1, 1, "ring")},
     "connect4-4608": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring")},
     "connect4-9216": {(8, 1, 1, "tower in-place"), (2, 1, 1, "ring")},
     # 256 trees leave a tower three-quarter-empty row tiles: its layers launch one by one

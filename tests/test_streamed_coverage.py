@@ -33,7 +33,7 @@ def bench():
 
 def test_bench_streamed_workloads_are_the_expected_ones(bench):
     # (if a workload joins or leaves the default line, the at-size table has to be looked at again)
-    assert sorted(sc.bench_streamed_workloads(bench)) == ["atari", "c4-large", "gomoku"]
+    assert sorted(sc.bench_streamed_workloads(bench)) == ["atari", "c4", "c4-large", "gomoku"]
     assert bench.WORKLOAD_NET_MODE == {"c4-large": "streamed"}
 
 
