@@ -829,6 +829,101 @@ rb_tower_kernel(const RbTowerArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// rb_heads_kernel: every head MLP of a program (dynamics fc = reward, prediction fc_value / fc_policy, models.py:379-389,
+// :418-433) in ONE launch at the end of the program.  A 256-thread workgroup takes HS samples of ONE chain through all of
+// its Linear (+ ELU) layers with the activations in LDS; an output neuron's weight row is read from L2 by one lane per k
+// (every lane walks its own row: cache lines are reused over 32 consecutive k), a lane accumulates SG samples of its
+// neuron.  Arithmetic per output = LinearOp's (mzx_ops.h): one fmaf chain over k in order, + bias, ELU on hidden layers.
+constexpr int RB_HS = 16;            // samples per workgroup
+struct RbHeadsArgs {
+  int32_t n_chains, batch;
+  int32_t in_region;       // floats of the LDS input region = RB_HS x the widest chain input (rounded to 4)
+  int32_t pad;
+  struct Chain {
+    const float* x;        // [batch][in_stride] chain input (the tail convolution's output, channel-major)
+    float* y;              // [batch][out of the last layer]
+    int64_t in_stride;
+    int32_t n_lin, in_features;
+    struct { const float* w; const float* b; int32_t in, out, elu, pad; } lin[RB_HEADS_MAX_LAYERS];
+  } chain[RB_HEADS_MAX_CHAINS];
+};
+
+__global__ void __launch_bounds__(256) rb_heads_kernel(const RbHeadsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float rb_lds[];
+  const RbHeadsArgs::Chain& c = a.chain[blockIdx.y];
+  const int tid = threadIdx.x;
+  const int b0 = blockIdx.x * RB_HS;
+  const int ns = min(RB_HS, a.batch - b0);
+  if (ns <= 0) return;
+  float* const buf_in = rb_lds;                                    // [RB_HS][in_features]
+  float* const buf_b = rb_lds + a.in_region;                       // [RB_HS][<= RB_HEADS_MAX_WIDTH]
+  float* const buf_c = buf_b + RB_HS * RB_HEADS_MAX_WIDTH;
+  const int K0 = c.in_features;
+  for (int i = tid; i < RB_HS * K0; i += 256) {
+    const int sidx = i / K0, k = i - sidx * K0;
+    buf_in[i] = sidx < ns ? c.x[(long long)(b0 + sidx) * c.in_stride + k] : 0.f;
+  }
+  __syncthreads();
+  const float* cur = buf_in;
+  float* nxt = buf_b;
+  int K = K0;
+  for (int l = 0; l < c.n_lin; ++l) {
+    const int O = c.lin[l].out;
+    const bool last = l + 1 == c.n_lin;
+    // thread -> (output neuron, group of SG samples): the 256 threads cover 256 / groups neurons per pass
+    const int groups = O >= 256 ? 1 : (O >= 128 ? 2 : (O >= 64 ? 4 : (O >= 32 ? 8 : 16)));
+    const int SG = RB_HS / groups, per_pass = 256 / groups;
+    const int grp = tid / per_pass, ot = tid - grp * per_pass;
+    const float* xs = cur + (size_t)grp * SG * K;
+    const bool vec = (K & 3) == 0 && (((uintptr_t)c.lin[l].w) & 15) == 0;
+    for (int o = ot; o < O; o += per_pass) {
+      const float* wr = c.lin[l].w + (size_t)o * K;
+      float acc[RB_HS];
+#pragma unroll
+      for (int u = 0; u < RB_HS; ++u) acc[u] = 0.f;
+      int k = 0;
+      if (vec)
+        for (; k + 3 < K; k += 4) {
+          const f32x4 w = *(const f32x4*)(wr + k);
+#pragma unroll
+          for (int u = 0; u < RB_HS; ++u)
+            if (u < SG) {
+              const f32x4 x = *(const f32x4*)(xs + u * K + k);
+              acc[u] = fmaf(x[0], w[0], acc[u]);
+              acc[u] = fmaf(x[1], w[1], acc[u]);
+              acc[u] = fmaf(x[2], w[2], acc[u]);
+              acc[u] = fmaf(x[3], w[3], acc[u]);
+            }
+        }
+      for (; k < K; ++k) {
+        const float w = wr[k];
+#pragma unroll
+        for (int u = 0; u < RB_HS; ++u)
+          if (u < SG) acc[u] = fmaf(xs[u * K + k], w, acc[u]);
+      }
+      const float bias = c.lin[l].b[o];
+#pragma unroll
+      for (int u = 0; u < RB_HS; ++u)
+        if (u < SG) {
+          const int sidx = grp * SG + u;
+          float v = acc[u] + bias;
+          if (c.lin[l].elu) v = mzx_elu(v);
+          if (last) {
+            if (sidx < ns) c.y[(long long)(b0 + sidx) * O + o] = v;
+          } else {
+            nxt[sidx * O + o] = v;
+          }
+        }
+    }
+    __syncthreads();
+    const float* t = cur;                    // layer 0: in -> B; layer 1: B -> C; layer 2: C -> B
+    cur = nxt;
+    nxt = (t == buf_in || t == buf_c) ? (nxt == buf_b ? buf_c : buf_b) : buf_b;
+    K = O;
+  }
+}
+
 // Per-plane min-max scaling of the hidden state (models.py:527-553, :574-599; MinMaxScaleOp's arithmetic): one
 // workgroup per sample, NHWC or NCHW in, NCHW out (into the search arena's node store when `node` is set).
 struct RbScaleArgs {
@@ -1162,10 +1257,26 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
     if (id == BUF_HIDDEN) { t.sstride = net->hidden_size; if (ix) { t.node = ix->out_node; t.nodes = ix->out_nodes; } }
     return t;
   };
+  // ---- head chains that run in ONE rb_heads_kernel launch at the end of the program: the whole program runs, their
+  // tower runs as a tower with its tail at this batch (the tail convolution then writes the chain's input into the
+  // private region behind the temporaries, where nothing can overwrite it)
+  const char* tail_env0 = getenv("MZX_RB_TAIL");
+  const char* heads_env = getenv("MZX_RB_HEADS");
+  const bool tails_on = !(tail_env0 && atoi(tail_env0) == 0);
+  bool chain_on[RB_HEADS_MAX_CHAINS] = {false, false, false};
+  int chains_on = 0;
+  float* head_region = nb.workspace + net->act_floats * net->n_temp * (int64_t)batch;
+  if (count == (int)prog.size() && tails_on && !net->rb_no_towers && !(heads_env && atoi(heads_env) == 0))
+    for (int q = 0; q < R.heads.n_chains; ++q) {
+      const RbHeadChain& hc = R.heads.chain[q];
+      const int t = R.ops[hc.conv_op].tower_of_tail;
+      if (t >= 0 && rb_tower_use(R.towers[t], batch)) { chain_on[q] = true; ++chains_on; }
+    }
   for (int k = 0; k < count; ++k) {
     const OpDesc& d = prog[k];
     const RbOp& o = R.ops[k];
     int rc = 0;
+    if (o.head_chain >= 0 && chain_on[o.head_chain] && d.kind == OP_LINEAR) continue;     // runs in rb_heads_kernel below
     if (o.kind == RB_GEMM && o.tower >= 0 && !net->rb_no_towers && R.towers[o.tower].first == k &&
         rb_tower_use(R.towers[o.tower], batch)) {
       // a whole tower (or, for a diagnostic prefix, its first layers) in one launch; inner outputs never reach memory
@@ -1186,6 +1297,10 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
           } else {
             auto& cv = tail.conv[tail.n_conv++];
             cv.w = flat + dm.w; cv.b = flat + dm.b; cv.y = resolve(net, nb, dm.out, batch); cv.R = dm.cout;
+            const int hq = R.ops[m].head_chain;
+            if (hq >= 0 && chain_on[hq]) {      // the chain's input: [batch][in_features] in the private region
+              cv.y = head_region + R.heads.chain[hq].in_off * (int64_t)batch;
+            }
           }
           ++n_tail;
         }
@@ -1264,6 +1379,38 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
       if (r2) return r2;
     }
     if (rc) { set_error("kernel launch failed: %s", runtime_error_string(rc)); return MZX_ERR_RUNTIME; }
+  }
+  if (chains_on > 0) {
+    RbHeadsArgs ha;
+    memset(&ha, 0, sizeof(ha));
+    ha.batch = batch;
+    int k0max = 4;
+    for (int q = 0; q < R.heads.n_chains; ++q) {
+      if (!chain_on[q]) continue;
+      const RbHeadChain& hc = R.heads.chain[q];
+      RbHeadsArgs::Chain& c = ha.chain[ha.n_chains++];
+      c.x = head_region + hc.in_off * (int64_t)batch;
+      c.in_stride = hc.in_features;
+      c.in_features = hc.in_features;
+      c.n_lin = hc.count;
+      for (int l = 0; l < hc.count; ++l) {
+        const OpDesc& dl = prog[hc.first + l];
+        c.lin[l].w = flat + dl.w; c.lin[l].b = flat + dl.b; c.lin[l].in = dl.in_features; c.lin[l].out = dl.out_features;
+        c.lin[l].elu = dl.elu;
+      }
+      c.y = resolve(net, nb, prog[hc.first + hc.count - 1].out, batch);
+      k0max = std::max(k0max, (hc.in_features + 3) & ~3);
+    }
+    ha.in_region = RB_HS * k0max;
+    const size_t lds = sizeof(float) * ((size_t)ha.in_region + 2 * (size_t)RB_HS * RB_HEADS_MAX_WIDTH);
+    static std::atomic<uint64_t> heads_attr_done{0};
+    if (const int ae = allow_large_lds((const void*)rb_heads_kernel, RB_LDS_MAX, heads_attr_done)) {
+      set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
+      return MZX_ERR_RUNTIME;
+    }
+    hipLaunchKernelGGL(rb_heads_kernel, dim3((batch + RB_HS - 1) / RB_HS, ha.n_chains), dim3(256), lds, stream, ha);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("heads launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
   }
   if (dump && count > 0) {   // diagnostics: the last operator's output in the per-operator kernels' layout
     const OpDesc& d = prog[count - 1];

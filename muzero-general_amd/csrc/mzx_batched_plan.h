@@ -46,6 +46,8 @@ struct RbOp {
   int64_t asum_off = -1;   // derived buffer: border-aware tap sums of the action plane's weights [cout][H*W]
   int32_t act = 0;         // RzAct
   int32_t tower = -1;      // index into RbProgram::towers when this operator is a layer of one
+  int32_t head_chain = -1; // index into RbProgram::heads.chain: a tail convolution feeding it / a Linear layer of it
+  int32_t tower_of_tail = -1;  // for an operator in a tower's tail: that tower
 };
 
 // A TOWER: a run of consecutive stride-1 3x3 convolutions of one width on one board size in which every operator reads
@@ -63,14 +65,35 @@ struct RbTower {
 };
 constexpr int RB_TAIL_MAX_R = 8;
 
+// HEADS: the MLPs behind the small 1x1 head convolutions (dynamics fc = reward, prediction fc_value / fc_policy,
+// models.py:379-389, :418-433) -- chains of Linear (+ ELU) layers a few dozen neurons wide.  Launched one layer at a time
+// they are latency-bound launches of a few microseconds each (six per connect4 / gomoku inference); rb_heads_kernel runs
+// ALL chains of a program in ONE launch at its end.  A chain qualifies when its input is written by a tower's tail
+// (which then writes it into a private region of the workspace: nothing else can overwrite it before the end of the
+// program) and its layers are at most RB_HEADS_MAX_WIDTH wide.
+constexpr int RB_HEADS_MAX_CHAINS = 3, RB_HEADS_MAX_LAYERS = 3, RB_HEADS_MAX_WIDTH = 256, RB_HEADS_MAX_IN = 1024;
+struct RbHeadChain {
+  int32_t conv_op = -1;      // the tail convolution that writes the chain's input
+  int32_t first = -1, count = 0;   // its Linear operators (consecutive in the program)
+  int32_t in_features = 0;
+  int64_t in_off = 0;        // per-sample offset of its input inside the private region
+};
+struct RbHeads {
+  int32_t n_chains = 0;
+  RbHeadChain chain[RB_HEADS_MAX_CHAINS];
+  int64_t floats_per_sample = 0;   // private region: the chains' inputs
+};
+
 struct RbProgram {
   int32_t ok = 0;
   std::vector<RbOp> ops;
   std::vector<RbTower> towers;
+  RbHeads heads;
 };
 
 struct RbPlan {
   int32_t ok = 0;
+  int64_t head_floats = 0;      // per sample: the larger of the two programs' private head-input regions
   RbProgram initial, recurrent;
   std::vector<RzPack> packs;
   std::vector<RzAsum> asums;

@@ -83,7 +83,7 @@ static int64_t derived_total(const mzx_net* net) {
 int64_t mzx_net_derived_floats(const mzx_net* net) { return net ? derived_total(net) : 0; }
 int64_t mzx_net_workspace_floats(const mzx_net* net, int32_t max_batch) {
   if (!net || max_batch < 1) return 0;
-  return net->act_floats * net->n_temp * (int64_t)max_batch;
+  return net_ws_per_sample(net) * (int64_t)max_batch;
 }
 
 int mzx_net_tensor_info(const mzx_net* net, int32_t i, char* name, int32_t name_cap, int64_t* offset,
@@ -201,6 +201,26 @@ int mzx_net_streamed_tower(const mzx_net* net, int32_t recurrent, int32_t index,
   return MZX_OK;
 }
 
+int mzx_net_streamed_heads(const mzx_net* net, int32_t recurrent, int32_t batch, int32_t out[16]) {
+  if (!net || !out || batch < 1) { set_error("null argument / batch < 1"); return MZX_ERR_INVALID; }
+  for (int k = 0; k < 16; ++k) out[k] = 0;
+  const RbProgram& R = recurrent ? net->rb.recurrent : net->rb.initial;
+  if (!net->rb.ok || !R.ok) return MZX_OK;
+  const char* tail_env = getenv("MZX_RB_TAIL");
+  const char* heads_env = getenv("MZX_RB_HEADS");
+  if (net->rb_no_towers || (tail_env && atoi(tail_env) == 0) || (heads_env && atoi(heads_env) == 0)) return MZX_OK;
+  int n = 0;
+  for (int q = 0; q < R.heads.n_chains; ++q) {
+    const RbHeadChain& hc = R.heads.chain[q];
+    const int t = R.ops[hc.conv_op].tower_of_tail;
+    if (t < 0 || !rb_tower_use(R.towers[t], batch)) continue;
+    ++out[1];
+    for (int l = 0; l < hc.count && n < 13; ++l) out[2 + n++] = hc.first + l;
+  }
+  out[0] = n;
+  return MZX_OK;
+}
+
 int mzx_net_streamed_split(const mzx_net* net, int32_t batch, int32_t out[2]) {
   if (!net || !out || batch < 1) { set_error("null argument / batch < 1"); return MZX_ERR_INVALID; }
   const int first = rb_split_first(net, batch);
@@ -271,9 +291,9 @@ static int check_net_call(const mzx_net* net, int32_t batch, int64_t workspace_f
   if (!net) { set_error("null network handle"); return MZX_ERR_INVALID; }
   if (!net->d_flat) { set_error("network has no weights bound (call mzx_net_set_weights)"); return MZX_ERR_INVALID; }
   if (batch < 1) { set_error("batch must be >= 1"); return MZX_ERR_INVALID; }
-  if (workspace_floats < net->act_floats * net->n_temp * (int64_t)batch) {
+  if (workspace_floats < net_ws_per_sample(net) * (int64_t)batch) {
     set_error("workspace too small: %lld floats given, %lld needed", (long long)workspace_floats,
-              (long long)(net->act_floats * net->n_temp * (int64_t)batch));
+              (long long)(net_ws_per_sample(net) * (int64_t)batch));
     return MZX_ERR_WORKSPACE;
   }
   return MZX_OK;

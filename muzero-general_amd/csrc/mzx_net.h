@@ -470,6 +470,10 @@ struct NetBuffers {
   float* workspace;
 };
 
+// Workspace floats per sample: the temporaries of the operator program, then the streamed engine's private head-input
+// region (mzx_batched_plan.h: RbHeads).  A workspace for `batch` samples is [temporaries x batch][head region x batch].
+inline int64_t net_ws_per_sample(const mzx_net* net) { return net->act_floats * net->n_temp + net->rb.head_floats; }
+
 inline float* resolve(const mzx_net* net, const NetBuffers& nb, int id, int batch) {
   switch (id) {
     case BUF_IN: return const_cast<float*>(nb.in);

@@ -246,7 +246,7 @@ inline bool rb_tower_use(const RbTower& tw, int batch) {
 // reader outside the run (it never reaches memory).  MZX_RB_TOWER=0 plans none (A/B).
 inline void rb_find_towers(const std::vector<OpDesc>& prog, RbProgram& R) {
   R.towers.clear();
-  for (RbOp& o : R.ops) o.tower = -1;
+  for (RbOp& o : R.ops) { o.tower = -1; o.tower_of_tail = -1; }
   static const int enabled = getenv("MZX_RB_TOWER") ? atoi(getenv("MZX_RB_TOWER")) : 1;
   if (!enabled) return;
   const int n = (int)prog.size();
@@ -313,10 +313,63 @@ inline void rb_find_towers(const std::vector<OpDesc>& prog, RbProgram& R) {
       }
       if (tw.t_max >= 1) {
         for (int j = k; j <= last; ++j) R.ops[j].tower = (int)R.towers.size();
+        for (int j = last + 1; j <= last + tw.n_tail; ++j) R.ops[j].tower_of_tail = (int)R.towers.size();
         R.towers.push_back(tw);
       }
     }
     k = last + 1;
+  }
+}
+
+// Finds the head chains of a program (after rb_find_towers): Linear chains fed by a tower's tail convolution.
+inline void rb_find_heads(const std::vector<OpDesc>& prog, RbProgram& R) {
+  R.heads = RbHeads();
+  for (RbOp& o : R.ops) o.head_chain = -1;
+  static const int enabled = getenv("MZX_RB_HEADS") ? atoi(getenv("MZX_RB_HEADS")) : 1;
+  if (!enabled) return;
+  const int n = (int)prog.size();
+  for (const RbTower& tw : R.towers) {
+    for (int m = tw.first + tw.count; m < tw.first + tw.count + tw.n_tail && m < n; ++m) {
+      if (prog[m].kind != OP_CONV1 || R.heads.n_chains >= RB_HEADS_MAX_CHAINS) continue;
+      const int src = prog[m].out;
+      // the chain: the first Linear that reads the convolution's output, then every Linear reading its predecessor
+      int first = -1;
+      for (int q = m + 1; q < n; ++q) {
+        if (prog[q].out == src) break;
+        if (prog[q].in == src || prog[q].res == src) { first = q; break; }
+      }
+      if (first < 0 || prog[first].kind != OP_LINEAR || prog[first].use_action) continue;
+      // the convolution's output must have no other reader
+      bool sole = true;
+      for (int q = m + 1; q < n && sole; ++q) {
+        if (q != first && (prog[q].in == src || prog[q].res == src)) sole = false;
+        if (prog[q].out == src) break;
+      }
+      if (!sole) continue;
+      int count = 1;
+      while (first + count < n && count < RB_HEADS_MAX_LAYERS && prog[first + count].kind == OP_LINEAR &&
+             !prog[first + count].use_action && prog[first + count].in == prog[first + count - 1].out)
+        ++count;
+      // a longer chain than the kernel takes, or an inner output somebody else reads: leave it to the layer launches
+      if (first + count < n && prog[first + count].kind == OP_LINEAR && prog[first + count].in == prog[first + count - 1].out) continue;
+      bool ok = prog[first].in_features == prog[m].cout * prog[m].hin && prog[first].in_features <= RB_HEADS_MAX_IN;
+      for (int q = first; q < first + count && ok; ++q) {
+        ok = prog[q].out_features <= RB_HEADS_MAX_WIDTH && prog[q].w_stride == prog[q].in_features;
+        if (q + 1 < first + count)      // inner outputs: read by the next layer only
+          for (int z = q + 2; z < n; ++z) {
+            if (prog[z].in == prog[q].out || prog[z].res == prog[q].out) { ok = false; break; }
+            if (prog[z].out == prog[q].out) break;
+          }
+      }
+      if (!ok) continue;
+      RbHeadChain& c = R.heads.chain[R.heads.n_chains];
+      c.conv_op = m; c.first = first; c.count = count; c.in_features = prog[first].in_features;
+      c.in_off = R.heads.floats_per_sample;
+      R.heads.floats_per_sample += (c.in_features + 3) & ~3;
+      R.ops[m].head_chain = R.heads.n_chains;
+      for (int q = first; q < first + count; ++q) R.ops[q].head_chain = R.heads.n_chains;
+      ++R.heads.n_chains;
+    }
   }
 }
 
@@ -440,6 +493,7 @@ inline bool rb_build_program(mzx_net* net, const std::vector<OpDesc>& prog, RbPl
   }
   R.ok = 1;
   rb_find_towers(prog, R);
+  rb_find_heads(prog, R);
   return true;
 }
 
@@ -457,6 +511,7 @@ inline void rb_plan(mzx_net* net) {
   if (!rb_build_program(net, net->prog_recurrent, P, P.recurrent, cursor, packed)) P.recurrent.ok = 0;
   if (!P.initial.ok && !P.recurrent.ok) { P = RbPlan(); return; }
   P.derived_floats = cursor;
+  P.head_floats = std::max(P.initial.ok ? P.initial.heads.floats_per_sample : 0, P.recurrent.ok ? P.recurrent.heads.floats_per_sample : 0);
   P.ok = 1;
 }
 

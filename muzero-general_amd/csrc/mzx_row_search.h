@@ -127,13 +127,14 @@ inline int row_search_apply(const RowSearchArgs& a, stream_t stream) {
 // are faster on this path since the trunks run as towers (rb_tower_kernel): measured whole steps, connect4 x 200
 // simulations -- 1024 trees 0.563 of the FP32 MFMA peak against 0.528 on rz_search_kernel, 2048 trees 0.59 against 0.53,
 // 3072 trees 0.69 against 0.53 (profiles/r04_c4_by_shard.txt).  MZX_SEARCH_STREAMED_MIN=<trees> moves the threshold
-// (default 1024; 0 = never: the whole-search kernel at every shard size).
+// (default 640; 0 = never: the whole-search kernel at every shard size).
 inline bool row_search_preferred(const mzx_search* s) {
   const mzx_net* net = s->net;
   if (!net || !net->rb.ok || !net->rb.initial.ok || !net->rb.recurrent.ok || net->rb_no_towers) return false;
   if (!row_search_supported(s->p)) return false;
   const char* e = getenv("MZX_SEARCH_STREAMED_MIN");
-  const int min_trees = e ? atoi(e) : 1024;
+  const int min_trees = e ? atoi(e) : 640;   // (512 trees: the whole-search kernel's one round of 256 workgroups wins, 0.53 against 0.45;
+                                             //  768 trees: its 1.5 rounds lose, 0.40 against 0.55)
   if (min_trees <= 0 || s->p.num_trees < min_trees) return false;
   if (net->cfg.channels < 48) return false;          // narrow networks: the wave / tile whole-search kernels win by far
   const int first = rb_split_first(net, s->p.num_trees);
@@ -228,7 +229,7 @@ inline int search_run_rows(mzx_search* s, const mzx_search_io* io, void* d_arena
     NetBuffers& n = nbs[h];
     n.in = v.arena.hidden + o * node_floats; n.hidden = v.arena.hidden + o * node_floats; n.action = a.sel_action;
     n.value = v.value + o * F; n.reward = v.reward + o * F; n.policy = v.policy + o * A;
-    n.workspace = v.ws + o * net->act_floats * net->n_temp;      // the workspace is linear in the batch
+    n.workspace = v.ws + o * net_ws_per_sample(net);             // the workspace is linear in the batch
     ixs[h].in_node = a.sel_parent; ixs[h].out_node = a.sel_leaf;
     ixs[h].in_nodes = s->p.num_nodes; ixs[h].out_nodes = s->p.num_nodes;
   }

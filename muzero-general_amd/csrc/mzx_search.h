@@ -62,7 +62,7 @@ inline void search_plan(mzx_search* s) {
   s->off_policy = o;    o += align256(int64_t(4) * B * A);
   s->off_sel = o;       o += align256(int64_t(4) * B * 3);
   s->off_rowsel = o;    o += align256(int64_t(4) * B * 64);   // path hand-off of the row kernels (mzx_row_search.h)
-  s->ws_floats = s->net ? s->net->act_floats * s->net->n_temp * (int64_t)B : 0;
+  s->ws_floats = s->net ? net_ws_per_sample(s->net) * (int64_t)B : 0;
   s->off_ws = o;        o += align256(int64_t(4) * s->ws_floats);
   s->arena_bytes = o;
 }

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "mzx_net_streamed_plan": (ctypes.c_int, [c_vp, c_i32, c_i32, ctypes.POINTER(c_i32 * 24)]),
     "mzx_net_streamed_shape": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32 * 16)]),
     "mzx_net_streamed_tower": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32 * 16)]),
+    "mzx_net_streamed_heads": (ctypes.c_int, [c_vp, c_i32, c_i32, ctypes.POINTER(c_i32 * 16)]),
     "mzx_net_streamed_split": (ctypes.c_int, [c_vp, c_i32, ctypes.POINTER(c_i32 * 2)]),
     "mzx_net_operator_out_floats": (c_i64, [c_vp, c_i32, c_i32]),
     "mzx_net_num_operators": (ctypes.c_int, [c_vp, c_i32]),

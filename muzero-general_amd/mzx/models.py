@@ -133,6 +133,13 @@ def streamed_launches(lib, handle, recurrent, batch):
         out.append(dict(op=t["first"], MT=t["MT"], NT=t["NT"], phases=1, k_loop="tower " + streamed_k_loop(t["MT"], t["NT"], tower=True),
                         WM=t["WM"], WN=t["WN"], T=t["T"], nsplit=1 + t["n_tail"], cpg=(t["C"] + 15) // 16, taps=9, stride=1,
                         in_layout=-t["count"], cin=t["C"], cout=t["C"]))
+    # the head MLPs that run in ONE rb_heads_kernel launch at the end of the program
+    hd = (ctypes.c_int32 * 16)()
+    lib.check(lib.mzx_net_streamed_heads(handle, int(bool(recurrent)), int(batch), ctypes.byref(hd)))
+    if hd[0] > 0:
+        in_tower.update(hd[2 + k] for k in range(hd[0]))
+        out.append(dict(op=int(hd[2]), MT=0, NT=int(hd[1]), phases=1, k_loop="heads", WM=0, WN=0, T=16, nsplit=int(hd[0]),
+                        cpg=0, taps=1, stride=1, in_layout=0, cin=0, cout=0))
     for op in range(lib.mzx_net_num_operators(handle, int(bool(recurrent)))):
         if op in in_tower:
             continue
@@ -169,7 +176,8 @@ def launch_key(launch):
 
 def summarize_launches(launches):
     """Compact, sorted labels '<MT,NT> phases K-loop' of a launch list (bench.py reports these per workload)."""
-    return [f"<{mt},{nt}> {ph}ph {kl}" for mt, nt, ph, kl in sorted({instantiation_key(l) for l in launches})]
+    return [(f"heads x{nt}" if kl == "heads" else f"<{mt},{nt}> {ph}ph {kl}")
+            for mt, nt, ph, kl in sorted({instantiation_key(l) for l in launches})]
 
 
 class MuZeroNetwork:
