@@ -133,9 +133,10 @@ int mzx_net_streamed_shape(const mzx_net* net, int32_t recurrent, int32_t op, in
  * tower are not launched one by one (mzx_net_streamed_shape still describes what the layer-by-layer path would do). */
 int mzx_net_streamed_tower(const mzx_net* net, int32_t recurrent, int32_t index, int32_t batch, int32_t out[16]);
 /* HEADS: the Linear chains behind the small 1x1 head convolutions (dynamics fc, prediction fc_value / fc_policy,
- * models.py:379-433) run in ONE launch of rb_heads_kernel at the end of a program when their tower runs with its tail
- * (MZX_RB_HEADS=0: one rb_gemm_kernel launch per layer, the A/B).  out = {Linear operators covered at `batch` samples,
- * chains, their operator indices ...}; all zero when no chain qualifies. */
+ * models.py:379-433) CAN run in ONE launch of rb_heads_kernel at the end of a program when their tower runs with its
+ * tail: MZX_RB_HEADS=1.  Off by default -- on the vector ALUs it measured slower than the one rb_gemm_kernel (MFMA)
+ * launch per layer it replaces.  out = {Linear operators covered at `batch` samples, chains, their
+ * operator indices ...}; all zero when off or when no chain qualifies. */
 int mzx_net_streamed_heads(const mzx_net* net, int32_t recurrent, int32_t batch, int32_t out[16]);
 /* The row-per-tree search runs large shards as two half-shards on two HIP streams (csrc/mzx_row_search.h; from 1024
  * trees, and only when both halves keep the channel groups -- the summation order -- of the undivided launch):

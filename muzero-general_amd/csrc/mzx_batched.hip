@@ -839,7 +839,8 @@ constexpr int RB_HS = 16;            // samples per workgroup
 struct RbHeadsArgs {
   int32_t n_chains, batch;
   int32_t in_region;       // floats of the LDS input region = RB_HS x the widest chain input (rounded to 4)
-  int32_t pad;
+  int32_t hid_region;      // floats of each of the two hidden-activation regions = RB_HS x the widest hidden layer (a small
+                           // footprint matters: the launch should fit BESIDE the other half-shard's tower workgroups)
   struct Chain {
     const float* x;        // [batch][in_stride] chain input (the tail convolution's output, channel-major)
     float* y;              // [batch][out of the last layer]
@@ -849,6 +850,72 @@ struct RbHeadsArgs {
   } chain[RB_HEADS_MAX_CHAINS];
 };
 
+// One Linear layer for the workgroup's RB_HS samples: thread = (output neuron o, group of SG samples), SG a template
+// parameter so that the register tile acc[SG] and every loop over it are static (a first version guarded a 16-wide tile
+// with run-time tests: every LDS read was waited for on its own, 84 us per launch).  Per block of 16 k: four 16-byte
+// weight loads (the lane's own row, L2) and SG x 4 LDS reads (the same address for the whole wave: broadcast) are issued
+// together, then their 64 SG fmaf -- per output one chain over k in order, as LinearOp (mzx_ops.h).
+template <int SG>
+__device__ __forceinline__ void rb_heads_layer(const float* __restrict__ w, const float* __restrict__ bias, const float* cur,
+                                               float* nxt, float* y, long long y_row0, int K, int O, int elu, bool last,
+                                               int ns, int tid) {
+  constexpr int groups = RB_HS / SG, per_pass = 256 / groups;
+  const int grp = tid / per_pass, ot = tid - grp * per_pass;
+  const float* xs = cur + (size_t)grp * SG * K;
+  const bool vec = (K & 3) == 0 && (((uintptr_t)w) & 15) == 0;
+  for (int o = ot; o < O; o += per_pass) {
+    const float* wr = w + (size_t)o * K;
+    float acc[SG];
+#pragma unroll
+    for (int u = 0; u < SG; ++u) acc[u] = 0.f;
+    int k = 0;
+    if (vec) {
+      constexpr int KQ = SG <= 4 ? 4 : (SG == 8 ? 2 : 1);      // 16-byte quads of k per block: at most 64 registers of x
+      for (; k + 4 * KQ - 1 < K; k += 4 * KQ) {
+        f32x4 wq[KQ], xq[SG][KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) wq[q] = *(const f32x4*)(wr + k + 4 * q);
+#pragma unroll
+        for (int u = 0; u < SG; ++u)
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) xq[u][q] = *(const f32x4*)(xs + u * K + k + 4 * q);
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int u = 0; u < SG; ++u) acc[u] = fmaf(xq[u][q][e], wq[q][e], acc[u]);
+      }
+      for (; k + 3 < K; k += 4) {
+        const f32x4 wq = *(const f32x4*)(wr + k);
+#pragma unroll
+        for (int u = 0; u < SG; ++u) {
+          const f32x4 x = *(const f32x4*)(xs + u * K + k);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[u] = fmaf(x[e], wq[e], acc[u]);
+        }
+      }
+    }
+    for (; k < K; ++k) {
+      const float wk = wr[k];
+#pragma unroll
+      for (int u = 0; u < SG; ++u) acc[u] = fmaf(xs[u * K + k], wk, acc[u]);
+    }
+    const float bo = bias[o];
+#pragma unroll
+    for (int u = 0; u < SG; ++u) {
+      const int sidx = grp * SG + u;
+      float v = acc[u] + bo;
+      if (elu) v = mzx_elu(v);
+      if (last) {
+        if (sidx < ns) y[(y_row0 + sidx) * O + o] = v;
+      } else {
+        nxt[sidx * O + o] = v;
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) rb_heads_kernel(const RbHeadsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float rb_lds[];
   const RbHeadsArgs::Chain& c = a.chain[blockIdx.y];
@@ -857,12 +924,12 @@ __global__ void __launch_bounds__(256) rb_heads_kernel(const RbHeadsArgs a) {
   const int ns = min(RB_HS, a.batch - b0);
   if (ns <= 0) return;
   float* const buf_in = rb_lds;                                    // [RB_HS][in_features]
-  float* const buf_b = rb_lds + a.in_region;                       // [RB_HS][<= RB_HEADS_MAX_WIDTH]
-  float* const buf_c = buf_b + RB_HS * RB_HEADS_MAX_WIDTH;
+  float* const buf_b = rb_lds + a.in_region;                       // [RB_HS][widest hidden layer]
+  float* const buf_c = buf_b + a.hid_region;
   const int K0 = c.in_features;
-  for (int i = tid; i < RB_HS * K0; i += 256) {
-    const int sidx = i / K0, k = i - sidx * K0;
-    buf_in[i] = sidx < ns ? c.x[(long long)(b0 + sidx) * c.in_stride + k] : 0.f;
+  for (int sidx = 0; sidx < RB_HS; ++sidx) {                       // (rows beyond the batch: zeros, never stored)
+    const float* xr = c.x + (long long)(b0 + (sidx < ns ? sidx : 0)) * c.in_stride;
+    for (int k = tid; k < K0; k += 256) buf_in[sidx * K0 + k] = sidx < ns ? xr[k] : 0.f;
   }
   __syncthreads();
   const float* cur = buf_in;
@@ -871,51 +938,12 @@ __global__ void __launch_bounds__(256) rb_heads_kernel(const RbHeadsArgs a) {
   for (int l = 0; l < c.n_lin; ++l) {
     const int O = c.lin[l].out;
     const bool last = l + 1 == c.n_lin;
-    // thread -> (output neuron, group of SG samples): the 256 threads cover 256 / groups neurons per pass
-    const int groups = O >= 256 ? 1 : (O >= 128 ? 2 : (O >= 64 ? 4 : (O >= 32 ? 8 : 16)));
-    const int SG = RB_HS / groups, per_pass = 256 / groups;
-    const int grp = tid / per_pass, ot = tid - grp * per_pass;
-    const float* xs = cur + (size_t)grp * SG * K;
-    const bool vec = (K & 3) == 0 && (((uintptr_t)c.lin[l].w) & 15) == 0;
-    for (int o = ot; o < O; o += per_pass) {
-      const float* wr = c.lin[l].w + (size_t)o * K;
-      float acc[RB_HS];
-#pragma unroll
-      for (int u = 0; u < RB_HS; ++u) acc[u] = 0.f;
-      int k = 0;
-      if (vec)
-        for (; k + 3 < K; k += 4) {
-          const f32x4 w = *(const f32x4*)(wr + k);
-#pragma unroll
-          for (int u = 0; u < RB_HS; ++u)
-            if (u < SG) {
-              const f32x4 x = *(const f32x4*)(xs + u * K + k);
-              acc[u] = fmaf(x[0], w[0], acc[u]);
-              acc[u] = fmaf(x[1], w[1], acc[u]);
-              acc[u] = fmaf(x[2], w[2], acc[u]);
-              acc[u] = fmaf(x[3], w[3], acc[u]);
-            }
-        }
-      for (; k < K; ++k) {
-        const float w = wr[k];
-#pragma unroll
-        for (int u = 0; u < RB_HS; ++u)
-          if (u < SG) acc[u] = fmaf(xs[u * K + k], w, acc[u]);
-      }
-      const float bias = c.lin[l].b[o];
-#pragma unroll
-      for (int u = 0; u < RB_HS; ++u)
-        if (u < SG) {
-          const int sidx = grp * SG + u;
-          float v = acc[u] + bias;
-          if (c.lin[l].elu) v = mzx_elu(v);
-          if (last) {
-            if (sidx < ns) c.y[(long long)(b0 + sidx) * O + o] = v;
-          } else {
-            nxt[sidx * O + o] = v;
-          }
-        }
-    }
+    // 256 threads = (256 / groups neurons per pass) x (groups of RB_HS / groups samples)
+    if (O >= 256) rb_heads_layer<16>(c.lin[l].w, c.lin[l].b, cur, nxt, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
+    else if (O >= 128) rb_heads_layer<8>(c.lin[l].w, c.lin[l].b, cur, nxt, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
+    else if (O >= 64) rb_heads_layer<4>(c.lin[l].w, c.lin[l].b, cur, nxt, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
+    else if (O >= 32) rb_heads_layer<2>(c.lin[l].w, c.lin[l].b, cur, nxt, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
+    else rb_heads_layer<1>(c.lin[l].w, c.lin[l].b, cur, nxt, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
     __syncthreads();
     const float* t = cur;                    // layer 0: in -> B; layer 1: B -> C; layer 2: C -> B
     cur = nxt;
@@ -1266,7 +1294,7 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
   bool chain_on[RB_HEADS_MAX_CHAINS] = {false, false, false};
   int chains_on = 0;
   float* head_region = nb.workspace + net->act_floats * net->n_temp * (int64_t)batch;
-  if (count == (int)prog.size() && tails_on && !net->rb_no_towers && !(heads_env && atoi(heads_env) == 0))
+  if (count == (int)prog.size() && tails_on && !net->rb_no_towers && heads_env && atoi(heads_env) == 1)
     for (int q = 0; q < R.heads.n_chains; ++q) {
       const RbHeadChain& hc = R.heads.chain[q];
       const int t = R.ops[hc.conv_op].tower_of_tail;
@@ -1384,7 +1412,7 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
     RbHeadsArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.batch = batch;
-    int k0max = 4;
+    int k0max = 4, wmax = 4;
     for (int q = 0; q < R.heads.n_chains; ++q) {
       if (!chain_on[q]) continue;
       const RbHeadChain& hc = R.heads.chain[q];
@@ -1397,12 +1425,14 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
         const OpDesc& dl = prog[hc.first + l];
         c.lin[l].w = flat + dl.w; c.lin[l].b = flat + dl.b; c.lin[l].in = dl.in_features; c.lin[l].out = dl.out_features;
         c.lin[l].elu = dl.elu;
+        if (l + 1 < hc.count) wmax = std::max(wmax, (dl.out_features + 3) & ~3);
       }
       c.y = resolve(net, nb, prog[hc.first + hc.count - 1].out, batch);
       k0max = std::max(k0max, (hc.in_features + 3) & ~3);
     }
     ha.in_region = RB_HS * k0max;
-    const size_t lds = sizeof(float) * ((size_t)ha.in_region + 2 * (size_t)RB_HS * RB_HEADS_MAX_WIDTH);
+    ha.hid_region = RB_HS * wmax;
+    const size_t lds = sizeof(float) * ((size_t)ha.in_region + 2 * (size_t)ha.hid_region);
     static std::atomic<uint64_t> heads_attr_done{0};
     if (const int ae = allow_large_lds((const void*)rb_heads_kernel, RB_LDS_MAX, heads_attr_done)) {
       set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));

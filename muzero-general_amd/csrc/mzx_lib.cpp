@@ -208,7 +208,7 @@ int mzx_net_streamed_heads(const mzx_net* net, int32_t recurrent, int32_t batch,
   if (!net->rb.ok || !R.ok) return MZX_OK;
   const char* tail_env = getenv("MZX_RB_TAIL");
   const char* heads_env = getenv("MZX_RB_HEADS");
-  if (net->rb_no_towers || (tail_env && atoi(tail_env) == 0) || (heads_env && atoi(heads_env) == 0)) return MZX_OK;
+  if (net->rb_no_towers || (tail_env && atoi(tail_env) == 0) || !(heads_env && atoi(heads_env) == 1)) return MZX_OK;
   int n = 0;
   for (int q = 0; q < R.heads.n_chains; ++q) {
     const RbHeadChain& hc = R.heads.chain[q];

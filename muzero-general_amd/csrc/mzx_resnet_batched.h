@@ -325,8 +325,8 @@ inline void rb_find_towers(const std::vector<OpDesc>& prog, RbProgram& R) {
 inline void rb_find_heads(const std::vector<OpDesc>& prog, RbProgram& R) {
   R.heads = RbHeads();
   for (RbOp& o : R.ops) o.head_chain = -1;
-  static const int enabled = getenv("MZX_RB_HEADS") ? atoi(getenv("MZX_RB_HEADS")) : 1;
-  if (!enabled) return;
+  // (always planned; whether a run uses it is decided per call: MZX_RB_HEADS=1, default off -- measured slower than the
+  // six MFMA launches it replaces at every shard size, profiles/r04_tower_experiments.txt section 6)
   const int n = (int)prog.size();
   for (const RbTower& tw : R.towers) {
     for (int m = tw.first + tw.count; m < tw.first + tw.count + tw.n_tail && m < n; ++m) {
