@@ -851,66 +851,110 @@ struct RbHeadsArgs {
 };
 
 // One Linear layer for the workgroup's RB_HS samples: thread = (output neuron o, group of SG samples), SG a template
-// parameter so that the register tile acc[SG] and every loop over it are static (a first version guarded a 16-wide tile
-// with run-time tests: every LDS read was waited for on its own, 84 us per launch).  Per block of 16 k: four 16-byte
-// weight loads (the lane's own row, L2) and SG x 4 LDS reads (the same address for the whole wave: broadcast) are issued
-// together, then their 64 SG fmaf -- per output one chain over k in order, as LinearOp (mzx_ops.h).
+// parameter so that the register tile acc[SG] is static.  The weights of the pass's neurons come through LDS in slabs of
+// `slab_k` inputs: the 256 threads load a slab cooperatively (16-byte pieces of the rows, coalesced) -- ONE L2 round
+// trip per slab instead of one per lane and k step (a lane walking its own row: 34 us per launch) --, the next slab is
+// requested before the current one is consumed.  Rows are pitched slab_k + 4 floats: the 16-byte reads of 16 consecutive
+// neurons fall on distinct LDS slots.  Per output one fmaf chain over k in order, as LinearOp (mzx_ops.h).
+constexpr int RB_HEADS_SLAB_FLOATS = 3328;     // 13 KB of LDS for a weight slab (64 neurons x 48 inputs + pitch)
 template <int SG>
 __device__ __forceinline__ void rb_heads_layer(const float* __restrict__ w, const float* __restrict__ bias, const float* cur,
-                                               float* nxt, float* y, long long y_row0, int K, int O, int elu, bool last,
-                                               int ns, int tid) {
+                                               float* nxt, float* wl, float* y, long long y_row0, int K, int O, int elu,
+                                               bool last, int ns, int tid) {
   constexpr int groups = RB_HS / SG, per_pass = 256 / groups;
+  constexpr int row_q = RB_HEADS_SLAB_FLOATS / per_pass / 4;                 // 16-byte slots a row may take
+  constexpr int slab_k = ((row_q - 1) * 4) & ~15;                            // whole 16-input chunks: 48 at 64 neurons per pass
+  constexpr int pitch = slab_k + 4;                                          // an ODD number of slots per row: no bank conflicts
+  static_assert(slab_k >= 16, "a weight slab holds at least one 16-input chunk");
+  constexpr int PF = (per_pass * slab_k / 4 + 255) / 256;                    // 16-byte pieces per thread and slab
   const int grp = tid / per_pass, ot = tid - grp * per_pass;
   const float* xs = cur + (size_t)grp * SG * K;
   const bool vec = (K & 3) == 0 && (((uintptr_t)w) & 15) == 0;
-  for (int o = ot; o < O; o += per_pass) {
-    const float* wr = w + (size_t)o * K;
+  for (int o_base = 0; o_base < O; o_base += per_pass) {
+    const int n_o = min(per_pass, O - o_base);
     float acc[SG];
 #pragma unroll
     for (int u = 0; u < SG; ++u) acc[u] = 0.f;
-    int k = 0;
-    if (vec) {
-      constexpr int KQ = SG <= 4 ? 4 : (SG == 8 ? 2 : 1);      // 16-byte quads of k per block: at most 64 registers of x
-      for (; k + 4 * KQ - 1 < K; k += 4 * KQ) {
-        f32x4 wq[KQ], xq[SG][KQ];
+    // slab s = inputs [s * slab_k, ...): requested into registers, written to LDS when the previous slab is consumed
+    f32x4 pf[PF];
+    auto request = [&](int k0) {
+      const int kc = min(slab_k, K - k0), q = (kc + 3) >> 2;                 // quads per row of this slab
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) wq[q] = *(const f32x4*)(wr + k + 4 * q);
-#pragma unroll
-        for (int u = 0; u < SG; ++u)
-#pragma unroll
-          for (int q = 0; q < KQ; ++q) xq[u][q] = *(const f32x4*)(xs + u * K + k + 4 * q);
-#pragma unroll
-        for (int q = 0; q < KQ; ++q)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int u = 0; u < SG; ++u) acc[u] = fmaf(xq[u][q][e], wq[q][e], acc[u]);
+      for (int t = 0; t < PF; ++t) {
+        const int i = tid + t * 256;
+        pf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < n_o * q) {
+          const int r = i / q, c = (i - r * q) * 4;
+          const float* src = w + (size_t)(o_base + r) * K + k0 + c;
+          if (vec && c + 3 < kc) pf[t] = *(const f32x4*)src;
+          else {
+            pf[t][0] = src[0];
+            if (c + 1 < kc) pf[t][1] = src[1];
+            if (c + 2 < kc) pf[t][2] = src[2];
+            if (c + 3 < kc) pf[t][3] = src[3];
+          }
+        }
       }
-      for (; k + 3 < K; k += 4) {
-        const f32x4 wq = *(const f32x4*)(wr + k);
+    };
+    auto deposit = [&](int k0) {
+      const int kc = min(slab_k, K - k0), q = (kc + 3) >> 2;
 #pragma unroll
-        for (int u = 0; u < SG; ++u) {
-          const f32x4 x = *(const f32x4*)(xs + u * K + k);
+      for (int t = 0; t < PF; ++t) {
+        const int i = tid + t * 256;
+        if (i < n_o * q) {
+          const int r = i / q, c = (i - r * q) * 4;
+          *(f32x4*)(wl + r * pitch + c) = pf[t];
+        }
+      }
+      // the last 16-input chunk of the layer may be partial: zero weights behind it (as the packed MFMA fragments have)
+      const int q16 = ((kc + 15) >> 4) << 2;
+      for (int i = tid; i < n_o * (q16 - q); i += 256) {
+        const int r = i / (q16 - q), c = (q + i - r * (q16 - q)) * 4;
+        *(f32x4*)(wl + r * pitch + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    request(0);
+    for (int k0 = 0; k0 < K; k0 += slab_k) {
+      const int kc = min(slab_k, K - k0);
+      __syncthreads();                       // the previous slab is consumed
+      deposit(k0);
+      if (k0 + slab_k < K) request(k0 + slab_k);
+      __syncthreads();
+      if (ot < n_o) {
+        // Summation order = rb_gemm_kernel's: per 16-input chunk the four MFMA K-steps j, each over the four lane groups g
+        // in order -- input 16 c + 4 g + j (the f32 MFMA is a k-ordered fmaf chain) -- so that this launch and the MFMA
+        // launch per layer it replaces give the SAME bits (asserted, test_tower_kernel_layer_by_layer)
+        const float* wrow = wl + ot * pitch;
+        for (int k = 0; k < kc; k += 16) {
+          f32x4 wq[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[u] = fmaf(x[e], wq[e], acc[u]);
+          for (int g = 0; g < 4; ++g) wq[g] = *(const f32x4*)(wrow + k + 4 * g);
+#pragma unroll
+          for (int u = 0; u < SG; ++u) {
+            float xv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) xv[e] = (k0 + k + e < K) ? xs[u * K + k0 + k + e] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) acc[u] = fmaf(xv[4 * g + j], wq[g][j], acc[u]);
+          }
         }
       }
     }
-    for (; k < K; ++k) {
-      const float wk = wr[k];
+    if (ot < n_o) {
+      const int o = o_base + ot;
+      const float bo = bias[o];
 #pragma unroll
-      for (int u = 0; u < SG; ++u) acc[u] = fmaf(xs[u * K + k], wk, acc[u]);
-    }
-    const float bo = bias[o];
-#pragma unroll
-    for (int u = 0; u < SG; ++u) {
-      const int sidx = grp * SG + u;
-      float v = acc[u] + bo;
-      if (elu) v = mzx_elu(v);
-      if (last) {
-        if (sidx < ns) y[(y_row0 + sidx) * O + o] = v;
-      } else {
-        nxt[sidx * O + o] = v;
+      for (int u = 0; u < SG; ++u) {
+        const int sidx = grp * SG + u;
+        float v = acc[u] + bo;
+        if (elu) v = mzx_elu(v);
+        if (last) {
+          if (sidx < ns) y[(y_row0 + sidx) * O + o] = v;
+        } else {
+          nxt[sidx * O + o] = v;
+        }
       }
     }
   }
@@ -921,11 +965,11 @@ __global__ void __launch_bounds__(256) rb_heads_kernel(const RbHeadsArgs a) {
   const RbHeadsArgs::Chain& c = a.chain[blockIdx.y];
   const int tid = threadIdx.x;
   const int b0 = blockIdx.x * RB_HS;
-  const int ns = min(RB_HS, a.batch - b0);
-  if (ns <= 0) return;
+  const int ns = min(RB_HS, a.batch - b0);        // (> 0: the grid covers the batch exactly)
   float* const buf_in = rb_lds;                                    // [RB_HS][in_features]
   float* const buf_b = rb_lds + a.in_region;                       // [RB_HS][widest hidden layer]
   float* const buf_c = buf_b + a.hid_region;
+  float* const wl = buf_c + a.hid_region;                          // weight slab
   const int K0 = c.in_features;
   for (int sidx = 0; sidx < RB_HS; ++sidx) {                       // (rows beyond the batch: zeros, never stored)
     const float* xr = c.x + (long long)(b0 + (sidx < ns ? sidx : 0)) * c.in_stride;
@@ -939,11 +983,10 @@ __global__ void __launch_bounds__(256) rb_heads_kernel(const RbHeadsArgs a) {
     const int O = c.lin[l].out;
     const bool last = l + 1 == c.n_lin;
     // 256 threads = (256 / groups neurons per pass) x (groups of RB_HS / groups samples)
-    if (O >= 256) rb_heads_layer<16>(c.lin[l].w, c.lin[l].b, cur, nxt, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
-    else if (O >= 128) rb_heads_layer<8>(c.lin[l].w, c.lin[l].b, cur, nxt, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
-    else if (O >= 64) rb_heads_layer<4>(c.lin[l].w, c.lin[l].b, cur, nxt, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
-    else if (O >= 32) rb_heads_layer<2>(c.lin[l].w, c.lin[l].b, cur, nxt, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
-    else rb_heads_layer<1>(c.lin[l].w, c.lin[l].b, cur, nxt, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
+    if (O >= 128) rb_heads_layer<8>(c.lin[l].w, c.lin[l].b, cur, nxt, wl, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
+    else if (O >= 64) rb_heads_layer<4>(c.lin[l].w, c.lin[l].b, cur, nxt, wl, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
+    else if (O >= 32) rb_heads_layer<2>(c.lin[l].w, c.lin[l].b, cur, nxt, wl, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
+    else rb_heads_layer<1>(c.lin[l].w, c.lin[l].b, cur, nxt, wl, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
     __syncthreads();
     const float* t = cur;                    // layer 0: in -> B; layer 1: B -> C; layer 2: C -> B
     cur = nxt;
@@ -1432,7 +1475,7 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
     }
     ha.in_region = RB_HS * k0max;
     ha.hid_region = RB_HS * wmax;
-    const size_t lds = sizeof(float) * ((size_t)ha.in_region + 2 * (size_t)ha.hid_region);
+    const size_t lds = sizeof(float) * ((size_t)ha.in_region + 2 * (size_t)ha.hid_region + RB_HEADS_SLAB_FLOATS + 64);
     static std::atomic<uint64_t> heads_attr_done{0};
     if (const int ae = allow_large_lds((const void*)rb_heads_kernel, RB_LDS_MAX, heads_attr_done)) {
       set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));

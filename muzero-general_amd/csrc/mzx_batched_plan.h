@@ -71,7 +71,7 @@ constexpr int RB_TAIL_MAX_R = 8;
 // ALL chains of a program in ONE launch at its end.  A chain qualifies when its input is written by a tower's tail
 // (which then writes it into a private region of the workspace: nothing else can overwrite it before the end of the
 // program) and its layers are at most RB_HEADS_MAX_WIDTH wide.
-constexpr int RB_HEADS_MAX_CHAINS = 3, RB_HEADS_MAX_LAYERS = 3, RB_HEADS_MAX_WIDTH = 256, RB_HEADS_MAX_IN = 1024;
+constexpr int RB_HEADS_MAX_CHAINS = 3, RB_HEADS_MAX_LAYERS = 3, RB_HEADS_MAX_WIDTH = 128, RB_HEADS_MAX_IN = 1024;
 struct RbHeadChain {
   int32_t conv_op = -1;      // the tail convolution that writes the chain's input
   int32_t first = -1, count = 0;   // its Linear operators (consecutive in the program)

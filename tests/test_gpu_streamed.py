@@ -187,10 +187,8 @@ def test_tower_kernel_layer_by_layer(backend, name, B, T, monkeypatch):
     assert not [l for l in net.streamed_launches(1, B) if l["k_loop"] == "heads"]
     if name in ("connect4", "gomoku", "breakout"):
         assert heads_on and heads_on[0]["NT"] == 3           # reward, value and policy chains in one launch
-    for got, want in zip(o3 + r3, o1 + r1):
-        g, w = got.cpu().numpy(), want.cpu().numpy()
-        fin = numpy.isfinite(w)
-        assert numpy.array_equal(numpy.isfinite(g), fin) and numpy.abs(numpy.where(fin, g - w, 0.0)).max() < 1e-5 * (1.0 + numpy.abs(w[fin]).max())
+    for got, want in zip(o3 + r3, o1 + r1):       # the same bits: the vector kernel sums in the MFMA's order
+        assert torch.equal(got, want), (name, T)
     # and the whole inferences (heads behind the towers) against the layer-by-layer streamed path
     net.set_mode(4)
     o0, r0 = net.initial_inference(obs), net.recurrent_inference(hid, act)
