@@ -166,3 +166,92 @@ def test_half_shards_keep_the_channel_groups_of_the_whole_shard(lib, name, B):
         assert {(s["phases"], s["cpg"]) for s in shapes} == {(shapes[0]["phases"], shapes[0]["cpg"])}, (name, op, shapes)
     assert gemms >= 10
     lib.mzx_net_destroy(h)
+
+
+# ---- round 4: towers (rb_tower_kernel), their tails, the head chains -- host-side planning through the C ABI
+
+TOWER = ("first", "count", "C", "H", "W", "T", "MT", "NT", "WM", "WN", "lds", "groups", "n_tail")
+
+
+def _towers(lib, h, recurrent, batch):
+    out, index = [], 0
+    buf = (ctypes.c_int32 * 16)()
+    while lib.mzx_net_streamed_tower(h, recurrent, index, batch, ctypes.byref(buf)) == 0:
+        out.append(dict(zip(TOWER, list(buf))))
+        index += 1
+    return out
+
+
+def test_towers_of_the_shipped_networks(lib):
+    """
+    Which runs of operators become ONE rb_tower_kernel launch: the representation / dynamics trunk (conv + residual
+    blocks) and the prediction trunk of every residual configuration; the per-plane scaling and the small 1x1 head
+    convolutions ride in the tail; boards too large for a whole-sample tile have none.
+    """
+    want = {   # name: (recurrent towers as (first, layers, tail operators), initial towers)
+        "connect4": ([(0, 7, 2), (11, 6, 2)], [(0, 7, 1), (8, 6, 2)]),
+        "gomoku": ([(0, 13, 2), (17, 12, 2)], [(0, 13, 1), (14, 12, 2)]),
+        "atari": ([(0, 33, 1), (38, 32, 0)], [(20, 32, 1), (53, 32, 0)]),          # 256-channel heads: GEMM launches
+        "tictactoe": ([(0, 3, 1), (7, 2, 0)], [(0, 3, 1), (4, 2, 0)]),            # 16 reduced channels: heads stay GEMMs
+    }
+    for name, (rec, init) in want.items():
+        h = _create(lib, configs.BY_NAME[name]())
+        for recurrent, expect in ((1, rec), (0, init)):
+            got = [(t["first"], t["count"], t["n_tail"]) for t in _towers(lib, h, recurrent, 1024)]
+            assert got == expect, (name, recurrent, got)
+        lib.mzx_net_destroy(h)
+    # 19 x 19: a sample's positions do not fit a workgroup's row tiles -> no towers, every layer launches on its own
+    h = _create(lib, configs.connect4(observation_shape=(3, 19, 19), action_space=list(range(361))))
+    assert _towers(lib, h, 1, 64) == []
+    lib.mzx_net_destroy(h)
+    # network modes 4 / 5: no towers
+    h = _create(lib, configs.gomoku())
+    lib.check(lib.mzx_net_set_mode(h, 5))
+    assert _towers(lib, h, 1, 512) == []
+    lib.mzx_net_destroy(h)
+
+
+def test_tower_shapes_follow_the_calibrated_cost_model(lib):
+    """
+    Samples per workgroup by batch (profiles/r04_tower_experiments.txt section 4: whole rounds of workgroups decide), the
+    LDS fit, and the refusal of shapes that waste more than a fifth of the MFMA rows.
+    """
+    h = _create(lib, configs.connect4())
+    lib.check(lib.mzx_net_set_mode(h, 3))
+    for batch, T, MT in ((512, 2, 3), (768, 3, 4), (1024, 4, 6), (3072, 6, 8), (4608, 6, 8)):
+        t = _towers(lib, h, 1, batch)[0]
+        assert (t["T"], t["MT"], t["NT"]) == (T, MT, 1), (batch, t)
+        assert t["groups"] == -(-batch // T) and t["lds"] <= 156 * 1024
+        assert t["WM"] * t["WN"] <= 8 and t["WM"] * t["MT"] * 16 >= t["T"] * 42
+    lib.mzx_net_destroy(h)
+    h = _create(lib, configs.atari())
+    assert [t["groups"] for t in _towers(lib, h, 1, 256)] == [0, 0]        # 36 rows in three tiles: layer by layer
+    big = _towers(lib, h, 1, 512)
+    assert [(t["T"], t["MT"], t["NT"]) for t in big] == [(2, 5, 2), (2, 5, 2)] and all(t["groups"] == 256 for t in big)
+    lib.mzx_net_destroy(h)
+    h = _create(lib, configs.gomoku())
+    t = _towers(lib, h, 1, 512)[0]
+    assert (t["T"], t["MT"], t["NT"], t["WN"], t["groups"]) == (1, 8, 1, 8, 512)    # one 11 x 11 board per workgroup
+    lib.mzx_net_destroy(h)
+
+
+def test_head_chains_are_planned_and_off_by_default(lib, monkeypatch):
+    """rb_heads_kernel (all head MLPs in one launch) is opt-in: MZX_RB_HEADS=1."""
+    h = _create(lib, configs.connect4())
+    lib.check(lib.mzx_net_set_mode(h, 3))
+    out = (ctypes.c_int32 * 16)()
+    lib.check(lib.mzx_net_streamed_heads(h, 1, 512, ctypes.byref(out)))
+    assert list(out)[:2] == [0, 0]
+    monkeypatch.setenv("MZX_RB_HEADS", "1")
+    lib.check(lib.mzx_net_streamed_heads(h, 1, 512, ctypes.byref(out)))
+    assert out[0] == 6 and out[1] == 3                         # reward, value, policy: two Linear layers each
+    lib.check(lib.mzx_net_streamed_heads(h, 0, 512, ctypes.byref(out)))
+    assert out[0] == 4 and out[1] == 2                         # initial_inference: value and policy
+    monkeypatch.setenv("MZX_RB_TAIL", "0")                     # no tails -> nobody writes the chains' private inputs
+    lib.check(lib.mzx_net_streamed_heads(h, 1, 512, ctypes.byref(out)))
+    assert out[0] == 0
+    lib.mzx_net_destroy(h)
+    # the workspace carries the private head-input region behind the temporaries
+    h2 = _create(lib, configs.connect4())
+    assert lib.mzx_net_workspace_floats(h2, 7) == 7 * lib.mzx_net_workspace_floats(h2, 1)
+    lib.mzx_net_destroy(h2)
