@@ -569,7 +569,7 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
             traffic = entry["bytes"]      # (its provenance: profiles/pmc_traffic.json "source")
     except (OSError, ValueError):
         pass
-    kernel_name = ("per-sim launches + streamed MFMA trunks / layers (rb_tower_kernel, rb_gemm_kernel)" +
+    kernel_name = ("per-sim launches + streamed MFMA trunks / layers (rb_tower_kernel, rb_gemm_kernel, rb_gemm_multi_kernel)" +
                    (", two half-shards on two HIP streams" if "two half-shards" in ran else "") if streamed else
                    "fused-lds" if fused else
                    "residual whole-search kernel (arena trees, fused MFMA network)" if fused_kind == 2 else
@@ -591,7 +591,7 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         roofline = {
             "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-            "kernel": "whole step: select / mzx::rb_tower_kernel per trunk + mzx::rb_gemm_kernel per head layer / expand+backprop per simulation" if streamed
+            "kernel": "whole step: select / mzx::rb_tower_kernel per trunk + mzx::rb_gemm_multi_kernel per head MLP level (mzx::rb_gemm_kernel per other layer) / expand+backprop per simulation" if streamed
                       else ("whole step: root kernels + " + ran) if fused_kind == 2
                       else "whole step: select / rz_network_kernel / expand+backprop per simulation"
                       if net_fused else "whole step (one kernel per operator)",

@@ -36,7 +36,7 @@ def up_to_date():
 def _object_up_to_date(obj, src):
     if not os.path.isfile(obj):
         return False
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [src, os.path.join(INCLUDE, "mzx.h"), __file__]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + [src, os.path.join(INCLUDE, "mzx.h"), __file__]
     return all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps)
 
 

@@ -67,6 +67,7 @@ struct RbGemmArgs {
   unsigned long long* stamps;   // diagnostics (env MZX_RB_STAMPS): s_memtime of the phases, wave 0 of the first 64 workgroups
   int32_t dbg;           // latency experiments (env MZX_RB_DBG): 1 skip the K loops, 2 skip the epilogue, 4 skip the staging
   uint32_t magic_thw, magic_tw, magic_phw, magic_pw;   // ceil(2^32 / d)
+  int32_t grid_x, grid_y;   // this operator's own grid (rb_gemm_multi_kernel: the launch's grid is the largest of its slices')
 };
 
 __device__ __forceinline__ int rb_div(int x, int d, uint32_t magic) {
@@ -86,364 +87,63 @@ constexpr int RB_STAMP_WGS = 1024, RB_STAMP_SLOTS = 24;
 template <int MT, int NT>
 __global__ void __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(MT * NT <= 8 ? 4 : 2, MT * NT <= 8 ? 4 : 2)))
 rb_gemm_kernel(const RbGemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float rb_lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform, and the compiler is told so: tile indices in SGPRs
-  const int mpad = a.mtiles * 16, Tpad = (a.T + 1) & ~1;
-  int* rowaddr = (int*)rb_lds;
-  int* rowt = rowaddr + mpad;
-  int* rowpos = rowt + mpad;
-  long long* soff_x = (long long*)(rowpos + mpad);
-  long long* soff_r = soff_x + Tpad;
-  float* tile = (float*)(soff_r + Tpad);
+#define RB_BX blockIdx.x
+#define RB_BY blockIdx.y
+#include "mzx_batched_gemm_body.inc"
+#undef RB_BX
+#undef RB_BY
+}
 
-  const int nsp = a.tiles_x * a.tiles_y;
-  const int sg = blockIdx.x / nsp, sp = blockIdx.x - sg * nsp;
-  const int tyi = sp / a.tiles_x, txi = sp - tyi * a.tiles_x;
-  const int b0 = sg * a.T;
-  const int pad = a.pad;
-  // row-range tiles: first position of the range and the board row it lies in
-  const int p_first = a.rowsplit > 0 ? sp * a.rowsplit * 16 : 0;
-  const int y_first = a.rowsplit > 0 ? p_first / a.wout : 0;
-  const int ty0 = a.rowsplit > 0 ? y_first : tyi * a.th, tx0 = a.rowsplit > 0 ? 0 : txi * a.tw;
-  const int thw = a.th * a.tw, phw = a.PH * a.PW, cells = a.T * phw;
-  const int HWo = a.hout * a.wout;
-  RB_STAMP(0);
-  if (a.stamps && blockIdx.y == 0 && blockIdx.x < RB_STAMP_WGS && (tid & 63) == 0)   // 100 MHz reference clock beside it
-    a.stamps[((size_t)blockIdx.x * 8 + (tid >> 6)) * RB_STAMP_SLOTS + RB_STAMP_SLOTS - 2] = __builtin_amdgcn_s_memrealtime();
+// Several INDEPENDENT operators of one shape class in one launch -- the k-th Linear layers of the head MLPs (reward, value,
+// policy: csrc/mzx_resnet_batched.h rb_find_heads): slice blockIdx.z runs operator z with its own arguments, launch shape
+// and grid (the launch's grid is the largest; a slice's surplus workgroups leave at once).  Same code, same shapes, same
+// bits as one launch per operator.
+constexpr int RB_MULTI_MAX = 3;
+struct RbGemmMulti { RbGemmArgs g[RB_MULTI_MAX]; };
 
-  // ---- row tables, per-sample offsets
-  for (int m = tid; m < mpad; m += RB_THREADS) {
-    if (a.rowsplit > 0) {   // position p of the sample in raster order, patch rows y_first - pad ...
-      const int p = p_first + m;
-      const bool ok = p < HWo && b0 < a.batch;
-      const int y = rb_div(p < HWo ? p : 0, a.wout, a.magic_tw), x = (p < HWo ? p : 0) - y * a.wout;
-      rowaddr[m] = ok ? ((y - y_first) * a.PW + x) * a.Cs : 0;     // top-left cell of the position's window
-      rowt[m] = 0;
-      rowpos[m] = ok ? p : -1;
-      continue;
+template <int MT, int NT>
+__global__ void __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(MT * NT <= 8 ? 4 : 2, MT * NT <= 8 ? 4 : 2)))
+rb_gemm_multi_kernel(const RbGemmMulti m) {
+  const RbGemmArgs& a = m.g[blockIdx.z];
+  if (blockIdx.x >= (unsigned)a.grid_x || blockIdx.y >= (unsigned)a.grid_y) return;
+#define RB_BX blockIdx.x
+#define RB_BY blockIdx.y
+#include "mzx_batched_gemm_body.inc"
+#undef RB_BX
+#undef RB_BY
+}
+
+// Whole head MLPs in one launch: slice blockIdx.z runs chain z, level after level; a workgroup owns the SAME samples at
+// every level (all output features of them: one workgroup column), so level l + 1 reads what this very workgroup wrote
+// at level l -- through memory (the private region), behind an agent-scope fence on both sides of the barrier (the
+// second one: a line another workgroup of the CU pulled into the L1 between a wave's fence and the barrier may hold the
+// old contents).  The same body, operator by operator: the same bits as one launch per layer.
+constexpr int RB_CHAIN_MAX_LEVELS = 3;
+struct RbGemmChain {
+  RbGemmArgs g[RB_MULTI_MAX][RB_CHAIN_MAX_LEVELS];
+  int32_t levels[RB_MULTI_MAX];
+};
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+rb_gemm_chain_kernel(const RbGemmChain m) {
+  const int q = blockIdx.z, levels = m.levels[q];
+  if (blockIdx.x >= (unsigned)m.g[q][0].grid_x) return;
+  for (int level = 0; level < levels; ++level) {
+    const RbGemmArgs& a = m.g[q][level];
+    if (level > 0) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     }
-    const int t = rb_div(m, thw, a.magic_thw), r = m - t * thw;
-    const int ty = rb_div(r, a.tw, a.magic_tw), tx = r - ty * a.tw;
-    const int oy = ty0 + ty, ox = tx0 + tx;
-    const bool valid = m < a.rows;
-    const bool ok = valid && (b0 + t) < a.batch && oy < a.hout && ox < a.wout;
-    rowaddr[m] = valid ? ((t * a.PH + ty * a.stride) * a.PW + tx * a.stride) * a.Cs : 0;   // top-left cell of the window
-    rowt[m] = valid ? t : 0;
-    rowpos[m] = ok ? oy * a.wout + ox : -1;
+    [&]() __attribute__((always_inline)) {
+#define RB_BX blockIdx.x
+#define RB_BY 0u
+#include "mzx_batched_gemm_body.inc"
+#undef RB_BX
+#undef RB_BY
+    }();
   }
-  for (int t = tid; t < a.T; t += RB_THREADS) {
-    const int b = (b0 + t < a.batch) ? b0 + t : a.batch - 1;
-    soff_x[t] = ((long long)b * a.x.nodes + (a.x.node ? a.x.node[b] : 0)) * a.x.sstride;
-    soff_r[t] = a.res.p ? ((long long)b * a.res.nodes + (a.res.node ? a.res.node[b] : 0)) * a.res.sstride : 0;
-  }
-  __syncthreads();
-
-  // ---- this wave's tiles
-  const int wn = wave % a.WN, wm = wave / a.WN;
-  const int nt_first = wn * NT;                               // first column tile inside the workgroup's share
-  const bool active = wm < a.WM && nt_first < a.ntiles_wg && (blockIdx.y * a.ntiles_wg + nt_first) < a.ntiles &&
-                      wm * MT < a.mtiles;
-  int ra[MT];
-  const float* wp[NT];
-  bool nvalid[NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int mt = wm * MT + i;
-    ra[i] = ((active && mt < a.mtiles) ? rowaddr[mt * 16 + (lane & 15)] : 0) + 4 * (lane >> 4);
-  }
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int nt = blockIdx.y * a.ntiles_wg + nt_first + j;
-    nvalid[j] = active && (nt_first + j) < a.ntiles_wg && nt < a.ntiles;
-    wp[j] = a.wpack + ((size_t)(nvalid[j] ? nt : 0) * a.wchunks) * 256;    // scalar base: the lane's 16 bytes are added per load
-  }
-  const unsigned lane4 = (unsigned)lane * 4;
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const float* xp = a.x.p;
-  const int gy0 = ty0 * a.stride - pad, gx0 = tx0 * a.stride - pad;
-
-  for (int g = 0; g < a.phases; ++g) {
-    const int c0 = g * a.cpg * 16;
-    const int cw = min(a.cpg * 16, a.cchunks * 16 - c0);   // channels of this phase (padded to whole chunks)
-    const int q = cw >> 2;
-    // ---- stage the input patch: tile[cell][c - c0], zero outside the image / beyond cin
-    if (a.dbg & 4) {
-      if (g > 0) __syncthreads();
-    } else if (a.x.layout == RB_NHWC) {
-      // SU 16-byte requests per thread before the first LDS write (eight where the kernel has the registers: a patch of
-      // up to 4096 quads -- every shipped trunk layer -- is then one round trip to memory), and the requests of the next
-      // channel group go out BEFORE the barrier that waits for the slowest wave's K loop: they land in registers, not
-      // in LDS, so they need not wait for it.
-      constexpr int SU = MT * NT >= 6 ? 8 : 4;
-      const uint32_t magic_q = (uint32_t)((0x100000000ull + (uint64_t)q - 1) / (uint64_t)q);
-      const int total = cells * q;
-      bool synced = g == 0;
-      for (int i0 = tid; i0 < total || !synced; i0 += SU * RB_THREADS) {
-        f32x4 v[SU];
-        int at[SU];
-#pragma unroll
-        for (int u = 0; u < SU; ++u) {
-          const int idx = i0 + u * RB_THREADS;
-          at[u] = -1;
-          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (idx < total) {
-            const int cell = rb_div(idx, q, magic_q), k = idx - cell * q;
-            const int t = rb_div(cell, phw, a.magic_phw), rem = cell - t * phw;
-            const int iy = rb_div(rem, a.PW, a.magic_pw), ix = rem - iy * a.PW;
-            const int gy = gy0 + iy, gx = gx0 + ix, c = c0 + 4 * k;
-            at[u] = cell * a.Cs + 4 * k;
-            if (b0 + t < a.batch && gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win && c < a.cin) {
-              const float* src = xp + soff_x[t] + ((long long)gy * a.win + gx) * a.cin + c;
-              if (a.x_vec && c + 3 < a.cin) v[u] = *(const f32x4*)src;
-              else {
-                v[u][0] = src[0];
-                if (c + 1 < a.cin) v[u][1] = src[1];
-                if (c + 2 < a.cin) v[u][2] = src[2];
-                if (c + 3 < a.cin) v[u][3] = src[3];
-              }
-            }
-          }
-        }
-        if (!synced) { __syncthreads(); synced = true; }     // every wave is done reading the previous group
-#pragma unroll
-        for (int u = 0; u < SU; ++u)
-          if (at[u] >= 0) *(f32x4*)(tile + at[u]) = v[u];
-      }
-    } else {
-      if (g > 0) __syncthreads();                          // every wave is done reading the previous group
-      // NCHW source: consecutive threads take consecutive cells of one channel quad (coalesced along x)
-      const uint32_t magic_cells = (uint32_t)((0x100000000ull + (uint64_t)cells - 1) / (uint64_t)cells);
-      const long long plane = (long long)a.hin * a.win;
-      const int total = cells * q;
-      for (int i0 = tid; i0 < total; i0 += 2 * RB_THREADS) {
-        f32x4 v[2];
-        int at[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int idx = i0 + u * RB_THREADS;
-          at[u] = -1;
-          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (idx < total) {
-            const int k = rb_div(idx, cells, magic_cells), cell = idx - k * cells;
-            const int t = rb_div(cell, phw, a.magic_phw), rem = cell - t * phw;
-            const int iy = rb_div(rem, a.PW, a.magic_pw), ix = rem - iy * a.PW;
-            const int gy = gy0 + iy, gx = gx0 + ix, c = c0 + 4 * k;
-            at[u] = cell * a.Cs + 4 * k;
-            if (b0 + t < a.batch && gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win && c < a.cin) {
-              const float* src = xp + soff_x[t] + (long long)c * plane + (long long)gy * a.win + gx;
-              v[u][0] = src[0];
-              if (c + 1 < a.cin) v[u][1] = src[plane];
-              if (c + 2 < a.cin) v[u][2] = src[2 * plane];
-              if (c + 3 < a.cin) v[u][3] = src[3 * plane];
-            }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-          if (at[u] >= 0) *(f32x4*)(tile + at[u]) = v[u];
-      }
-    }
-    __syncthreads();
-    RB_STAMP(1 + 2 * g);
-
-    // ---- K loop of this phase: (tap, chunk) pairs, operands one chunk ahead in registers
-    if (active && !(a.dbg & 1)) {
-      const int cpg_g = cw >> 4;
-      const int n_it = a.taps * cpg_g;
-      int tap = 0, cc = 0;                      // tap = ky * ksize + kx of the square kernel
-      f32x4 fa0[MT], fa1[MT], fb0[NT], fb1[NT];
-      auto load = [&](f32x4 (&fa)[MT], f32x4 (&fb)[NT]) {
-        // cell (ky, kx) of the window = tap cells on, plus the rest of a patch row per kernel row: few scalar
-        // registers live across the loop (a (ky, kx) cursor pushed the 9-tile kernel's fragments to scratch)
-        const int aoff = tap * a.Cs + ((tap * a.kmagic) >> 16) * a.rowskip + cc * 16;
-        const size_t widx = (size_t)(tap * a.cchunks + g * a.cpg + cc) * 256;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) fb[j] = *(const f32x4*)(wp[j] + widx + lane4);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) fa[i] = *(const f32x4*)(tile + ra[i] + aoff);
-        if (++cc == cpg_g) { cc = 0; ++tap; }
-      };
-      auto mma = [&](const f32x4 (&fa)[MT], const f32x4 (&fb)[NT]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][k], fa[i][k], acc[i][j], 0, 0, 0);
-      };
-      if constexpr ((MT - 1) * NT >= 5) {
-        // ONE set of position fragments, refilled IN PLACE: tile i's fragment is dead after its last k = 3 MFMA, its
-        // read for the next chunk goes out right there and is first needed (MT - 1) NT MFMAs (>= 160 cycles, the LDS
-        // latency) later.  Two full sets (2 x 4 MT registers) plus the accumulators leave the 128-register kernels
-        // (four waves per SIMD) NO slack, and whether that loop compiles without scratch traffic, or with each
-        // chunk's LDS reads sunk next to their first use, changed with every edit nearby (0.68 <-> 0.62 of the peak).
-        // Weight fragments (L2 latency) stay double-buffered, one chunk ahead.
-        auto step = [&](const f32x4 (&fbc)[NT], f32x4 (&fbn)[NT]) {
-          const int aoff = tap * a.Cs + ((tap * a.kmagic) >> 16) * a.rowskip + cc * 16;
-          const size_t widx = (size_t)(tap * a.cchunks + g * a.cpg + cc) * 256;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) fbn[j] = *(const f32x4*)(wp[j] + widx + lane4);
-          // pinned only where registers are plentiful (two waves per SIMD): in the 128-register kernels the extra
-          // barriers cost a fragment spill inside the loop, and the scheduler keeps this order there by itself
-          constexpr bool PIN = MT * NT > 8;
-          if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);   // a whole chunk of MFMAs between the request and its use
-#pragma unroll
-          for (int i = 0; i < MT; ++i) {           // k = 0 in tile order: the order the refills were requested in
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fbc[j][0], fa0[i][0], acc[i][j], 0, 0, 0);
-            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
-          }
-#pragma unroll
-          for (int k = 1; k < 3; ++k)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-              for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fbc[j][k], fa0[i][k], acc[i][j], 0, 0, 0);
-          if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fbc[j][3], fa0[i][3], acc[i][j], 0, 0, 0);
-            fa0[i] = *(const f32x4*)(tile + ra[i] + aoff);
-            __builtin_amdgcn_sched_barrier(0);     // the read goes out HERE, not next to its first use
-          }
-          if (++cc == cpg_g) { cc = 0; ++tap; }
-        };
-        load(fa0, fb0);                           // chunk 0; the cursor now names chunk 1
-        int it = 0;
-        for (; it + 2 < n_it; it += 2) { step(fb0, fb1); step(fb1, fb0); }
-        if (it + 1 < n_it) { step(fb0, fb1); mma(fa0, fb1); }
-        else mma(fa0, fb0);
-      } else if constexpr (MT * NT <= MZX_RB_RING_MAX) {
-        // Few accumulator tiles per wave (small launches, head layers): a chunk is at most 16 MFMAs = 512 cycles, less
-        // than the L2 round trip of its weight fragment -- a ring of FOUR chunks in flight instead of two.
-        f32x4 fa2[MT], fa3[MT], fb2[NT], fb3[NT];
-        load(fa0, fb0);
-        if (n_it > 1) load(fa1, fb1);
-        if (n_it > 2) load(fa2, fb2);
-        if (n_it > 3) load(fa3, fb3);
-        int it = 0;
-        for (; it + 8 <= n_it; it += 4) {      // branch-free: every slot has a successor four chunks ahead
-          mma(fa0, fb0); load(fa0, fb0);
-          mma(fa1, fb1); load(fa1, fb1);
-          mma(fa2, fb2); load(fa2, fb2);
-          mma(fa3, fb3); load(fa3, fb3);
-        }
-        // it .. it + 3 are in flight; up to four more chunks follow
-        mma(fa0, fb0); if (it + 4 < n_it) load(fa0, fb0);
-        if (it + 1 < n_it) { mma(fa1, fb1); if (it + 5 < n_it) load(fa1, fb1); }
-        if (it + 2 < n_it) { mma(fa2, fb2); if (it + 6 < n_it) load(fa2, fb2); }
-        if (it + 3 < n_it) { mma(fa3, fb3); if (it + 7 < n_it) load(fa3, fb3); }
-        if (it + 4 < n_it) mma(fa0, fb0);
-        if (it + 5 < n_it) mma(fa1, fb1);
-        if (it + 6 < n_it) mma(fa2, fb2);
-        if (it + 7 < n_it) mma(fa3, fb3);
-      } else {
-        // branch-free steady state (the wait counters of the next chunk's loads stay exact), one- or two-chunk tail
-        load(fa0, fb0);
-        int it = 0;
-        for (; it + 2 < n_it; it += 2) {
-          load(fa1, fb1);
-          mma(fa0, fb0);
-          load(fa0, fb0);
-          mma(fa1, fb1);
-        }
-        if (it + 1 < n_it) {
-          load(fa1, fb1);
-          mma(fa0, fb0);
-          mma(fa1, fb1);
-        } else {
-          mma(fa0, fb0);
-        }
-      }
-    }
-    RB_STAMP(2 + 2 * g);
-  }
-
-  // ---- epilogue.  The MFMAs were issued with the weight fragment as the FIRST operand: D = (A . B)^T, so lane l
-  // holds position row l & 15 of the tile and four CONSECUTIVE output channels 4 (l >> 4) .. + 3 -- one 16-byte
-  // residual load and one 16-byte store per lane and tile (16 lanes x 4 groups = 64 contiguous bytes per position).
-  if (!active || (a.dbg & 2)) return;
-  const int m_lane = lane & 15, nq = 4 * (lane >> 4);
-  const bool y_vec = a.y_vec != 0, r_vec = a.r_vec != 0;
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    if (!nvalid[j]) continue;
-    const int n0 = (blockIdx.y * a.ntiles_wg + nt_first + j) * 16 + nq;
-    if (n0 >= a.cout) continue;
-    float al[4], be[4], bi[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bool ok = n0 + u < a.cout;
-      al[u] = (a.alpha && ok) ? a.alpha[n0 + u] : 1.f;
-      be[u] = (a.alpha && ok) ? a.beta[n0 + u] : 0.f;
-      bi[u] = (a.bias && ok) ? a.bias[n0 + u] : 0.f;
-    }
-    // residuals of every tile first (independent loads in flight together), then arithmetic and stores
-    int pos_i[MT], t_i[MT];
-    f32x4 rv[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int mt = wm * MT + i;
-      pos_i[i] = mt < a.mtiles ? rowpos[mt * 16 + m_lane] : -1;
-      t_i[i] = mt < a.mtiles ? rowt[mt * 16 + m_lane] : 0;
-      rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a.res.p && pos_i[i] >= 0) {
-        const float* rp = a.res.p + soff_r[t_i[i]];
-        if (r_vec) rv[i] = *(const f32x4*)(rp + (long long)pos_i[i] * a.cout + n0);
-        else {
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (n0 + u < a.cout)
-              rv[i][u] = rp[a.res.layout == RB_NHWC ? (long long)pos_i[i] * a.cout + n0 + u : (long long)(n0 + u) * HWo + pos_i[i]];
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int pos = pos_i[i];
-      if (pos < 0) continue;
-      const int b = b0 + t_i[i];
-      f32x4 v = acc[i][j];
-      if (a.asum) {
-        const float av = (float)a.action[b] / (float)a.num_actions;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (n0 + u < a.cout) v[u] += av * a.asum[(size_t)(n0 + u) * HWo + pos];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        float x = v[u];
-        if (a.alpha) x = x * al[u] + be[u];
-        if (a.bias) x += bi[u];
-        if (a.res.p) x += rv[i][u];
-        if (a.act == RZ_ACT_RELU) x = fmaxf(x, 0.f);
-        else if (a.act == RZ_ACT_ELU) x = mzx_elu(x);
-        v[u] = x;
-      }
-      float* yp = a.y + (long long)b * a.y_sstride;
-      if (y_vec) *(f32x4*)(yp + (long long)pos * a.cout + n0) = v;
-      else {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (n0 + u < a.cout)
-            yp[a.y_layout == RB_NHWC ? (long long)pos * a.cout + n0 + u : (long long)(n0 + u) * HWo + pos] = v[u];
-      }
-    }
-  }
-  RB_STAMP(1 + 2 * a.phases);
-  if (a.stamps && blockIdx.y == 0 && blockIdx.x < RB_STAMP_WGS && (tid & 63) == 0)
-    a.stamps[((size_t)blockIdx.x * 8 + (tid >> 6)) * RB_STAMP_SLOTS + RB_STAMP_SLOTS - 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1131,9 +831,9 @@ RbGemmFn rb_pick_mt(int mt) {
   }
 }
 
-int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
-  const RbShape sh = rb_choose_shape(o, batch);
-  const int groups_m = sh.groups, nsplit = sh.nsplit, NT = sh.NT, WN = sh.WN, WM = sh.WM, MT = sh.MT;
+// A launch shape of operator `o`, written into its arguments.
+void rb_apply_shape(RbGemmArgs& a, const RbOp& o, const RbShape& sh) {
+  const int WN = sh.WN, WM = sh.WM;
   a.T = sh.T; a.rows = sh.rows; a.mtiles = sh.mtiles;
   a.cpg = sh.cpg; a.phases = sh.phases; a.Cs = sh.Cs;
   a.kmagic = (65536 + o.ksize - 1) / o.ksize; a.rowskip = (o.PW - o.ksize) * sh.Cs;   // the launch's Cs, not the plan's
@@ -1145,6 +845,19 @@ int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
   a.ntiles_wg = sh.ntiles_wg; a.WN = WN; a.WM = WM;
   static const int dbg = getenv("MZX_RB_DBG") ? atoi(getenv("MZX_RB_DBG")) : 0;
   a.dbg = dbg;
+  a.grid_x = sh.groups; a.grid_y = sh.nsplit;
+}
+
+// The launch shape of operator `o` at `batch` (rb_choose_shape), written into its arguments.
+RbShape rb_shape_args(RbGemmArgs& a, const RbOp& o, int batch) {
+  const RbShape sh = rb_choose_shape(o, batch);
+  rb_apply_shape(a, o, sh);
+  return sh;
+}
+
+int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
+  const RbShape sh = rb_shape_args(a, o, batch);
+  const int groups_m = sh.groups, nsplit = sh.nsplit, NT = sh.NT, WN = sh.WN, WM = sh.WM, MT = sh.MT;
   // MZX_RB_STAMPS=<launch number>: phase clocks of that GEMM launch (counted from the first one of the process),
   // printed to stderr after a blocking copy -- a diagnostic, never set in production
   static const int stamp_launch = getenv("MZX_RB_STAMPS") ? atoi(getenv("MZX_RB_STAMPS")) : -1;
@@ -1216,6 +929,63 @@ int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
                              ticks / 100.0, cycles / ticks * 100.0);
     }
   }
+  return MZX_OK;
+}
+
+// n operators of one (MT, NT) class in ONE launch (rb_gemm_multi_kernel: blockIdx.z = operator).  The arguments carry
+// their own shapes (rb_shape_args); returns MZX_ERR_INVALID without launching when the class has no multi instantiation.
+typedef void (*RbGemmMultiFn)(const RbGemmMulti);
+inline RbGemmMultiFn rb_pick_multi(int mt, int nt) {
+  if (nt != 1) return nullptr;
+  switch (mt) {
+    case 1: return rb_gemm_multi_kernel<1, 1>;
+    case 2: return rb_gemm_multi_kernel<2, 1>;
+    case 3: return rb_gemm_multi_kernel<3, 1>;
+    case 4: return rb_gemm_multi_kernel<4, 1>;
+    default: return nullptr;
+  }
+}
+
+int rb_launch_gemm_multi(const RbGemmMulti& m, const RbShape* sh, int n, stream_t stream) {
+  RbGemmMultiFn fn = rb_pick_multi(sh[0].MT, sh[0].NT);
+  if (!fn || n < 1 || n > RB_MULTI_MAX) { set_error("grouped GEMM launch: no instantiation"); return MZX_ERR_INVALID; }
+  int gx = 0, gy = 0, lds = 0;
+  for (int q = 0; q < n; ++q) { gx = std::max(gx, sh[q].groups); gy = std::max(gy, sh[q].nsplit); lds = std::max(lds, sh[q].lds); }
+  static std::atomic<uint64_t> lds_attr_done[RB_MULTI_MT + 1];
+  if (const int ae = allow_large_lds((const void*)fn, RB_LDS_MAX, lds_attr_done[sh[0].MT])) {
+    set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
+    return MZX_ERR_RUNTIME;
+  }
+  void* params[] = {(void*)&m};
+  const hipError_t e = hipLaunchKernel((const void*)fn, dim3(gx, gy, n), dim3(RB_THREADS), params, (size_t)lds, stream);
+  if (e != hipSuccess) { set_error("grouped GEMM launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
+  return MZX_OK;
+}
+
+// Whole head chains in one launch (rb_gemm_chain_kernel).  A chain qualifies when its first layer's launch shape is one
+// workgroup column of whole samples and every later layer fits the same samples per workgroup (rb_chain_shape).
+typedef void (*RbGemmChainFn)(const RbGemmChain);
+inline RbGemmChainFn rb_pick_chain(int mt) {
+  switch (mt) {
+    case 1: return rb_gemm_chain_kernel<1, 1>;
+    case 2: return rb_gemm_chain_kernel<2, 1>;
+    case 3: return rb_gemm_chain_kernel<3, 1>;
+    case 4: return rb_gemm_chain_kernel<4, 1>;
+    default: return nullptr;
+  }
+}
+
+int rb_launch_gemm_chain(const RbGemmChain& m, int n, int mt, int groups, int lds, stream_t stream) {
+  RbGemmChainFn fn = rb_pick_chain(mt);
+  if (!fn) { set_error("head chain launch: no instantiation"); return MZX_ERR_INVALID; }
+  static std::atomic<uint64_t> lds_attr_done[RB_MULTI_MT + 1];
+  if (const int ae = allow_large_lds((const void*)fn, RB_LDS_MAX, lds_attr_done[mt])) {
+    set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
+    return MZX_ERR_RUNTIME;
+  }
+  void* params[] = {(void*)&m};
+  const hipError_t e = hipLaunchKernel((const void*)fn, dim3(groups, 1, n), dim3(RB_THREADS), params, (size_t)lds, stream);
+  if (e != hipSuccess) { set_error("head chain launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
   return MZX_OK;
 }
 
@@ -1332,17 +1102,50 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
   // tower runs as a tower with its tail at this batch (the tail convolution then writes the chain's input into the
   // private region behind the temporaries, where nothing can overwrite it)
   const char* tail_env0 = getenv("MZX_RB_TAIL");
-  const char* heads_env = getenv("MZX_RB_HEADS");
   const bool tails_on = !(tail_env0 && atoi(tail_env0) == 0);
   bool chain_on[RB_HEADS_MAX_CHAINS] = {false, false, false};
   int chains_on = 0;
   float* head_region = nb.workspace + net->act_floats * net->n_temp * (int64_t)batch;
-  if (count == (int)prog.size() && tails_on && !net->rb_no_towers && heads_env && atoi(heads_env) == 1)
+  // MZX_RB_HEADS: 0 one launch per Linear layer; 2 ONE MFMA launch per chain LEVEL (rb_gemm_multi_kernel: the k-th layers of
+  // all chains); 3 ONE MFMA launch for all chains and levels (rb_gemm_chain_kernel; chains it cannot take: as 2) -- the
+  // same arithmetic as mode 0 both; 1 all chains in one VALU launch (rb_heads_kernel, measured slower)
+  const int heads_mode = rb_heads_mode();
+  if (count == (int)prog.size() && tails_on && !net->rb_no_towers && heads_mode >= 1 && heads_mode <= 3)
     for (int q = 0; q < R.heads.n_chains; ++q) {
       const RbHeadChain& hc = R.heads.chain[q];
       const int t = R.ops[hc.conv_op].tower_of_tail;
       if (t >= 0 && rb_tower_use(R.towers[t], batch)) { chain_on[q] = true; ++chains_on; }
     }
+  // the arguments of GEMM operator k (x_private / y_private: a head chain's input / inner output in the private region
+  // behind the temporaries instead of the program's buffers -- same strides)
+  auto gemm_args = [&](int k, const float* x_private, float* y_private) {
+    const OpDesc& d = prog[k];
+    const RbOp& o = R.ops[k];
+    RbGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = tensor(d.in, (int64_t)o.cin * o.hin * o.win, o.in_layout);
+    if (x_private) { a.x.p = x_private; a.x.node = nullptr; a.x.nodes = 1; }
+    if (d.res != -100) a.res = tensor(d.res, (int64_t)o.cout * o.hout * o.wout, o.res_layout);
+    a.y = y_private ? y_private : resolve(net, nb, d.out, batch);
+    a.y_sstride = (int64_t)o.cout * o.hout * o.wout;
+    a.y_layout = o.out_layout;
+    a.wpack = der + o.w_off;
+    if (d.kind == OP_CONV3 && d.bn.channels) { a.alpha = der + d.bn.alpha; a.beta = der + d.bn.beta; }
+    if (d.kind != OP_CONV3) a.bias = flat + d.b;   // 1x1 heads, Linear, DownsampleCNN convolutions
+    if (o.asum_off >= 0) { a.asum = der + o.asum_off; a.action = nb.action; a.num_actions = net->cfg.action_space_size; }
+    a.batch = batch;
+    a.cin = o.cin; a.cout = o.cout; a.hin = o.hin; a.win = o.win; a.hout = o.hout; a.wout = o.wout;
+    a.stride = o.stride; a.taps = o.taps; a.ksize = o.ksize; a.pad = o.pad;
+    a.T = o.T; a.th = o.th; a.tw = o.tw; a.tiles_x = o.tiles_x; a.tiles_y = o.tiles_y; a.PH = o.PH; a.PW = o.PW;
+    a.Cs = o.Cs; a.cpg = o.cpg; a.phases = o.phases; a.cchunks = o.cchunks; a.wchunks = o.wchunks;
+    a.rows = o.rows; a.mtiles = o.mtiles; a.ntiles = o.ntiles; a.act = o.act;
+    a.x_vec = (o.in_layout == RB_NHWC && o.cin % 4 == 0 && a.x.sstride % 4 == 0 && ((uintptr_t)a.x.p % 16) == 0) ? 1 : 0;
+    a.y_vec = (o.out_layout == RB_NHWC && o.cout % 4 == 0 && a.y_sstride % 4 == 0 && ((uintptr_t)a.y % 16) == 0) ? 1 : 0;
+    a.r_vec = (a.res.p && o.res_layout == RB_NHWC && o.cout % 4 == 0 && a.res.sstride % 4 == 0 && ((uintptr_t)a.res.p % 16) == 0) ? 1 : 0;
+    a.magic_thw = rb_magic(o.th * o.tw); a.magic_tw = rb_magic(o.tw);
+    a.magic_phw = rb_magic(o.PH * o.PW); a.magic_pw = rb_magic(o.PW);
+    return a;
+  };
   for (int k = 0; k < count; ++k) {
     const OpDesc& d = prog[k];
     const RbOp& o = R.ops[k];
@@ -1389,28 +1192,7 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
       continue;
     }
     if (o.kind == RB_GEMM) {
-      RbGemmArgs a;
-      memset(&a, 0, sizeof(a));
-      a.x = tensor(d.in, (int64_t)o.cin * o.hin * o.win, o.in_layout);
-      if (d.res != -100) a.res = tensor(d.res, (int64_t)o.cout * o.hout * o.wout, o.res_layout);
-      a.y = resolve(net, nb, d.out, batch);
-      a.y_sstride = (int64_t)o.cout * o.hout * o.wout;
-      a.y_layout = o.out_layout;
-      a.wpack = der + o.w_off;
-      if (d.kind == OP_CONV3 && d.bn.channels) { a.alpha = der + d.bn.alpha; a.beta = der + d.bn.beta; }
-      if (d.kind != OP_CONV3) a.bias = flat + d.b;   // 1x1 heads, Linear, DownsampleCNN convolutions
-      if (o.asum_off >= 0) { a.asum = der + o.asum_off; a.action = nb.action; a.num_actions = net->cfg.action_space_size; }
-      a.batch = batch;
-      a.cin = o.cin; a.cout = o.cout; a.hin = o.hin; a.win = o.win; a.hout = o.hout; a.wout = o.wout;
-      a.stride = o.stride; a.taps = o.taps; a.ksize = o.ksize; a.pad = o.pad;
-      a.T = o.T; a.th = o.th; a.tw = o.tw; a.tiles_x = o.tiles_x; a.tiles_y = o.tiles_y; a.PH = o.PH; a.PW = o.PW;
-      a.Cs = o.Cs; a.cpg = o.cpg; a.phases = o.phases; a.cchunks = o.cchunks; a.wchunks = o.wchunks;
-      a.rows = o.rows; a.mtiles = o.mtiles; a.ntiles = o.ntiles; a.act = o.act;
-      a.x_vec = (o.in_layout == RB_NHWC && o.cin % 4 == 0 && a.x.sstride % 4 == 0 && ((uintptr_t)a.x.p % 16) == 0) ? 1 : 0;
-      a.y_vec = (o.out_layout == RB_NHWC && o.cout % 4 == 0 && a.y_sstride % 4 == 0 && ((uintptr_t)a.y % 16) == 0) ? 1 : 0;
-      a.r_vec = (a.res.p && o.res_layout == RB_NHWC && o.cout % 4 == 0 && a.res.sstride % 4 == 0 && ((uintptr_t)a.res.p % 16) == 0) ? 1 : 0;
-      a.magic_thw = rb_magic(o.th * o.tw); a.magic_tw = rb_magic(o.tw);
-      a.magic_phw = rb_magic(o.PH * o.PW); a.magic_pw = rb_magic(o.PW);
+      RbGemmArgs a = gemm_args(k, nullptr, nullptr);
       rc = rb_launch_gemm(a, o, batch, stream);
       if (rc) return rc;
       continue;
@@ -1451,7 +1233,69 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
     }
     if (rc) { set_error("kernel launch failed: %s", runtime_error_string(rc)); return MZX_ERR_RUNTIME; }
   }
-  if (chains_on > 0) {
+  bool chained[RB_HEADS_MAX_CHAINS] = {false, false, false};
+  if (chains_on > 0 && heads_mode == 3) {
+    // whole chains in ONE launch, where every chain's shapes allow it (rb_heads_chainable); the others level by level
+    RbGemmChain m;
+    memset(&m, 0, sizeof(m));
+    int n = 0, mt = 0, groups = 0, lds = 0;
+    for (int q = 0; q < R.heads.n_chains; ++q) {
+      const RbHeadChain& hc = R.heads.chain[q];
+      RbShape sh[RB_HEADS_MAX_LAYERS];
+      if (!chain_on[q] || n >= RB_MULTI_MAX || !rb_heads_chainable(prog, R, hc, batch, sh)) continue;
+      for (int level = 0; level < hc.count; ++level) {
+        const float* x = head_region + (level == 0 ? hc.in_off : hc.hid_off[level - 1]) * (int64_t)batch;
+        float* y = level + 1 < hc.count ? head_region + hc.hid_off[level] * (int64_t)batch : nullptr;
+        m.g[n][level] = gemm_args(hc.first + level, x, y);
+        rb_apply_shape(m.g[n][level], R.ops[hc.first + level], sh[level]);
+        mt = std::max(mt, sh[level].MT); lds = std::max(lds, sh[level].lds);
+      }
+      groups = std::max(groups, sh[0].groups);
+      m.levels[n++] = hc.count;
+      chained[q] = true;
+    }
+    if (n > 0 && mt <= RB_MULTI_MT) {
+      if (const int rc = rb_launch_gemm_chain(m, n, mt, groups, lds, stream)) return rc;
+    } else {
+      for (int q = 0; q < RB_HEADS_MAX_CHAINS; ++q) chained[q] = false;
+    }
+  }
+  if (chains_on > 0 && (heads_mode == 2 || heads_mode == 3)) {
+    for (int level = 0; level < RB_HEADS_MAX_LAYERS; ++level) {
+      RbGemmArgs args[RB_HEADS_MAX_CHAINS];
+      RbShape shapes[RB_HEADS_MAX_CHAINS];
+      int ops[RB_HEADS_MAX_CHAINS], n = 0;
+      for (int q = 0; q < R.heads.n_chains; ++q) {
+        const RbHeadChain& hc = R.heads.chain[q];
+        if (!chain_on[q] || chained[q] || level >= hc.count) continue;
+        const float* x = head_region + (level == 0 ? hc.in_off : hc.hid_off[level - 1]) * (int64_t)batch;
+        float* y = level + 1 < hc.count ? head_region + hc.hid_off[level] * (int64_t)batch : nullptr;
+        ops[n] = hc.first + level;
+        args[n] = gemm_args(ops[n], x, y);
+        shapes[n] = rb_shape_args(args[n], R.ops[ops[n]], batch);
+        ++n;
+      }
+      // one launch per (MT, NT) class of this level (every shipped configuration: one class); a class without a grouped
+      // instantiation runs its operators one by one
+      bool done[RB_HEADS_MAX_CHAINS] = {false, false, false};
+      for (int q = 0; q < n; ++q) {
+        if (done[q]) continue;
+        RbGemmMulti m;
+        memset(&m, 0, sizeof(m));
+        RbShape sh[RB_MULTI_MAX];
+        int member[RB_MULTI_MAX], members = 0;
+        for (int z = q; z < n; ++z)
+          if (!done[z] && shapes[z].MT == shapes[q].MT && shapes[z].NT == shapes[q].NT) {
+            m.g[members] = args[z]; sh[members] = shapes[z]; member[members++] = z; done[z] = true;
+          }
+        int rc = MZX_OK;
+        if (members > 1 && rb_pick_multi(sh[0].MT, sh[0].NT)) rc = rb_launch_gemm_multi(m, sh, members, stream);
+        else
+          for (int z = 0; z < members && !rc; ++z) rc = rb_launch_gemm(args[member[z]], R.ops[ops[member[z]]], batch, stream);
+        if (rc) return rc;
+      }
+    }
+  } else if (chains_on > 0) {
     RbHeadsArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.batch = batch;

@@ -10,6 +10,7 @@
 // L2 / HBM between layers in a position-major (NHWC) layout.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -71,17 +72,30 @@ constexpr int RB_TAIL_MAX_R = 8;
 // ALL chains of a program in ONE launch at its end.  A chain qualifies when its input is written by a tower's tail
 // (which then writes it into a private region of the workspace: nothing else can overwrite it before the end of the
 // program) and its layers are at most RB_HEADS_MAX_WIDTH wide.
+// How the chains run (env MZX_RB_HEADS, read per call): 0 one rb_gemm_kernel launch per layer; 2 (default) one
+// rb_gemm_multi_kernel launch per LEVEL -- the k-th layers of all chains as blockIdx.z slices, inputs and inner outputs in
+// the private region; 3 rb_gemm_chain_kernel, all chains and levels in one launch; 1 rb_heads_kernel on the vector ALUs.
+// 0 / 2 / 3 run the same kernel body on the same shapes' channel groups: the same bits.  Measured (connect4, 512 samples):
+// 0.292 / 0.269 / 0.290 / 0.30 ms per recurrent_inference for 0 / 2 / 3 / 1 (profiles/r04_tower_experiments.txt section 10).
+constexpr int RB_HEADS_MODE_DEFAULT = 2;
+inline int rb_heads_mode() {
+  const char* e = getenv("MZX_RB_HEADS");
+  const int m = e ? atoi(e) : RB_HEADS_MODE_DEFAULT;
+  return (m >= 0 && m <= 3) ? m : RB_HEADS_MODE_DEFAULT;
+}
+constexpr int RB_MULTI_MT = 4;     // grouped / chained launches are instantiated for NT = 1, MT <= 4 (head layers: <1,1> or <2,1>)
 constexpr int RB_HEADS_MAX_CHAINS = 3, RB_HEADS_MAX_LAYERS = 3, RB_HEADS_MAX_WIDTH = 128, RB_HEADS_MAX_IN = 1024;
 struct RbHeadChain {
   int32_t conv_op = -1;      // the tail convolution that writes the chain's input
   int32_t first = -1, count = 0;   // its Linear operators (consecutive in the program)
   int32_t in_features = 0;
   int64_t in_off = 0;        // per-sample offset of its input inside the private region
+  int64_t hid_off[RB_HEADS_MAX_LAYERS] = {0, 0, 0};   // ... of its inner outputs (grouped launches: one level of all chains at a time)
 };
 struct RbHeads {
   int32_t n_chains = 0;
   RbHeadChain chain[RB_HEADS_MAX_CHAINS];
-  int64_t floats_per_sample = 0;   // private region: the chains' inputs
+  int64_t floats_per_sample = 0;   // private region: the chains' inputs and inner outputs
 };
 
 struct RbProgram {

@@ -207,17 +207,20 @@ int mzx_net_streamed_heads(const mzx_net* net, int32_t recurrent, int32_t batch,
   const RbProgram& R = recurrent ? net->rb.recurrent : net->rb.initial;
   if (!net->rb.ok || !R.ok) return MZX_OK;
   const char* tail_env = getenv("MZX_RB_TAIL");
-  const char* heads_env = getenv("MZX_RB_HEADS");
-  if (net->rb_no_towers || (tail_env && atoi(tail_env) == 0) || !(heads_env && atoi(heads_env) == 1)) return MZX_OK;
+  const int mode = rb_heads_mode();
+  if (net->rb_no_towers || (tail_env && atoi(tail_env) == 0) || mode == 0) return MZX_OK;
+  // out: [0] Linear operators that leave the layer-by-layer path, [1] chains, [2 .. 13] the operators, [14] their levels
+  // inside their chains (2 bits each), [15] the mode (rb_heads_mode)
   int n = 0;
   for (int q = 0; q < R.heads.n_chains; ++q) {
     const RbHeadChain& hc = R.heads.chain[q];
     const int t = R.ops[hc.conv_op].tower_of_tail;
     if (t < 0 || !rb_tower_use(R.towers[t], batch)) continue;
     ++out[1];
-    for (int l = 0; l < hc.count && n < 13; ++l) out[2 + n++] = hc.first + l;
+    for (int l = 0; l < hc.count && n < 12; ++l) { out[14] |= l << (2 * n); out[2 + n++] = hc.first + l; }
   }
   out[0] = n;
+  out[15] = n ? mode : 0;
   return MZX_OK;
 }
 
@@ -455,19 +458,19 @@ int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_
   }
   if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) {
     if (row_search_preferred(s)) {      // a wide network at a large shard: trunks as towers between the row-per-tree kernels
-      s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel (streamed FP32-MFMA trunks and layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
+      s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel / mzx::rb_gemm_multi_kernel (streamed FP32-MFMA trunks, layers, head MLP levels) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
       return search_run_rows(s, io, d_arena, (stream_t)stream, nullptr, true);
     }
     return rz_search_run(s, io, d_arena, (stream_t)stream);
   }
   if ((s->mode & 1) && rb_enabled(s->net, true) && row_search_supported(s->p)) {
-    s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel (streamed FP32-MFMA trunks and layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
+    s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel / mzx::rb_gemm_multi_kernel (streamed FP32-MFMA trunks, layers, head MLP levels) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
     return search_run_rows(s, io, d_arena, (stream_t)stream);   // (renames last_kernel when it runs two half-shards)
   }
 #endif
   s->last_kernel = "one kernel per step of a simulation (select / network / expand + back-propagate)";
 #ifndef MZX_HOSTCHECK
-  if (rb_enabled(s->net, true)) s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel (streamed FP32-MFMA trunks and layers) between one-thread-per-tree kernels";
+  if (rb_enabled(s->net, true)) s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel / mzx::rb_gemm_multi_kernel (streamed FP32-MFMA trunks, layers, head MLP levels) between one-thread-per-tree kernels";
 #endif
   return search_run_generic(s, io, d_arena, (stream_t)stream);
 }
@@ -494,13 +497,13 @@ int mzx_search_run_from_roots(mzx_search* s, const mzx_search_io* io, const floa
   }
   if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) {
     if (row_search_preferred(s)) {
-      s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel (streamed FP32-MFMA trunks and layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
+      s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel / mzx::rb_gemm_multi_kernel (streamed FP32-MFMA trunks, layers, head MLP levels) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
       return search_run_rows(s, io, d_arena, (stream_t)stream, &ov, true);
     }
     return rz_search_run(s, io, d_arena, (stream_t)stream, &ov);
   }
   if ((s->mode & 1) && rb_enabled(s->net, true) && row_search_supported(s->p)) {
-    s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel (streamed FP32-MFMA trunks and layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
+    s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel / mzx::rb_gemm_multi_kernel (streamed FP32-MFMA trunks, layers, head MLP levels) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
     return search_run_rows(s, io, d_arena, (stream_t)stream, &ov);
   }
 #endif

@@ -366,11 +366,42 @@ inline void rb_find_heads(const std::vector<OpDesc>& prog, RbProgram& R) {
       c.conv_op = m; c.first = first; c.count = count; c.in_features = prog[first].in_features;
       c.in_off = R.heads.floats_per_sample;
       R.heads.floats_per_sample += (c.in_features + 3) & ~3;
+      for (int l = 0; l + 1 < count; ++l) {
+        c.hid_off[l] = R.heads.floats_per_sample;
+        R.heads.floats_per_sample += (prog[first + l].out_features + 3) & ~3;
+      }
       R.ops[m].head_chain = R.heads.n_chains;
       for (int q = first; q < first + count; ++q) R.ops[q].head_chain = R.heads.n_chains;
       ++R.heads.n_chains;
     }
   }
+}
+
+// Launch shapes of a head chain's layers for rb_gemm_chain_kernel (one workgroup keeps its samples through all levels):
+// the first layer's own shape when that is whole samples and one workgroup column; the later layers with the SAME samples
+// per workgroup, all column tiles in the workgroup (one per wave: at most eight).  Channel groups as planned (one phase),
+// so the sums are the layer launches'.
+inline bool rb_heads_chainable(const std::vector<OpDesc>& prog, const RbProgram& R, const RbHeadChain& hc, int batch, RbShape* sh) {
+  if (hc.count < 1 || hc.count > RB_HEADS_MAX_LAYERS) return false;
+  for (int l = 0; l < hc.count; ++l) {
+    const RbOp& o = R.ops[hc.first + l];
+    if (o.kind != RB_GEMM || o.tiles_x * o.tiles_y != 1 || o.th * o.tw != 1 || o.phases != 1 || o.ntiles > 8) return false;
+    if (l == 0) {
+      sh[0] = rb_choose_shape(o, batch);
+      if (sh[0].nsplit != 1 || sh[0].NT != 1 || sh[0].rowsplit != 0 || sh[0].phases != 1) return false;
+      continue;
+    }
+    RbShape c{};
+    c.T = sh[0].T; c.rows = c.T; c.mtiles = (c.rows + 15) / 16;
+    c.lds = (int)rb_lds_bytes(c.T, c.mtiles, c.T * o.PH * o.PW, o.Cs);
+    c.groups = sh[0].groups;
+    c.ntiles_wg = o.ntiles; c.nsplit = 1; c.NT = 1;
+    c.WN = std::min(8, (int)o.ntiles); c.WM = std::max(1, std::min(8 / c.WN, c.mtiles)); c.MT = (c.mtiles + c.WM - 1) / c.WM;
+    c.cpg = o.cpg; c.phases = o.phases; c.Cs = o.Cs; c.rowsplit = 0; c.splits = 1; c.PH = o.PH;
+    if (c.lds > RB_LDS_MAX) return false;
+    sh[l] = c;
+  }
+  return true;
 }
 
 // Two half-shards on two streams (mzx_row_search.h): size of the FIRST half for a shard of `batch` trees, 0 = the shard

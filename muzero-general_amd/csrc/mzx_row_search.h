@@ -208,7 +208,7 @@ inline int search_run_rows(mzx_search* s, const mzx_search_io* io, void* d_arena
     if (s->side_stream) parts = 2;
   }
   if (parts == 2)
-    s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel (streamed FP32-MFMA trunks and layers) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel, two half-shards on two streams";
+    s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel / mzx::rb_gemm_multi_kernel (streamed FP32-MFMA trunks, layers, head MLP levels) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel, two half-shards on two streams";
   const bool wide = s->p.num_actions > FUSED_ROW || 2 * s->p.support_size + 1 > 2 * FUSED_ROW;
   const int aw = wide ? 0 : (s->p.num_actions <= 4 ? 4 : 16);
   const int F = 2 * s->p.support_size + 1, A = s->p.num_actions;

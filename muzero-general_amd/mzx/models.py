@@ -136,10 +136,14 @@ def streamed_launches(lib, handle, recurrent, batch):
     # the head MLPs that run in ONE rb_heads_kernel launch at the end of the program
     hd = (ctypes.c_int32 * 16)()
     lib.check(lib.mzx_net_streamed_heads(handle, int(bool(recurrent)), int(batch), ctypes.byref(hd)))
-    if hd[0] > 0:
+    level_of = {}       # Linear operator of a head chain -> its level (grouped launches, MZX_RB_HEADS=2 -- the default -- or 3)
+    if hd[0] > 0 and hd[15] == 1:
         in_tower.update(hd[2 + k] for k in range(hd[0]))
         out.append(dict(op=int(hd[2]), MT=0, NT=int(hd[1]), phases=1, k_loop="heads", WM=0, WN=0, T=16, nsplit=int(hd[0]),
                         cpg=0, taps=1, stride=1, in_layout=0, cin=0, cout=0))
+    elif hd[0] > 0:
+        level_of = {int(hd[2 + k]): (int(hd[14]) >> (2 * k)) & 3 for k in range(hd[0])}
+    first_gemm = len(out)
     for op in range(lib.mzx_net_num_operators(handle, int(bool(recurrent)))):
         if op in in_tower:
             continue
@@ -152,6 +156,14 @@ def streamed_launches(lib, handle, recurrent, batch):
         out.append(dict(op=op, MT=s["MT"], NT=s["NT"], phases=s["phases"], k_loop=streamed_k_loop(s["MT"], s["NT"]),
                         WM=s["WM"], WN=s["WN"], T=s["T"], nsplit=s["nsplit"], cpg=s["cpg"], taps=p["taps"],
                         stride=p["stride"], in_layout=p["in_layout"], cin=p["cin"], cout=p["cout"]))
+    # head chains: the operators of one level that share an instantiation run as slices of ONE rb_gemm_multi_kernel launch
+    # (csrc/mzx_batched.hip rb_run_program; instantiated for NT = 1, MT <= 4) -- same shapes, another entry point
+    for level in sorted(set(level_of.values())):
+        members = [l for l in out[first_gemm:] if level_of.get(l["op"]) == level]
+        for l in members:
+            same = [m for m in members if (m["MT"], m["NT"]) == (l["MT"], l["NT"])]
+            if len(same) > 1 and l["NT"] == 1 and l["MT"] <= 4:
+                l["k_loop"] += " chained" if hd[15] == 3 else " grouped"     # (3: rb_gemm_chain_kernel, opt-in A/B)
     return out
 
 

@@ -189,6 +189,18 @@ def test_tower_kernel_layer_by_layer(backend, name, B, T, monkeypatch):
         assert heads_on and heads_on[0]["NT"] == 3           # reward, value and policy chains in one launch
     for got, want in zip(o3 + r3, o1 + r1):       # the same bits: the vector kernel sums in the MFMA's order
         assert torch.equal(got, want), (name, T)
+    # grouped head launches (MZX_RB_HEADS=2: the k-th Linear layers of all chains as blockIdx.z slices of ONE
+    # rb_gemm_multi_kernel launch, inputs and inner outputs in the private region) -- the same kernel body, the same bits
+    # -- and whole chains in one launch (MZX_RB_HEADS=3: rb_gemm_chain_kernel, a workgroup keeps its samples through the
+    # levels of a chain)
+    monkeypatch.setenv("MZX_RB_HEADS", "0")
+    o5, r5 = net.initial_inference(obs), net.recurrent_inference(hid, act)
+    for mode in ("2", "3"):
+        monkeypatch.setenv("MZX_RB_HEADS", mode)
+        o4, r4 = net.initial_inference(obs), net.recurrent_inference(hid, act)
+        for got, want in zip(o4 + r4, o5 + r5):
+            assert torch.equal(got, want), (name, T, "heads mode " + mode)
+    monkeypatch.delenv("MZX_RB_HEADS")
     # and the whole inferences (heads behind the towers) against the layer-by-layer streamed path
     net.set_mode(4)
     o0, r0 = net.initial_inference(obs), net.recurrent_inference(hid, act)

@@ -46,13 +46,14 @@ def backend():
 # moves a workload onto other code paths fails HERE and has to be acknowledged (together with streamed_coverage)
 MUST_LAUNCH = {
     # trunks as towers (rb_tower_kernel): one sample (gomoku) / two to six boards (connect4) / two samples (atari) per
-    # workgroup, with the scaling and the small 1x1 head convolutions in their tails; head MLP layers: rb_gemm_kernel<1,1>
-    "gomoku-512": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring")},
-    "gomoku-1024": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring")},
-    "connect4-512": {(3, 1, 1, "tower two-sets"), (1, 1, 1, "ring")},
-    "connect4-1024": {(6, 1, 1, "tower in-place"), (1, 1, 1, "ring")},
-    "connect4-4608": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring")},
-    "connect4-9216": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring")},
+    # workgroup, with the scaling and the small 1x1 head convolutions in their tails; head MLPs: one rb_gemm_multi_kernel<1,1>
+    # launch per level (the same layers' shapes as slices)
+    "gomoku-512": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring grouped")},
+    "gomoku-1024": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring grouped")},
+    "connect4-512": {(3, 1, 1, "tower two-sets"), (1, 1, 1, "ring grouped")},
+    "connect4-1024": {(6, 1, 1, "tower in-place"), (1, 1, 1, "ring grouped")},
+    "connect4-4608": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring grouped")},
+    "connect4-9216": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring grouped")},
     # 256 trees leave a tower three-quarter-empty row tiles: its layers launch one by one
     "atari-256": {(5, 1, 1, "two-sets"), (9, 1, 2, "in-place"), (9, 2, 2, "in-place"), (6, 2, 4, "in-place"),
                   (6, 2, 2, "in-place"), (4, 1, 3, "ring"), (1, 1, 4, "ring")},

@@ -235,18 +235,37 @@ def test_tower_shapes_follow_the_calibrated_cost_model(lib):
     lib.mzx_net_destroy(h)
 
 
-def test_head_chains_are_planned_and_off_by_default(lib, monkeypatch):
-    """rb_heads_kernel (all head MLPs in one launch) is opt-in: MZX_RB_HEADS=1."""
+def test_head_chains_run_level_by_level_in_grouped_launches(lib, monkeypatch):
+    """The head MLPs behind a tower's tail: by default ONE rb_gemm_multi_kernel launch per level (MZX_RB_HEADS=2); 0 = one
+    launch per layer, 1 = rb_heads_kernel on the vector ALUs, 3 = rb_gemm_chain_kernel (both opt-in: measured slower)."""
+    from mzx import models
+
     h = _create(lib, configs.connect4())
     lib.check(lib.mzx_net_set_mode(h, 3))
     out = (ctypes.c_int32 * 16)()
     lib.check(lib.mzx_net_streamed_heads(h, 1, 512, ctypes.byref(out)))
-    assert list(out)[:2] == [0, 0]
+    assert out[0] == 6 and out[1] == 3 and out[15] == 2          # reward, value, policy: two Linear layers each
+    assert [(out[14] >> (2 * k)) & 3 for k in range(6)] == [0, 1, 0, 1, 0, 1]
+    launches = models.streamed_launches(lib, h, 1, 512)
+    heads = [l for l in launches if l["op"] in set(out[2:8])]
+    assert len(heads) == 6 and all(l["k_loop"] == "ring grouped" and (l["MT"], l["NT"]) == (1, 1) for l in heads)
+    monkeypatch.setenv("MZX_RB_HEADS", "0")
+    lib.check(lib.mzx_net_streamed_heads(h, 1, 512, ctypes.byref(out)))
+    assert list(out)[:2] == [0, 0] and out[15] == 0
+    assert all(l["k_loop"] == "ring" for l in models.streamed_launches(lib, h, 1, 512) if l["taps"] == 1)
     monkeypatch.setenv("MZX_RB_HEADS", "1")
     lib.check(lib.mzx_net_streamed_heads(h, 1, 512, ctypes.byref(out)))
-    assert out[0] == 6 and out[1] == 3                         # reward, value, policy: two Linear layers each
+    assert out[0] == 6 and out[1] == 3 and out[15] == 1
+    assert [l["k_loop"] for l in models.streamed_launches(lib, h, 1, 512) if l["taps"] == 1] == ["heads"]
     lib.check(lib.mzx_net_streamed_heads(h, 0, 512, ctypes.byref(out)))
     assert out[0] == 4 and out[1] == 2                         # initial_inference: value and policy
+    # atari: 256-channel head convolutions are GEMM launches, not tails -> no chains; tictactoe: 16 reduced channels, same
+    monkeypatch.delenv("MZX_RB_HEADS")
+    for name in ("atari", "tictactoe"):
+        h3 = _create(lib, configs.BY_NAME[name]())
+        lib.check(lib.mzx_net_streamed_heads(h3, 1, 512, ctypes.byref(out)))
+        assert out[0] == 0, name
+        lib.mzx_net_destroy(h3)
     monkeypatch.setenv("MZX_RB_TAIL", "0")                     # no tails -> nobody writes the chains' private inputs
     lib.check(lib.mzx_net_streamed_heads(h, 1, 512, ctypes.byref(out)))
     assert out[0] == 0
