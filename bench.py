@@ -355,7 +355,7 @@ def observation_stacker_leg(backend, games=64, stacked=32, iters=20):
             "algorithmic_bytes_per_launch": nbytes, "launch_ms": ms, "games": games, "stacked_observations": stacked}
 
 
-def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=False):
+def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=False, pipeline=None):
     """
     What a user of the drop-in engine sees per process -- game stepping, per-game numpy-compatible streams (native
     bank), temperature sampling and GameHistory records around one batched search per move.  Default:
@@ -364,7 +364,9 @@ def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=F
     steps.  lockstep=True: play_games, one whole shard of games searched as a thinning batch until its longest game ends
     (rounds 1-3's number, kept as the A/B).  game = "synthetic": the fixed-shape synthetic game, `moves` moves per game;
     game = "connect4" / "tictactoe": the real rules (mzx.games: per-object classes with the reference plugin surface, or
-    the batched protocol), whole games to their natural end.
+    the batched protocol), whole games to their natural end.  pipeline: config.self_play_pipeline (None = the engine's
+    default: per-object shards from 256 games on run as two slot groups that take turns on the GPU, one searched while the
+    host steps the other's Game objects; `search_share` is then search time / wall with the two overlapping).
     """
     import copy
 
@@ -372,6 +374,7 @@ def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=F
     from mzx import self_play, synthetic
 
     c = copy.copy(cfg)
+    c.self_play_pipeline = pipeline
     if game == "synthetic":
         c.max_moves = moves
         make = synthetic.make_synthetic_batched_game if batched else synthetic.make_synthetic_game
@@ -408,6 +411,7 @@ def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=F
         "wall_s": wall, "search_share": sp.stats["search_seconds"] / wall,
         "steps_per_sec_with_all_histories_as_lists": steps / (wall + (materialize if batched else 0.0)),
         "game_protocol": "batched" if batched else "reference plugin surface (B Game objects)",
+        "slot_groups": len((sp._live or {}).get("groups", ())) or 1,
     }
 
 
@@ -691,6 +695,9 @@ def main():
                 # (games/connect4.py:125-346 semantics, mzx.games), C4 network, 1024 games per process
                 c4_cfg, c4_model = c4_net
                 line["selfplay_end_to_end_connect4"] = selfplay_leg(c4_cfg, c4_model, WORKLOADS["c4"][2], 0, game="connect4")
+                # (the same with ONE slot group: search, then step every Game object, in turn -- the A/B of the pipelining)
+                line["selfplay_end_to_end_connect4"]["one_group_steps_per_sec"] = selfplay_leg(
+                    c4_cfg, c4_model, WORKLOADS["c4"][2], 0, game="connect4", pipeline=False)["steps_per_sec"]
                 line["selfplay_end_to_end_connect4_batched_game"] = selfplay_leg(c4_cfg, c4_model, WORKLOADS["c4"][2], 0,
                                                                                  batched=True, game="connect4")
                 # rounds 1-3 played whole shards in lock-step (the batch thins out while the longest game ends): the A/B

@@ -771,6 +771,7 @@ class SelfPlay:
 
     def play_games(self, temperature, temperature_threshold, render, opponent, muzero_player):
         """All ``num_games`` games of this shard in lock-step; returns their GameHistory list."""
+        self._drain_searches()
         self._live = None       # (games in progress under play_rounds end here: every game object is reset)
         if self.batched_game is not None:
             if opponent != "self" or render:
@@ -1117,6 +1118,35 @@ class SelfPlay:
             return self._rounds_batched(temperature, temperature_threshold, min_games, max_rounds)
         return self._rounds_shard(temperature, temperature_threshold, min_games, max_rounds)
 
+    def _slot_groups(self, G):
+        """
+        The slots of a shard of B ``Game`` objects as ONE group, or as TWO that take turns on the GPU: while the search of
+        one group runs (a worker thread inside the C call / the stream synchronisation, both of which release the GIL),
+        the host steps the other group's ``Game`` objects -- the Python work of the reference plugin surface (a third of
+        the wall for connect4 at 1024 games) hides behind the other half's search.  Slots are independent actors (own
+        ``Game``, own numpy stream), so which ones share a launch does not change what any of them plays.
+        ``config.self_play_pipeline``: True / False; unset = from 256 games on.
+        """
+        want = getattr(self.config, "self_play_pipeline", None)
+        if want is None:
+            want = G >= 256
+        if not want or G < 2:
+            return [(0, G)]
+        half = (G + 1) // 2
+        return [(0, half), (half, G)]
+
+    def _search_job(self, group, stacked, legal, to_play, stream):
+        """One search of a slot group (runs on the worker thread when the shard is pipelined)."""
+        device = self.model.backend.device
+        t0 = time.perf_counter()
+        if stream is not None:       # the submitting thread's device and stream (both are thread-local in torch)
+            torch.cuda.set_device(device)
+            with torch.cuda.stream(stream):
+                result = group["engine"].run(stacked, legal, to_play, True, (self.bank, group["slots"]))
+        else:
+            result = group["engine"].run(stacked, legal, to_play, True, (self.bank, group["slots"]))
+        return result, time.perf_counter() - t0
+
     def _rounds_shard(self, temperature, temperature_threshold, min_games, max_rounds):
         """``play_rounds`` through the reference plugin surface (B ``Game`` objects); bookkeeping as ``_play_shard``."""
         cfg, games = self.config, self.games
@@ -1125,7 +1155,7 @@ class SelfPlay:
         cfg_shape_is_tuple = cfg.observation_shape if isinstance(cfg.observation_shape, tuple) else shape
         live = self._live
 
-        def start(s):
+        def start(s, group):
             gh = GameHistory()
             observation = games[s].reset()
             gh.action_history.append(0)
@@ -1133,73 +1163,115 @@ class SelfPlay:
             gh.reward_history.append(0)
             gh.to_play_history.append(games[s].to_play())
             self._check_observation(observation)
-            live["batch"][s] = observation
+            group["batch"][s - group["first"]] = observation
             live["histories"][s] = gh
             live["temps"][s] = temperature
 
         if live is None:
-            live = self._live = dict(batch=numpy.empty((G,) + shape, numpy.float32), histories=[None] * G,
-                                     temps=[temperature] * G, store=None, everyone=list(range(G)))
-            for s in range(G):
-                start(s)
-            if cfg.stacked_observations > 0:
-                live["store"] = self._frame_store(G)
-                live["store"].push(live["batch"], None)
-        batch, histories, store, everyone = live["batch"], live["histories"], live["store"], live["everyone"]
+            live = self._live = dict(histories=[None] * G, temps=[temperature] * G, groups=[])
+            spans = self._slot_groups(G)
+            for first, last in spans:
+                n = last - first
+                group = dict(first=first, slots=list(range(first, last)), batch=numpy.empty((n,) + shape, numpy.float32),
+                             moved=numpy.zeros(n, numpy.int32), store=None, pending=None,
+                             engine=self.engine if len(spans) == 1 else BatchedMCTS(cfg, self.model, n))
+                live["groups"].append(group)
+                for s in group["slots"]:
+                    start(s, group)
+                if cfg.stacked_observations > 0:
+                    group["store"] = (self._frame_store(G) if len(spans) == 1 else
+                                      observations_mod.FrameStore(cfg, n, self.model.backend))
+                    group["store"].push(group["batch"], None)
+        histories, groups = live["histories"], live["groups"]
+        pipelined = len(groups) > 1
+        if pipelined and getattr(self, "_search_worker", None) is None:
+            import concurrent.futures
+            self._search_worker = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="mzx-search")
         max_moves = cfg.max_moves
-        moved = numpy.zeros(G, numpy.int32)
         finished, rounds = [], 0
-        while len(finished) < min_games and (max_rounds is None or rounds < max_rounds):
-            legal = [game.legal_actions() for game in games]
-            to_play = [game.to_play() for game in games]
-            stacked = store.stacked(None) if store is not None else batch
-            t0 = time.perf_counter()
-            result = self.engine.run(stacked, legal, to_play, True, (self.bank, everyone))
-            self.stats["search_seconds"] += time.perf_counter() - t0
-            self.stats["searches"] += G
-            self.stats["simulations"] += G * self.engine.num_simulations
-            slot_temps = live["temps"]
+
+        def submit(group):
+            slots = group["slots"]
+            legal = [games[s].legal_actions() for s in slots]
+            to_play = [games[s].to_play() for s in slots]
+            stacked = group["store"].stacked(None) if group["store"] is not None else group["batch"]
+            if pipelined:
+                device = self.model.backend.device
+                stream = torch.cuda.current_stream(device) if device.type == "cuda" else None
+                group["pending"] = self._search_worker.submit(self._search_job, group, stacked, legal, to_play, stream)
+            else:
+                group["pending"] = self._search_job(group, stacked, legal, to_play, None)
+
+        def consume(group):
+            pending, group["pending"] = group["pending"], None
+            result, seconds = pending.result() if pipelined else pending
+            slots, first, batch, moved, store = group["slots"], group["first"], group["batch"], group["moved"], group["store"]
+            n = len(slots)
+            self.stats["search_seconds"] += seconds
+            self.stats["searches"] += n
+            self.stats["simulations"] += n * group["engine"].num_simulations
+            slot_temps = live["temps"][first:first + n]
             if temperature_threshold:
-                temps = [slot_temps[s] if len(histories[s].action_history) < temperature_threshold else 0 for s in everyone]
-            elif slot_temps.count(slot_temps[0]) == G:
+                temps = [slot_temps[s - first] if len(histories[s].action_history) < temperature_threshold else 0 for s in slots]
+            elif slot_temps.count(slot_temps[0]) == n:
                 temps = slot_temps[0]
             else:
                 temps = list(slot_temps)
-            actions = self._select_actions_bank(result, everyone, temps)
+            actions = self._select_actions_bank(result, slots, temps)
             vis = result.visit_counts
             totals = vis.sum(1)
             rows = (vis / numpy.maximum(totals, 1)[:, None]).tolist()     # int / int true division, as Python's
             values = result.root_values.tolist()
             plain = bool((totals > 0).all()) and all(len(l) == A for l in result.legal_actions)
             restarted = []
-            for s in everyone:
-                game, gh, action = games[s], histories[s], actions[s]
+            for k, s in enumerate(slots):
+                game, gh, action = games[s], histories[s], actions[k]
                 observation, reward, done = game.step(action)
                 if plain:
-                    gh.child_visits.append(rows[s])
-                    gh.root_values.append(values[s])
+                    gh.child_visits.append(rows[k])
+                    gh.root_values.append(values[k])
                 else:      # illegal actions get 0, an unvisited root reports value 0 (self_play.py:496-511, :446-449)
-                    total, legal_set = int(totals[s]), set(result.legal_actions[s])
-                    gh.child_visits.append([int(vis[s][a]) / total if a in legal_set else 0 for a in cfg.action_space])
-                    gh.root_values.append(values[s] if total else 0)
+                    total, legal_set = int(totals[k]), set(result.legal_actions[k])
+                    gh.child_visits.append([int(vis[k][a]) / total if a in legal_set else 0 for a in cfg.action_space])
+                    gh.root_values.append(values[k] if total else 0)
                 gh.action_history.append(action)
                 gh.observation_history.append(observation)
                 gh.reward_history.append(reward)
                 gh.to_play_history.append(game.to_play())
                 if getattr(observation, "shape", None) != cfg_shape_is_tuple:
                     self._check_observation(observation)
-                batch[s] = observation
-                moved[s] = action
+                batch[k] = observation
+                moved[k] = action
                 if done or len(gh.action_history) > max_moves:     # self_play.py:129: the game is over
                     finished.append(gh)
                     self.finished_slots.append(s)
-                    start(s)                                       # ... and the slot's next game begins (:31-52)
-                    moved[s] = 0
-                    restarted.append(s)
+                    start(s, group)                                # ... and the slot's next game begins (:31-52)
+                    moved[k] = 0
+                    restarted.append(k)
             if store is not None:
                 store.clear_history(restarted)
                 store.push(batch, moved)
+
+        while len(finished) < min_games and (max_rounds is None or rounds < max_rounds):
+            for group in groups:
+                if group["pending"] is None:     # (a pipelined shard may hold a search from the end of the last call)
+                    submit(group)
+            for k, group in enumerate(groups):
+                consume(group)
+                # pipelined: this group's NEXT search is queued now, so that it runs while the host steps the groups
+                # after it -- unless this is known to be the last round of the call
+                if (pipelined and k + 1 < len(groups) and len(finished) < min_games
+                        and (max_rounds is None or rounds + 1 < max_rounds)):
+                    submit(group)
             rounds += 1
+        if pipelined:
+            # nothing runs on the worker between calls (the caller may load new weights): a search queued for the next
+            # round finishes here, its result waits in the group (a round is one move of EVERY slot, so the call ends on
+            # a round boundary; the slots of that group have already drawn their root noise for the next move -- in the
+            # order a lone actor draws it)
+            for group in groups:
+                if group["pending"] is not None:
+                    group["pending"].result()
         return finished
 
     def _rounds_batched(self, temperature, temperature_threshold, min_games, max_rounds):
@@ -1342,7 +1414,22 @@ class SelfPlay:
             store.reset()
         return store
 
+    def _drain_searches(self):
+        """Waits for a search a pipelined ``play_rounds`` left on the worker thread (normally none: every call drains)."""
+        for group in (self._live or {}).get("groups", ()):
+            pending = group.get("pending")
+            if pending is not None and hasattr(pending, "result"):
+                try:
+                    pending.result()
+                except Exception:
+                    pass
+
     def close_game(self):
+        self._drain_searches()
+        worker = getattr(self, "_search_worker", None)
+        if worker is not None:
+            worker.shutdown(wait=True)
+            self._search_worker = None
         if self.batched_game is not None:
             self.batched_game.close()
         for g in self.games:
