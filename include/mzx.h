@@ -133,10 +133,13 @@ int mzx_net_streamed_shape(const mzx_net* net, int32_t recurrent, int32_t op, in
  * tower are not launched one by one (mzx_net_streamed_shape still describes what the layer-by-layer path would do). */
 int mzx_net_streamed_tower(const mzx_net* net, int32_t recurrent, int32_t index, int32_t batch, int32_t out[16]);
 /* HEADS: the Linear chains behind the small 1x1 head convolutions (dynamics fc, prediction fc_value / fc_policy,
- * models.py:379-433) CAN run in ONE launch of rb_heads_kernel at the end of a program when their tower runs with its
- * tail: MZX_RB_HEADS=1.  Off by default -- on the vector ALUs it measured slower than the one rb_gemm_kernel (MFMA)
- * launch per layer it replaces.  out = {Linear operators covered at `batch` samples, chains, their
- * operator indices ...}; all zero when off or when no chain qualifies. */
+ * models.py:379-433), when their tower runs with its tail, leave the one-launch-per-layer path: by default the k-th
+ * layers of all chains run as slices of ONE rb_gemm_multi_kernel launch per level (env MZX_RB_HEADS=2; the layer
+ * kernel's own body and shapes: the same bits); MZX_RB_HEADS=0 one rb_gemm_kernel launch per layer, =3 one
+ * rb_gemm_chain_kernel launch for all chains and levels, =1 rb_heads_kernel on the vector ALUs (3 and 1 measured slower,
+ * DESIGN.md 4.10).  out = {[0] Linear operators covered at `batch` samples, [1] chains, [2..13] their operator indices,
+ * [14] their levels inside their chains (2 bits each, operator k at bits 2k), [15] the mode in effect}; all zero when
+ * off or when no chain qualifies. */
 int mzx_net_streamed_heads(const mzx_net* net, int32_t recurrent, int32_t batch, int32_t out[16]);
 /* The row-per-tree search runs large shards as two half-shards on two HIP streams (csrc/mzx_row_search.h; from 1024
  * trees, and only when both halves keep the channel groups -- the summation order -- of the undivided launch):
