@@ -110,6 +110,26 @@ def test_whole_game_matches_reference(backend, name):
     common.test_whole_game_matches_reference(backend, name)
 
 
+@pytest.mark.parametrize("protocol", ["per-object", "per-object-pipelined", "batched"])
+def test_refilled_slots_equal_lone_actors_on_device(backend, protocol):
+    """SelfPlay.play_rounds on the device (tests/test_selfplay_refill.py runs the host logic on the CPU double): slot s's
+    games = a lone actor's seeded seed + s, also when two slot groups take turns on the GPU (a worker thread launches the
+    searches on the submitting thread's stream while the main thread steps the other group and pushes its frames)."""
+    import test_selfplay_refill as refill
+
+    refill.test_refill_with_stacked_observations_and_fixed_length_games(backend, protocol)
+
+
+@pytest.mark.parametrize("protocol", ["per-object", "per-object-pipelined", "batched"])
+@pytest.mark.parametrize("name", ["tictactoe", "tictactoe-threshold", "connect4"])
+def test_refilled_board_game_slots_equal_lone_actors_on_device(backend, name, protocol):
+    """The same contract with the real rules and residual networks (ragged game lengths, temperature threshold): a
+    tree's arithmetic does not depend on how many trees share the launch."""
+    import test_selfplay_refill as refill
+
+    refill.test_slot_games_equal_a_lone_actor_s_sequence(backend, name, protocol)
+
+
 def _tree_invariants(cfg, res, S):
     assert (res.visit_counts.sum(1) == S).all()          # every simulation passes the root once
     assert (res.visit_counts >= 0).all()
