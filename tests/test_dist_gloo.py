@@ -11,6 +11,7 @@ import socket
 import sys
 
 import numpy
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -112,7 +113,7 @@ class _ListBuffer:
             shared_storage.set_info("num_played_steps", self.steps)
 
 
-def _actor_worker(rank, world, port, out_dir):
+def _actor_worker(rank, world, port, out_dir, pipeline=False):
     for p in (os.path.join(ROOT, "muzero-general_amd"), ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -130,6 +131,7 @@ def _actor_worker(rank, world, port, out_dir):
     cfg.ratio = None
     cfg.self_play_delay = 0
     cfg.PER, cfg.PER_alpha, cfg.td_steps = True, 0.5, 9      # games/tictactoe.py:87-96
+    cfg.self_play_pipeline = bool(pipeline)   # True: two slot groups take turns, searches on a worker thread (SelfPlay._slot_groups)
     G = 3
     template = models.MuZeroNetwork(cfg, _backend=be).state_dict()
     wa, wb = synthetic.fill_state_dict(template, 1), synthetic.fill_state_dict(template, 2)
@@ -165,9 +167,10 @@ def _actor_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_continuous_self_play_two_ranks_with_midrun_weight_update(tmp_path):
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_continuous_self_play_two_ranks_with_midrun_weight_update(tmp_path, pipeline):
     world, port = 2, _free_port()
-    mp.spawn(_actor_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_actor_worker, args=(world, port, str(tmp_path), pipeline), nprocs=world, join=True)
     r = [torch.load(tmp_path / f"actor{k}.pt", weights_only=False) for k in range(world)]
     # disjoint game shards, seeded like the reference's workers (muzero.py:185)
     assert r[0]["seeds"] == [0, 1, 2] and r[1]["seeds"] == [3, 4, 5]
