@@ -365,7 +365,7 @@ def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=F
     (rounds 1-3's number, kept as the A/B).  game = "synthetic": the fixed-shape synthetic game, `moves` moves per game;
     game = "connect4" / "tictactoe": the real rules (mzx.games: per-object classes with the reference plugin surface, or
     the batched protocol), whole games to their natural end.  pipeline: config.self_play_pipeline (None = the engine's
-    default: per-object shards from 256 games on run as two slot groups that take turns on the GPU, one searched while the
+    default: per-object shards from 1024 games on run as two slot groups that take turns on the GPU, one searched while the
     host steps the other's Game objects; `search_share` is then search time / wall with the two overlapping).
     """
     import copy

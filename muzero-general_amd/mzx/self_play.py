@@ -1125,11 +1125,13 @@ class SelfPlay:
         the host steps the other group's ``Game`` objects -- the Python work of the reference plugin surface (a third of
         the wall for connect4 at 1024 games) hides behind the other half's search.  Slots are independent actors (own
         ``Game``, own numpy stream), so which ones share a launch does not change what any of them plays.
-        ``config.self_play_pipeline``: True / False; unset = from 256 games on.
+        ``config.self_play_pipeline``: True / False; unset = from 1024 games on -- each half must still fill the chip: the
+        residual whole-search kernels run a workgroup per tree or pair of trees, so a search of fewer than ~512 trees takes as
+        long as one of 512 and two half searches would cost more than they hide.
         """
         want = getattr(self.config, "self_play_pipeline", None)
         if want is None:
-            want = G >= 256
+            want = G >= 1024
         if not want or G < 2:
             return [(0, G)]
         half = (G + 1) // 2
