@@ -149,3 +149,29 @@ def test_continuous_self_play_refills_by_default(backend):
     moves = sum(len(g.action_history) - 1 for g in buf.games)
     assert actor.stats["searches"] >= moves                   # (games in progress at the stop are not handed out)
     assert all(g.priorities is not None or not getattr(cfg, "PER", False) for g in buf.games)
+
+
+def test_two_slot_groups_play_what_one_group_plays(backend):
+    """A whole shard, several calls (so that a call ends with a search queued for the next round), stacked observations:
+    two slot groups taking turns hand out, slot by slot, the games one group hands out."""
+    def run(pipeline, B=96):
+        cfg = configs.cartpole(num_simulations=6, max_moves=9, stacked_observations=2)
+        cfg.self_play_pipeline = pipeline
+        Game = synthetic.make_synthetic_game(cfg.observation_shape, len(cfg.action_space), len(cfg.players))
+        weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 3)
+        shard = self_play.SelfPlay({"weights": weights}, Game, cfg, 7, num_games=B, _backend=backend)
+        by_slot = {}
+        for min_games in (1, 40, 40, 150):       # calls that end in the middle of the games of most slots
+            for gh, slot in zip(shard.play_rounds(0.7, None, min_games=min_games), shard.finished_slots):
+                by_slot.setdefault(slot, []).append(gh)
+        groups = len(shard._live["groups"])
+        shard.close_game()
+        return by_slot, groups, shard.stats["searches"]
+
+    one, g1, s1 = run(False)
+    two, g2, s2 = run(True)
+    assert (g1, g2) == (1, 2) and s1 == s2 and one.keys() == two.keys()
+    for slot in one:
+        assert len(one[slot]) == len(two[slot])
+        for a, b in zip(one[slot], two[slot]):
+            _same(a, b, slot)
