@@ -61,8 +61,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # dense FP32-input MFMA peak (= FP32 vector peak),
 
 # workloads that choose their network engine themselves (unless --net-mode says otherwise)
 WORKLOAD_NET_MODE = {"c4-large": "streamed"}
-# workloads that run with an environment knob of the library set (A/B legs)
-WORKLOAD_ENV = {"c4-ws": {"MZX_SEARCH_STREAMED_MIN": "0"}}
+# workloads that run with entries of the library's tuning table moved (include/mzx.h "Tuning": the A/B legs)
+WORKLOAD_TUNING = {"c4-ws": {"wide_towers": 0}, "c4-rows": {"rt_search": 0}}
 DEFAULT_WORKLOAD = "c2"
 # measured in the same invocation and reported under "workloads" when the main workload is the default one.  Every
 # launch the streamed ones make (c4-large, gomoku, atari) is parity-tested at size: tests/test_streamed_coverage.py
@@ -76,6 +76,7 @@ WORKLOADS = {
     # kernels --, which overtook the LDS-resident whole-search kernel; "c4-ws" is the same workload on that kernel)
     "c4": ("connect4", {}, 1024, "C4 Connect4 ResNet, 1024 trees x 200 sims per GPU"),
     "c4-ws": ("connect4", {}, 1024, "C4 Connect4 ResNet, 1024 trees x 200 sims per GPU, LDS-resident whole-search kernel (A/B)"),
+    "c4-rows": ("connect4", {}, 1024, "C4 Connect4 ResNet, 1024 trees x 200 sims per GPU, per-simulation launches (A/B)"),
     # the same network and search at a shard large enough for layer-by-layer launches: from ~3000 trees per GPU the
     # streamed MFMA engine + row-per-tree kernels overtake the LDS-resident whole-search kernel (0.60 against 0.53 of
     # the FP32 MFMA peak, profiles/r03_streamed_experiments.txt section 10)
@@ -111,6 +112,8 @@ def parse():
     ap.add_argument("--selfplay-moves", type=int, default=32,
                     help="moves per game of the end-to-end self-play legs (SelfPlay(num_games=B) on the synthetic game; "
                          "0 = skip); the games of the path's configurations run for hundreds of moves (cartpole: 500)")
+    ap.add_argument("--tuning", default="",
+                    help="name=value,... entries of the library's tuning table (include/mzx.h) for this run (A/B measurements)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CI plumbing check on the CPU (gloo + tests/hostcheck); not a measurement")
     return ap.parse_args()
@@ -424,8 +427,6 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     from mzx import configs, models, self_play, shared_storage, synthetic
 
     name, overrides, default_trees, description = WORKLOADS[workload]
-    for k, v in WORKLOAD_ENV.get(workload, {}).items():      # (read by the library per call; removed again below)
-        os.environ[k] = v
     cfg = configs.BY_NAME[name](**overrides)
     B = trees or default_trees
     if B != default_trees:       # --trees: the label follows what ran
@@ -461,6 +462,11 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         fused_kind = 0
     fused = fused_kind == 1
     be, lib = engine.backend, engine.backend.lib
+    tuning = dict(WORKLOAD_TUNING.get(workload, {}))
+    tuning.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tuning.split(",") if kv})
+    tuning_saved = {k: lib.tuning_get(k) for k in tuning}
+    for k, v in tuning.items():      # (restored below)
+        lib.tuning_set(k, v)
 
     # synthetic inputs, resident in HBM: a few distinct input sets rotated over the steps
     c_in = cfg.observation_shape[0] * (cfg.stacked_observations + 1) + cfg.stacked_observations
@@ -538,13 +544,13 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     block_rates = [world * B * S * steps / b[0] for b in blocks]
 
     # sanity: the timed work is real (every tree ran S simulations, no flags)
-    for _, out, _ in sets[: min(n_sets, max(steps, warmup, 1))]:
+    for _, out, _ in sets[: 0 if tuning.get("rt_dbg") else min(n_sets, max(steps, warmup, 1))]:
         visits, info = out["visits"].cpu().numpy(), out["info"].cpu().numpy()
         assert (visits.sum(1) == S).all(), "a tree did not complete its simulations"
         assert (info[:, 1] == 0).all(), "search flagged an overflow"
     mean_leaf_depth = float(sets[0][1]["info"].cpu().numpy()[:, 3].mean() / S)
-    for k in WORKLOAD_ENV.get(workload, {}):
-        os.environ.pop(k, None)
+    for k, v in tuning_saved.items():
+        lib.tuning_set(k, v)
     if rank != 0:
         return None, cfg, net
 

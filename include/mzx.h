@@ -44,6 +44,28 @@ const char* mzx_last_error(void);
 int mzx_is_device_build(void);
 
 /* ------------------------------------------------------------------------- *
+ * Tuning: the library's routing / launch-shape choices as ONE process-wide table of named integers
+ * (csrc/mzx_tuning.h), in place of environment variables.  No entry changes WHAT is computed (the reference
+ * has no counterpart: it has one code path); the defaults are the measured best, tests
+ * and bench.py move them for A/B runs.  Set a value before the calls it should affect, from the calling thread.
+ *   rb_heads       head MLP levels of the streamed engine: 0 one launch per Linear layer, 2 one grouped launch per level
+ *   rb_tail        1: per-plane scaling / small 1x1 head convolutions run inside the tower launch
+ *   rb_tower_t     > 0: samples per tower workgroup (0: cost model)
+ *   row_split_min  per-simulation launches: two half-shards on two HIP streams from this many trees (0: never)
+ *   wide_towers    1: wide residual networks that would also fit the LDS-resident whole-search kernel search on the
+ *                  tower arithmetic at EVERY shard size (a tree's result must not depend on the shard it is searched
+ *                  in); 0: mzx::rz_search_kernel (the A/B)
+ *   rt_search      the tower whole-search kernel (every simulation in one launch): -1 automatic, 0 never, 1 whenever
+ *                  the network fits;  rt_trees > 0: trees per workgroup;  rt_max_trees: largest shard routed to it
+ * mzx_tuning_set / _get return MZX_ERR_INVALID for an unknown name or a value out of range; mzx_tuning_name /
+ * _help enumerate the table (NULL past its end).
+ * ------------------------------------------------------------------------- */
+int mzx_tuning_set(const char* name, int32_t value);
+int mzx_tuning_get(const char* name, int32_t* value /* nullable */, int32_t* default_value /* nullable */);
+const char* mzx_tuning_name(int32_t index);
+const char* mzx_tuning_help(int32_t index);
+
+/* ------------------------------------------------------------------------- *
  * Network: replaces models.MuZeroNetwork(config) -- models.py:7-41 (factory),
  * :80-195 (MuZeroFullyConnectedNetwork), :436-623 (MuZeroResidualNetwork).
  * Field names are the MuZeroConfig attributes the factory reads.
@@ -134,10 +156,8 @@ int mzx_net_streamed_shape(const mzx_net* net, int32_t recurrent, int32_t op, in
 int mzx_net_streamed_tower(const mzx_net* net, int32_t recurrent, int32_t index, int32_t batch, int32_t out[16]);
 /* HEADS: the Linear chains behind the small 1x1 head convolutions (dynamics fc, prediction fc_value / fc_policy,
  * models.py:379-433), when their tower runs with its tail, leave the one-launch-per-layer path: by default the k-th
- * layers of all chains run as slices of ONE rb_gemm_multi_kernel launch per level (env MZX_RB_HEADS=2; the layer
- * kernel's own body and shapes: the same bits); MZX_RB_HEADS=0 one rb_gemm_kernel launch per layer, =3 one
- * rb_gemm_chain_kernel launch for all chains and levels, =1 rb_heads_kernel on the vector ALUs (3 and 1 measured slower,
- * DESIGN.md 4.10).  out = {[0] Linear operators covered at `batch` samples, [1] chains, [2..13] their operator indices,
+ * layers of all chains run as slices of ONE rb_gemm_multi_kernel launch per level (tuning "rb_heads" = 2; the layer
+ * kernel's own body and shapes: the same bits); "rb_heads" = 0: one rb_gemm_kernel launch per layer.  out = {[0] Linear operators covered at `batch` samples, [1] chains, [2..13] their operator indices,
  * [14] their levels inside their chains (2 bits each, operator k at bits 2k), [15] the mode in effect}; all zero when
  * off or when no chain qualifies. */
 int mzx_net_streamed_heads(const mzx_net* net, int32_t recurrent, int32_t batch, int32_t out[16]);
@@ -269,6 +289,13 @@ int mzx_search_fused_supported(const mzx_search* s);
  * whole-search kernels a configuration is routed to is decided per launch (network family, board size, LDS fit). */
 const char* mzx_search_kernel_name(const mzx_search* s);
 int mzx_search_set_mode(mzx_search* s, int32_t mode);
+/* What the NEXT mzx_search_run of this handle would launch (host-side, no GPU): out[0] = 0 the generic path, 1
+ * mzx::rz_search_kernel or one of its small-board siblings, 2 per-simulation launches around the streamed engine, 3
+ * mzx::rt_search_kernel (every simulation in one launch, csrc/mzx_tower_search.hip), 4 the fully connected whole-search
+ * kernel; for 3: out[1..5] = {trees per workgroup, row tiles per wave, workgroups, workgroups per CU, LDS bytes}; for 2:
+ * out[6..7] = trees of the two half-shards (second 0: undivided). */
+int mzx_search_route(const mzx_search* s, int32_t out[8]);
+
 /* Byte offsets inside the arena (diagnostics): out[0..6] = (unused, 0), trees, hidden states,
  * network workspace, bytes per tree, workspace bytes, total bytes. */
 int mzx_search_arena_offsets(const mzx_search* s, int64_t out[8]);

@@ -27,6 +27,7 @@
 
 #include "mzx_pack.h"
 #include "mzx_resnet_batched.h"
+#include "mzx_tower.h"
 
 #ifndef MZX_RB_RING_MAX
 #define MZX_RB_RING_MAX 4   // accumulator tiles per wave up to which the K loop keeps four chunks in flight
@@ -34,18 +35,6 @@
 namespace mzx {
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int RB_THREADS = 512;
-
-struct RbTensor {
-  const float* p;
-  const int32_t* node;   // node of sample b inside [batch][nodes][sstride] (null: node 0)
-  int64_t sstride;       // floats per node
-  int32_t nodes;
-  int32_t layout;        // RbLayout
-};
 
 struct RbGemmArgs {
   RbTensor x, res;       // res.p null: no residual
@@ -69,10 +58,6 @@ struct RbGemmArgs {
   uint32_t magic_thw, magic_tw, magic_phw, magic_pw;   // ceil(2^32 / d)
   int32_t grid_x, grid_y;   // this operator's own grid (rb_gemm_multi_kernel: the launch's grid is the largest of its slices')
 };
-
-__device__ __forceinline__ int rb_div(int x, int d, uint32_t magic) {
-  return d == 1 ? x : (int)__umulhi((unsigned)x, magic);
-}
 
 // Two workgroups share a CU (their LDS tiles are planned for it, RB_LDS_BUDGET): one stages its patch or writes its
 // outputs while the other keeps the matrix pipes busy.  Four waves per SIMD = 128 registers per lane, which the
@@ -113,39 +98,6 @@ rb_gemm_multi_kernel(const RbGemmMulti m) {
 #undef RB_BY
 }
 
-// Whole head MLPs in one launch: slice blockIdx.z runs chain z, level after level; a workgroup owns the SAME samples at
-// every level (all output features of them: one workgroup column), so level l + 1 reads what this very workgroup wrote
-// at level l -- through memory (the private region), behind an agent-scope fence on both sides of the barrier (the
-// second one: a line another workgroup of the CU pulled into the L1 between a wave's fence and the barrier may hold the
-// old contents).  The same body, operator by operator: the same bits as one launch per layer.
-constexpr int RB_CHAIN_MAX_LEVELS = 3;
-struct RbGemmChain {
-  RbGemmArgs g[RB_MULTI_MAX][RB_CHAIN_MAX_LEVELS];
-  int32_t levels[RB_MULTI_MAX];
-};
-
-template <int MT, int NT>
-__global__ void __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-rb_gemm_chain_kernel(const RbGemmChain m) {
-  const int q = blockIdx.z, levels = m.levels[q];
-  if (blockIdx.x >= (unsigned)m.g[q][0].grid_x) return;
-  for (int level = 0; level < levels; ++level) {
-    const RbGemmArgs& a = m.g[q][level];
-    if (level > 0) {
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-      __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-    }
-    [&]() __attribute__((always_inline)) {
-#define RB_BX blockIdx.x
-#define RB_BY 0u
-#include "mzx_batched_gemm_body.inc"
-#undef RB_BX
-#undef RB_BY
-    }();
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // rb_tower_kernel<MT, NT>: a whole TOWER -- conv3x3 + BatchNorm + ReLU followed by residual blocks (ResidualBlock.forward,
 // models.py:213-229), i.e. the representation / dynamics / prediction trunks of MuZeroResidualNetwork -- in ONE launch.
@@ -166,40 +118,6 @@ rb_gemm_chain_kernel(const RbGemmChain m) {
 // five transfers per block of the layer-by-layer path, and pays no launch / staging / epilogue tail per layer.
 // Summation order per output: taps in order, 16-channel chunks in order, the MFMA's k order -- independent of T and of
 // the batch (two half-shards build the trees of the undivided run).
-__device__ __forceinline__ uint32_t rb_magic_dev(int d) {      // ceil(2^32 / d), as rb_magic on the host
-  return d > 1 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u;
-}
-
-struct RbTowerLayer {
-  int64_t w_off;       // derived buffer: packed B fragments (RzPackOp) of the layer
-  int64_t bn_alpha;    // derived buffer offsets of the folded BatchNorm terms (-1: none)
-  int64_t bn_beta;
-  int32_t cchunks;     // 16-channel chunks of the layer's input
-  int32_t flags;       // 1: ReLU, 2: the layer's INPUT is the residual of the next layer (keep it), 4: add the kept residual
-};
-
-struct RbTowerArgs {
-  RbTensor x;
-  float* y;
-  int64_t y_sstride;
-  const float* der;
-  const float* asum;       // first layer only: border-aware tap sums of the action plane (null: none)
-  const int32_t* action;
-  int32_t num_actions, batch;
-  int32_t cin0, C, H, W, PH, PW, Cs, cchunks, T, rows, mtiles, ntiles, WN, WM, layers, y_vec, rowskip;
-  int32_t dbg;             // latency experiments (env MZX_RB_DBG, never set in production): 1 skip the K loops, 2 skip the epilogues
-  uint32_t magic_hw, magic_w, magic_phw, magic_pw, magic_chw;
-  // ---- the tower's TAIL: operators that read nothing but the tower's output run on the LDS-resident tile before the
-  // workgroup retires (a workgroup owns whole samples, so a per-plane reduction is an intra-workgroup one)
-  int32_t write_out;       // 0: nobody else reads the tower's output -- it never goes to memory
-  float* scale_y;          // per-plane min-max scaling (models.py:527-553, :574-599; MinMaxScaleOp's arithmetic) of the output,
-  const int32_t* scale_node;   // written NCHW into the search arena's node store (null scale_y: none)
-  int64_t scale_sstride;
-  int32_t scale_nodes;
-  int32_t n_conv;          // 1x1 head convolutions with few output channels (conv1x1_reward / _value / _policy, models.py:369-433)
-  struct { const float* w; const float* b; float* y; int32_t R; int32_t pad; } conv[2];
-  RbTowerLayer layer[RB_TOWER_MAX_LAYERS];
-};
 
 template <int MT, int NT>
 __global__ void __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(MT * NT <= 4 ? 4 : 2, MT * NT <= 4 ? 4 : 2)))
@@ -304,170 +222,13 @@ rb_tower_kernel(const RbTowerArgs a) {
     }
   }
 
-  // ---- this wave's tiles: column tiles first (a disjoint slice of every layer's weights), row tiles next
-  const int wn = wave % a.WN, wm = wave / a.WN;
-  const bool active = wm < a.WM && wn * NT < a.ntiles && wm * MT < a.mtiles;
-  const int m_lane = lane & 15, g4 = 4 * (lane >> 4);
-  int ra[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int mt = wm * MT + i;
-    const bool ok = active && mt < a.mtiles;
-    ra[i] = (ok ? rowaddr[mt * 16 + m_lane] : 0) + g4;       // A operand: row m_lane of the tile, channels g4 .. g4 + 3 of a chunk
-  }
-  const int ctr = (a.PW + 1) * a.Cs;                         // from a window's top-left cell to its centre = the output cell
-  const unsigned lane4 = (unsigned)lane * 4;
-  f32x4 acc[MT][NT], res[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; res[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  __syncthreads();
-
-  const bool has_tail = a.scale_y != nullptr || a.n_conv > 0;
-  for (int l = 0; l < a.layers; ++l) {
-    const RbTowerLayer& L = a.layer[l];
-    const bool last = l + 1 == a.layers;
-    // ---- K loop: (tap, chunk) pairs, operands one chunk ahead in registers
-    if (active && !(a.dbg & 1)) {
-      const int cpl = L.cchunks, n_it = 9 * cpl;
-      const float* wp[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int nt = wn * NT + j;
-        wp[j] = a.der + L.w_off + (size_t)(nt < a.ntiles ? nt : 0) * (size_t)n_it * 256;
-      }
-      int tap = 0, cc = 0;
-      f32x4 fa0[MT], fb0[NT], fb1[NT];
-      auto load = [&](f32x4 (&fa)[MT], f32x4 (&fb)[NT]) {
-        const int aoff = tap * a.Cs + ((tap * 21846) >> 16) * a.rowskip + cc * 16;     // tap / 3 by multiply-shift
-        const size_t widx = (size_t)(tap * cpl + cc) * 256;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) fb[j] = *(const f32x4*)(wp[j] + widx + lane4);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) fa[i] = *(const f32x4*)(tile + ra[i] + aoff);
-        if (++cc == cpl) { cc = 0; ++tap; }
-      };
-      auto mma = [&](const f32x4 (&fa)[MT], const f32x4 (&fb)[NT]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][k], fa[i][k], acc[i][j], 0, 0, 0);
-      };
-      if constexpr ((MT - 1) * NT >= 5) {
-        // one set of position fragments refilled in place (rb_gemm_kernel's loop for the deep tilings)
-        auto step = [&](const f32x4 (&fbc)[NT], f32x4 (&fbn)[NT]) {
-          const int aoff = tap * a.Cs + ((tap * 21846) >> 16) * a.rowskip + cc * 16;
-          const size_t widx = (size_t)(tap * cpl + cc) * 256;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) fbn[j] = *(const f32x4*)(wp[j] + widx + lane4);
-#pragma unroll
-          for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-              for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fbc[j][k], fa0[i][k], acc[i][j], 0, 0, 0);
-#pragma unroll
-          for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fbc[j][3], fa0[i][3], acc[i][j], 0, 0, 0);
-            fa0[i] = *(const f32x4*)(tile + ra[i] + aoff);
-            __builtin_amdgcn_sched_barrier(0);     // the read goes out HERE, not next to its first use
-          }
-          if (++cc == cpl) { cc = 0; ++tap; }
-        };
-        load(fa0, fb0);
-        int it = 0;
-        for (; it + 2 < n_it; it += 2) { step(fb0, fb1); step(fb1, fb0); }
-        if (it + 1 < n_it) { step(fb0, fb1); mma(fa0, fb1); }
-        else mma(fa0, fb0);
-      } else {
-        // two fragment sets; the requests of chunk n + 1 are pinned IN FRONT of the MFMAs of chunk n (left alone, the
-        // scheduler sinks them behind: the wave then waits out the LDS / L2 latency at the top of every chunk)
-        f32x4 fa1[MT];
-        load(fa0, fb0);
-        int it = 0;
-        for (; it + 2 < n_it; it += 2) {
-          load(fa1, fb1);
-          __builtin_amdgcn_sched_barrier(0);
-          mma(fa0, fb0);
-          __builtin_amdgcn_sched_barrier(0);
-          load(fa0, fb0);
-          __builtin_amdgcn_sched_barrier(0);
-          mma(fa1, fb1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (it + 1 < n_it) {
-          load(fa1, fb1);
-          __builtin_amdgcn_sched_barrier(0);
-          mma(fa0, fb0);
-          mma(fa1, fb1);
-        } else {
-          mma(fa0, fb0);
-        }
-      }
-    }
-    __syncthreads();                                   // every wave is done reading the layer's input
-    // ---- epilogue: lane = position row m_lane of a tile, four consecutive output channels
-    if (active && !(a.dbg & 2)) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n0 = (wn * NT + j) * 16 + g4;
-        if (n0 >= a.C || (wn * NT + j) >= a.ntiles) continue;
-        float al[4], be[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bool ok = n0 + u < a.C;
-          al[u] = (L.bn_alpha >= 0 && ok) ? a.der[L.bn_alpha + n0 + u] : 1.f;
-          be[u] = (L.bn_alpha >= 0 && ok) ? a.der[L.bn_beta + n0 + u] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int mt = wm * MT + i;
-          // (position / sample of the row come from the LDS tables again: two registers per tile less in the K loop)
-          const int pos = mt < a.mtiles ? rowpos[mt * 16 + m_lane] : -1;
-          f32x4 v = acc[i][j];
-          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (pos < 0) continue;
-          const int b = b0 + rowt[mt * 16 + m_lane];
-          if (l == 0 && a.asum) {
-            const float av = (float)a.action[b] / (float)a.num_actions;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-              if (n0 + u < a.C) v[u] += av * a.asum[(size_t)(n0 + u) * HW + pos];
-          }
-          float* cell = tile + (ra[i] - g4) + ctr + n0;   // the output cell of this row, channels n0 .. n0 + 3
-          f32x4 keep = f32x4{0.f, 0.f, 0.f, 0.f};
-          if ((L.flags & 2) && !last) keep = *(const f32x4*)cell;       // the block input, before it is overwritten
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            float x = v[u];
-            if (L.bn_alpha >= 0) x = x * al[u] + be[u];
-            if (L.flags & 4) x += res[i][j][u];
-            if (L.flags & 1) x = fmaxf(x, 0.f);
-            v[u] = (n0 + u < a.C) ? x : 0.f;
-          }
-          if (L.flags & 2) res[i][j] = keep;
-          if (!last || has_tail) *(f32x4*)cell = v;
-          if (last && a.write_out) {
-            float* yp = a.y + (long long)b * a.y_sstride + (long long)pos * a.C + n0;
-            if (a.y_vec) *(f32x4*)yp = v;
-            else {
-#pragma unroll
-              for (int u = 0; u < 4; ++u)
-                if (n0 + u < a.C) yp[u] = v[u];
-            }
-          }
-        }
-      }
-    }
-    if (!last) __syncthreads();                        // the next layer reads what every wave wrote
-  }
+#define RB_TOWER_HAS_TAIL (a.scale_y != nullptr || a.n_conv > 0)
+#define RB_TOWER_ACTION(b, t) a.action[b]
+#define RB_TOWER_BRING false
+#include "mzx_tower_layers.inc"
+#undef RB_TOWER_HAS_TAIL
+#undef RB_TOWER_ACTION
+#undef RB_TOWER_BRING
   if (!has_tail) return;
   __syncthreads();                                     // the last layer's output is in the tile's interior cells
   const int in0 = (a.PW + 1) * a.Cs;                   // cell (0, 0) of a board inside its halo
@@ -526,172 +287,6 @@ rb_tower_kernel(const RbTowerArgs a) {
       for (; c < a.C; ++c) acc = fmaf(xin[c], w[c], acc);
       a.conv[q].y[(long long)b * RHW + r] = acc + a.conv[q].b[rc];
     }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// rb_heads_kernel: every head MLP of a program (dynamics fc = reward, prediction fc_value / fc_policy, models.py:379-389,
-// :418-433) in ONE launch at the end of the program.  A 256-thread workgroup takes HS samples of ONE chain through all of
-// its Linear (+ ELU) layers with the activations in LDS; an output neuron's weight row is read from L2 by one lane per k
-// (every lane walks its own row: cache lines are reused over 32 consecutive k), a lane accumulates SG samples of its
-// neuron.  Arithmetic per output = LinearOp's (mzx_ops.h): one fmaf chain over k in order, + bias, ELU on hidden layers.
-constexpr int RB_HS = 16;            // samples per workgroup
-struct RbHeadsArgs {
-  int32_t n_chains, batch;
-  int32_t in_region;       // floats of the LDS input region = RB_HS x the widest chain input (rounded to 4)
-  int32_t hid_region;      // floats of each of the two hidden-activation regions = RB_HS x the widest hidden layer (a small
-                           // footprint matters: the launch should fit BESIDE the other half-shard's tower workgroups)
-  struct Chain {
-    const float* x;        // [batch][in_stride] chain input (the tail convolution's output, channel-major)
-    float* y;              // [batch][out of the last layer]
-    int64_t in_stride;
-    int32_t n_lin, in_features;
-    struct { const float* w; const float* b; int32_t in, out, elu, pad; } lin[RB_HEADS_MAX_LAYERS];
-  } chain[RB_HEADS_MAX_CHAINS];
-};
-
-// One Linear layer for the workgroup's RB_HS samples: thread = (output neuron o, group of SG samples), SG a template
-// parameter so that the register tile acc[SG] is static.  The weights of the pass's neurons come through LDS in slabs of
-// `slab_k` inputs: the 256 threads load a slab cooperatively (16-byte pieces of the rows, coalesced) -- ONE L2 round
-// trip per slab instead of one per lane and k step (a lane walking its own row: 34 us per launch) --, the next slab is
-// requested before the current one is consumed.  Rows are pitched slab_k + 4 floats: the 16-byte reads of 16 consecutive
-// neurons fall on distinct LDS slots.  Per output one fmaf chain over k in order, as LinearOp (mzx_ops.h).
-constexpr int RB_HEADS_SLAB_FLOATS = 3328;     // 13 KB of LDS for a weight slab (64 neurons x 48 inputs + pitch)
-template <int SG>
-__device__ __forceinline__ void rb_heads_layer(const float* __restrict__ w, const float* __restrict__ bias, const float* cur,
-                                               float* nxt, float* wl, float* y, long long y_row0, int K, int O, int elu,
-                                               bool last, int ns, int tid) {
-  constexpr int groups = RB_HS / SG, per_pass = 256 / groups;
-  constexpr int row_q = RB_HEADS_SLAB_FLOATS / per_pass / 4;                 // 16-byte slots a row may take
-  constexpr int slab_k = ((row_q - 1) * 4) & ~15;                            // whole 16-input chunks: 48 at 64 neurons per pass
-  constexpr int pitch = slab_k + 4;                                          // an ODD number of slots per row: no bank conflicts
-  static_assert(slab_k >= 16, "a weight slab holds at least one 16-input chunk");
-  constexpr int PF = (per_pass * slab_k / 4 + 255) / 256;                    // 16-byte pieces per thread and slab
-  const int grp = tid / per_pass, ot = tid - grp * per_pass;
-  const float* xs = cur + (size_t)grp * SG * K;
-  const bool vec = (K & 3) == 0 && (((uintptr_t)w) & 15) == 0;
-  for (int o_base = 0; o_base < O; o_base += per_pass) {
-    const int n_o = min(per_pass, O - o_base);
-    float acc[SG];
-#pragma unroll
-    for (int u = 0; u < SG; ++u) acc[u] = 0.f;
-    // slab s = inputs [s * slab_k, ...): requested into registers, written to LDS when the previous slab is consumed
-    f32x4 pf[PF];
-    auto request = [&](int k0) {
-      const int kc = min(slab_k, K - k0), q = (kc + 3) >> 2;                 // quads per row of this slab
-#pragma unroll
-      for (int t = 0; t < PF; ++t) {
-        const int i = tid + t * 256;
-        pf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (i < n_o * q) {
-          const int r = i / q, c = (i - r * q) * 4;
-          const float* src = w + (size_t)(o_base + r) * K + k0 + c;
-          if (vec && c + 3 < kc) pf[t] = *(const f32x4*)src;
-          else {
-            pf[t][0] = src[0];
-            if (c + 1 < kc) pf[t][1] = src[1];
-            if (c + 2 < kc) pf[t][2] = src[2];
-            if (c + 3 < kc) pf[t][3] = src[3];
-          }
-        }
-      }
-    };
-    auto deposit = [&](int k0) {
-      const int kc = min(slab_k, K - k0), q = (kc + 3) >> 2;
-#pragma unroll
-      for (int t = 0; t < PF; ++t) {
-        const int i = tid + t * 256;
-        if (i < n_o * q) {
-          const int r = i / q, c = (i - r * q) * 4;
-          *(f32x4*)(wl + r * pitch + c) = pf[t];
-        }
-      }
-      // the last 16-input chunk of the layer may be partial: zero weights behind it (as the packed MFMA fragments have)
-      const int q16 = ((kc + 15) >> 4) << 2;
-      for (int i = tid; i < n_o * (q16 - q); i += 256) {
-        const int r = i / (q16 - q), c = (q + i - r * (q16 - q)) * 4;
-        *(f32x4*)(wl + r * pitch + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    };
-    request(0);
-    for (int k0 = 0; k0 < K; k0 += slab_k) {
-      const int kc = min(slab_k, K - k0);
-      __syncthreads();                       // the previous slab is consumed
-      deposit(k0);
-      if (k0 + slab_k < K) request(k0 + slab_k);
-      __syncthreads();
-      if (ot < n_o) {
-        // Summation order = rb_gemm_kernel's: per 16-input chunk the four MFMA K-steps j, each over the four lane groups g
-        // in order -- input 16 c + 4 g + j (the f32 MFMA is a k-ordered fmaf chain) -- so that this launch and the MFMA
-        // launch per layer it replaces give the SAME bits (asserted, test_tower_kernel_layer_by_layer)
-        const float* wrow = wl + ot * pitch;
-        for (int k = 0; k < kc; k += 16) {
-          f32x4 wq[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) wq[g] = *(const f32x4*)(wrow + k + 4 * g);
-#pragma unroll
-          for (int u = 0; u < SG; ++u) {
-            float xv[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) xv[e] = (k0 + k + e < K) ? xs[u * K + k0 + k + e] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int g = 0; g < 4; ++g) acc[u] = fmaf(xv[4 * g + j], wq[g][j], acc[u]);
-          }
-        }
-      }
-    }
-    if (ot < n_o) {
-      const int o = o_base + ot;
-      const float bo = bias[o];
-#pragma unroll
-      for (int u = 0; u < SG; ++u) {
-        const int sidx = grp * SG + u;
-        float v = acc[u] + bo;
-        if (elu) v = mzx_elu(v);
-        if (last) {
-          if (sidx < ns) y[(y_row0 + sidx) * O + o] = v;
-        } else {
-          nxt[sidx * O + o] = v;
-        }
-      }
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256) rb_heads_kernel(const RbHeadsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float rb_lds[];
-  const RbHeadsArgs::Chain& c = a.chain[blockIdx.y];
-  const int tid = threadIdx.x;
-  const int b0 = blockIdx.x * RB_HS;
-  const int ns = min(RB_HS, a.batch - b0);        // (> 0: the grid covers the batch exactly)
-  float* const buf_in = rb_lds;                                    // [RB_HS][in_features]
-  float* const buf_b = rb_lds + a.in_region;                       // [RB_HS][widest hidden layer]
-  float* const buf_c = buf_b + a.hid_region;
-  float* const wl = buf_c + a.hid_region;                          // weight slab
-  const int K0 = c.in_features;
-  for (int sidx = 0; sidx < RB_HS; ++sidx) {                       // (rows beyond the batch: zeros, never stored)
-    const float* xr = c.x + (long long)(b0 + (sidx < ns ? sidx : 0)) * c.in_stride;
-    for (int k = tid; k < K0; k += 256) buf_in[sidx * K0 + k] = sidx < ns ? xr[k] : 0.f;
-  }
-  __syncthreads();
-  const float* cur = buf_in;
-  float* nxt = buf_b;
-  int K = K0;
-  for (int l = 0; l < c.n_lin; ++l) {
-    const int O = c.lin[l].out;
-    const bool last = l + 1 == c.n_lin;
-    // 256 threads = (256 / groups neurons per pass) x (groups of RB_HS / groups samples)
-    if (O >= 128) rb_heads_layer<8>(c.lin[l].w, c.lin[l].b, cur, nxt, wl, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
-    else if (O >= 64) rb_heads_layer<4>(c.lin[l].w, c.lin[l].b, cur, nxt, wl, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
-    else if (O >= 32) rb_heads_layer<2>(c.lin[l].w, c.lin[l].b, cur, nxt, wl, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
-    else rb_heads_layer<1>(c.lin[l].w, c.lin[l].b, cur, nxt, wl, c.y, b0, K, O, c.lin[l].elu, last, ns, tid);
-    __syncthreads();
-    const float* t = cur;                    // layer 0: in -> B; layer 1: B -> C; layer 2: C -> B
-    cur = nxt;
-    nxt = (t == buf_in || t == buf_c) ? (nxt == buf_b ? buf_c : buf_b) : buf_b;
-    K = O;
   }
 }
 
@@ -962,33 +557,6 @@ int rb_launch_gemm_multi(const RbGemmMulti& m, const RbShape* sh, int n, stream_
   return MZX_OK;
 }
 
-// Whole head chains in one launch (rb_gemm_chain_kernel).  A chain qualifies when its first layer's launch shape is one
-// workgroup column of whole samples and every later layer fits the same samples per workgroup (rb_chain_shape).
-typedef void (*RbGemmChainFn)(const RbGemmChain);
-inline RbGemmChainFn rb_pick_chain(int mt) {
-  switch (mt) {
-    case 1: return rb_gemm_chain_kernel<1, 1>;
-    case 2: return rb_gemm_chain_kernel<2, 1>;
-    case 3: return rb_gemm_chain_kernel<3, 1>;
-    case 4: return rb_gemm_chain_kernel<4, 1>;
-    default: return nullptr;
-  }
-}
-
-int rb_launch_gemm_chain(const RbGemmChain& m, int n, int mt, int groups, int lds, stream_t stream) {
-  RbGemmChainFn fn = rb_pick_chain(mt);
-  if (!fn) { set_error("head chain launch: no instantiation"); return MZX_ERR_INVALID; }
-  static std::atomic<uint64_t> lds_attr_done[RB_MULTI_MT + 1];
-  if (const int ae = allow_large_lds((const void*)fn, RB_LDS_MAX, lds_attr_done[mt])) {
-    set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
-    return MZX_ERR_RUNTIME;
-  }
-  void* params[] = {(void*)&m};
-  const hipError_t e = hipLaunchKernel((const void*)fn, dim3(groups, 1, n), dim3(RB_THREADS), params, (size_t)lds, stream);
-  if (e != hipSuccess) { set_error("head chain launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
-  return MZX_OK;
-}
-
 typedef void (*RbTowerFn)(const RbTowerArgs);
 
 template <int NT>
@@ -1098,19 +666,17 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
     if (id == BUF_HIDDEN) { t.sstride = net->hidden_size; if (ix) { t.node = ix->out_node; t.nodes = ix->out_nodes; } }
     return t;
   };
-  // ---- head chains that run in ONE rb_heads_kernel launch at the end of the program: the whole program runs, their
+  // ---- head chains whose levels run as grouped launches at the end of the program: the whole program runs, their
   // tower runs as a tower with its tail at this batch (the tail convolution then writes the chain's input into the
   // private region behind the temporaries, where nothing can overwrite it)
-  const char* tail_env0 = getenv("MZX_RB_TAIL");
-  const bool tails_on = !(tail_env0 && atoi(tail_env0) == 0);
+  const bool tails_on = tune(TUNE_RB_TAIL) != 0;
   bool chain_on[RB_HEADS_MAX_CHAINS] = {false, false, false};
   int chains_on = 0;
   float* head_region = nb.workspace + net->act_floats * net->n_temp * (int64_t)batch;
-  // MZX_RB_HEADS: 0 one launch per Linear layer; 2 ONE MFMA launch per chain LEVEL (rb_gemm_multi_kernel: the k-th layers of
-  // all chains); 3 ONE MFMA launch for all chains and levels (rb_gemm_chain_kernel; chains it cannot take: as 2) -- the
-  // same arithmetic as mode 0 both; 1 all chains in one VALU launch (rb_heads_kernel, measured slower)
+  // tuning "rb_heads": 0 one launch per Linear layer; 2 ONE MFMA launch per chain LEVEL (rb_gemm_multi_kernel: the k-th
+  // layers of all chains) -- the same body, shapes and channel groups, hence the same bits
   const int heads_mode = rb_heads_mode();
-  if (count == (int)prog.size() && tails_on && !net->rb_no_towers && heads_mode >= 1 && heads_mode <= 3)
+  if (count == (int)prog.size() && tails_on && !net->rb_no_towers && heads_mode == 2)
     for (int q = 0; q < R.heads.n_chains; ++q) {
       const RbHeadChain& hc = R.heads.chain[q];
       const int t = R.ops[hc.conv_op].tower_of_tail;
@@ -1162,8 +728,7 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
       // its output run inside the tower launch, on the LDS-resident tile (a diagnostic prefix takes as many as it covers)
       RbTowerTail tail;
       int n_tail = 0;
-      const char* tail_env = getenv("MZX_RB_TAIL");       // 0: towers end at their last convolution (A/B; read per call)
-      if (layers == tw.count && !(tail_env && atoi(tail_env) == 0)) {
+      if (layers == tw.count && tails_on) {      // (tuning "rb_tail" = 0: towers end at their last convolution, the A/B)
         for (int m = k + layers; m < count && m < k + layers + tw.n_tail; ++m) {
           const OpDesc& dm = prog[m];
           if (dm.kind == OP_SCALE) {
@@ -1233,41 +798,14 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
     }
     if (rc) { set_error("kernel launch failed: %s", runtime_error_string(rc)); return MZX_ERR_RUNTIME; }
   }
-  bool chained[RB_HEADS_MAX_CHAINS] = {false, false, false};
-  if (chains_on > 0 && heads_mode == 3) {
-    // whole chains in ONE launch, where every chain's shapes allow it (rb_heads_chainable); the others level by level
-    RbGemmChain m;
-    memset(&m, 0, sizeof(m));
-    int n = 0, mt = 0, groups = 0, lds = 0;
-    for (int q = 0; q < R.heads.n_chains; ++q) {
-      const RbHeadChain& hc = R.heads.chain[q];
-      RbShape sh[RB_HEADS_MAX_LAYERS];
-      if (!chain_on[q] || n >= RB_MULTI_MAX || !rb_heads_chainable(prog, R, hc, batch, sh)) continue;
-      for (int level = 0; level < hc.count; ++level) {
-        const float* x = head_region + (level == 0 ? hc.in_off : hc.hid_off[level - 1]) * (int64_t)batch;
-        float* y = level + 1 < hc.count ? head_region + hc.hid_off[level] * (int64_t)batch : nullptr;
-        m.g[n][level] = gemm_args(hc.first + level, x, y);
-        rb_apply_shape(m.g[n][level], R.ops[hc.first + level], sh[level]);
-        mt = std::max(mt, sh[level].MT); lds = std::max(lds, sh[level].lds);
-      }
-      groups = std::max(groups, sh[0].groups);
-      m.levels[n++] = hc.count;
-      chained[q] = true;
-    }
-    if (n > 0 && mt <= RB_MULTI_MT) {
-      if (const int rc = rb_launch_gemm_chain(m, n, mt, groups, lds, stream)) return rc;
-    } else {
-      for (int q = 0; q < RB_HEADS_MAX_CHAINS; ++q) chained[q] = false;
-    }
-  }
-  if (chains_on > 0 && (heads_mode == 2 || heads_mode == 3)) {
+  if (chains_on > 0) {
     for (int level = 0; level < RB_HEADS_MAX_LAYERS; ++level) {
       RbGemmArgs args[RB_HEADS_MAX_CHAINS];
       RbShape shapes[RB_HEADS_MAX_CHAINS];
       int ops[RB_HEADS_MAX_CHAINS], n = 0;
       for (int q = 0; q < R.heads.n_chains; ++q) {
         const RbHeadChain& hc = R.heads.chain[q];
-        if (!chain_on[q] || chained[q] || level >= hc.count) continue;
+        if (!chain_on[q] || level >= hc.count) continue;
         const float* x = head_region + (level == 0 ? hc.in_off : hc.hid_off[level - 1]) * (int64_t)batch;
         float* y = level + 1 < hc.count ? head_region + hc.hid_off[level] * (int64_t)batch : nullptr;
         ops[n] = hc.first + level;
@@ -1295,39 +833,6 @@ int rb_run_program(const mzx_net* net, bool recurrent, const NetBuffers& nb, int
         if (rc) return rc;
       }
     }
-  } else if (chains_on > 0) {
-    RbHeadsArgs ha;
-    memset(&ha, 0, sizeof(ha));
-    ha.batch = batch;
-    int k0max = 4, wmax = 4;
-    for (int q = 0; q < R.heads.n_chains; ++q) {
-      if (!chain_on[q]) continue;
-      const RbHeadChain& hc = R.heads.chain[q];
-      RbHeadsArgs::Chain& c = ha.chain[ha.n_chains++];
-      c.x = head_region + hc.in_off * (int64_t)batch;
-      c.in_stride = hc.in_features;
-      c.in_features = hc.in_features;
-      c.n_lin = hc.count;
-      for (int l = 0; l < hc.count; ++l) {
-        const OpDesc& dl = prog[hc.first + l];
-        c.lin[l].w = flat + dl.w; c.lin[l].b = flat + dl.b; c.lin[l].in = dl.in_features; c.lin[l].out = dl.out_features;
-        c.lin[l].elu = dl.elu;
-        if (l + 1 < hc.count) wmax = std::max(wmax, (dl.out_features + 3) & ~3);
-      }
-      c.y = resolve(net, nb, prog[hc.first + hc.count - 1].out, batch);
-      k0max = std::max(k0max, (hc.in_features + 3) & ~3);
-    }
-    ha.in_region = RB_HS * k0max;
-    ha.hid_region = RB_HS * wmax;
-    const size_t lds = sizeof(float) * ((size_t)ha.in_region + 2 * (size_t)ha.hid_region + RB_HEADS_SLAB_FLOATS + 64);
-    static std::atomic<uint64_t> heads_attr_done{0};
-    if (const int ae = allow_large_lds((const void*)rb_heads_kernel, RB_LDS_MAX, heads_attr_done)) {
-      set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
-      return MZX_ERR_RUNTIME;
-    }
-    hipLaunchKernelGGL(rb_heads_kernel, dim3((batch + RB_HS - 1) / RB_HS, ha.n_chains), dim3(256), lds, stream, ha);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { set_error("heads launch failed: %s", hipGetErrorString(e)); return MZX_ERR_RUNTIME; }
   }
   if (dump && count > 0) {   // diagnostics: the last operator's output in the per-operator kernels' layout
     const OpDesc& d = prog[count - 1];

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "mzx_resnet_plan.h"
+#include "mzx_tuning.h"
 
 namespace mzx {
 
@@ -68,21 +69,16 @@ constexpr int RB_TAIL_MAX_R = 8;
 
 // HEADS: the MLPs behind the small 1x1 head convolutions (dynamics fc = reward, prediction fc_value / fc_policy,
 // models.py:379-389, :418-433) -- chains of Linear (+ ELU) layers a few dozen neurons wide.  Launched one layer at a time
-// they are latency-bound launches of a few microseconds each (six per connect4 / gomoku inference); rb_heads_kernel runs
-// ALL chains of a program in ONE launch at its end.  A chain qualifies when its input is written by a tower's tail
-// (which then writes it into a private region of the workspace: nothing else can overwrite it before the end of the
-// program) and its layers are at most RB_HEADS_MAX_WIDTH wide.
-// How the chains run (env MZX_RB_HEADS, read per call): 0 one rb_gemm_kernel launch per layer; 2 (default) one
+// they are latency-bound launches of a few microseconds each (six per connect4 / gomoku inference).  A chain qualifies
+// for grouping when its input is written by a tower's tail (which then writes it into a private region of the workspace:
+// nothing else can overwrite it before the end of the program) and its layers are at most RB_HEADS_MAX_WIDTH wide.
+// How the chains run (tuning "rb_heads", mzx_tuning.h): 0 one rb_gemm_kernel launch per layer; 2 (default) one
 // rb_gemm_multi_kernel launch per LEVEL -- the k-th layers of all chains as blockIdx.z slices, inputs and inner outputs in
-// the private region; 3 rb_gemm_chain_kernel, all chains and levels in one launch; 1 rb_heads_kernel on the vector ALUs.
-// 0 / 2 / 3 run the same kernel body on the same shapes' channel groups: the same bits.  Measured (connect4, 512 samples):
-// 0.292 / 0.269 / 0.290 / 0.30 ms per recurrent_inference for 0 / 2 / 3 / 1 (profiles/r04_tower_experiments.txt section 10).
-constexpr int RB_HEADS_MODE_DEFAULT = 2;
-inline int rb_heads_mode() {
-  const char* e = getenv("MZX_RB_HEADS");
-  const int m = e ? atoi(e) : RB_HEADS_MODE_DEFAULT;
-  return (m >= 0 && m <= 3) ? m : RB_HEADS_MODE_DEFAULT;
-}
+// the private region.  Both run the same kernel body on the same shapes' channel groups: the same bits.  Measured
+// (connect4, 512 samples): 0.292 / 0.269 ms per recurrent_inference (profiles/r04_tower_experiments.txt section 10; two
+// more variants measured there -- all chains and levels in one MFMA launch with fences between the levels, all chains on
+// the vector ALUs -- were slower at every shard size and left the tree in round 5).
+inline int rb_heads_mode() { return tune(TUNE_RB_HEADS); }
 constexpr int RB_MULTI_MT = 4;     // grouped / chained launches are instantiated for NT = 1, MT <= 4 (head layers: <1,1> or <2,1>)
 constexpr int RB_HEADS_MAX_CHAINS = 3, RB_HEADS_MAX_LAYERS = 3, RB_HEADS_MAX_WIDTH = 128, RB_HEADS_MAX_IN = 1024;
 struct RbHeadChain {

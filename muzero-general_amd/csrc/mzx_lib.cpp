@@ -194,9 +194,8 @@ int mzx_net_streamed_tower(const mzx_net* net, int32_t recurrent, int32_t index,
   const RbTower& tw = R.towers[index];
   const RbTowerShape sh = rb_tower_shape(tw, batch);
   // (groups = 0: at this batch the tower's layers launch one by one, rb_tower_use)
-  const char* tail_env = getenv("MZX_RB_TAIL");
   const int32_t v[16] = {tw.first, tw.count, tw.C, tw.H, tw.W, sh.T, sh.MT, sh.NT, sh.WM, sh.WN, sh.lds,
-                         rb_tower_use(tw, batch) ? sh.groups : 0, (tail_env && atoi(tail_env) == 0) ? 0 : tw.n_tail, 0, 0, 0};
+                         rb_tower_use(tw, batch) ? sh.groups : 0, tune(TUNE_RB_TAIL) == 0 ? 0 : tw.n_tail, 0, 0, 0};
   for (int k = 0; k < 16; ++k) out[k] = v[k];
   return MZX_OK;
 }
@@ -206,9 +205,8 @@ int mzx_net_streamed_heads(const mzx_net* net, int32_t recurrent, int32_t batch,
   for (int k = 0; k < 16; ++k) out[k] = 0;
   const RbProgram& R = recurrent ? net->rb.recurrent : net->rb.initial;
   if (!net->rb.ok || !R.ok) return MZX_OK;
-  const char* tail_env = getenv("MZX_RB_TAIL");
   const int mode = rb_heads_mode();
-  if (net->rb_no_towers || (tail_env && atoi(tail_env) == 0) || mode == 0) return MZX_OK;
+  if (net->rb_no_towers || tune(TUNE_RB_TAIL) == 0 || mode != 2) return MZX_OK;
   // out: [0] Linear operators that leave the layer-by-layer path, [1] chains, [2 .. 13] the operators, [14] their levels
   // inside their chains (2 bits each), [15] the mode (rb_heads_mode)
   int n = 0;
@@ -226,7 +224,7 @@ int mzx_net_streamed_heads(const mzx_net* net, int32_t recurrent, int32_t batch,
 
 int mzx_net_streamed_split(const mzx_net* net, int32_t batch, int32_t out[2]) {
   if (!net || !out || batch < 1) { set_error("null argument / batch < 1"); return MZX_ERR_INVALID; }
-  const int first = rb_split_first(net, batch);
+  const int first = rb_split_first(net, batch, tune(TUNE_ROW_SPLIT_MIN));
   out[0] = first > 0 ? first : batch;
   out[1] = first > 0 ? batch - first : 0;
   return MZX_OK;
@@ -417,6 +415,52 @@ int mzx_search_arena_offsets(const mzx_search* s, int64_t out[8]) {
   return MZX_OK;
 }
 
+int mzx_tuning_set(const char* name, int32_t value) {
+  const int k = tuning_find(name);
+  if (k < 0) { set_error("unknown tuning entry '%s'", name ? name : "(null)"); return MZX_ERR_INVALID; }
+  TuningEntry& e = tuning_table()[k];
+  if (value < e.lo || value > e.hi) { set_error("tuning entry '%s' takes %d .. %d", e.name, e.lo, e.hi); return MZX_ERR_INVALID; }
+  e.value = value;
+  return MZX_OK;
+}
+
+int mzx_tuning_get(const char* name, int32_t* value, int32_t* dflt) {
+  const int k = tuning_find(name);
+  if (k < 0) { set_error("unknown tuning entry '%s'", name ? name : "(null)"); return MZX_ERR_INVALID; }
+  if (value) *value = tuning_table()[k].value;
+  if (dflt) *dflt = tuning_table()[k].dflt;
+  return MZX_OK;
+}
+
+const char* mzx_tuning_name(int32_t index) { return (index >= 0 && index < TUNE_COUNT) ? tuning_table()[index].name : nullptr; }
+const char* mzx_tuning_help(int32_t index) { return (index >= 0 && index < TUNE_COUNT) ? tuning_table()[index].what : nullptr; }
+
+int mzx_search_route(const mzx_search* s, int32_t out[8]) {
+  if (!s || !out) { set_error("null argument"); return MZX_ERR_INVALID; }
+  for (int k = 0; k < 8; ++k) out[k] = 0;
+#ifndef MZX_HOSTCHECK
+  if (!s->net) return MZX_OK;
+  int whole = 0;
+  if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) {
+    const int route = wide_search_route(s);
+    out[0] = route == ROUTE_RZ ? 1 : (route == ROUTE_ROWS ? 2 : 3);
+    whole = route == ROUTE_RT;
+  } else if ((s->mode & 1) && s->fused_ok == 1) {
+    out[0] = 4;
+  } else if ((s->mode & 1) && rb_enabled(s->net, true) && row_search_supported(s->p)) {
+    whole = streamed_whole_search(s);
+    out[0] = whole ? 3 : 2;
+  }
+  if (whole) rt_search_shape(s, out + 1);
+  if (out[0] == 2) {
+    const int first = rb_split_first(s->net, s->p.num_trees, tune(TUNE_ROW_SPLIT_MIN));
+    out[6] = first > 0 ? first : s->p.num_trees;
+    out[7] = first > 0 ? s->p.num_trees - first : 0;
+  }
+#endif
+  return MZX_OK;
+}
+
 int mzx_search_set_mode(mzx_search* s, int32_t mode) {
   if (!s) { set_error("null search handle"); return MZX_ERR_INVALID; }
   if (mode < 0 || mode > 31) { set_error("mode is a 5-bit flag set"); return MZX_ERR_INVALID; }
@@ -457,15 +501,19 @@ int mzx_search_run(mzx_search* s, const mzx_search_io* io, void* d_arena, int64_
     return (s->mode & 16) ? fused_fc_run(s, io, d_arena, (stream_t)stream) : fc2_run(s, io, d_arena, (stream_t)stream);
   }
   if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) {
-    if (row_search_preferred(s)) {      // a wide network at a large shard: trunks as towers between the row-per-tree kernels
+    // a wide network: the tower arithmetic at every shard size (wide_search_route, mzx_row_search.h) -- all simulations in
+    // one launch of rt_search_kernel, or the trunks as towers between the row-per-tree kernels
+    const int route = wide_search_route(s);
+    if (route != ROUTE_RZ) {
       s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel / mzx::rb_gemm_multi_kernel (streamed FP32-MFMA trunks, layers, head MLP levels) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
-      return search_run_rows(s, io, d_arena, (stream_t)stream, nullptr, true);
+      return search_run_rows(s, io, d_arena, (stream_t)stream, nullptr, true, route == ROUTE_RT);
     }
     return rz_search_run(s, io, d_arena, (stream_t)stream);
   }
   if ((s->mode & 1) && rb_enabled(s->net, true) && row_search_supported(s->p)) {
     s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel / mzx::rb_gemm_multi_kernel (streamed FP32-MFMA trunks, layers, head MLP levels) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
-    return search_run_rows(s, io, d_arena, (stream_t)stream);   // (renames last_kernel when it runs two half-shards)
+    // (renames last_kernel when it runs two half-shards or the whole-search kernel)
+    return search_run_rows(s, io, d_arena, (stream_t)stream, nullptr, false, streamed_whole_search(s));
   }
 #endif
   s->last_kernel = "one kernel per step of a simulation (select / network / expand + back-propagate)";
@@ -496,15 +544,16 @@ int mzx_search_run_from_roots(mzx_search* s, const mzx_search_io* io, const floa
     return fc2_run(s, io, d_arena, (stream_t)stream, &ov);
   }
   if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) {
-    if (row_search_preferred(s)) {
+    const int route = wide_search_route(s);
+    if (route != ROUTE_RZ) {
       s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel / mzx::rb_gemm_multi_kernel (streamed FP32-MFMA trunks, layers, head MLP levels) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
-      return search_run_rows(s, io, d_arena, (stream_t)stream, &ov, true);
+      return search_run_rows(s, io, d_arena, (stream_t)stream, &ov, true, route == ROUTE_RT);
     }
     return rz_search_run(s, io, d_arena, (stream_t)stream, &ov);
   }
   if ((s->mode & 1) && rb_enabled(s->net, true) && row_search_supported(s->p)) {
     s->last_kernel = "mzx::rb_tower_kernel / mzx::rb_gemm_kernel / mzx::rb_gemm_multi_kernel (streamed FP32-MFMA trunks, layers, head MLP levels) between mzx::row_select_kernel / mzx::row_expand_backprop_kernel";
-    return search_run_rows(s, io, d_arena, (stream_t)stream, &ov);
+    return search_run_rows(s, io, d_arena, (stream_t)stream, &ov, false, streamed_whole_search(s));
   }
 #endif
   s->last_kernel = "one kernel per step of a simulation (select / network / expand + back-propagate)";

@@ -212,8 +212,7 @@ inline bool rb_tower_grid(const RbTower& tw, int T, RbTowerShape& c) {
 // four cases -- whole rounds of workgroups matter more than anything else (4608 trees: six boards = 768 workgroups =
 // three rounds of 256 -> 0.663; four boards = 4.5 rounds -> 0.545).  MZX_RB_TOWER_T=<n>: force (A/B).
 inline RbTowerShape rb_tower_shape(const RbTower& tw, int batch) {
-  const char* force_env = getenv("MZX_RB_TOWER_T");      // read per call: the tests force several values in one process
-  const int force_t = force_env ? atoi(force_env) : 0;
+  const int force_t = tune(TUNE_RB_TOWER_T);             // > 0: forced (tests, A/B)
   RbTowerShape best{};
   double best_cost = 1e30;
   for (int T = tw.t_max; T >= 1; --T) {
@@ -236,7 +235,7 @@ inline RbTowerShape rb_tower_shape(const RbTower& tw, int batch) {
 inline bool rb_tower_use(const RbTower& tw, int batch) {
   const RbTowerShape sh = rb_tower_shape(tw, batch);
   if (sh.T < 1) return false;
-  if (getenv("MZX_RB_TOWER_T")) return true;      // a forced shape (tests, A/B) is taken as given
+  if (tune(TUNE_RB_TOWER_T) > 0) return true;     // a forced shape (tests, A/B) is taken as given
   return sh.rows * 5 >= sh.mtiles * 16 * 4;
 }
 
@@ -325,8 +324,7 @@ inline void rb_find_towers(const std::vector<OpDesc>& prog, RbProgram& R) {
 inline void rb_find_heads(const std::vector<OpDesc>& prog, RbProgram& R) {
   R.heads = RbHeads();
   for (RbOp& o : R.ops) o.head_chain = -1;
-  // (always planned; whether a run uses it is decided per call: MZX_RB_HEADS=1, default off -- measured slower than the
-  // six MFMA launches it replaces at every shard size, profiles/r04_tower_experiments.txt section 6)
+  // (always planned; how a run launches the chains' layers is decided per call: tuning "rb_heads", mzx_batched_plan.h)
   const int n = (int)prog.size();
   for (const RbTower& tw : R.towers) {
     for (int m = tw.first + tw.count; m < tw.first + tw.count + tw.n_tail && m < n; ++m) {
@@ -375,33 +373,6 @@ inline void rb_find_heads(const std::vector<OpDesc>& prog, RbProgram& R) {
       ++R.heads.n_chains;
     }
   }
-}
-
-// Launch shapes of a head chain's layers for rb_gemm_chain_kernel (one workgroup keeps its samples through all levels):
-// the first layer's own shape when that is whole samples and one workgroup column; the later layers with the SAME samples
-// per workgroup, all column tiles in the workgroup (one per wave: at most eight).  Channel groups as planned (one phase),
-// so the sums are the layer launches'.
-inline bool rb_heads_chainable(const std::vector<OpDesc>& prog, const RbProgram& R, const RbHeadChain& hc, int batch, RbShape* sh) {
-  if (hc.count < 1 || hc.count > RB_HEADS_MAX_LAYERS) return false;
-  for (int l = 0; l < hc.count; ++l) {
-    const RbOp& o = R.ops[hc.first + l];
-    if (o.kind != RB_GEMM || o.tiles_x * o.tiles_y != 1 || o.th * o.tw != 1 || o.phases != 1 || o.ntiles > 8) return false;
-    if (l == 0) {
-      sh[0] = rb_choose_shape(o, batch);
-      if (sh[0].nsplit != 1 || sh[0].NT != 1 || sh[0].rowsplit != 0 || sh[0].phases != 1) return false;
-      continue;
-    }
-    RbShape c{};
-    c.T = sh[0].T; c.rows = c.T; c.mtiles = (c.rows + 15) / 16;
-    c.lds = (int)rb_lds_bytes(c.T, c.mtiles, c.T * o.PH * o.PW, o.Cs);
-    c.groups = sh[0].groups;
-    c.ntiles_wg = o.ntiles; c.nsplit = 1; c.NT = 1;
-    c.WN = std::min(8, (int)o.ntiles); c.WM = std::max(1, std::min(8 / c.WN, c.mtiles)); c.MT = (c.mtiles + c.WM - 1) / c.WM;
-    c.cpg = o.cpg; c.phases = o.phases; c.Cs = o.Cs; c.rowsplit = 0; c.splits = 1; c.PH = o.PH;
-    if (c.lds > RB_LDS_MAX) return false;
-    sh[l] = c;
-  }
-  return true;
 }
 
 // Two half-shards on two streams (mzx_row_search.h): size of the FIRST half for a shard of `batch` trees, 0 = the shard

@@ -1361,7 +1361,7 @@ struct RzStemArgs {
 // phase, separated by workgroup barriers -- alone on a CU it exposes every one of those latencies (measured
 // ~21 us per 16 x 16 tile at 48 x 48 x 8, 89 % of a breakout Reanalyse pass).  Registers are capped so that two or
 // three workgroups share a CU (their LDS tiles are sized for it, rz_stem_launch) and overlap each other's phases.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) rz_stem_conv_kernel(const RzStemArgs sa) {
+static __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) rz_stem_conv_kernel(const RzStemArgs sa) {
   extern __shared__ __attribute__((aligned(16))) float rz_lds[];
   const int tid = threadIdx.x;
   const int tile = blockIdx.x, b = blockIdx.y;

@@ -13,6 +13,7 @@
 // half-shards on two HIP streams (search_run_rows).
 #pragma once
 #include "mzx_resnet_search.h"
+#include "mzx_tuning.h"
 
 namespace mzx {
 #ifndef MZX_HOSTCHECK
@@ -36,51 +37,49 @@ constexpr int ROWSEL_INTS = 64;
 
 inline bool row_search_supported(const SearchParams& p) { return p.num_actions <= WIDE_MAX_CHUNKS * FUSED_ROW; }
 
+// The tower whole-search kernel (mzx_tower_search.hip): every simulation of a search in ONE launch for wide residual
+// networks whose recurrent program is two towers + tails + head chains; bit-identical trees to the per-simulation
+// launches of search_run_rows on its tower route.  rt_search_shape: {trees per workgroup, row tiles per wave, workgroups,
+// workgroups per CU, LDS bytes}, zeros when the kernel does not take the search.
+bool rt_search_supported(const mzx_search* s);
+void rt_search_shape(const mzx_search* s, int32_t out[5]);
+int rt_search_simulations(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream);
+
+// One selection walk of tree `t` by its 16-lane row (self_play.py:325-334): the walk's result for the network
+// (parent node, action, leaf) and the row's share of the path -- 64 ints at `rs`: SelCtx (5), action, then (node, parent,
+// parent slot) of path depth d at 16 + 3 d -- for row_expand_backprop_body.  Shared by row_select_kernel (rs in the arena)
+// and rt_search_kernel (mzx_tower_search.hip: rs in LDS).
 template <int AW>
-__global__ void __launch_bounds__(64) row_select_kernel(const RowSearchArgs a) {
-  const int tid = threadIdx.x, sub = tid & (FUSED_ROW - 1), row = tid / FUSED_ROW;
-  const int tree = blockIdx.x * 4 + row;
-  if (tree >= a.p.num_trees) return;     // whole rows leave: the row-level DPP / ballot steps stay row-uniform
-  TreeRef t;
-  t.base = a.trees + (size_t)tree * a.L.tree_bytes;
-  t.L = a.L;
+__device__ __forceinline__ void row_select_body(const SearchParams& p, const TreeRef& t, const uint32_t* tape, int sim, int sub,
+                                                int row_in_wave, int32_t* rs, int32_t* out_parent, int32_t* out_action,
+                                                int32_t* out_leaf) {
   RowState st;
   load_state(t, st);
-  const uint32_t* tape = a.tape + (size_t)tree * a.p.tape_words;
   RowSel sel;
   if constexpr (AW == 0) {
-    if (a.p.num_actions <= 8 * FUSED_ROW) sel = row_select_wide<8>(t, a.p, tape, sub, row, a.sim, st);
-    else sel = row_select_wide<WIDE_MAX_CHUNKS>(t, a.p, tape, sub, row, a.sim, st);
+    if (p.num_actions <= 8 * FUSED_ROW) sel = row_select_wide<8>(t, p, tape, sub, row_in_wave, sim, st);
+    else sel = row_select_wide<WIDE_MAX_CHUNKS>(t, p, tape, sub, row_in_wave, sim, st);
   }
-  else sel = row_select<AW>(t, a.p, tape, sub, row, a.sim, st);
-  int32_t* rs = a.rowsel + (size_t)tree * ROWSEL_INTS;
+  else sel = row_select<AW>(t, p, tape, sub, row_in_wave, sim, st);
   rs[16 + 3 * sub] = sel.my_node; rs[17 + 3 * sub] = sel.my_parent; rs[18 + 3 * sub] = sel.my_pslot;
   if (sub == 0) {
-    a.sel_parent[tree] = sel.c.parent; a.sel_action[tree] = sel.action; a.sel_leaf[tree] = sel.c.leaf;
+    *out_parent = sel.c.parent; *out_action = sel.action; *out_leaf = sel.c.leaf;
     rs[0] = sel.c.parent; rs[1] = sel.c.slot; rs[2] = sel.c.leaf; rs[3] = sel.c.depth; rs[4] = sel.c.to_play; rs[5] = sel.action;
     store_state(t, st);                  // tape position, tie draws, flags moved
   }
 }
 
+// Decode of the three heads, expansion of the leaf and back-propagation (self_play.py:343-353) by the tree's 16-lane row:
+// vl / rl = value / reward logits [2 support + 1], pl = policy logits [A] of the leaf's recurrent_inference.
 template <int AW>
-__global__ void __launch_bounds__(64) row_expand_backprop_kernel(const RowSearchArgs a) {
-  const int tid = threadIdx.x, sub = tid & (FUSED_ROW - 1), row = tid / FUSED_ROW;
-  const int tree = blockIdx.x * 4 + row;
-  if (tree >= a.p.num_trees) return;
-  const SearchParams& p = a.p;
-  TreeRef t;
-  t.base = a.trees + (size_t)tree * a.L.tree_bytes;
-  t.L = a.L;
+__device__ __forceinline__ void row_expand_backprop_body(const SearchParams& p, const TreeRef& t, int sub, int row_in_wave,
+                                                         const int32_t* rs, const float* vl, const float* rl, const float* pl) {
   RowState st;
   load_state(t, st);
-  const int32_t* rs = a.rowsel + (size_t)tree * ROWSEL_INTS;
   RowSel sel;
   sel.c.parent = rs[0]; sel.c.slot = rs[1]; sel.c.leaf = rs[2]; sel.c.depth = rs[3]; sel.c.to_play = rs[4]; sel.action = rs[5];
   sel.my_node = rs[16 + 3 * sub]; sel.my_parent = rs[17 + 3 * sub]; sel.my_pslot = rs[18 + 3 * sub];
   const int F = 2 * p.support_size + 1, A = p.num_actions;
-  const float* vl = a.value + (size_t)tree * F;
-  const float* rl = a.reward + (size_t)tree * F;
-  const float* pl = a.policy + (size_t)tree * A;
   float value, reward;
   if constexpr (AW == 0) {
     value = row_decode_wide(vl, F, p.support_size, sub);
@@ -103,8 +102,33 @@ __global__ void __launch_bounds__(64) row_expand_backprop_kernel(const RowSearch
     const float den = row_sum(e);
     if (in) tree_init_slot(t, sel.c.leaf, sub, (double)mzx_div(e, den));
   }
-  row_backprop(t, p, sel, sub, row, (double)value, (double)reward, st);
+  row_backprop(t, p, sel, sub, row_in_wave, (double)value, (double)reward, st);
   if (sub == 0) store_state(t, st);
+}
+
+template <int AW>
+__global__ void __launch_bounds__(64) row_select_kernel(const RowSearchArgs a) {
+  const int tid = threadIdx.x, sub = tid & (FUSED_ROW - 1), row = tid / FUSED_ROW;
+  const int tree = blockIdx.x * 4 + row;
+  if (tree >= a.p.num_trees) return;     // whole rows leave: the row-level DPP / ballot steps stay row-uniform
+  TreeRef t;
+  t.base = a.trees + (size_t)tree * a.L.tree_bytes;
+  t.L = a.L;
+  row_select_body<AW>(a.p, t, a.tape + (size_t)tree * a.p.tape_words, a.sim, sub, row, a.rowsel + (size_t)tree * ROWSEL_INTS,
+                      a.sel_parent + tree, a.sel_action + tree, a.sel_leaf + tree);
+}
+
+template <int AW>
+__global__ void __launch_bounds__(64) row_expand_backprop_kernel(const RowSearchArgs a) {
+  const int tid = threadIdx.x, sub = tid & (FUSED_ROW - 1), row = tid / FUSED_ROW;
+  const int tree = blockIdx.x * 4 + row;
+  if (tree >= a.p.num_trees) return;
+  TreeRef t;
+  t.base = a.trees + (size_t)tree * a.L.tree_bytes;
+  t.L = a.L;
+  const int F = 2 * a.p.support_size + 1, A = a.p.num_actions;
+  row_expand_backprop_body<AW>(a.p, t, sub, row, a.rowsel + (size_t)tree * ROWSEL_INTS, a.value + (size_t)tree * F,
+                               a.reward + (size_t)tree * F, a.policy + (size_t)tree * A);
 }
 
 template <int AW>
@@ -122,30 +146,48 @@ inline int row_search_apply(const RowSearchArgs& a, stream_t stream) {
 
 // MCTS.run for B roots with a network that runs layer by layer on an engine taking indexed hidden states (the
 // streamed MFMA engine): root by the generic kernels, then per simulation row-select, recurrent_inference straight
-// from / into the arena's node store, row-expand + back-propagate.
-// Large shards of a WIDE residual network that also fits the LDS-resident whole-search kernel (connect4: 64 channels)
-// are faster on this path since the trunks run as towers (rb_tower_kernel): measured whole steps, connect4 x 200
-// simulations -- 1024 trees 0.563 of the FP32 MFMA peak against 0.528 on rz_search_kernel, 2048 trees 0.59 against 0.53,
-// 3072 trees 0.69 against 0.53 (profiles/r04_c4_by_shard.txt).  MZX_SEARCH_STREAMED_MIN=<trees> moves the threshold
-// (default 640; 0 = never: the whole-search kernel at every shard size).
-inline bool row_search_preferred(const mzx_search* s) {
+// from / into the arena's node store, row-expand + back-propagate -- or, where the recurrent program is two towers with
+// tails and head chains (connect4-class networks), ALL simulations in one launch of rt_search_kernel.
+//
+// Routing of a WIDE residual network that also fits the LDS-resident whole-search kernel (connect4: 64 channels).  The
+// LDS-resident engine (mzx_resnet_fused.h) and the streamed engine sum a convolution in different orders, so which of
+// them a search runs on must not depend on the shard size (a tree's result would): such a network ALWAYS takes the
+// tower arithmetic -- rt_search_kernel, or (tuning "rt_search" = 0, or shards above "rt_max_trees") the per-simulation
+// launches with the trunks as towers, which build bit-identical trees -- unless the streamed route is switched off
+// altogether ("wide_towers" = 0: rz_search_kernel at every shard size, the A/B).  Measured whole steps, connect4 x
+// 200 simulations, of the FP32 MFMA peak (profiles/r04_c4_by_shard.txt, profiles/r05_c4_by_shard.txt): rz_search_kernel
+// 0.53 at every shard size; per-simulation launches 0.45 / 0.58 / 0.67 / 0.70 / 0.72 at 512 / 1024 / 1536 / 3072 / 9216.
+enum SearchRoute { ROUTE_RZ = 0, ROUTE_ROWS = 1, ROUTE_RT = 2 };
+
+inline bool wide_tower_network(const mzx_search* s) {
   const mzx_net* net = s->net;
   if (!net || !net->rb.ok || !net->rb.initial.ok || !net->rb.recurrent.ok || net->rb_no_towers) return false;
   if (!row_search_supported(s->p)) return false;
-  const char* e = getenv("MZX_SEARCH_STREAMED_MIN");
-  const int min_trees = e ? atoi(e) : 640;   // (512 trees: the whole-search kernel's one round of 256 workgroups wins, 0.53 against 0.45;
-                                             //  768 trees: its 1.5 rounds lose, 0.40 against 0.55)
-  if (min_trees <= 0 || s->p.num_trees < min_trees) return false;
   if (net->cfg.channels < 48) return false;          // narrow networks: the wave / tile whole-search kernels win by far
-  const int first = rb_split_first(net, s->p.num_trees);
-  const int per_launch = first > 0 ? first : s->p.num_trees;
   bool any = false;
-  for (const RbTower& tw : net->rb.recurrent.towers) any |= rb_tower_use(tw, per_launch);
+  for (const RbTower& tw : net->rb.recurrent.towers) any |= rb_tower_use(tw, std::max(1, s->p.num_trees));
   return any;
 }
 
+// Networks that run on the streamed engine anyway (forced by the network mode, or too large for the LDS-resident
+// engine): rt_search_kernel when it takes them and the shard is within "rt_max_trees" -- the same trees either way.
+inline bool streamed_whole_search(const mzx_search* s) {
+  const int rt = tune(TUNE_RT_SEARCH);
+  if (rt == 0 || !s->net || s->net->rb_no_towers || tune(TUNE_RB_TAIL) == 0 || tune(TUNE_RB_TOWER_T) > 0) return false;
+  // (the per-simulation launches must take the tower route at this shard as well -- a tower whose shape would waste too
+  // many MFMA rows launches layer by layer, rb_tower_use, with the layer kernel's channel groups: another summation order)
+  for (const RbTower& tw : s->net->rb.recurrent.towers)
+    if (!rb_tower_use(tw, std::max(1, s->p.num_trees))) return false;
+  return rt_search_supported(s) && (rt == 1 || s->p.num_trees <= tune(TUNE_RT_MAX_TREES));
+}
+
+inline int wide_search_route(const mzx_search* s) {
+  if (tune(TUNE_WIDE_TOWERS) == 0 || !wide_tower_network(s)) return ROUTE_RZ;
+  return streamed_whole_search(s) ? ROUTE_RT : ROUTE_ROWS;
+}
+
 inline int search_run_rows(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream,
-                   const RootOverride* ov = nullptr, bool force_streamed = false) {
+                   const RootOverride* ov = nullptr, bool force_streamed = false, bool whole_search = false) {
   const ArenaView v = arena_view(s, d_arena);
   mzx_net* net = s->net;
   const int B = s->p.num_trees;
@@ -180,16 +222,23 @@ inline int search_run_rows(mzx_search* s, const mzx_search_io* io, void* d_arena
     mv.dense = ov ? const_cast<float*>(ov->hidden) : v.dense_out; mv.node = nullptr; mv.to_arena = 1;
     MZX_TRY_LAUNCH(launch<256>(mv, stream));
   }
-  // ---- the simulations.  Large shards run as TWO HALF-SHARDS on two HIP streams: the layers of one half start under
+  // ---- the simulations, all of them in one launch (rt_search_kernel, mzx_tower_search.hip) ...
+  if (whole_search) {
+    s->last_kernel = "mzx::rt_search_kernel";
+    rc = rt_search_simulations(s, io, d_arena, stream);
+    if (rc) return rc;
+    return search_finish(s, io, d_arena, stream);
+  }
+  // ---- ... or launch by launch.  Large shards run as TWO HALF-SHARDS on two HIP streams: the layers of one half start under
   // the tail of the other's (a launch ends with a few workgroups on a mostly idle chip, and ~6 us pass before a
   // dependent launch starts), and the small per-simulation kernels (select, expand, heads, scaling) of one half hide
   // under the trunk layers of the other.  Trees are independent and a sample's arithmetic does not depend on the
   // batch it runs in (the halves keep the planned launch shape), so the trees are the ones of the undivided run.
-  const char* split_env = getenv("MZX_ROW_SPLIT_MIN");       // read per run: the tests run both ways in one process
-  const int split_min = split_env ? atoi(split_env) : RB_SPLIT_MIN_DEFAULT;  // 0: never
+  const int split_min = tune(TUNE_ROW_SPLIT_MIN);            // 0: never
   int parts = 1;
-  // the decision (rb_split_first: three launch-shape evaluations per layer) is made once per handle and threshold
-  if (s->split_for != split_min) { s->split_first = rb_split_first(net, B, split_min); s->split_for = split_min; }
+  // (decided per run: it depends on the threshold, on the network handle's mode and on the launch-shape tuning, all of
+  // which may move between two runs of one handle; a few dozen host-side shape evaluations)
+  s->split_first = rb_split_first(net, B, split_min);
   const int first = s->split_first > 0 ? s->split_first : B;
   if (s->split_first > 0) {
     if (!s->side_stream) {

@@ -32,8 +32,7 @@ struct mzx_search {
   void* side_stream = nullptr;
   void* ev_fork = nullptr;
   void* ev_join = nullptr;
-  int32_t split_for = -1;      // MZX_ROW_SPLIT_MIN value split_first was computed for (-1: not yet)
-  int32_t split_first = 0;     // trees of the first half-shard (rb_split_first), 0 = undivided
+  int32_t split_first = 0;     // trees of the first half-shard of the last run (rb_split_first), 0 = undivided
 };
 
 namespace mzx {

@@ -106,6 +106,11 @@ PROTOTYPES = {
     "mzx_search_fused_supported": (ctypes.c_int, [c_vp]),
     "mzx_search_kernel_name": (ctypes.c_char_p, [c_vp]),
     "mzx_search_set_mode": (ctypes.c_int, [c_vp, c_i32]),
+    "mzx_search_route": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32 * 8)]),
+    "mzx_tuning_set": (ctypes.c_int, [ctypes.c_char_p, c_i32]),
+    "mzx_tuning_get": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "mzx_tuning_name": (ctypes.c_char_p, [c_i32]),
+    "mzx_tuning_help": (ctypes.c_char_p, [c_i32]),
     "mzx_search_arena_offsets": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64 * 8)]),
     "mzx_search_lockstep_begin": (ctypes.c_int, [c_vp, ctypes.POINTER(SearchIO), c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mzx_search_lockstep_select": (ctypes.c_int, [c_vp, ctypes.POINTER(SearchIO), c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -155,6 +160,44 @@ class Library:
     def check(self, rc):
         if rc != 0:
             raise MzxError(f"mzx error {rc}: {self.mzx_last_error().decode()}")
+
+    # ---- the tuning table (include/mzx.h "Tuning"): process-wide named integers, no environment variables
+    def tuning_get(self, name):
+        v = c_i32()
+        self.check(self.mzx_tuning_get(name.encode(), ctypes.byref(v), None))
+        return int(v.value)
+
+    def tuning_set(self, name, value):
+        self.check(self.mzx_tuning_set(name.encode(), int(value)))
+
+    def tuning(self, **values):
+        """Context manager: ``with lib.tuning(rt_search=0, row_split_min=0): ...`` sets entries and restores them."""
+        return _TuningScope(self, values)
+
+    def tuning_table(self):
+        out, i = {}, 0
+        while True:
+            name = self.mzx_tuning_name(i)
+            if name is None:
+                return out
+            out[name.decode()] = self.tuning_get(name.decode())
+            i += 1
+
+
+class _TuningScope:
+    def __init__(self, lib, values):
+        self.lib, self.values, self.saved = lib, values, {}
+
+    def __enter__(self):
+        for k, v in self.values.items():
+            self.saved[k] = self.lib.tuning_get(k)
+            self.lib.tuning_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            self.lib.tuning_set(k, v)
+        return False
 
 
 class Backend:

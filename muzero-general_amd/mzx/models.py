@@ -133,16 +133,10 @@ def streamed_launches(lib, handle, recurrent, batch):
         out.append(dict(op=t["first"], MT=t["MT"], NT=t["NT"], phases=1, k_loop="tower " + streamed_k_loop(t["MT"], t["NT"], tower=True),
                         WM=t["WM"], WN=t["WN"], T=t["T"], nsplit=1 + t["n_tail"], cpg=(t["C"] + 15) // 16, taps=9, stride=1,
                         in_layout=-t["count"], cin=t["C"], cout=t["C"]))
-    # the head MLPs that run in ONE rb_heads_kernel launch at the end of the program
+    # head chains whose levels run as grouped launches (tuning "rb_heads" = 2, the default)
     hd = (ctypes.c_int32 * 16)()
     lib.check(lib.mzx_net_streamed_heads(handle, int(bool(recurrent)), int(batch), ctypes.byref(hd)))
-    level_of = {}       # Linear operator of a head chain -> its level (grouped launches, MZX_RB_HEADS=2 -- the default -- or 3)
-    if hd[0] > 0 and hd[15] == 1:
-        in_tower.update(hd[2 + k] for k in range(hd[0]))
-        out.append(dict(op=int(hd[2]), MT=0, NT=int(hd[1]), phases=1, k_loop="heads", WM=0, WN=0, T=16, nsplit=int(hd[0]),
-                        cpg=0, taps=1, stride=1, in_layout=0, cin=0, cout=0))
-    elif hd[0] > 0:
-        level_of = {int(hd[2 + k]): (int(hd[14]) >> (2 * k)) & 3 for k in range(hd[0])}
+    level_of = {int(hd[2 + k]): (int(hd[14]) >> (2 * k)) & 3 for k in range(hd[0])}    # Linear operator -> its level in its chain
     first_gemm = len(out)
     for op in range(lib.mzx_net_num_operators(handle, int(bool(recurrent)))):
         if op in in_tower:
@@ -163,7 +157,7 @@ def streamed_launches(lib, handle, recurrent, batch):
         for l in members:
             same = [m for m in members if (m["MT"], m["NT"]) == (l["MT"], l["NT"])]
             if len(same) > 1 and l["NT"] == 1 and l["MT"] <= 4:
-                l["k_loop"] += " chained" if hd[15] == 3 else " grouped"     # (3: rb_gemm_chain_kernel, opt-in A/B)
+                l["k_loop"] += " grouped"
     return out
 
 

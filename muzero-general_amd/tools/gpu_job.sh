@@ -1,0 +1,141 @@
+#!/bin/bash
+# GPU jobs of this repository, one parameterised script (run through gpurun from the repository root):
+#   gpu_job.sh <job> [tag]      results under gpurun_out/<tag>/ (default tag = the job's name)
+# Jobs
+#   rt-first     tests of rt_search_kernel, then connect4 whole steps by shard size on the three routes
+#   c4-shards    connect4 whole steps by shard size (routes: rt_search_kernel, per-simulation launches, rz_search_kernel)
+#   tests        the -m gpu suite + smoke
+#   bench        the default bench line (as the driver runs it) + rocprofv3 kernel stats of the same command
+#   pmc          PMC passes (separate --pmc runs: FETCH_SIZE, WRITE_SIZE, MFMA-busy) of every default workload's search
+#   final        tests + bench + pmc
+JOB=${1:?job}
+TAG=${2:-$JOB}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+Q="--also none --cpu-seconds 0 --selfplay-moves 0"
+
+c4_shards() {   # trees...
+  for t in "$@"; do
+    for w in c4 c4-rows; do
+      timeout 300 python bench.py --workload $w --trees $t --steps 3 --warmup 1 $Q 2>> $OUT/c4_by_shard.err |
+        python -c "import sys, json; d = json.loads(sys.stdin.readline()); print('$w', $t, 'trees: %.4g sims/s, %.2f ms per step, %.4f of the FP32 MFMA peak, kernel %s' % (d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernel'][:90]))"
+    done
+  done
+  timeout 300 python bench.py --workload c4-ws --steps 3 --warmup 1 $Q 2>> $OUT/c4_by_shard.err |
+    python -c "import sys, json; d = json.loads(sys.stdin.readline()); print('c4-ws 1024 trees: %.4g sims/s, %.2f ms per step, %.4f of the FP32 MFMA peak' % (d['value'], d['ms_per_step'], d['roofline']['frac']))"
+}
+
+run_tests() {
+  timeout 1700 python -m pytest tests -m gpu -q -s -x > $OUT/pytest_gpu.log 2>&1
+  echo "pytest rc $?" >> $OUT/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+  echo "smoke rc $?" >> $OUT/smoke.log
+  grep -E "passed|failed|^FAILED|^ERROR|rc " $OUT/pytest_gpu.log | tail -20
+  tail -3 $OUT/smoke.log
+}
+
+run_bench() {
+  timeout 900 python bench.py > $OUT/bench_default.log 2> $OUT/bench_default.err
+  echo "bench rc $?" >> $OUT/bench_default.err
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench/stats -o run -- python bench.py --cpu-seconds 0 --selfplay-moves 0 > $OUT/rocprof_bench_stats.log 2>&1
+  python muzero-general_amd/tools/rocprof_summary.py $OUT/bench > $OUT/summary_bench.txt 2>&1
+  tail -c 1500 $OUT/bench_default.log
+}
+
+run_pmc() {   # one workload per profile directory: the search kernels' HBM traffic and matrix-pipe occupancy per launch
+  for w in "$@"; do
+    local CMD="python bench.py --workload $w --steps 2 --warmup 1 $Q"
+    local D=$OUT/pmc_$w
+    mkdir -p $D
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -o run -- $CMD > $D/rocprof_stats.log 2>&1
+    timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -o run -- $CMD > $D/rocprof_fetch.log 2>&1
+    timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -o run -- $CMD > $D/rocprof_write.log 2>&1
+    timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $D/pmc_mfma -o run -- $CMD > $D/rocprof_mfma.log 2>&1
+    python muzero-general_amd/tools/rocprof_summary.py $D > $D/summary.txt 2>&1
+  done
+}
+
+one() {   # label, bench arguments...: one line per run
+  local label=$1; shift
+  timeout 300 python bench.py --steps 3 --warmup 1 $Q "$@" 2>> $OUT/err.log |
+    python -c "import sys, json; d = json.loads(sys.stdin.readline()); print('%-40s %.4g sims/s, %.2f ms per step, %.4f of peak' % ('$label', d['value'], d['ms_per_step'], d['roofline']['frac']))"
+}
+
+case $JOB in
+  rt-occ)       # is rt_search_kernel bound by the matrix pipes a CU's workgroups share, or does every workgroup run at its own pace?
+    {
+    one "rt 1024, 2 trees per workgroup, two per CU" --workload c4
+    one "rt 1024, 2 trees per workgroup, ONE per CU (LDS padded)" --workload c4 --tuning rt_lds_pad_kb=40
+    one "rt 512, 2 trees per workgroup (256 workgroups)" --workload c4 --trees 512 --tuning rt_trees=2
+    one "rt 256, 2 trees per workgroup (128 workgroups)" --workload c4 --trees 256 --tuning rt_trees=2
+    one "rt 512, 1 tree per workgroup (512 workgroups)" --workload c4 --trees 512 --tuning rt_trees=1
+    one "rt 256, 1 tree per workgroup (256 workgroups)" --workload c4 --trees 256 --tuning rt_trees=1
+    one "rt 1024 K loops only, ONE per CU" --workload c4 --tuning rt_dbg=30,rt_lds_pad_kb=40
+    one "rz 512 (LDS-resident whole-search kernel)" --workload c4-ws --trees 512
+    one "rz 256" --workload c4-ws --trees 256
+    } > $OUT/rt_occ.txt 2>&1
+    cat $OUT/rt_occ.txt
+    rocprofv3 -L > $OUT/counters.txt 2>&1
+    CMD="python bench.py --workload c4 --steps 2 --warmup 1 $Q"
+    timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc_a -o run -- $CMD > $OUT/pmc_a.log 2>&1
+    timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/pmc_b -o run -- $CMD > $OUT/pmc_b.log 2>&1
+    timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_IFETCH --output-format csv -d $OUT/pmc_c -o run -- $CMD > $OUT/pmc_c.log 2>&1
+    python muzero-general_amd/tools/rocprof_summary.py $OUT rt_search > $OUT/summary.txt 2>&1
+    tail -40 $OUT/summary.txt
+    ;;
+  rt-stagger)
+    {
+    for us in 0 20 50 100 150 200 300 500; do
+      one "rt 1024 stagger $us us" --workload c4 --tuning rt_stagger_us=$us
+    done
+    for us in 50 100 200; do
+      one "rt 1024 K loops only, stagger $us" --workload c4 --tuning rt_dbg=30,rt_stagger_us=$us
+      one "rt 1536 stagger $us us" --workload c4 --trees 1536 --tuning rt_stagger_us=$us
+      one "rt 512 stagger $us us" --workload c4 --trees 512 --tuning rt_stagger_us=$us
+      one "rt 2048 stagger $us us" --workload c4 --trees 2048 --tuning rt_stagger_us=$us
+    done
+    } > $OUT/rt_stagger.txt 2>&1
+    cat $OUT/rt_stagger.txt
+    timeout 600 python -m pytest tests/test_gpu_tower_search.py -m gpu -q -s -x -k "bit_identical or routing" > $OUT/pytest_rt.log 2>&1
+    grep -E "passed|failed|^FAILED|^ERROR|Error" $OUT/pytest_rt.log | tail
+    ;;
+  rt-exp)      # where a simulation of rt_search_kernel goes (knock-outs; results are wrong, timings are not) and the ring K loop
+    {
+    for t in 1024 512 1536; do
+      one "rt $t" --workload c4 --trees $t
+      one "rt $t ring" --workload c4 --trees $t --tuning rt_ring=1
+    done
+    one "rt 1024 no K loops" --workload c4 --tuning rt_dbg=1
+    one "rt 1024 no K loops, no epilogues" --workload c4 --tuning rt_dbg=3
+    one "rt 1024 no epilogues" --workload c4 --tuning rt_dbg=2
+    one "rt 1024 no tree phases" --workload c4 --tuning rt_dbg=4
+    one "rt 1024 no staging / tails" --workload c4 --tuning rt_dbg=8
+    one "rt 1024 no heads" --workload c4 --tuning rt_dbg=16
+    one "rt 1024 K loops only" --workload c4 --tuning rt_dbg=30
+    one "rt 1024 K loops only, ring" --workload c4 --tuning rt_dbg=30,rt_ring=1
+    one "rt 1024 nothing" --workload c4 --tuning rt_dbg=31
+    one "rt 1024 one tree per workgroup" --workload c4 --tuning rt_trees=1
+    one "rt 1024 one tree per workgroup, ring" --workload c4 --tuning rt_trees=1,rt_ring=1
+    one "rt 1024 three trees per workgroup" --workload c4 --tuning rt_trees=3
+    one "rt 1024 three trees per workgroup, ring" --workload c4 --tuning rt_trees=3,rt_ring=1
+    } > $OUT/rt_exp.txt 2>&1
+    cat $OUT/rt_exp.txt
+    timeout 600 python -m pytest tests/test_gpu_tower_search.py -m gpu -q -s -x -k "bit_identical or routing" > $OUT/pytest_rt.log 2>&1
+    grep -E "passed|failed|^FAILED|^ERROR|Error" $OUT/pytest_rt.log | tail
+    ;;
+  rt-first)
+    timeout 900 python -m pytest tests/test_gpu_tower_search.py -m gpu -q -s -x > $OUT/pytest_rt.log 2>&1
+    echo "pytest rc $?" >> $OUT/pytest_rt.log
+    grep -E "passed|failed|^FAILED|^ERROR|Error|rc |rt_search_kernel with|identical" $OUT/pytest_rt.log | tail -40
+    c4_shards 1024 512 1536 2048 3072 9216 > $OUT/c4_by_shard.txt 2>&1
+    cat $OUT/c4_by_shard.txt
+    ;;
+  c4-shards) shift; shift; c4_shards ${@:-512 768 1024 1536 2048 3072 4608 9216} > $OUT/c4_by_shard.txt 2>&1; cat $OUT/c4_by_shard.txt ;;
+  tests) run_tests ;;
+  bench) run_bench ;;
+  pmc) shift; shift; run_pmc ${@:-c2 c3 c4 c4-ws c4-large c5 gomoku atari} ;;
+  final) run_tests; run_bench; run_pmc c2 c3 c4 c4-ws c4-large c5 gomoku atari ;;
+  *) echo "unknown job $JOB"; exit 2 ;;
+esac
+find $OUT -size +4M -delete

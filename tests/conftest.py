@@ -40,3 +40,33 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _tuning_defaults():
+    """Every test starts from, and leaves behind, the library's default tuning table (include/mzx.h "Tuning")."""
+    yield
+    lib_path = os.path.join(ROOT, "muzero-general_amd", "mzx", "libmzx.so")
+    try:
+        with open("/proc/self/maps") as f:
+            loaded = "libmzx.so" in f.read()
+    except OSError:
+        loaded = False
+    if not loaded or not os.path.isfile(lib_path):
+        return      # (no test of this process has loaded the product library: nothing to restore)
+    import ctypes
+
+    cdll = ctypes.CDLL(lib_path)      # the handle of the library already mapped: the process-wide table
+    cdll.mzx_tuning_name.restype = ctypes.c_char_p
+    cdll.mzx_tuning_name.argtypes = [ctypes.c_int32]
+    cdll.mzx_tuning_get.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
+    cdll.mzx_tuning_set.argtypes = [ctypes.c_char_p, ctypes.c_int32]
+    i = 0
+    while True:
+        name = cdll.mzx_tuning_name(i)
+        if name is None:
+            break
+        dflt = ctypes.c_int32()
+        assert cdll.mzx_tuning_get(name, None, ctypes.byref(dflt)) == 0
+        assert cdll.mzx_tuning_set(name, dflt.value) == 0
+        i += 1

@@ -102,7 +102,7 @@ def bench_streamed_workloads(bench):
         game, overrides, trees, _ = bench.WORKLOADS[w]
         forced = bench.WORKLOAD_NET_MODE.get(w) == "streamed"
         # (connect4 from 1024 trees: csrc/mzx_row_search.h row_search_preferred, unless the workload's environment says no)
-        routed = game == "connect4" and trees >= 1024 and "MZX_SEARCH_STREAMED_MIN" not in bench.WORKLOAD_ENV.get(w, {})
+        routed = game == "connect4" and bench.WORKLOAD_TUNING.get(w, {}).get("rt_search") == 0      # (per-simulation launches)
         if forced or routed or game in ("gomoku", "atari"):
             out[w] = (game, overrides, trees, 3 if forced else None)
     return out

@@ -476,6 +476,10 @@ def test_residual_whole_search_kernel_bit_identical_to_generic(backend, name, B)
     """
     cfg = RESNET_CASES[name]()
     cfg.num_simulations = 30
+    # (wide networks -- "connect4": 64 channels -- search on the tower arithmetic by default, whose bit-identity chain is
+    # generic == row kernels == rt_search_kernel on the streamed engine: tests/test_gpu_streamed.py,
+    # tests/test_gpu_tower_search.py; THIS test is about the LDS-resident kernels)
+    backend.lib.tuning_set("wide_towers", 0)
     net = models.MuZeroNetwork(cfg)
     net.set_weights(synthetic.fill_state_dict(net.state_dict(), 12))
     obs = synthetic.observations(B, net.input_shape, seed=6)
@@ -608,7 +612,7 @@ def test_small_board_kernels_other_shapes(backend, case):
 
 def test_baseline_configurations_are_routed_to_their_kernels(backend):
     want = {"cartpole": "mzx::fc2_search_kernel", "tictactoe": "mzx::rz_wave_search_kernel",
-            "connect4": "mzx::rz_search_kernel", "breakout": "mzx::rz_tile_search_kernel"}
+            "connect4": "mzx::rt_search_kernel", "breakout": "mzx::rz_tile_search_kernel"}
     for name, kernel in want.items():
         cfg = configs.BY_NAME[name](num_simulations=3)
         net = models.MuZeroNetwork(cfg)
@@ -618,6 +622,16 @@ def test_baseline_configurations_are_routed_to_their_kernels(backend):
         obs = synthetic.observations(B, net.input_shape, seed=1)
         engine.run(list(obs), [list(cfg.action_space)] * B, [0] * B, True, [numpy.random.RandomState(i) for i in range(B)])
         assert _kernel_name(backend, engine, B) == kernel, name
+    # the A/B routes of the wide network: the LDS-resident whole-search kernel, the per-simulation launches
+    cfg = configs.connect4(num_simulations=3)
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 2))
+    obs = synthetic.observations(8, net.input_shape, seed=1)
+    for tuning, kernel in (({"wide_towers": 0}, "mzx::rz_search_kernel"), ({"rt_search": 0}, "mzx::rb_tower_kernel")):
+        with backend.lib.tuning(**tuning):
+            engine = self_play.BatchedMCTS(cfg, net, 8)
+            engine.run(list(obs), [list(cfg.action_space)] * 8, [0] * 8, True, [numpy.random.RandomState(i) for i in range(8)])
+            assert _kernel_name(backend, engine, 8).startswith(kernel), tuning
 
 
 def test_every_shipped_game_architecture_runs_on_a_tuned_kernel(backend):
@@ -629,7 +643,7 @@ def test_every_shipped_game_architecture_runs_on_a_tuned_kernel(backend):
     """
     shapes = shipped_shapes.shapes()
     tuned = ("mzx::fc2_search_kernel", "mzx::rz_wave_search_kernel", "mzx::rz_tile_search_kernel", "mzx::rz_search_kernel",
-             "mzx::rb_tower_kernel / mzx::rb_gemm_kernel")
+             "mzx::rt_search_kernel", "mzx::rb_tower_kernel / mzx::rb_gemm_kernel")
     for name, cfg in shapes.items():
         cfg.num_simulations = 6
         net = models.MuZeroNetwork(cfg)
@@ -714,7 +728,8 @@ def test_zero_simulations(backend):
         assert (res.visit_counts == 0).all() and (res.root_values == 0).all() and (res.max_tree_depth == 0).all()
 
 
-@pytest.mark.parametrize("name,B,n_sample", [("tictactoe", 1024, 256), ("connect4", 1024, 256), ("breakout", 64, 32)])
+@pytest.mark.parametrize("name,B,n_sample", [("tictactoe", 1024, 256), ("connect4", 1024, 256), ("connect4-ws", 1024, 64),
+                                             ("breakout", 64, 32)])
 def test_full_size_residual_configs(backend, name, B, n_sample):
     """
     BASELINE configs C3 (tic-tac-toe, 1024 trees x 25 simulations), C4 (connect4, 1024 x 200) and C5 (breakout
@@ -722,6 +737,10 @@ def test_full_size_residual_configs(backend, name, B, n_sample):
     whole-search kernel: size-independent invariants, determinism, and a sample of trees against the CPU
     oracle (the reference's algorithm with its torch network).
     """
+    want_kernel = {"connect4": "mzx::rt_search_kernel", "connect4-ws": "mzx::rz_search_kernel"}.get(name, "mzx::rz_")
+    if name == "connect4-ws":      # bench.py's `c4-ws`: the LDS-resident whole-search kernel at the 1024-tree shard
+        backend.lib.tuning_set("wide_towers", 0)
+        name = "connect4"
     cfg = configs.BY_NAME[name](**({"num_simulations": 50} if name == "breakout" else {}))
     S = cfg.num_simulations
     net = models.MuZeroNetwork(cfg)
@@ -743,12 +762,12 @@ def test_full_size_residual_configs(backend, name, B, n_sample):
     assert numpy.array_equal(res.visit_counts, res2.visit_counts)
     assert numpy.array_equal(res.root_values.view(numpy.int64), res2.root_values.view(numpy.int64))
     sample = list(range(0, B, B // n_sample))
-    # the sampled trees OF THIS RUN (residual kernels keep / write back their trees in the arena): since round 4 the
-    # library routes connect4 at this shard to the streamed engine (towers between the row-per-tree kernels), a re-run of
-    # the sample at another batch size would take another kernel
+    # the sampled trees OF THIS RUN (residual kernels keep / write back their trees in the arena), whatever kernel the
+    # library routed the shard to: connect4 runs on rt_search_kernel (every simulation in one launch, towers inside), as
+    # `connect4-ws` on the LDS-resident rz_search_kernel
     kernel = _kernel_name(backend, engine, B)
     print(f"{name}: {B} trees on {kernel}")
-    assert kernel.startswith("mzx::rb_tower_kernel" if name == "connect4" else "mzx::rz_")
+    assert kernel.startswith(want_kernel)
     exported = engine.export_trees(B)
     traces = []
     for i in sample:

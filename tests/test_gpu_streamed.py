@@ -31,6 +31,14 @@ def backend():
     return _lib.default_backend()
 
 
+@pytest.fixture(autouse=True)
+def _launch_by_launch(backend):
+    """This file tests the streamed engine's LAUNCHES (towers, layers, grouped head levels between the row-per-tree
+    kernels); searches the library would run as one launch of rt_search_kernel (tests/test_gpu_tower_search.py) stay
+    on the per-simulation launches here.  conftest restores the default afterwards."""
+    backend.lib.tuning_set("rt_search", 0)
+
+
 def _fixture_obs(z):
     if "obs" in z.files:
         return z["obs"]
@@ -130,7 +138,7 @@ def test_tower_kernel_layer_by_layer(backend, name, B, T, monkeypatch):
     rb_tower_kernel (a whole trunk -- conv + residual blocks -- in one launch, activations in LDS in place, the block
     input kept in registers as the residual) against the element kernels, LAYER BY LAYER: a prefix that ends inside a
     tower runs the tower's first layers only, so every layer's output is compared.  Forced samples per workgroup T
-    (MZX_RB_TOWER_T) walk the instantiations <MT, NT> -- one to nine row tiles per wave, one and two column tiles, the
+    (tuning "rb_tower_t") walk the instantiations <MT, NT> -- one to nine row tiles per wave, one and two column tiles, the
     in-place and the two-set K loops -- with batches that do not fill the last workgroup.
     """
     make, _ = STREAMED_CASES[name]
@@ -138,7 +146,7 @@ def test_tower_kernel_layer_by_layer(backend, name, B, T, monkeypatch):
     net = models.MuZeroNetwork(cfg)
     net.set_weights(synthetic.fill_state_dict(net.state_dict(), 33))
     net.set_mode(3)
-    monkeypatch.setenv("MZX_RB_TOWER_T", str(T))
+    backend.lib.tuning_set("rb_tower_t", T)
     rs = numpy.random.RandomState(7)
     obs = torch.tensor(rs.rand(B, *net.input_shape).astype(numpy.float32))
     hid = torch.tensor(rs.rand(B, *net.hidden_shape).astype(numpy.float32))
@@ -168,39 +176,28 @@ def test_tower_kernel_layer_by_layer(backend, name, B, T, monkeypatch):
     # the tail (per-plane scaling, small 1x1 head convolutions on the LDS-resident output) against the same operators
     # launched on their own: the scaled hidden state bit for bit (same arithmetic on the same values), everything else tightly
     o1, r1 = net.initial_inference(obs), net.recurrent_inference(hid, act)
-    monkeypatch.setenv("MZX_RB_TAIL", "0")
+    backend.lib.tuning_set("rb_tail", 0)
     assert all(l["nsplit"] == 1 for l in net.streamed_launches(1, B) if l["k_loop"].startswith("tower"))
     o2, r2 = net.initial_inference(obs), net.recurrent_inference(hid, act)
-    monkeypatch.delenv("MZX_RB_TAIL")
+    backend.lib.tuning_set("rb_tail", 1)
     assert any(l["nsplit"] > 1 for l in net.streamed_launches(1, B) if l["k_loop"].startswith("tower")), "no tower has a tail"
     assert torch.equal(o1[3], o2[3]) and torch.equal(r1[3], r2[3])
     for got, want in zip(o1 + r1, o2 + r2):
         g, w = got.cpu().numpy(), want.cpu().numpy()
         fin = numpy.isfinite(w)
         assert numpy.array_equal(numpy.isfinite(g), fin) and numpy.abs(numpy.where(fin, g - w, 0.0)).max() < 1e-5 * (1.0 + numpy.abs(w[fin]).max())
-    # rb_heads_kernel (MZX_RB_HEADS=1, off by default: every head MLP of a program in one launch on the vector ALUs, chain
-    # inputs in the private workspace region) against the MFMA launch per layer
-    monkeypatch.setenv("MZX_RB_HEADS", "1")
-    heads_on = [l for l in net.streamed_launches(1, B) if l["k_loop"] == "heads"]
-    o3, r3 = net.initial_inference(obs), net.recurrent_inference(hid, act)
-    monkeypatch.delenv("MZX_RB_HEADS")
-    assert not [l for l in net.streamed_launches(1, B) if l["k_loop"] == "heads"]
+    # grouped head launches (tuning "rb_heads" = 2, the default: the k-th Linear layers of all chains as blockIdx.z slices
+    # of ONE rb_gemm_multi_kernel launch, inputs and inner outputs in the private region) against one launch per layer
+    # ("rb_heads" = 0) -- the same kernel body on the same shapes: the same bits
+    assert backend.lib.tuning_get("rb_heads") == 2
     if name in ("connect4", "gomoku", "breakout"):
-        assert heads_on and heads_on[0]["NT"] == 3           # reward, value and policy chains in one launch
-    for got, want in zip(o3 + r3, o1 + r1):       # the same bits: the vector kernel sums in the MFMA's order
-        assert torch.equal(got, want), (name, T)
-    # grouped head launches (MZX_RB_HEADS=2: the k-th Linear layers of all chains as blockIdx.z slices of ONE
-    # rb_gemm_multi_kernel launch, inputs and inner outputs in the private region) -- the same kernel body, the same bits
-    # -- and whole chains in one launch (MZX_RB_HEADS=3: rb_gemm_chain_kernel, a workgroup keeps its samples through the
-    # levels of a chain)
-    monkeypatch.setenv("MZX_RB_HEADS", "0")
+        assert any("grouped" in l["k_loop"] for l in net.streamed_launches(1, B))
+    backend.lib.tuning_set("rb_heads", 0)
+    assert not any("grouped" in l["k_loop"] for l in net.streamed_launches(1, B))
     o5, r5 = net.initial_inference(obs), net.recurrent_inference(hid, act)
-    for mode in ("2", "3"):
-        monkeypatch.setenv("MZX_RB_HEADS", mode)
-        o4, r4 = net.initial_inference(obs), net.recurrent_inference(hid, act)
-        for got, want in zip(o4 + r4, o5 + r5):
-            assert torch.equal(got, want), (name, T, "heads mode " + mode)
-    monkeypatch.delenv("MZX_RB_HEADS")
+    backend.lib.tuning_set("rb_heads", 2)
+    for got, want in zip(o1 + r1, o5 + r5):
+        assert torch.equal(got, want), (name, T, "grouped head launches")
     # and the whole inferences (heads behind the towers) against the layer-by-layer streamed path
     net.set_mode(4)
     o0, r0 = net.initial_inference(obs), net.recurrent_inference(hid, act)
@@ -415,7 +412,7 @@ def test_row_kernels_bit_identical_to_one_thread_per_tree(backend, name, B, S):
 def test_two_half_shards_on_two_streams_build_the_same_trees(backend, name, B, S, split, monkeypatch):
     """
     search_run_rows splits large shards into two halves on two HIP streams (default: from 1024 trees).  With the
-    threshold lowered (MZX_ROW_SPLIT_MIN, read per run) the halves -- 16-tree aligned, the second one ragged -- must
+    threshold lowered (tuning "row_split_min") the halves -- 16-tree aligned, the second one ragged -- must
     build bit for bit the trees of the undivided run, and a second run on the same handle (stream and events reused) too.
     Halves whose layers would run with other channel groups than the undivided launch (another summation order:
     gomoku at 48 + 29 trees) are not split.
@@ -432,13 +429,13 @@ def test_two_half_shards_on_two_streams_build_the_same_trees(backend, name, B, S
     legal = [sorted(rs.choice(A, size=rs.randint(1, A + 1), replace=False).tolist()) for _ in range(B)]
     to_play = [int(i % len(cfg.players)) for i in range(B)]
     out = []
-    for split_min in ("0", "32", "32"):
-        monkeypatch.setenv("MZX_ROW_SPLIT_MIN", split_min)
-        engine = self_play.BatchedMCTS(cfg, net, B, mode=1) if split_min == "0" or len(out) == 1 else engine
+    for split_min in (0, 32, 32):
+        backend.lib.tuning_set("row_split_min", split_min)
+        engine = self_play.BatchedMCTS(cfg, net, B, mode=1) if split_min == 0 or len(out) == 1 else engine
         res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(500 + i) for i in range(B)])
         kernel = engine.kernel_name(B)
         assert "row_select_kernel" in kernel
-        if split_min == "0":
+        if split_min == 0:
             assert "two half-shards" not in kernel
         elif split:      # halves whose layers keep the channel groups of the undivided launch
             assert "two half-shards" in kernel

@@ -42,6 +42,14 @@ def backend():
     return _lib.default_backend()
 
 
+@pytest.fixture(autouse=True)
+def _launch_by_launch(backend):
+    """This file tests the streamed engine's LAUNCHES at the sizes the bench times; a search the library would run as one
+    launch of rt_search_kernel stays on the per-simulation launches here (its own at-size cases:
+    tests/test_gpu_tower_search.py).  conftest restores the default afterwards."""
+    backend.lib.tuning_set("rt_search", 0)
+
+
 # The instantiations every case must launch (MT, NT, channel phases, K loop): hard-wired, so that a planner change that
 # moves a workload onto other code paths fails HERE and has to be acknowledged (together with streamed_coverage)
 MUST_LAUNCH = {
@@ -214,7 +222,6 @@ def test_at_size_search_two_streams_and_oracle(backend, case, monkeypatch):
     launches, parts = sc.search_launches(backend.lib, game, B, mode=mode)
     print(f"{case}: half-shards {parts}; launches {sc.summarize(launches)}")
     assert MUST_LAUNCH[f"{game}-{parts[0]}"] & {models.instantiation_key(l) for l in launches if l["program"] == "recurrent"}
-    monkeypatch.delenv("MZX_ROW_SPLIT_MIN", raising=False)
 
     obs = _device_rand((B,) + tuple(net.input_shape), 4)
     rs = numpy.random.RandomState(2)
@@ -233,10 +240,10 @@ def test_at_size_search_two_streams_and_oracle(backend, case, monkeypatch):
 
     # (d) the undivided shard: every statistic of every tree bit for bit
     if parts[1] > 0:
-        monkeypatch.setenv("MZX_ROW_SPLIT_MIN", "0")
+        backend.lib.tuning_set("row_split_min", 0)
         res1 = engine.run(obs, legal, to_play, True, [numpy.random.RandomState(s) for s in seeds])
         assert "two half-shards" not in engine.kernel_name(B)
-        monkeypatch.delenv("MZX_ROW_SPLIT_MIN")
+        backend.lib.tuning_set("row_split_min", 1024)
         trees1 = engine.export_trees(B)
         assert numpy.array_equal(res.visit_counts, res1.visit_counts)
         assert numpy.array_equal(res.root_values.view(numpy.int64), res1.root_values.view(numpy.int64))

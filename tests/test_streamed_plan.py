@@ -235,9 +235,9 @@ def test_tower_shapes_follow_the_calibrated_cost_model(lib):
     lib.mzx_net_destroy(h)
 
 
-def test_head_chains_run_level_by_level_in_grouped_launches(lib, monkeypatch):
-    """The head MLPs behind a tower's tail: by default ONE rb_gemm_multi_kernel launch per level (MZX_RB_HEADS=2); 0 = one
-    launch per layer, 1 = rb_heads_kernel on the vector ALUs, 3 = rb_gemm_chain_kernel (both opt-in: measured slower)."""
+def test_head_chains_run_level_by_level_in_grouped_launches(lib):
+    """The head MLPs behind a tower's tail: by default ONE rb_gemm_multi_kernel launch per level (tuning "rb_heads" = 2);
+    0 = one launch per layer."""
     from mzx import models
 
     h = _create(lib, configs.connect4())
@@ -249,24 +249,20 @@ def test_head_chains_run_level_by_level_in_grouped_launches(lib, monkeypatch):
     launches = models.streamed_launches(lib, h, 1, 512)
     heads = [l for l in launches if l["op"] in set(out[2:8])]
     assert len(heads) == 6 and all(l["k_loop"] == "ring grouped" and (l["MT"], l["NT"]) == (1, 1) for l in heads)
-    monkeypatch.setenv("MZX_RB_HEADS", "0")
+    lib.tuning_set("rb_heads", 0)
     lib.check(lib.mzx_net_streamed_heads(h, 1, 512, ctypes.byref(out)))
     assert list(out)[:2] == [0, 0] and out[15] == 0
     assert all(l["k_loop"] == "ring" for l in models.streamed_launches(lib, h, 1, 512) if l["taps"] == 1)
-    monkeypatch.setenv("MZX_RB_HEADS", "1")
-    lib.check(lib.mzx_net_streamed_heads(h, 1, 512, ctypes.byref(out)))
-    assert out[0] == 6 and out[1] == 3 and out[15] == 1
-    assert [l["k_loop"] for l in models.streamed_launches(lib, h, 1, 512) if l["taps"] == 1] == ["heads"]
+    lib.tuning_set("rb_heads", 2)
     lib.check(lib.mzx_net_streamed_heads(h, 0, 512, ctypes.byref(out)))
     assert out[0] == 4 and out[1] == 2                         # initial_inference: value and policy
     # atari: 256-channel head convolutions are GEMM launches, not tails -> no chains; tictactoe: 16 reduced channels, same
-    monkeypatch.delenv("MZX_RB_HEADS")
     for name in ("atari", "tictactoe"):
         h3 = _create(lib, configs.BY_NAME[name]())
         lib.check(lib.mzx_net_streamed_heads(h3, 1, 512, ctypes.byref(out)))
         assert out[0] == 0, name
         lib.mzx_net_destroy(h3)
-    monkeypatch.setenv("MZX_RB_TAIL", "0")                     # no tails -> nobody writes the chains' private inputs
+    lib.tuning_set("rb_tail", 0)                               # no tails -> nobody writes the chains' private inputs
     lib.check(lib.mzx_net_streamed_heads(h, 1, 512, ctypes.byref(out)))
     assert out[0] == 0
     lib.mzx_net_destroy(h)
