@@ -56,7 +56,8 @@ int mzx_is_device_build(void);
  *                  tower arithmetic at EVERY shard size (a tree's result must not depend on the shard it is searched
  *                  in); 0: mzx::rz_search_kernel (the A/B)
  *   rt_search      the tower whole-search kernel (every simulation in one launch): -1 automatic, 0 never, 1 whenever
- *                  the network fits;  rt_trees > 0: trees per workgroup;  rt_max_trees: largest shard routed to it
+ *                  the network fits;  rt_trees > 0: trees per workgroup;  rt_waves 8 | 16: waves per workgroup (0: cost
+ *                  model);  rt_max_trees: largest shard routed to it;  rt_dbg: timing knock-outs (wrong results)
  * mzx_tuning_set / _get return MZX_ERR_INVALID for an unknown name or a value out of range; mzx_tuning_name /
  * _help enumerate the table (NULL past its end).
  * ------------------------------------------------------------------------- */
@@ -292,8 +293,8 @@ int mzx_search_set_mode(mzx_search* s, int32_t mode);
 /* What the NEXT mzx_search_run of this handle would launch (host-side, no GPU): out[0] = 0 the generic path, 1
  * mzx::rz_search_kernel or one of its small-board siblings, 2 per-simulation launches around the streamed engine, 3
  * mzx::rt_search_kernel (every simulation in one launch, csrc/mzx_tower_search.hip), 4 the fully connected whole-search
- * kernel; for 3: out[1..5] = {trees per workgroup, row tiles per wave, workgroups, workgroups per CU, LDS bytes}; for 2:
- * out[6..7] = trees of the two half-shards (second 0: undivided). */
+ * kernel; for 3: out[1..6] = {trees per workgroup, row tiles per wave, workgroups, workgroups per CU, LDS bytes, threads per
+ * workgroup}; for 2: out[6..7] = trees of the two half-shards (second 0: undivided). */
 int mzx_search_route(const mzx_search* s, int32_t out[8]);
 
 /* Byte offsets inside the arena (diagnostics): out[0..6] = (unused, 0), trees, hidden states,

@@ -451,7 +451,7 @@ int mzx_search_route(const mzx_search* s, int32_t out[8]) {
     whole = streamed_whole_search(s);
     out[0] = whole ? 3 : 2;
   }
-  if (whole) rt_search_shape(s, out + 1);
+  if (whole) rt_search_shape(s, out + 1);      // out[1 .. 6]
   if (out[0] == 2) {
     const int first = rb_split_first(s->net, s->p.num_trees, tune(TUNE_ROW_SPLIT_MIN));
     out[6] = first > 0 ? first : s->p.num_trees;

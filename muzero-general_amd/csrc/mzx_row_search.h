@@ -40,9 +40,9 @@ inline bool row_search_supported(const SearchParams& p) { return p.num_actions <
 // The tower whole-search kernel (mzx_tower_search.hip): every simulation of a search in ONE launch for wide residual
 // networks whose recurrent program is two towers + tails + head chains; bit-identical trees to the per-simulation
 // launches of search_run_rows on its tower route.  rt_search_shape: {trees per workgroup, row tiles per wave, workgroups,
-// workgroups per CU, LDS bytes}, zeros when the kernel does not take the search.
+// workgroups per CU, LDS bytes, threads per workgroup}, zeros when the kernel does not take the search.
 bool rt_search_supported(const mzx_search* s);
-void rt_search_shape(const mzx_search* s, int32_t out[5]);
+void rt_search_shape(const mzx_search* s, int32_t out[6]);
 int rt_search_simulations(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream);
 
 // One selection walk of tree `t` by its 16-lane row (self_play.py:325-334): the walk's result for the network
@@ -178,7 +178,12 @@ inline bool streamed_whole_search(const mzx_search* s) {
   // many MFMA rows launches layer by layer, rb_tower_use, with the layer kernel's channel groups: another summation order)
   for (const RbTower& tw : s->net->rb.recurrent.towers)
     if (!rb_tower_use(tw, std::max(1, s->p.num_trees))) return false;
-  return rt_search_supported(s) && (rt == 1 || s->p.num_trees <= tune(TUNE_RT_MAX_TREES));
+  if (!rt_search_supported(s)) return false;
+  if (rt == 1) return true;
+  // automatic: networks of at most 64 channels.  A 128-channel tower (games/gomoku.py) is one board per workgroup and one
+  // workgroup per CU, and nothing hides its 121-action tree walks: measured 0.735 of the peak against 0.744 launch by
+  // launch on two streams (profiles/r05_rt_experiments.txt section 8)
+  return s->net->rb.recurrent.towers[0].ntiles <= 4 && s->p.num_trees <= tune(TUNE_RT_MAX_TREES);
 }
 
 inline int wide_search_route(const mzx_search* s) {

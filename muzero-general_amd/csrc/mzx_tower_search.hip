@@ -46,6 +46,8 @@ constexpr int RT_MAX_LAYERS = 16;                       // layers per tower (con
 constexpr int RT_MAX_CHAINS = RB_HEADS_MAX_CHAINS;      // reward, value, policy
 constexpr int RT_MAX_LEVELS = RB_HEADS_MAX_LAYERS;
 constexpr int RT_LDS_MAX = 160 * 1024;
+constexpr int RT_MAX_ROWS = 256;                        // rows of a workgroup: eight row tiles per wave, two waves deep
+constexpr int RT_MAX_T = 16;                            // trees per workgroup
 
 // What mzx_tower_layers.inc reads of a tower (the field names of RbTowerArgs).
 struct RtTower {
@@ -81,13 +83,18 @@ struct RtSearchArgs {
   const float* flat;
   const float* der;
   int32_t num_sims, sim0, batch;
-  int32_t stagger_us, stagger_period;   // workgroups of every second run of `stagger_period` (= the CUs) start this much later
   int32_t dbg;             // timing experiments (tuning "rt_dbg", never set in production; results are WRONG with any bit set): 1 skip the
                            // K loops, 2 skip the epilogues, 4 skip select / expand, 8 skip staging and tails, 16 skip the head MLPs
   int32_t C, H, W, PH, PW, Cs, cchunks, T, rows, mtiles;
   uint32_t magic_hw, magic_w, magic_rows, magic_chw, magic_c;
   int32_t off_tables, off_rowtab, off_tile, off_scale, off_sel, off_rowsel, off_heads, heads_floats;   // LDS carve (bytes)
   int32_t value_lds, reward_lds, policy_lds, value_stride, reward_stride, policy_stride;              // final logits (floats)
+  // Row r of the workgroup's MFMA tiles is (sample, position) perm[r] -- NOT raster order: rt_row_order deals the positions
+  // so that the sixteen lanes a ds_read_b128 serves together read sixteen distinct 16-byte LDS slots (0x8000 | k: no
+  // position, the row reads cell k); shift[t]: cells board t is moved by inside the tile (the same purpose).
+  uint16_t perm[RT_MAX_ROWS];
+  uint8_t shift[RT_MAX_T];
+  int32_t tile_cells;      // cells of the tile: T boards with their halo + the last board's shift
   int32_t n_conv[2];       // tail convolutions of the dynamics / prediction tower: conv[0 .. n_conv[0]) / conv[n_conv[0] ..)
   int32_t n_chains, n_levels;
   int32_t levels[RT_MAX_CHAINS];
@@ -97,10 +104,12 @@ struct RtSearchArgs {
 };
 
 // AW: lanes that can hold a child slot (4, 16), or 0 = wide (several slots per lane, any support size).
-// RING: the K loops keep the weight fragments of four chunks in flight (mzx_tower_layers.inc RB_TOWER_BRING).
-template <int MT, int NT, int AW, bool RING>
-__global__ void __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(MT * NT <= 4 ? 4 : 2, MT * NT <= 4 ? 4 : 2)))
+// NW: waves of the workgroup -- 8 (column tiles x two row groups for a 64-channel network) or 4 (one wave per column tile:
+// every row tile of the workgroup on each wave).
+template <int MT, int NT, int AW, int NW>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MT * NT <= 4 ? 4 : 2, MT * NT <= 4 ? 4 : 2)))
 rt_search_kernel(const RtSearchArgs sa) {
+  constexpr int RT_THREADS = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float rb_lds[];
   char* const lds = (char*)rb_lds;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -120,32 +129,24 @@ rt_search_kernel(const RtSearchArgs sa) {
   float* const heads = (float*)(lds + sa.off_heads);
   const int b0 = blockIdx.x * T;
   const int ntree = min(T, sa.batch - b0);
-  const int HW = sa.H * sa.W, phw = sa.PH * sa.PW, cells = T * phw;
+  const int HW = sa.H * sa.W, phw = sa.PH * sa.PW, cells = sa.tile_cells;
   const int NN = sa.p.num_nodes;
 
   // ---- once per launch: the search's tables, the row tables, a ZERO tile (the halo and the channels beyond the
   // network's width are never written again), zero head rows (the padding of a chain's input up to whole 16-input chunks)
-  for (int i = tid; i < 2 * (NN + 1); i += RB_THREADS) tables[i] = sa.p.pbc_table[i];   // pbc[N + 1] then sqrt[N + 1], contiguous
-  for (int m = tid; m < mpad; m += RB_THREADS) {
-    const int t = rb_div(m, HW, sa.magic_hw), r = m - t * HW;
+  for (int i = tid; i < 2 * (NN + 1); i += RT_THREADS) tables[i] = sa.p.pbc_table[i];   // pbc[N + 1] then sqrt[N + 1], contiguous
+  for (int m = tid; m < mpad; m += RT_THREADS) {
+    const unsigned pm = sa.perm[m];
+    const bool valid = !(pm & 0x8000u);
+    const int t = valid ? rb_div((int)pm, HW, sa.magic_hw) : 0, r = (int)pm - t * HW;
     const int y = rb_div(r, sa.W, sa.magic_w), x = r - y * sa.W;
-    const bool valid = m < sa.rows;
-    rowaddr[m] = valid ? ((t * sa.PH + y) * sa.PW + x) * sa.Cs : 0;     // top-left cell of the position's 3 x 3 window
+    rowaddr[m] = valid ? ((t * sa.PH + y) * sa.PW + x + sa.shift[t]) * sa.Cs : (int)(pm & 7u) * sa.Cs;   // top-left cell of the 3 x 3 window
     rowt[m] = valid ? t : 0;
     rowpos[m] = (valid && b0 + t < sa.batch) ? r : -1;
   }
-  for (int i = tid; i < cells * sa.Cs / 4; i += RB_THREADS) ((f32x4*)tile)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int i = tid; i < sa.heads_floats; i += RB_THREADS) heads[i] = 0.f;
+  for (int i = tid; i < cells * sa.Cs / 4; i += RT_THREADS) ((f32x4*)tile)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < sa.heads_floats; i += RT_THREADS) heads[i] = 0.f;
   if (tid < 3 * Tp) sel_parent[tid] = 0;
-  // Two workgroups that share a CU start together and, doing the same work at the same rate, STAY in step: both walk
-  // their trees, both stage, both sit in a layer's barrier at the same time, and the matrix pipes idle through all of it
-  // (measured: the phases outside the K loops are 13 % of a step and add to it in full).  The dispatcher fills every CU
-  // once before any CU twice, so the workgroups of every second run of 256 are the partners: they start a fixed time
-  // later, and one workgroup's tree / staging / barrier phases fall into the other's K loops.
-  if (sa.stagger_us > 0 && ((blockIdx.x / sa.stagger_period) & 1)) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)sa.stagger_us * 100ull) __builtin_amdgcn_s_sleep(64);
-  }
   SearchParams p = sa.p;
   p.pbc_table = tables;
   p.sqrt_table = tables + (NN + 1);
@@ -174,17 +175,17 @@ rt_search_kernel(const RtSearchArgs sa) {
     // take consecutive positions of one channel quad (coalesced along the board); rows of trees beyond the shard stay zero.
     if (!(sa.dbg & 8)) {
       const int q = sa.cchunks * 4;
-      const int total = sa.rows * q;
-      for (int i0 = tid; i0 < total; i0 += 2 * RB_THREADS) {
+      const int total = mpad * q;
+      for (int i0 = tid; i0 < total; i0 += 2 * RT_THREADS) {
         f32x4 v[2];
         int at[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int idx = i0 + u * RB_THREADS;
+          const int idx = i0 + u * RT_THREADS;
           at[u] = -1;
           v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (idx < total) {
-            const int k = rb_div(idx, sa.rows, sa.magic_rows), m = idx - k * sa.rows;
+            const int k = rb_div(idx, mpad, sa.magic_rows), m = idx - k * mpad;
             const int pos = rowpos[m], c = 4 * k;
             if (pos >= 0) {
               const int tt = rowt[m];
@@ -210,11 +211,9 @@ rt_search_kernel(const RtSearchArgs sa) {
       const RtTower& a = sa.tw[0];
 #define RB_TOWER_HAS_TAIL true
 #define RB_TOWER_ACTION(b, t) sel_action[t]
-#define RB_TOWER_BRING RING
 #include "mzx_tower_layers.inc"
 #undef RB_TOWER_HAS_TAIL
 #undef RB_TOWER_ACTION
-#undef RB_TOWER_BRING
     }
     __syncthreads();                                     // the dynamics tower's output is in the tile's interior cells
     // ---- its tail, as rb_tower_kernel's: the reward head's 1x1 convolution and the per-plane (min, range) pairs read
@@ -226,12 +225,12 @@ rt_search_kernel(const RtSearchArgs sa) {
       const uint32_t magic_rhw = rb_magic_dev(RHW);
       const float* wq = sa.flat + cv.w;
       const float* bq = sa.flat + cv.b;
-      for (int i = tid; i < total; i += RB_THREADS) {
+      for (int i = tid; i < total; i += RT_THREADS) {
         const int tt = rb_div(i, RHW, magic_rhw), r = i - tt * RHW;
         const int rc = rb_div(r, HW, sa.magic_hw), pp = r - rc * HW;
         const int y = rb_div(pp, sa.W, sa.magic_w), x = pp - y * sa.W;
         if (b0 + tt >= sa.batch) continue;
-        const float* xin = tile + (size_t)tt * phw * sa.Cs + in0 + (y * sa.PW + x) * sa.Cs;
+        const float* xin = tile + (size_t)(tt * phw + sa.shift[tt]) * sa.Cs + in0 + (y * sa.PW + x) * sa.Cs;
         const float* w = wq + (size_t)rc * sa.C;
         float acc = 0.f;
         int c = 0;
@@ -246,9 +245,9 @@ rt_search_kernel(const RtSearchArgs sa) {
         heads[cv.out_lds + tt * cv.out_stride + r] = acc + bq[rc];
       }
     }
-    for (int idx = tid; idx < ((sa.dbg & 8) ? 0 : T * sa.C); idx += RB_THREADS) {
+    for (int idx = tid; idx < ((sa.dbg & 8) ? 0 : T * sa.C); idx += RT_THREADS) {
       const int tt = rb_div(idx, sa.C, sa.magic_c), c = idx - tt * sa.C;
-      const float* base = tile + (size_t)tt * phw * sa.Cs + in0 + c;
+      const float* base = tile + (size_t)(tt * phw + sa.shift[tt]) * sa.Cs + in0 + c;
       float l = base[0], h = l;
       for (int y = 0; y < sa.H; ++y)
         for (int x = 0; x < sa.W; ++x) {
@@ -264,12 +263,12 @@ rt_search_kernel(const RtSearchArgs sa) {
     __syncthreads();
     if (!(sa.dbg & 8)) {
       const int CHW = sa.C * HW, total = T * CHW;
-      for (int i = tid; i < total; i += RB_THREADS) {
+      for (int i = tid; i < total; i += RT_THREADS) {
         const int tt = rb_div(i, CHW, sa.magic_chw), r = i - tt * CHW;
         const int c = rb_div(r, HW, sa.magic_hw), pp = r - c * HW;
         const int y = rb_div(pp, sa.W, sa.magic_w), x = pp - y * sa.W;
         if (b0 + tt >= sa.batch) continue;
-        float* cell = tile + (size_t)tt * phw * sa.Cs + in0 + (y * sa.PW + x) * sa.Cs + c;
+        float* cell = tile + (size_t)(tt * phw + sa.shift[tt]) * sa.Cs + in0 + (y * sa.PW + x) * sa.Cs + c;
         const float s = mzx_div(*cell - lo[tt * sa.C + c], sc[tt * sa.C + c]);
         sa.hidden[((int64_t)(b0 + tt) * NN + sel_leaf[tt]) * Hf + r] = s;
         *cell = s;                                       // the prediction tower's input, in place
@@ -281,11 +280,9 @@ rt_search_kernel(const RtSearchArgs sa) {
       const RtTower& a = sa.tw[1];
 #define RB_TOWER_HAS_TAIL true
 #define RB_TOWER_ACTION(b, t) 0
-#define RB_TOWER_BRING RING
 #include "mzx_tower_layers.inc"
 #undef RB_TOWER_HAS_TAIL
 #undef RB_TOWER_ACTION
-#undef RB_TOWER_BRING
     }
     __syncthreads();
     for (int q = sa.n_conv[0]; q < ((sa.dbg & 8) ? 0 : sa.n_conv[0] + sa.n_conv[1]); ++q) {
@@ -294,12 +291,12 @@ rt_search_kernel(const RtSearchArgs sa) {
       const uint32_t magic_rhw = rb_magic_dev(RHW);
       const float* wq = sa.flat + cv.w;
       const float* bq = sa.flat + cv.b;
-      for (int i = tid; i < total; i += RB_THREADS) {
+      for (int i = tid; i < total; i += RT_THREADS) {
         const int tt = rb_div(i, RHW, magic_rhw), r = i - tt * RHW;
         const int rc = rb_div(r, HW, sa.magic_hw), pp = r - rc * HW;
         const int y = rb_div(pp, sa.W, sa.magic_w), x = pp - y * sa.W;
         if (b0 + tt >= sa.batch) continue;
-        const float* xin = tile + (size_t)tt * phw * sa.Cs + in0 + (y * sa.PW + x) * sa.Cs;
+        const float* xin = tile + (size_t)(tt * phw + sa.shift[tt]) * sa.Cs + in0 + (y * sa.PW + x) * sa.Cs;
         const float* w = wq + (size_t)rc * sa.C;
         float acc = 0.f;
         int c = 0;
@@ -324,18 +321,25 @@ rt_search_kernel(const RtSearchArgs sa) {
       for (int q = 0; q < sa.n_chains; ++q) {
         if (level >= sa.levels[q]) continue;
         const RtHeadLayer& Ld = sa.lin[q][level];
-        for (; unit < Ld.ntiles; unit += RB_THREADS / 64) {
+        for (; unit < Ld.ntiles; unit += RT_THREADS / 64) {
           const int m_lane = lane & 15, g4 = 4 * (lane >> 4);
           const float* wp = sa.der + Ld.w_off + (size_t)unit * (size_t)Ld.cchunks * 256 + (unsigned)lane * 4;
           const float* xr = heads + Ld.in_lds + (m_lane < T ? m_lane : 0) * Ld.in_stride + g4;
           f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-          f32x4 fb = *(const f32x4*)wp;
-          for (int cc = 0; cc < Ld.cchunks; ++cc) {
-            const f32x4 fbc = fb;
-            if (cc + 1 < Ld.cchunks) fb = *(const f32x4*)(wp + (size_t)(cc + 1) * 256);
-            const f32x4 fa = *(const f32x4*)(xr + cc * 16);
+          // (a layer is 4 .. 11 chunks: the weight fragments of up to eight chunks are requested together -- one L2 round
+          // trip per group instead of one per chunk; a head level was 13 us of a 450 us simulation with one fragment ahead)
+          for (int c0 = 0; c0 < Ld.cchunks; c0 += 8) {
+            f32x4 fb[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fbc[k], fa[k], acc, 0, 0, 0);
+            for (int u = 0; u < 8; ++u)
+              if (c0 + u < Ld.cchunks) fb[u] = *(const f32x4*)(wp + (size_t)(c0 + u) * 256);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (c0 + u < Ld.cchunks) {
+                const f32x4 fa = *(const f32x4*)(xr + (c0 + u) * 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[u][k], fa[k], acc, 0, 0, 0);
+              }
           }
           const int n0 = unit * 16 + g4;
           if (m_lane < T && b0 + m_lane < sa.batch) {
@@ -364,29 +368,31 @@ rt_search_kernel(const RtSearchArgs sa) {
 
 typedef void (*RtSearchFn)(const RtSearchArgs);
 
-template <int AW, bool RING>
+template <int AW, int NW>
 RtSearchFn rt_pick_mt(int mt) {
   switch (mt) {
-    case 1: return rt_search_kernel<1, 1, AW, RING>;
-    case 2: return rt_search_kernel<2, 1, AW, RING>;
-    case 3: return rt_search_kernel<3, 1, AW, RING>;
-    case 4: return rt_search_kernel<4, 1, AW, RING>;
+    case 1: return rt_search_kernel<1, 1, AW, NW>;
+    case 2: return rt_search_kernel<2, 1, AW, NW>;
+    case 3: return rt_search_kernel<3, 1, AW, NW>;
+    case 4: return rt_search_kernel<4, 1, AW, NW>;
+    case 5: return rt_search_kernel<5, 1, AW, NW>;
+    case 6: return rt_search_kernel<6, 1, AW, NW>;
+    case 7: return rt_search_kernel<7, 1, AW, NW>;
+    case 8: return rt_search_kernel<8, 1, AW, NW>;
     default: return nullptr;
   }
 }
-constexpr int RT_MT_MAX = 4;
+template <int NW>
+RtSearchFn rt_pick(int mt, bool wide, int num_actions) {
+  return wide ? rt_pick_mt<0, NW>(mt) : (num_actions <= 4 ? rt_pick_mt<4, NW>(mt) : rt_pick_mt<16, NW>(mt));
+}
+constexpr int RT_MT_MAX = 8;
 
 inline int64_t rt_align(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 // ---- planning (host).  The recurrent program must be EXACTLY: dynamics tower with the scaling operator and one small
 // 1x1 convolution in its tail, prediction tower reading the scaled state with two small 1x1 convolutions in its tail, and
 // three head chains behind those convolutions -- every operator of the program in one of these.
-struct RtPlan {
-  bool ok = false;
-  int T = 0, MT = 0, groups = 0, per_cu = 1;
-  size_t lds = 0;
-  RtSearchArgs a;
-};
 
 bool rt_structure(const mzx_net* net, const char** why) {
   auto no = [&](const char* m) { if (why) *why = m; return false; };
@@ -449,13 +455,100 @@ bool rt_structure(const mzx_net* net, const char** why) {
 }
 
 // LDS carve for T trees per workgroup; fills the geometry and head descriptors of `a`.
-size_t rt_carve(const mzx_search* s, int T, RtSearchArgs& a) {
+// Wave grid of a workgroup of `waves` waves that owns T samples of tower `tw` (rb_tower_grid's for 8 waves, one column
+// tile per wave): column tiles over WN waves, the other waves deep in rows.
+bool rt_grid(const RbTower& tw, int T, int waves, RbTowerShape& c) {
+  if (tw.ntiles > 8 || tw.ntiles > waves) return false;
+  c.T = T;
+  c.rows = T * tw.H * tw.W;
+  c.mtiles = (c.rows + 15) / 16;
+  c.NT = 1;
+  c.WN = tw.ntiles;
+  c.WM = std::max(1, std::min(waves / c.WN, c.mtiles));
+  c.MT = (c.mtiles + c.WM - 1) / c.WM;
+  c.Cs = 16 * tw.cchunks + 8;
+  c.lds = 0; c.groups = 0; c.per_cu = 1;
+  return true;
+}
+
+// Which (sample, position) every row of the workgroup's MFMA tiles is, and where the boards lie in the tile.
+// ds_read_b128 serves a wave in four groups of sixteen lanes, a group in one LDS cycle when its sixteen 16-byte slots are
+// distinct modulo 16 (MI355X_MICROARCH.md, LDS); lane l = (row l & 15, channel quad l >> 4) of a tile reads slot 18 cell +
+// quad (Cs = 72 floats: 18 slots per cell), and a group holds rows {0-3, 12-15} with one quad and rows {4-11} with the
+// next: conflict-free exactly when the cells of rows {0-3, 12-15} are distinct modulo 8 and those of rows {4-11} too.  In
+// raster order they are not (a 7-wide board in a 9-wide halo: cells 0-6, 9-15, 18, 19 -- half of all LDS cycles of the K
+// loops were conflict cycles, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  No output depends on which row computes it, so the
+// positions are DEALT: eight residues to every half tile, boards shifted by a few cells so that the residues of the
+// workgroup's positions are evenly filled.  Rows without a position read a cell of a residue their half tile lacks.
+void rt_row_order(RtSearchArgs& a, int mtiles) {
+  const int T = a.T, HW = a.H * a.W, phw = a.PH * a.PW, halves = 2 * mtiles;
+  const bool deal = (a.Cs / 4) % 2 == 0 && (a.Cs / 4) % 4 != 0 && T <= RT_MAX_T && 16 * mtiles <= RT_MAX_ROWS;   // slot stride 2 (mod 4)
+  int count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int shift = 0;
+  for (int t = 0; t < T; ++t) {
+    // shift of board t: the smallest (not below its predecessor's: boards must not overlap) that fills the emptiest residues
+    int best = shift, best_max = 1 << 30;
+    for (int sft = shift; deal && sft < shift + 8 && sft < 256; ++sft) {
+      int c[8];
+      for (int r = 0; r < 8; ++r) c[r] = count[r];
+      for (int p = 0; p < HW; ++p) ++c[(t * phw + sft + (p / a.W) * a.PW + p % a.W) & 7];
+      int mx = 0;
+      for (int r = 0; r < 8; ++r) mx = std::max(mx, c[r]);
+      if (mx < best_max) { best_max = mx; best = sft; }
+    }
+    shift = best;
+    a.shift[t] = (uint8_t)shift;
+    for (int p = 0; p < HW; ++p) ++count[(t * phw + shift + (p / a.W) * a.PW + p % a.W) & 7];
+  }
+  a.tile_cells = T * phw + shift;
+  // buckets of rows by residue, dealt to the half tiles: every half takes one row of each of the (up to eight) fullest buckets
+  std::vector<uint16_t> bucket[8];
+  for (int t = 0; t < T; ++t)
+    for (int p = 0; p < HW; ++p) bucket[(t * phw + a.shift[t] + (p / a.W) * a.PW + p % a.W) & 7].push_back((uint16_t)(t * HW + p));
+  std::vector<std::vector<uint16_t>> half(halves);
+  bool ok = deal;
+  for (int h = 0; h < halves && ok; ++h) {
+    // (a bucket with more rows than halves left cannot be emptied without a conflict: raster order then)
+    for (int r = 0; r < 8; ++r) ok = ok && (int)bucket[r].size() <= halves - h;
+    for (int r = 0; r < 8 && ok; ++r)
+      if (!bucket[r].empty()) { half[h].push_back(bucket[r].back()); bucket[r].pop_back(); }
+  }
+  for (int r = 0; r < 8; ++r) ok = ok && bucket[r].empty();
+  if (!ok) {      // raster order, boards unshifted
+    for (int t = 0; t < T; ++t) a.shift[t] = 0;
+    a.tile_cells = T * phw;
+    for (int m = 0; m < 16 * mtiles; ++m) a.perm[m] = m < T * HW ? (uint16_t)m : (uint16_t)0x8000;
+    return;
+  }
+  // the fullest halves first would leave the tail tiles empty; interleave so that every tile's two halves are balanced:
+  // half h -> tile h / 2; rows {0-3, 12-15} of the tile = its even half, rows {4-11} = its odd half
+  static const int slot_a[8] = {0, 1, 2, 3, 12, 13, 14, 15}, slot_b[8] = {4, 5, 6, 7, 8, 9, 10, 11};
+  for (int h = 0; h < halves; ++h) {
+    const int* slot = (h & 1) ? slot_b : slot_a;
+    bool used[8] = {false, false, false, false, false, false, false, false};
+    auto residue = [&](uint16_t pm) { const int t = pm / HW, p = pm % HW; return (t * phw + a.shift[t] + (p / a.W) * a.PW + p % a.W) & 7; };
+    for (uint16_t pm : half[h]) used[residue(pm)] = true;
+    int free_r = 0;
+    for (int k = 0; k < 8; ++k) {
+      uint16_t v;
+      if (k < (int)half[h].size()) v = half[h][k];
+      else {
+        while (free_r < 8 && used[free_r]) ++free_r;      // a cell of a residue this half lacks (cells 0 .. 7 of the tile)
+        v = (uint16_t)(0x8000 | (free_r & 7));
+        if (free_r < 8) used[free_r] = true;
+      }
+      a.perm[(h / 2) * 16 + slot[k]] = v;
+    }
+  }
+}
+
+size_t rt_carve(const mzx_search* s, int T, int waves, RtSearchArgs& a) {
   const mzx_net* net = s->net;
   const std::vector<OpDesc>& prog = net->prog_recurrent;
   const RbProgram& R = net->rb.recurrent;
   const RbTower& t0 = R.towers[0];
   RbTowerShape sh;
-  if (!rb_tower_grid(t0, T, sh) || sh.NT != 1) return 0;
+  if (!rt_grid(t0, T, waves, sh)) return 0;
   a.C = t0.C; a.H = t0.H; a.W = t0.W; a.PH = t0.H + 2; a.PW = t0.W + 2; a.Cs = sh.Cs; a.cchunks = t0.cchunks;
   a.T = T; a.rows = sh.rows; a.mtiles = sh.mtiles;
   int64_t o = 0;
@@ -463,7 +556,8 @@ size_t rt_carve(const mzx_search* s, int T, RtSearchArgs& a) {
   o = rt_align(o, 16);
   a.off_rowtab = (int32_t)o; o += (int64_t)3 * 16 * sh.mtiles * 4;
   o = rt_align(o, 16);
-  a.off_tile = (int32_t)o; o += (int64_t)T * a.PH * a.PW * a.Cs * 4;
+  rt_row_order(a, sh.mtiles);
+  a.off_tile = (int32_t)o; o += (int64_t)a.tile_cells * a.Cs * 4;
   a.off_scale = (int32_t)o; o += (int64_t)2 * T * a.C * 4;
   o = rt_align(o, 16);
   a.off_sel = (int32_t)o; o += (int64_t)3 * ((T + 3) & ~3) * 4;
@@ -540,37 +634,63 @@ void rt_fill_tower(const mzx_net* net, const RbTower& tw, const RbTowerShape& sh
 
 uint32_t rt_magic(int d) { return d > 1 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u; }
 
-// Trees per workgroup for a shard of `batch` trees: whole searches run in ROUNDS of co-resident workgroups, a round costs
-// the row tiles of a workgroup times the workgroups sharing a CU's matrix pipes; a workgroup alone on its CU cannot hide
-// its tree phases, staging and barriers behind a partner's MFMAs (measured ~0.8 of the paired rate).
+// Trees per workgroup and waves per workgroup for a shard of `batch` trees.  Whole searches run in ROUNDS of co-resident
+// workgroups (a workgroup keeps its trees for all simulations: a partly filled last round costs a whole one); a round
+// costs the row tiles its workgroups put on a CU's matrix pipes, over what the tiling gets out of them.
+// What the measurements say (profiles/r05_rt_experiments.txt): the K loops are bound by OPERAND DELIVERY and by what a wave
+// can issue between its MFMAs, not by the matrix pipe -- with the position and weight loads knocked out they run at 0.98 of
+// it -- and a workgroup's phases outside the K loops (tree walks, staging, tails, head MLPs, epilogues: 15 % of a step)
+// are hidden by a co-resident workgroup only in part.  So: few, fat waves.  A wave with six or eight row tiles feeds 24 /
+// 32 MFMAs from one weight fragment (256 registers, two waves per SIMD); up to four row tiles per wave compile to 128
+// registers and run four waves per SIMD.  Whole steps, connect4 x 200 simulations, of the FP32 MFMA peak per PADDED row
+// tile (measured fraction / share of valid rows; section 9 of the experiments file):
+//   <3,1> 0.71 (two trees per 512-thread workgroup, two workgroups per CU, 1024 trees), <4,1> 0.72, <6,1> 0.72, <8,1> 0.74;
+//   a CU's wave slots half empty: x 0.92 (shallow tilings), x 0.83 (deep); a single workgroup on the CU (nobody runs while it
+//   walks its trees): x 0.95.
+struct RtPlan {
+  bool ok = false;
+  int T = 0, MT = 0, waves = 8, groups = 0, per_cu = 1;
+  size_t lds = 0;
+  RtSearchArgs a;
+};
+
 RtPlan rt_plan(const mzx_search* s) {
   RtPlan best;
   if (!rt_structure(s->net, nullptr) || !row_search_supported(s->p)) return best;
   const RbProgram& R = s->net->rb.recurrent;
-  const int force_t = tune(TUNE_RT_TREES);
+  const int force_t = tune(TUNE_RT_TREES), force_w = tune(TUNE_RT_WAVES);
   const int batch = s->p.num_trees;
+  static const double eff_mt[RT_MT_MAX + 1] = {1.0, 0.45, 0.50, 0.706, 0.718, 0.71, 0.723, 0.73, 0.74};
   double best_cost = 1e30;
-  for (int T = 16; T >= 1; --T) {
-    RbTowerShape sh;
-    if (!rb_tower_grid(R.towers[0], T, sh) || sh.NT != 1 || sh.MT > RT_MT_MAX) continue;
-    if (T * 16 > RB_THREADS) continue;                       // a 16-lane row per tree
-    RtPlan c;
-    memset(&c.a, 0, sizeof(c.a));
-    c.lds = rt_carve(s, T, c.a);
-    if (c.lds == 0) continue;
-    c.lds += (size_t)tune(TUNE_RT_LDS_PAD_KB) * 1024;      // (occupancy experiments: fewer workgroups per CU)
-    if (c.lds > (size_t)RT_LDS_MAX) continue;
-    c.T = T; c.MT = sh.MT; c.groups = (batch + T - 1) / T;
-    c.per_cu = (int)std::min<size_t>(2, (size_t)RT_LDS_MAX / c.lds);      // (128-register instantiations: at most two)
-    const int64_t cap = (int64_t)256 * c.per_cu;
-    const int64_t full = c.groups / cap, rem = c.groups % cap;
-    auto round_cost = [&](int ways) { return ways <= 1 ? sh.mtiles / 0.8 : (double)ways * sh.mtiles; };
-    double cost = (double)full * round_cost(c.per_cu);
-    if (rem) cost += round_cost((int)std::min<int64_t>(c.per_cu, (rem + 255) / 256));
-    cost += 1e-6 * c.groups;
-    c.ok = true;
-    if (force_t > 0 && T == force_t) { best = c; break; }
-    if (cost < best_cost) { best_cost = cost; best = c; }
+  for (int waves = 8; waves >= 4; waves >>= 1) {
+    if (force_w > 0 && waves != force_w) continue;
+    for (int T = 16; T >= 1; --T) {
+      if (force_t > 0 && T != force_t) continue;
+      RbTowerShape sh;
+      if (!rt_grid(R.towers[0], T, waves, sh) || sh.MT > RT_MT_MAX) continue;
+      if (T * 16 > waves * 64) continue;                     // a 16-lane row per tree
+      RtPlan c;
+      memset(&c.a, 0, sizeof(c.a));
+      c.lds = rt_carve(s, T, waves, c.a);
+      if (c.lds == 0 || c.lds > (size_t)RT_LDS_MAX) continue;
+      c.T = T; c.MT = sh.MT; c.waves = waves; c.groups = (batch + T - 1) / T;
+      // up to four row tiles per wave: 128-register instantiations, four waves per SIMD = sixteen per CU; deeper: two per SIMD
+      const int slots = sh.MT <= 4 ? 16 : 8;
+      c.per_cu = (int)std::min<size_t>((size_t)(slots / waves), (size_t)RT_LDS_MAX / c.lds);
+      if (c.per_cu < 1) continue;
+      const int64_t cap = (int64_t)256 * c.per_cu;
+      const int64_t full = c.groups / cap, rem = c.groups % cap;
+      auto round_cost = [&](int ways) {
+        const double filled = (double)(ways * waves) / slots;      // share of the CU's wave slots (of this register class) in use
+        const double occ = filled >= 1.0 ? 1.0 : (sh.MT <= 4 ? (filled >= 0.5 ? 0.92 : 0.72) : 0.83);
+        return (double)ways * sh.mtiles / (eff_mt[sh.MT] * occ * (ways == 1 ? 0.95 : 1.0));
+      };
+      double cost = (double)full * round_cost(c.per_cu);
+      if (rem) cost += round_cost((int)std::min<int64_t>(c.per_cu, (rem + 255) / 256));
+      cost += 1e-6 * c.groups;
+      c.ok = true;
+      if (cost < best_cost) { best_cost = cost; best = c; }
+    }
   }
   return best;
 }
@@ -579,11 +699,12 @@ RtPlan rt_plan(const mzx_search* s) {
 
 bool rt_search_supported(const mzx_search* s) { return s && s->net && rt_plan(s).ok; }
 
-// {trees per workgroup, row tiles per wave, workgroups, workgroups per CU, LDS bytes}; zeros when the kernel does not take the search
-void rt_search_shape(const mzx_search* s, int32_t out[5]) {
+// {trees per workgroup, row tiles per wave, workgroups, workgroups per CU, LDS bytes, threads per workgroup}; zeros when the
+// kernel does not take the search
+void rt_search_shape(const mzx_search* s, int32_t out[6]) {
   const RtPlan P = rt_plan(s);
   out[0] = P.ok ? P.T : 0; out[1] = P.ok ? P.MT : 0; out[2] = P.ok ? P.groups : 0; out[3] = P.ok ? P.per_cu : 0;
-  out[4] = P.ok ? (int32_t)P.lds : 0;
+  out[4] = P.ok ? (int32_t)P.lds : 0; out[5] = P.ok ? P.waves * 64 : 0;
 }
 
 // The simulations of a search whose roots are in the arena (RootInitOp done, root states in the node store).
@@ -598,29 +719,26 @@ int rt_search_simulations(mzx_search* s, const mzx_search_io* io, void* d_arena,
   a.trees = v.arena.trees; a.tape = io->d_tape; a.hidden = v.arena.hidden;
   a.flat = net->d_flat; a.der = net->d_derived;
   a.num_sims = s->p.num_sims; a.sim0 = 0; a.batch = s->p.num_trees;
-  a.magic_hw = rt_magic(a.H * a.W); a.magic_w = rt_magic(a.W); a.magic_rows = rt_magic(a.rows);
+  a.magic_hw = rt_magic(a.H * a.W); a.magic_w = rt_magic(a.W); a.magic_rows = rt_magic(16 * a.mtiles);
   a.magic_chw = rt_magic(a.C * a.H * a.W); a.magic_c = rt_magic(a.C);
   RbTowerShape sh;
-  rb_tower_grid(R.towers[0], P.T, sh);
+  rt_grid(R.towers[0], P.T, P.waves, sh);
   rt_fill_tower(net, R.towers[0], sh, a.tw[0]);
   rt_fill_tower(net, R.towers[1], sh, a.tw[1]);
   const bool wide = s->p.num_actions > FUSED_ROW || 2 * s->p.support_size + 1 > 2 * FUSED_ROW;
-  const bool ring = tune(TUNE_RT_RING) != 0;
-  RtSearchFn fn = wide ? rt_pick_mt<0, false>(P.MT) : (s->p.num_actions <= 4 ? rt_pick_mt<4, false>(P.MT) :
-                  ring ? rt_pick_mt<16, true>(P.MT) : rt_pick_mt<16, false>(P.MT));
-  a.stagger_us = P.per_cu > 1 ? tune(TUNE_RT_STAGGER_US) : 0;
-  a.stagger_period = 256;
+  RtSearchFn fn = P.waves == 8 ? rt_pick<8>(P.MT, wide, s->p.num_actions) : rt_pick<4>(P.MT, wide, s->p.num_actions);
   const int dbg = tune(TUNE_RT_DBG);
   a.tw[0].dbg = a.tw[1].dbg = dbg & 3;
   a.dbg = dbg;
   if (!fn) { set_error("tower whole-search kernel: no instantiation for %d row tiles per wave", P.MT); return MZX_ERR_INVALID; }
-  static std::atomic<uint64_t> lds_attr_done[4][RT_MT_MAX + 1];
-  if (const int ae = allow_large_lds((const void*)fn, RT_LDS_MAX, lds_attr_done[wide ? 0 : (s->p.num_actions <= 4 ? 1 : (ring ? 3 : 2))][P.MT])) {
+  static std::atomic<uint64_t> lds_attr_done[2][3][RT_MT_MAX + 1];
+  if (const int ae = allow_large_lds((const void*)fn, RT_LDS_MAX,
+                                     lds_attr_done[P.waves == 8][wide ? 0 : (s->p.num_actions <= 4 ? 1 : 2)][P.MT])) {
     set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));
     return MZX_ERR_RUNTIME;
   }
   void* params[] = {(void*)&a};
-  const hipError_t e = hipLaunchKernel((const void*)fn, dim3(P.groups), dim3(RB_THREADS), params, P.lds, stream);
+  const hipError_t e = hipLaunchKernel((const void*)fn, dim3(P.groups), dim3(P.waves * 64), params, P.lds, stream);
   if (e != hipSuccess) {
     set_error("tower whole-search launch failed: %s (grid %d, %zu bytes of LDS, %d trees per workgroup)", hipGetErrorString(e),
               P.groups, P.lds, P.T);

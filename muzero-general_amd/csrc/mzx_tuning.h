@@ -24,10 +24,8 @@ enum TuningKey {
   TUNE_WIDE_TOWERS,           // 1: wide residual networks that also fit the LDS-resident engine search on the tower arithmetic (0: rz_search_kernel)
   TUNE_RT_SEARCH,             // tower whole-search kernel (rt_search_kernel): -1 automatic, 0 never, 1 whenever the network fits
   TUNE_RT_TREES,              // > 0: trees per workgroup of rt_search_kernel (0: the planner's cost model)
+  TUNE_RT_WAVES,              // 4 / 8: waves per workgroup of rt_search_kernel (0: the planner's cost model)
   TUNE_RT_MAX_TREES,          // automatic routing: shards above this many trees stay on the two-stream streamed path
-  TUNE_RT_RING,               // 1: rt_search_kernel's K loops keep the weight fragments of four chunks in flight
-  TUNE_RT_STAGGER_US,         // the second workgroup of a CU starts this many microseconds after the first (0: together)
-  TUNE_RT_LDS_PAD_KB,         // occupancy experiments: extra LDS per workgroup of rt_search_kernel (fewer workgroups per CU)
   TUNE_RT_DBG,                // timing experiments of rt_search_kernel (results are wrong with any bit set; never set in production)
   TUNE_COUNT
 };
@@ -41,10 +39,8 @@ inline TuningEntry* tuning_table() {
       {"wide_towers", 1, 1, 0, 1, "wide residual networks search on the tower arithmetic (0 = the LDS-resident whole-search kernel)"},
       {"rt_search", -1, -1, -1, 1, "tower whole-search kernel: -1 automatic, 0 never, 1 whenever supported"},
       {"rt_trees", 0, 0, 0, 16, "trees per workgroup of the tower whole-search kernel (0 = cost model)"},
+      {"rt_waves", 0, 0, 0, 8, "waves per workgroup of the tower whole-search kernel: 4 or 8 (0 = cost model)"},
       {"rt_max_trees", 1 << 30, 1 << 30, 0, 1 << 30, "automatic routing: largest shard sent to the tower whole-search kernel"},
-      {"rt_ring", 0, 0, 0, 1, "tower whole-search kernel: weight fragments of four chunks in flight"},
-      {"rt_stagger_us", 0, 0, 0, 100000, "tower whole-search kernel: start offset of the second workgroup of a CU, microseconds"},
-      {"rt_lds_pad_kb", 0, 0, 0, 128, "tower whole-search kernel: extra LDS per workgroup, KB (occupancy experiments)"},
       {"rt_dbg", 0, 0, 0, 31, "timing experiments: 1 no K loops, 2 no epilogues, 4 no tree phases, 8 no staging / tails, 16 no head MLPs (wrong results)"},
   };
   return t;

@@ -63,6 +63,147 @@ one() {   # label, bench arguments...: one line per run
 }
 
 case $JOB in
+  rt-sweep)      # forced (trees per workgroup, waves) at the BASELINE shard and around it
+    {
+    for cfg in "4 8" "2 4" "2 8" "1 4" "3 8" "3 4"; do
+      set -- $cfg
+      one "1024: $1 trees x $(($2 * 64)) threads" --workload c4 --tuning rt_trees=$1,rt_waves=$2
+    done
+    for cfg in "3 8" "3 4" "2 4" "1 4" "6 8"; do
+      set -- $cfg
+      one "768: $1 trees x $(($2 * 64)) threads" --workload c4 --trees 768 --tuning rt_trees=$1,rt_waves=$2
+    done
+    for cfg in "2 8" "2 4" "1 4" "4 8"; do
+      set -- $cfg
+      one "512: $1 trees x $(($2 * 64)) threads" --workload c4 --trees 512 --tuning rt_trees=$1,rt_waves=$2
+    done
+    for cfg in "6 8" "3 4" "4 8" "2 4"; do
+      set -- $cfg
+      one "1280: $1 trees x $(($2 * 64)) threads" --workload c4 --trees 1280 --tuning rt_trees=$1,rt_waves=$2
+    done
+    one "1024 planner, no tree phases" --workload c4 --tuning rt_dbg=4
+    one "1024 planner, no heads" --workload c4 --tuning rt_dbg=16
+    one "1024 planner, no staging / tails" --workload c4 --tuning rt_dbg=8
+    one "1024 planner, no epilogues" --workload c4 --tuning rt_dbg=2
+    one "1024 planner, nothing but K loops" --workload c4 --tuning rt_dbg=30
+    } > $OUT/rt_sweep.txt 2>&1
+    cat $OUT/rt_sweep.txt
+    ;;
+  kloop2)      # the K loop with incremental cursors and requests / scalar work interleaved with the MFMAs
+    timeout 600 python -m pytest tests/test_gpu_tower_search.py -m gpu -q -s -x -k "bit_identical or same_trees" > $OUT/pytest_rt.log 2>&1
+    grep -E "passed|failed|^FAILED|^ERROR|Error" $OUT/pytest_rt.log | tail
+    {
+    for t in 512 1024 1536 2048; do
+      one "rt $t (planner)" --workload c4 --trees $t
+    done
+    one "rt 1024 K loops only" --workload c4 --tuning rt_dbg=30
+    one "rt 1024, 2 trees x 512 threads <3,1>" --workload c4 --tuning rt_trees=2,rt_waves=8
+    one "rt 1024, 2 trees x 512 threads <3,1>, K loops only" --workload c4 --tuning rt_trees=2,rt_waves=8,rt_dbg=30
+    one "rt 256, 1 tree x 256 threads <3,1> ONE wave per SIMD, K loops only" --workload c4 --trees 256 --tuning rt_trees=1,rt_waves=4,rt_dbg=30
+    one "rt 1536, 3 trees x 512 threads <4,1>" --workload c4 --trees 1536 --tuning rt_trees=3,rt_waves=8
+    one "launches 1024" --workload c4-rows
+    one "launches 9216" --workload c4-rows --trees 9216
+    one "gomoku as shipped, launches" --workload gomoku --steps 1 --tuning rt_search=0
+    one "atari as shipped" --workload atari --steps 1
+    } > $OUT/kloop2.txt 2>&1
+    cat $OUT/kloop2.txt
+    timeout 900 python -m pytest tests/test_gpu_streamed.py -m gpu -q -x -k "tower_kernel_layer_by_layer" > $OUT/pytest_tower.log 2>&1
+    grep -E "passed|failed|^FAILED|^ERROR|Error" $OUT/pytest_tower.log | tail -5
+    ;;
+  rt-deal)      # positions dealt to the row tiles for conflict-free LDS reads
+    timeout 600 python -m pytest tests/test_gpu_tower_search.py -m gpu -q -s -x -k "bit_identical or same_trees" > $OUT/pytest_rt.log 2>&1
+    grep -E "passed|failed|^FAILED|^ERROR|Error" $OUT/pytest_rt.log | tail
+    {
+    for t in 512 1024 1536 2048; do
+      one "rt $t (planner)" --workload c4 --trees $t
+    done
+    one "rt 1024 K loops only" --workload c4 --tuning rt_dbg=30
+    one "rt 1024, 2 trees x 512 threads <3,1>" --workload c4 --tuning rt_trees=2,rt_waves=8
+    one "gomoku as shipped, rt_search_kernel" --workload gomoku --steps 1 --tuning rt_search=1
+    one "gomoku as shipped, launches" --workload gomoku --steps 1 --tuning rt_search=0
+    } > $OUT/rt_deal.txt 2>&1
+    cat $OUT/rt_deal.txt
+    CMD="python bench.py --workload c4 --steps 2 --warmup 1 $Q"
+    timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_a -o run -- $CMD > $OUT/pmc_a.log 2>&1
+    python muzero-general_amd/tools/rocprof_summary.py $OUT rt_search > $OUT/summary.txt 2>&1
+    grep -E "^SQ_|^GRBM" $OUT/summary.txt | cut -c1-70
+    ;;
+  rt-plan)      # the planner's choice by shard size, against the per-simulation launches
+    timeout 600 python -m pytest tests/test_gpu_tower_search.py -m gpu -q -s -x -k "bit_identical or routing or same_trees" > $OUT/pytest_rt.log 2>&1
+    grep -E "passed|failed|^FAILED|^ERROR|Error" $OUT/pytest_rt.log | tail
+    {
+    for t in 256 512 768 1024 1280 1536 2048 3072 4096 4608 9216; do
+      one "rt $t (planner)" --workload c4 --trees $t
+      one "launches $t" --workload c4-rows --trees $t
+    done
+    } > $OUT/rt_plan.txt 2>&1
+    cat $OUT/rt_plan.txt
+    ;;
+  rt-deep)      # fewer, fatter waves: more MFMAs per weight fragment
+    {
+    one "1024: 2 trees x 256 threads <6,1>, two per CU" --workload c4 --tuning rt_trees=2,rt_waves=4
+    one "1024: 2 trees x 256 threads <6,1>, K loops only" --workload c4 --tuning rt_trees=2,rt_waves=4,rt_dbg=30
+    one "1024: 4 trees x 512 threads <6,1>, one per CU" --workload c4 --tuning rt_trees=4,rt_waves=8
+    one "1024: 4 trees x 512 threads <6,1>, K loops only" --workload c4 --tuning rt_trees=4,rt_waves=8,rt_dbg=30
+    one "1536: 2 trees x 256 threads <6,1>, three per CU" --workload c4 --trees 1536 --tuning rt_trees=2,rt_waves=4
+    one "1536: 3 trees x 256 threads <8,1>, two per CU" --workload c4 --trees 1536 --tuning rt_trees=3,rt_waves=4
+    one "1536: 6 trees x 512 threads <8,1>, one per CU" --workload c4 --trees 1536 --tuning rt_trees=6,rt_waves=8
+    one "2048: 4 trees x 512 threads <6,1>" --workload c4 --trees 2048 --tuning rt_trees=4,rt_waves=8
+    one "512: 2 trees x 256 threads <6,1>, one per CU" --workload c4 --trees 512 --tuning rt_trees=2,rt_waves=4
+    } > $OUT/rt_deep.txt 2>&1
+    cat $OUT/rt_deep.txt
+    ;;
+  kloop)      # what the K loop of <3,1> waits for: variants of the library that leave loads / address arithmetic out (kloop_experiment.sh)
+    {
+    F="--workload c4 --tuning rt_trees=2,rt_waves=8,rt_dbg=30"
+    one "K loops only (product build)" $F
+    for n in 1 2 3 4; do
+      MZX_LIB=$PWD/muzero-general_amd/mzx/libmzx_exp$n.so one "K loops only, experiment $n" $F
+    done
+    F1="--workload c4 --trees 256 --tuning rt_trees=1,rt_waves=4,rt_dbg=30"
+    one "ONE wave per SIMD: K loops only (product build)" $F1
+    for n in 1 2 3 4; do
+      MZX_LIB=$PWD/muzero-general_amd/mzx/libmzx_exp$n.so one "ONE wave per SIMD: K loops only, experiment $n" $F1
+    done
+    } > $OUT/kloop.txt 2>&1
+    cat $OUT/kloop.txt
+    ;;
+  rt-w4)      # 256-thread workgroups, one tree each, four per CU
+    {
+    for t in 512 1024 2048; do
+      one "rt $t, 1 tree x 256 threads" --workload c4 --trees $t --tuning rt_trees=1,rt_waves=4
+    done
+    one "rt 1024, 1 tree x 256 threads, K loops only" --workload c4 --tuning rt_trees=1,rt_waves=4,rt_dbg=30
+    one "rt 1024, 1 tree x 256 threads, no tree phases" --workload c4 --tuning rt_trees=1,rt_waves=4,rt_dbg=4
+    one "rt 256, 1 tree x 256 threads" --workload c4 --trees 256 --tuning rt_trees=1,rt_waves=4
+    one "rt 768, 1 tree x 256 threads" --workload c4 --trees 768 --tuning rt_trees=1,rt_waves=4
+    } > $OUT/rt_w4.txt 2>&1
+    cat $OUT/rt_w4.txt
+    ;;
+  rt-waves)     # 512-thread workgroups (two per CU) against 1024-thread ones (one per CU, twice the trees per tile)
+    timeout 600 python -m pytest tests/test_gpu_tower_search.py -m gpu -q -s -x -k "bit_identical or routing" > $OUT/pytest_rt.log 2>&1
+    grep -E "passed|failed|^FAILED|^ERROR|Error" $OUT/pytest_rt.log | tail
+    {
+    for t in 256 512 768 1024 1536 2048 3072 4096 9216; do
+      one "rt $t (planner)" --workload c4 --trees $t
+    done
+    one "rt 1024, 2 trees x 512 threads" --workload c4 --tuning rt_trees=2,rt_waves=8
+    one "rt 1024, 4 trees x 1024 threads" --workload c4 --tuning rt_trees=4,rt_waves=16
+    one "rt 1024, 4 trees x 1024 threads, K loops only" --workload c4 --tuning rt_trees=4,rt_waves=16,rt_dbg=30
+    one "rt 1024, 4 trees x 1024 threads, no heads" --workload c4 --tuning rt_trees=4,rt_waves=16,rt_dbg=16
+    one "rt 1024, 4 trees x 1024 threads, no tree phases" --workload c4 --tuning rt_trees=4,rt_waves=16,rt_dbg=4
+    one "rt 512, 2 trees x 512 threads" --workload c4 --trees 512 --tuning rt_trees=2,rt_waves=8
+    one "rt 512, 2 trees x 1024 threads" --workload c4 --trees 512 --tuning rt_trees=2,rt_waves=16
+    one "rt 512, 4 trees x 1024 threads" --workload c4 --trees 512 --tuning rt_trees=4,rt_waves=16
+    one "rt 1536, 3 trees x 512 threads" --workload c4 --trees 1536 --tuning rt_trees=3,rt_waves=8
+    one "rt 1536, 6 trees x 1024 threads" --workload c4 --trees 1536 --tuning rt_trees=6,rt_waves=16
+    one "rt 2048, 4 trees x 1024 threads" --workload c4 --trees 2048 --tuning rt_trees=4,rt_waves=16
+    one "rt 2048, 2 trees x 512 threads" --workload c4 --trees 2048 --tuning rt_trees=2,rt_waves=8
+    one "rt 3072, 6 trees x 1024 threads" --workload c4 --trees 3072 --tuning rt_trees=6,rt_waves=16
+    one "rt 3072, 3 trees x 512 threads" --workload c4 --trees 3072 --tuning rt_trees=3,rt_waves=8
+    } > $OUT/rt_waves.txt 2>&1
+    cat $OUT/rt_waves.txt
+    ;;
   rt-occ)       # is rt_search_kernel bound by the matrix pipes a CU's workgroups share, or does every workgroup run at its own pace?
     {
     one "rt 1024, 2 trees per workgroup, two per CU" --workload c4

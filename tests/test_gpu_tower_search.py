@@ -41,6 +41,9 @@ CASES = {
     "narrow4": lambda: configs.connect4(observation_shape=(3, 4, 4), action_space=list(range(4)), channels=64, blocks=2),
     # 32 actions on 4 x 8: several child slots per lane (AW = 0), head inputs that are no multiple of 16, head chains of
     # one and three Linear layers
+    # games/gomoku.py as shipped (128 channels x 6 blocks, 11 x 11, 121 actions): one board per 512-thread workgroup, <8,1>,
+    # eight column tiles; the library does not route it here by itself (launch by launch is faster), "rt_search" = 1 does
+    "gomoku": lambda: configs.gomoku(),
     "wide32": lambda: configs.connect4(observation_shape=(3, 4, 8), action_space=list(range(32)), channels=64, blocks=1,
                                        reduced_channels_reward=3, reduced_channels_value=5, reduced_channels_policy=7,
                                        resnet_fc_reward_layers=[24], resnet_fc_value_layers=[40, 16], resnet_fc_policy_layers=[]),
@@ -75,17 +78,20 @@ def _assert_same(a, b, label):
         assert numpy.array_equal(x, y), (label, key)
 
 
-@pytest.mark.parametrize("ring", [0, 1])
-@pytest.mark.parametrize("name,B,S,trees_per_wg", [
-    ("connect4", 19, 40, 0), ("connect4", 50, 30, 1), ("connect4", 51, 30, 2), ("connect4", 131, 24, 3),
-    ("board4x4", 37, 30, 0), ("board4x4", 9, 30, 5), ("narrow4", 23, 30, 0), ("narrow4", 10, 30, 3),
-    ("wide32", 21, 36, 0), ("wide32", 13, 20, 1)])
-def test_tower_search_kernel_bit_identical_to_per_simulation_launches(backend, name, B, S, trees_per_wg, ring):
+@pytest.mark.parametrize("name,B,S,trees_per_wg,waves", [
+    ("connect4", 19, 40, 0, 0), ("connect4", 50, 30, 1, 8), ("connect4", 51, 30, 2, 8), ("connect4", 131, 24, 3, 8),
+    ("connect4", 37, 30, 1, 4), ("connect4", 21, 30, 2, 4), ("connect4", 133, 24, 4, 8), ("connect4", 50, 24, 5, 8),
+    ("connect4", 67, 20, 6, 8), ("connect4", 40, 20, 3, 4),
+    ("board4x4", 37, 30, 0, 0), ("board4x4", 9, 30, 5, 8), ("board4x4", 50, 24, 12, 8), ("narrow4", 23, 30, 0, 0),
+    ("narrow4", 10, 30, 3, 8), ("narrow4", 29, 20, 7, 4), ("wide32", 21, 36, 0, 0), ("wide32", 13, 20, 1, 8), ("wide32", 19, 20, 3, 4),
+    ("gomoku", 6, 12, 0, 0)])
+def test_tower_search_kernel_bit_identical_to_per_simulation_launches(backend, name, B, S, trees_per_wg, waves):
     """
     rt_search_kernel against the launch-by-launch route of the SAME engine (tuning "rt_search" = 0) on ragged shards (a
     last workgroup with missing trees, partial wavefronts of rows, ragged legal sets, both players): every statistic of
-    every finished tree bit for bit, whatever the trees per workgroup and the K loop (one weight fragment ahead / a ring
-    of four) -- and a second run on the same handle too.
+    every finished tree bit for bit, whatever the trees per workgroup and the workgroup size (512 / 256 threads) -- row tiles
+    per wave 1 .. 8, i.e. the 128-register instantiations with four waves per SIMD and the deep ones with two -- and a second
+    run on the same handle too.
     """
     cfg = CASES[name]()
     cfg.num_simulations = S
@@ -96,7 +102,7 @@ def test_tower_search_kernel_bit_identical_to_per_simulation_launches(backend, n
     for rt in (0, 1, 1):
         backend.lib.tuning_set("rt_search", rt)
         backend.lib.tuning_set("rt_trees", trees_per_wg if rt else 0)
-        backend.lib.tuning_set("rt_ring", ring)
+        backend.lib.tuning_set("rt_waves", waves if rt else 0)
         backend.lib.tuning_set("row_split_min", 0 if len(outs) == 0 else 32)
         engine = self_play.BatchedMCTS(cfg, net, B, mode=1) if len(outs) < 2 else engine
         route = _route(backend, engine, B)
@@ -110,8 +116,10 @@ def test_tower_search_kernel_bit_identical_to_per_simulation_launches(backend, n
             assert "rb_tower_kernel" in kernel and "row_select_kernel" in kernel
         outs.append((res, engine.export_trees(B)))
         if rt:
-            print(f"{name}: {B} trees, rt_search_kernel with {route[1]} trees per workgroup, <{route[2]},1>, {route[3]} workgroups, "
-                  f"{route[4]} per CU, {route[5]} bytes of LDS")
+            if waves:
+                assert route[6] == waves * 64, route
+            print(f"{name}: {B} trees, rt_search_kernel with {route[1]} trees per workgroup of {route[6]} threads, <{route[2]},1>, "
+                  f"{route[3]} workgroups, {route[4]} per CU, {route[5]} bytes of LDS")
     assert (outs[0][0].visit_counts.sum(1) == S).all()
     _assert_same(outs[0], outs[1], (name, "rt vs launches"))
     _assert_same(outs[1], outs[2], (name, "second run"))
@@ -121,19 +129,22 @@ def test_tower_search_routing(backend):
     """Which searches the library sends to rt_search_kernel (mzx_search_route, host-side): connect4 at every shard size --
     the same arithmetic whatever the shard, csrc/mzx_row_search.h wide_search_route --, never a narrow network, a network
     whose towers are too wide for the kernel's tilings, or a fully connected one."""
-    for B, want_t in ((8, None), (512, None), (1024, 2), (1536, 3), (2048, 2)):
+    for B, want in ((8, (1, 256)), (512, (1, 256)), (768, (3, 512)), (1024, (4, 512)), (1536, (3, 256)), (2048, (4, 512))):
         cfg = configs.connect4()
         net = models.MuZeroNetwork(cfg)
         net.set_weights(synthetic.fill_state_dict(net.state_dict(), 1))
         engine = self_play.BatchedMCTS(cfg, net, B)
         route = _route(backend, engine, B)
         assert route[0] == 3, (B, route)
-        assert route[3] == -(-B // route[1]) and route[5] <= 160 * 1024 and route[2] <= 4
-        if want_t is not None:
-            assert route[1] == want_t and route[4] == 2, (B, route)        # whole rounds of two workgroups per CU
+        assert route[3] == -(-B // route[1]) and route[5] <= 160 * 1024 and route[2] <= 8
+        # whole rounds of few, fat workgroups: four boards = 168 rows in eleven row tiles <6,1> at 1024 trees, three <8,1> at 1536
+        assert (route[1], route[6]) == want, (B, route)
         with backend.lib.tuning(rt_search=0):
             r2 = _route(backend, engine, B)
             assert r2[0] == 2 and r2[6] + r2[7] == B and (r2[7] > 0) == (B >= 1024), (B, r2)
+        with backend.lib.tuning(rt_trees=2, rt_waves=8):
+            r3 = _route(backend, engine, B)
+            assert r3[:3] == [3, 2, 3] and r3[6] == 512, (B, r3)
         with backend.lib.tuning(wide_towers=0):
             assert _route(backend, engine, B)[0] == 1
     for name, want in (("tictactoe", 1), ("breakout", 1), ("gomoku", 2), ("cartpole", 4)):
@@ -170,9 +181,9 @@ def test_tower_search_at_size_same_trees_as_launches(backend):
 
 @pytest.mark.parametrize("B,trees_per_wg,n_sample", [(512, 1, 32), (1536, 3, 48)])
 def test_tower_search_other_shards_against_oracle(backend, B, trees_per_wg, n_sample):
-    """The other tilings of the kernel at full size (one tree per workgroup = <2,1> at 512 trees, three = <4,1> at 1536;
-    two = <3,1> at 1024 trees: test_full_size_residual_configs[connect4]) against the CPU oracle, simulation by simulation,
-    with the oracle's own fp32-vs-binary64 divergence as the yardstick."""
+    """The other tilings the planner picks at full size (one tree per 256-thread workgroup = <3,1> at 512 trees, three = <8,1>
+    at 1536; four per 512-thread workgroup = <6,1> at 1024 trees: test_full_size_residual_configs[connect4]) against the CPU
+    oracle, simulation by simulation, with the oracle's own fp32-vs-binary64 divergence as the yardstick."""
     cfg = configs.connect4()
     S = cfg.num_simulations
     net = models.MuZeroNetwork(cfg)
