@@ -21,14 +21,20 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   "roofline"      algorithmic tree bytes (SURVEY.md section 8d formula, with the measured mean leaf depth) /
                   HIP-event time of the search launch, vs the HBM peak (residual networks: network FLOPs vs the
                   dense FP32-input MFMA peak)
-  "workloads"     the other BASELINE configurations (C3, C4 = the Connect4 half of the metric, C5) and the reference's
-                  games/gomoku.py as shipped (streamed MFMA engine) measured in this invocation, same fields
+  "workloads"     the other BASELINE configurations (C3, C4 = the Connect4 half of the metric, C5), C2 on the reference's
+                  shipped checkpoint, and the reference's games/gomoku.py / games/atari.py as shipped, measured in this
+                  invocation -- compact entries: w workload, v sims/s (median block; min / max beside it), ms per step, B
+                  trees, S simulations, L mean leaf depth, k the search kernel (+ its shape), roofline {bound, achieved
+                  (TFLOP/s | GB/s), frac, traffic (PMC HBM bytes per step | null), launch_ms}
   "per_rank" / "single_gpu_reference"   N > 1: every rank's own rate, and rank 0 timed alone just before
   "selfplay_end_to_end*"  self-play steps/s through the plugin surface (N = 1)
   "observation_stacker"   the path's HBM-bound kernel (mzx_obs_stack, atari geometry) against the HBM peak
   "cpu_baseline"  kind "reference": the UNMODIFIED reference MCTS(config).run + models.py (oracle/_ref, compiled
-                  from /root/reference by oracle/build_ref.py) on this box's host cores, bounded sample;
-                  "cpu_baseline_port": the CPU oracle (oracle/*.py) on the same sample.
+                  from /root/reference by oracle/build_ref.py) on this box's host cores, bounded sample (kind "port": the
+                  CPU oracle oracle/*.py, when the bytecode did not travel).
+Weights: the reference constructor's under torch.manual_seed(0) (--weights synthetic = rounds 1-4's).
+N > 1 validates itself: after the RCCL broadcast every rank's flat buffer has rank 0's checksum, and one search on
+rank-independent inputs builds the same trees on every rank -- or the run fails ("collective" in the line).
 ``--dry-run`` (CI only): gloo + the serial test double of the ABI on the CPU -- exercises the launch / sharding /
 broadcast / JSON plumbing without a GPU; its numbers are NOT measurements and the line says so.
 """
@@ -60,28 +66,33 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense FP32-input MFMA peak (= FP32 vector peak), same guide
 
 # workloads that choose their network engine themselves (unless --net-mode says otherwise)
-WORKLOAD_NET_MODE = {"c4-large": "streamed"}
+WORKLOAD_NET_MODE = {}
 # workloads that run with entries of the library's tuning table moved (include/mzx.h "Tuning": the A/B legs)
 WORKLOAD_TUNING = {"c4-ws": {"wide_towers": 0}, "c4-rows": {"rt_search": 0}}
 DEFAULT_WORKLOAD = "c2"
 # measured in the same invocation and reported under "workloads" when the main workload is the default one.  Every
 # launch the streamed ones make (c4-large, gomoku, atari) is parity-tested at size: tests/test_streamed_coverage.py
-DEFAULT_ALSO = "c3,c4,c4-ws,c4-large,c5,gomoku,atari"
+DEFAULT_ALSO = "c2-ckpt,c3,c4,c4-ws,c4-large,c5,c5-512,gomoku,atari"
+# workloads whose weights are not the reference constructor's: the checkpoint the reference ships (results/cartpole/
+# model.checkpoint, muzero.py:426-464), carried by the committed fixture tests/golden/net_fc_cartpole_pretrained.npz
+WORKLOAD_WEIGHTS = {"c2-ckpt": "checkpoint:net_fc_cartpole_pretrained.npz"}
 
 WORKLOADS = {
     # name: (config factory name, overrides, trees per GPU, description)
     "c2": ("cartpole", {}, 4096, "C2 CartPole FullyConnectedNetwork, 4096 trees x 50 sims per GPU"),
+    "c2-ckpt": ("cartpole", {}, 4096, "C2 on the reference's shipped results/cartpole/model.checkpoint"),
     "c3": ("tictactoe", {}, 1024, "C3 Tic-tac-toe MuZeroResidualNetwork, 1024 trees x 25 sims per GPU"),
-    # (since round 4 the library routes this shard to the streamed engine -- trunks as towers between the row-per-tree
-    # kernels --, which overtook the LDS-resident whole-search kernel; "c4-ws" is the same workload on that kernel)
+    # (round 5: the library runs every simulation of this search in ONE launch, mzx::rt_search_kernel -- the trunks as towers
+    # inside; "c4-rows" is round 4's route, the same towers launch by launch, "c4-ws" the LDS-resident whole-search kernel)
     "c4": ("connect4", {}, 1024, "C4 Connect4 ResNet, 1024 trees x 200 sims per GPU"),
-    "c4-ws": ("connect4", {}, 1024, "C4 Connect4 ResNet, 1024 trees x 200 sims per GPU, LDS-resident whole-search kernel (A/B)"),
-    "c4-rows": ("connect4", {}, 1024, "C4 Connect4 ResNet, 1024 trees x 200 sims per GPU, per-simulation launches (A/B)"),
-    # the same network and search at a shard large enough for layer-by-layer launches: from ~3000 trees per GPU the
-    # streamed MFMA engine + row-per-tree kernels overtake the LDS-resident whole-search kernel (0.60 against 0.53 of
-    # the FP32 MFMA peak, profiles/r03_streamed_experiments.txt section 10)
+    "c4-ws": ("connect4", {}, 1024, "C4 on mzx::rz_search_kernel (LDS-resident engine, A/B)"),
+    "c4-rows": ("connect4", {}, 1024, "C4 on per-simulation launches (A/B)"),
+    # the same network and search at a large shard (nine rounds of the shape rt_search_kernel runs best on: three boards per
+    # 256-thread workgroup, <8,1>)
     "c4-large": ("connect4", {}, 9216, "C4 Connect4 ResNet at a large shard, 9216 trees x 200 sims per GPU"),
     "c5": ("breakout", {"num_simulations": 50}, 64, "C5 Breakout ResNet (resnet stem), 64 trees x 50 sims per GPU"),
+    # (BASELINE's C5 is 512 trees over 8 GPUs = 64 workgroups on 256 CUs; the same kernel with the 512 trees on ONE GPU)
+    "c5-512": ("breakout", {"num_simulations": 50}, 512, "C5 Breakout ResNet, 512 trees x 50 sims on one GPU"),
     # the reference's large residual configurations as shipped (streamed MFMA engine, csrc/mzx_batched.hip)
     "gomoku": ("gomoku", {}, 1024, "games/gomoku.py as shipped: 128 ch x 6 blocks, 11 x 11, 1024 trees x 400 sims per GPU"),
     # (1024 trees: two half-shards of 512 on two streams, 0.75 of the MFMA peak for the whole step; --trees 256: 0.61)
@@ -112,6 +123,9 @@ def parse():
     ap.add_argument("--selfplay-moves", type=int, default=32,
                     help="moves per game of the end-to-end self-play legs (SelfPlay(num_games=B) on the synthetic game; "
                          "0 = skip); the games of the path's configurations run for hundreds of moves (cartpole: 500)")
+    ap.add_argument("--weights", default="reference", choices=["reference", "synthetic"],
+                    help="reference: torch.manual_seed(0); models.MuZeroNetwork(config) of the UNMODIFIED reference (oracle/_ref "
+                         "bytecode; SURVEY.md section 8d); synthetic: mzx.synthetic.fill_state_dict(seed 0), rounds 1-4's weights")
     ap.add_argument("--tuning", default="",
                     help="name=value,... entries of the library's tuning table (include/mzx.h) for this run (A/B measurements)")
     ap.add_argument("--dry-run", action="store_true",
@@ -223,7 +237,7 @@ class Stopwatch:
 # ----------------------------------------------------------------------------- CPU baselines
 def _cpu_worker_port(args):
     """One host core: the oracle's per-node MCTS with its batch-1 torch network (restatement of the reference)."""
-    workload, worker, seconds = args
+    workload, worker, seconds, _ = args
     torch.set_num_threads(1)
     from mzx import configs, synthetic
     from oracle import mcts_oracle, net_oracle
@@ -247,7 +261,7 @@ def _cpu_worker_port(args):
 
 def _cpu_worker_reference(args):
     """One host core: the UNMODIFIED reference -- self_play.MCTS(config).run on models.MuZeroNetwork (oracle/_ref)."""
-    workload, worker, seconds = args
+    workload, worker, seconds, weights_kind = args
     torch.set_num_threads(1)
     from mzx import configs, synthetic
     from oracle import build_ref
@@ -256,8 +270,9 @@ def _cpu_worker_reference(args):
     name, overrides, _, _ = WORKLOADS[workload]
     cfg = configs.BY_NAME[name](**overrides)
     torch.manual_seed(0)
-    model = ref_models.MuZeroNetwork(cfg)
-    model.set_weights(synthetic.fill_state_dict(model.get_weights(), 0))   # the weights the GPU leg uses
+    model = ref_models.MuZeroNetwork(cfg)      # (the weights the GPU leg uses: this very constructor under this very seed)
+    if weights_kind == "synthetic":
+        model.set_weights(synthetic.fill_state_dict(model.get_weights(), 0))
     model.eval()
     c_in = cfg.observation_shape[0] * (cfg.stacked_observations + 1) + cfg.stacked_observations
     obs = synthetic.observations(64, (c_in,) + tuple(cfg.observation_shape[1:]), seed=123 + worker)
@@ -292,7 +307,7 @@ def _state_dict_template(cfg):
     return out
 
 
-def cpu_baseline(workload, seconds, cores, kind):
+def cpu_baseline(workload, seconds, cores, kind, weights_kind="reference"):
     import multiprocessing as mp
 
     cores = cores or min(os.cpu_count() or 1, 64)
@@ -305,7 +320,7 @@ def cpu_baseline(workload, seconds, cores, kind):
     os.environ.update({"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": "", "MZX_BENCH_CPU_WORKER": "1"})
     try:
         with ctx.Pool(cores) as pool:
-            res = pool.map(worker, [(workload, w, seconds) for w in range(cores)])
+            res = pool.map(worker, [(workload, w, seconds, weights_kind) for w in range(cores)])
     finally:
         for k, v in hidden.items():
             if v is None:
@@ -315,12 +330,11 @@ def cpu_baseline(workload, seconds, cores, kind):
     sims = sum(r[0] for r in res)
     wall = max(r[2] for r in res)
     rates = [r[0] / r[2] for r in res]
-    what = ("unmodified reference self_play.MCTS(config).run + models.py (oracle/_ref bytecode of /root/reference)"
-            if kind == "reference" else "CPU oracle (oracle/mcts_oracle.py + net_oracle.py)")
+    what = ("unmodified reference MCTS.run + models.py (oracle/_ref)" if kind == "reference" else "oracle/mcts_oracle.py + net_oracle.py")
     return {
         "value": sims / wall, "unit": "sims/s", "cores": cores, "kind": kind,
-        "sample": f"{sum(r[1] for r in res)} searches x {sims // max(1, sum(r[1] for r in res))} sims of the same "
-                  f"workload, {cores} processes x {seconds:.0f} s, torch.set_num_threads(1) each; {what}",
+        "sample": f"{sum(r[1] for r in res)} searches x {sims // max(1, sum(r[1] for r in res))} sims of the same workload, "
+                  f"{cores} processes x {seconds:.0f} s, 1 thread each; {what}",
         "per_core": res[0][0] / res[0][2],
         # spread over the worker processes (each one's own sims / wall): one aggregate number hides a slow socket / a
         # busy host; the aggregate above is sum(sims) / max(wall)
@@ -353,7 +367,7 @@ def observation_stacker_leg(backend, games=64, stacked=32, iters=20):
     planes_in, planes_out = 3 * (stacked + 1), 3 * (stacked + 1) + stacked
     nbytes = games * (planes_in + planes_out) * 96 * 96 * 4
     gbs = nbytes / (ms * 1e-3) / 1e9
-    return {"kernel": "mzx_obs_stack (GameHistory.get_stacked_observations on the device)", "bound": "hbm",
+    return {"kernel": "mzx_obs_stack", "bound": "hbm",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": nbytes, "launch_ms": ms, "games": games, "stacked_observations": stacked}
 
@@ -410,12 +424,49 @@ def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=F
         "steps_per_sec": steps / wall, "sims_per_sec": steps * c.num_simulations / wall, "games": B,
         "games_finished": len(histories), "moves_per_finished_game": (sum(len(h.action_history) - 1 for h in histories) /
                                                                       max(1, len(histories))),
-        "game": game, "mode": "lock-step shards (play_games)" if lockstep else "finished slots refilled (play_rounds)",
+        "game": game, "mode": "play_games (lock-step)" if lockstep else "play_rounds (slots refilled)",
         "wall_s": wall, "search_share": sp.stats["search_seconds"] / wall,
         "steps_per_sec_with_all_histories_as_lists": steps / (wall + (materialize if batched else 0.0)),
-        "game_protocol": "batched" if batched else "reference plugin surface (B Game objects)",
+        "game_protocol": "batched" if batched else "B Game objects",
         "slot_groups": len((sp._live or {}).get("groups", ())) or 1,
     }
+
+
+# ----------------------------------------------------------------------------- weights
+def bench_weights(cfg, net, workload, kind):
+    """(state_dict, label).  SURVEY.md section 8(d): the weights of the reference's own constructor under
+    torch.manual_seed(0) -- models.MuZeroNetwork(config).get_weights(), models.py:7-41, from the oracle/_ref bytecode of the
+    unmodified file (the GPU leg only takes the TENSORS; nothing of the reference runs in the timed region)."""
+    from mzx import synthetic
+
+    special = WORKLOAD_WEIGHTS.get(workload)
+    if special and special.startswith("checkpoint:"):
+        z = numpy.load(os.path.join(ROOT, "tests", "golden", special.split(":", 1)[1]), allow_pickle=True)
+        sd, off = {}, 0
+        for k, t in net.state_dict().items():
+            if t.dtype.is_floating_point:
+                sd[k] = torch.from_numpy(z["flat_weights"][off:off + t.numel()].reshape(tuple(t.shape)).copy())
+                off += t.numel()
+        assert off == z["flat_weights"].size
+        return sd, "results/cartpole/model.checkpoint of the reference (tests/golden fixture)"
+    if kind == "reference":
+        try:
+            from oracle import build_ref
+            if build_ref.available():
+                ref_models, _ = build_ref.load()
+                torch.manual_seed(0)
+                model = ref_models.MuZeroNetwork(cfg)
+                return {k: v.clone() for k, v in model.get_weights().items()}, "reference constructor, torch.manual_seed(0)"
+        except Exception as e:      # (oracle/_ref missing or built for another interpreter: say so in the line)
+            print(f"bench: reference constructor unavailable ({e}); synthetic weights", file=sys.stderr)
+    return synthetic.fill_state_dict(net.state_dict(), 0), "synthetic seed 0 (mzx.synthetic.fill_state_dict)"
+
+
+def _checksum(t):
+    """Order-independent 64-bit checksum of a tensor's bits (sum of the int32 words as int64 + a weighted sum)."""
+    w = t.detach().contiguous().view(torch.int32).to(torch.int64).flatten()
+    idx = torch.arange(1, w.numel() + 1, device=w.device, dtype=torch.int64)
+    return int(w.sum().item()), int((w * (idx % 65521)).sum().item())
 
 
 # ----------------------------------------------------------------------------- the search workload
@@ -435,14 +486,25 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     rank, world = env.rank, env.world
 
     net = models.MuZeroNetwork(cfg, _backend=env.backend)
-    # rank 0 holds the "trainer's" weights; every other rank starts from different ones and receives
-    # them through the RCCL broadcast of the flat buffer (the reference's per-game weight pull)
-    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 0 if rank == 0 else 100 + rank))
+    # rank 0 holds the "trainer's" weights; every other rank starts from DIFFERENT ones and receives rank 0's through the
+    # RCCL broadcast of the flat buffer (the reference's per-game weight pull, self_play.py:37)
+    weights, weights_label = bench_weights(cfg, net, workload, args.weights)
+    if rank != 0:
+        weights = synthetic.fill_state_dict(net.state_dict(), 100 + rank)
+    net.set_weights(weights)
     env.fence()
     t_b0 = time.perf_counter()
     shared_storage.broadcast_weights(net, src=0)
     env.sync()
     broadcast_ms = (time.perf_counter() - t_b0) * 1e3
+    # self-validation (N > 1): every rank must now hold rank 0's buffer -- checksums of the flat device buffer, gathered
+    # and compared on every rank; a wrong broadcast fails the run instead of producing a plausible number
+    flat_sum = _checksum(net.flat_weights()) if hasattr(net, "flat_weights") else (0, 0)
+    if world > 1:
+        sums = [None] * world
+        torch.distributed.all_gather_object(sums, flat_sum)
+        if any(x != sums[0] for x in sums):
+            raise SystemExit(f"rank {rank}: weight buffers differ after the broadcast: {sums}")
 
     net_mode = WORKLOAD_NET_MODE.get(workload, "fused") if args.net_mode == "fused" else args.net_mode
     if net_mode == "per-operator":
@@ -516,6 +578,37 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
 
     for k in range(warmup):
         step(k)
+    search_check = None
+    if world > 1:
+        # one search on inputs that do NOT depend on the rank (rank 0's first set: seeds without the rank term): with equal
+        # weights every rank must build the same trees -- visit counts and root values compared as checksums on every rank
+        common = sets[0] if rank == 0 else None
+        obs_c = synthetic.observations(B, obs_shape, seed=123) if not big else None
+        if obs_c is None:
+            gen = torch.Generator(device="cuda")
+            gen.manual_seed(123)
+            obs_c = torch.rand((B, int(numpy.prod(obs_shape))), device="cuda", generator=gen)
+        noise_c = numpy.zeros((B, A))
+        tape_c = numpy.zeros((B, self_play.TAPE_WORDS), numpy.uint32)
+        for i in range(B):
+            rs = numpy.random.RandomState(1000 + i)
+            noise_c[i] = rs.dirichlet([cfg.root_dirichlet_alpha] * A)
+            tape_c[i] = rs.randint(0, 2 ** 32, size=self_play.TAPE_WORDS, dtype=numpy.uint32)
+        io_c, out_c, _keep = engine.make_io(B, obs_c.reshape(B, -1), numpy.tile(numpy.arange(A, dtype=numpy.int32), (B, 1)),
+                                            numpy.zeros(B, numpy.int32), noise_c, tape_c)
+        lib.check(lib.mzx_search_run(handle, ctypes.byref(io_c), be.ptr(arena), arena.numel(), be.stream()))
+        env.sync()
+        mine = (_checksum(out_c["visits"]), _checksum(out_c["root_value"]))
+        alls = [None] * world
+        torch.distributed.all_gather_object(alls, mine)
+        if any(x != alls[0] for x in alls):
+            raise SystemExit(f"rank {rank}: the same search on the same inputs gave different trees across ranks: {alls}")
+        search_check = {"visit_count_checksum": mine[0][0], "ranks_equal": True}
+        del common
+    devs = None
+    if world > 1:
+        devs = [None] * world
+        torch.distributed.all_gather_object(devs, "cpu" if env.dry else torch.cuda.get_device_name(torch.cuda.current_device()))
     solo = None
     if solo_reference and world > 1:
         # rank 0 alone, every other GPU idle: the N = 1 rate on this very box, for the weak-scaling ratio
@@ -560,38 +653,30 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     achieved = bytes_per_sim * B * S / (launch_ms * 1e-3) / 1e9
     ran = lib.mzx_search_kernel_name(handle)      # the search kernel the last step launched
     ran = ran.decode() if ran else ""
-    if "row_select_kernel" in ran:                # (the library routes wide networks at large shards there by itself)
-        streamed = True
+    route = (ctypes.c_int32 * 8)()
+    lib.check(lib.mzx_search_route(handle, route))
+    # short tag of what ran: the search kernel (+ its shape where the library plans one per shard)
+    if route[0] == 3:
+        tag = f"mzx::rt_search_kernel<{route[2]},1> {route[1]} trees x {route[6]} threads, {route[4]} per CU"
+    elif route[0] == 2 or "row_select_kernel" in ran:
+        tag = "launches: row_select / rb_tower x2 / rb_gemm_multi x2 / row_expand" + (", two streams" if "two half-shards" in ran else "")
+    elif ran.startswith("mzx::"):
+        tag = ran
+    else:
+        tag = "one kernel per operator"
     traffic = None
-    try:  # PMC-measured HBM bytes per launch of this kernel (collected by a separate rocprofv3 --pmc run)
+    try:  # PMC-measured HBM bytes per STEP of this workload (muzero-general_amd/tools/pmc_traffic.py from separate rocprofv3 --pmc passes)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            key = "fused-lds" if fused else ("residual-whole-search" if fused_kind == 2 else "generic-per-op")
-            if streamed:
-                key = "streamed"
-            if fused_kind == 2 and ran == "mzx::rz_wave_search_kernel":
-                key = "residual-wave-per-tree"
-            if fused_kind == 2 and ran == "mzx::rz_tile_search_kernel":
-                key = "residual-tile-per-wave"
-            entry = json.load(f).get(f"{workload}:{key}")
-        if not fused and fused_kind != 2 and net_fused and not streamed:
-            entry = None
-        if entry and B == default_trees:
-            traffic = entry["bytes"]      # (its provenance: profiles/pmc_traffic.json "source")
+            entry = json.load(f).get(workload)
+        if entry and B == default_trees and entry.get("kernel_tag", tag).split(" ")[0] == tag.split(" ")[0]:
+            traffic = entry["bytes_per_step"]
     except (OSError, ValueError):
         pass
-    kernel_name = ("per-sim launches + streamed MFMA trunks / layers (rb_tower_kernel, rb_gemm_kernel, rb_gemm_multi_kernel)" +
-                   (", two half-shards on two HIP streams" if "two half-shards" in ran else "") if streamed else
-                   "fused-lds" if fused else
-                   "residual whole-search kernel (arena trees, fused MFMA network)" if fused_kind == 2 else
-                   "per-sim launches + fused-mfma network" if net_fused else "generic-per-op")
-    # (what the fields mean: module docstring / DESIGN.md section 5; prose is kept out of the line so that the driver's
-    # stdout tail holds the whole JSON)
     roofline = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "algorithmic_bytes_per_launch": bytes_per_sim * B * S,
-        "kernel": ran if fused else "whole step (one kernel per operator)",
-        "launch_ms": launch_ms, "algorithmic_bytes_per_sim": bytes_per_sim,
+        "kernel": tag, "launch_ms": launch_ms, "algorithmic_bytes_per_sim": bytes_per_sim,
     }
     if cfg.network == "resnet":  # dense contractions: FP32 MFMA roofline
         f_init = int(lib.mzx_net_flops(net.handle, 0))
@@ -600,17 +685,12 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         tf = flops / (launch_ms * 1e-3) / 1e12
         roofline = {
             "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-            "kernel": "whole step: select / mzx::rb_tower_kernel per trunk + mzx::rb_gemm_multi_kernel per head MLP level (mzx::rb_gemm_kernel per other layer) / expand+backprop per simulation" if streamed
-                      else ("whole step: root kernels + " + ran) if fused_kind == 2
-                      else "whole step: select / rz_network_kernel / expand+backprop per simulation"
-                      if net_fused else "whole step (one kernel per operator)",
-            "launch_ms": launch_ms, "flops_per_simulation": f_rec, "flops_initial_inference": f_init,
-            "flops_per_step": flops,
+            "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "kernel": "whole step: " + tag,
+            "launch_ms": launch_ms, "flops_per_simulation": f_rec, "flops_initial_inference": f_init, "flops_per_step": flops,
         }
     instantiations = None
-    if streamed:     # WHICH rb_gemm_kernel<MT, NT> / channel phases / K loop this workload launched (host-side planner)
-        first, second = net.streamed_split(B) if "two half-shards" in ran else (B, 0)
+    if route[0] == 2:     # WHICH rb_tower_kernel / rb_gemm_kernel<MT, NT> instantiations this workload launched (host-side planner)
+        first, second = int(route[6]), int(route[7])
         launches = net.streamed_launches(0, B)
         for b in sorted({first, second} - {0}):
             launches += net.streamed_launches(1, b)
@@ -622,9 +702,8 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         "data": "synthetic",
         "config": {
             "workload": description, "trees_per_gpu": B, "num_simulations": S, "action_space": A,
-            "network": cfg.network, "search_kernel": kernel_name,
-            "tree_statistics_dtype": "f64", "weights": "synthetic seed 0 (RCCL-broadcast flat buffer)",
-            "mean_leaf_depth": L,
+            "network": cfg.network, "search_kernel": tag, "tree_statistics_dtype": "f64",
+            "weights": weights_label + " (RCCL-broadcast flat buffer)", "mean_leaf_depth": L,
         },
         "repeats": {"n": len(blocks), "steps_per_block": steps, "median": sorted(block_rates)[len(block_rates) // 2],
                     "min": min(block_rates), "max": max(block_rates), "unit": "sims/s"},
@@ -634,20 +713,26 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         "collective_backend": (torch.distributed.get_backend() if world > 1 else None),
         "roofline": roofline,
     }
-    if instantiations:
-        result["config"]["instantiations"] = instantiations
-    if compact:      # an entry of "workloads": the same measurement, the fields that are not constant across entries
-        result = {
-            "workload": workload, "value": value, "unit": "sims/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
-            "config": {"workload": description, "trees_per_gpu": B, "num_simulations": S, "search_kernel": kernel_name,
-                       "mean_leaf_depth": round(L, 3)},
-            "repeats": {"n": len(blocks), "min": min(block_rates), "max": max(block_rates)},
-            "roofline": {k: roofline[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms") if k in roofline},
+    if world > 1:       # what the collective ran on, and that it did what it claims (checked above, on every rank)
+        result["collective"] = {
+            "library_version": None if env.dry else ".".join(str(v) for v in torch.cuda.nccl.version()),
+            "devices": devs, "weights_equal_after_broadcast": True, "weights_checksum": flat_sum[0],
+            "same_search_same_trees_on_every_rank": search_check,
         }
-        if "flops_per_step" in roofline:
-            result["roofline"]["flops_per_step"] = roofline["flops_per_step"]
+    if compact:      # an entry of "workloads": the same measurement, short keys (the whole line must fit the driver's stdout tail)
+        result = {
+            "w": workload, "v": round(value, 1), "ms": round(elapsed / steps * 1e3, 4), "B": B, "S": S, "L": round(L, 2), "k": tag,
+            "min": round(min(block_rates), 1), "max": round(max(block_rates), 1), "n": len(blocks),
+            "roofline": {"bound": roofline["bound"], "achieved": round(roofline["achieved"], 3), "frac": round(roofline["frac"], 4),
+                         "traffic": traffic, "launch_ms": round(launch_ms, 4)},
+        }
+        if WORKLOAD_WEIGHTS.get(workload):
+            result["weights"] = weights_label
         if instantiations:
-            result["config"]["instantiations"] = instantiations
+            result["inst"] = "; ".join(instantiations["kernels"]) if isinstance(instantiations["kernels"], (list, tuple)) else instantiations["kernels"]
+            result["halves"] = instantiations["half_shards"]
+    elif instantiations:
+        result["config"]["instantiations"] = instantiations
     if world > 1:
         result["per_rank"] = {"sims_per_sec": per_rank, "min": min(per_rank), "max": max(per_rank)}
         if solo is not None:
@@ -714,12 +799,9 @@ def main():
         line["cpu_baseline"] = None
         if env.world == 1 and args.cpu_seconds > 0 and not args.dry_run:
             from oracle import build_ref
-            port = cpu_baseline(args.workload, min(args.cpu_seconds, 6.0), args.cpu_cores, "port")
-            if build_ref.available():
-                line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_cores, "reference")
-                line["cpu_baseline_port"] = port
-            else:   # oracle/_ref was not built (no /root/reference at build time): the restatement stands in
-                line["cpu_baseline"] = port
+            # the UNMODIFIED reference when its bytecode travelled (oracle/_ref), else the oracle's restatement stands in
+            line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_cores,
+                                                "reference" if build_ref.available() else "port", args.weights)
         print(json.dumps(line), flush=True)
     env.barrier()
     env.close()

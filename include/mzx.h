@@ -296,6 +296,9 @@ int mzx_search_set_mode(mzx_search* s, int32_t mode);
  * kernel; for 3: out[1..6] = {trees per workgroup, row tiles per wave, workgroups, workgroups per CU, LDS bytes, threads per
  * workgroup}; for 2: out[6..7] = trees of the two half-shards (second 0: undivided). */
 int mzx_search_route(const mzx_search* s, int32_t out[8]);
+/* The same for a search of `num_trees` roots x `num_simulations` on `net` in the default mode, WITHOUT a search handle (no
+ * device needed: tests/test_streamed_coverage.py keeps bench.py's workloads inside the GPU-tested launch shapes with it). */
+int mzx_net_search_route(const mzx_net* net, int32_t num_trees, int32_t num_simulations, int32_t out[8]);
 
 /* Byte offsets inside the arena (diagnostics): out[0..6] = (unused, 0), trees, hidden states,
  * network workspace, bytes per tree, workspace bytes, total bytes. */

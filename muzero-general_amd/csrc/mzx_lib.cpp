@@ -435,11 +435,10 @@ int mzx_tuning_get(const char* name, int32_t* value, int32_t* dflt) {
 const char* mzx_tuning_name(int32_t index) { return (index >= 0 && index < TUNE_COUNT) ? tuning_table()[index].name : nullptr; }
 const char* mzx_tuning_help(int32_t index) { return (index >= 0 && index < TUNE_COUNT) ? tuning_table()[index].what : nullptr; }
 
-int mzx_search_route(const mzx_search* s, int32_t out[8]) {
-  if (!s || !out) { set_error("null argument"); return MZX_ERR_INVALID; }
+static void search_route_of(const mzx_search* s, int32_t out[8]) {
   for (int k = 0; k < 8; ++k) out[k] = 0;
 #ifndef MZX_HOSTCHECK
-  if (!s->net) return MZX_OK;
+  if (!s->net) return;
   int whole = 0;
   if ((s->mode & 1) && s->fused_ok == 2 && rz_enabled(s->net, true)) {
     const int route = wide_search_route(s);
@@ -458,6 +457,29 @@ int mzx_search_route(const mzx_search* s, int32_t out[8]) {
     out[7] = first > 0 ? s->p.num_trees - first : 0;
   }
 #endif
+}
+
+int mzx_search_route(const mzx_search* s, int32_t out[8]) {
+  if (!s || !out) { set_error("null argument"); return MZX_ERR_INVALID; }
+  search_route_of(s, out);
+  return MZX_OK;
+}
+
+int mzx_net_search_route(const mzx_net* net, int32_t num_trees, int32_t num_simulations, int32_t out[8]) {
+  if (!net || !out || num_trees < 1 || num_simulations < 0) { set_error("null argument / sizes out of range"); return MZX_ERR_INVALID; }
+  // a search descriptor without device tables: the planner only reads sizes (host-side, no GPU)
+  mzx_search tmp;
+  memset(&tmp.cfg, 0, sizeof(tmp.cfg));
+  tmp.cfg.num_trees = num_trees; tmp.cfg.num_simulations = num_simulations;
+  tmp.cfg.action_space_size = net->cfg.action_space_size; tmp.cfg.support_size = net->cfg.support_size;
+  tmp.cfg.num_players = 1; tmp.cfg.tape_words = 16; tmp.cfg.discount = 1.0; tmp.cfg.root_exploration_fraction = 0.25;
+  tmp.net = const_cast<mzx_net*>(net);
+  search_plan(&tmp);
+#ifndef MZX_HOSTCHECK
+  tmp.fused_ok = fc2_plan(&tmp).ok ? 1 : (rz_search_supported(&tmp) ? 2 : ((net->rb.ok && net->rb.recurrent.ok && row_search_supported(tmp.p)) ? 3 : 0));
+#endif
+  tmp.mode = tmp.fused_ok ? 1 : 0;
+  search_route_of(&tmp, out);
   return MZX_OK;
 }
 

@@ -107,6 +107,7 @@ PROTOTYPES = {
     "mzx_search_kernel_name": (ctypes.c_char_p, [c_vp]),
     "mzx_search_set_mode": (ctypes.c_int, [c_vp, c_i32]),
     "mzx_search_route": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32 * 8)]),
+    "mzx_net_search_route": (ctypes.c_int, [c_vp, c_i32, c_i32, ctypes.POINTER(c_i32 * 8)]),
     "mzx_tuning_set": (ctypes.c_int, [ctypes.c_char_p, c_i32]),
     "mzx_tuning_get": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "mzx_tuning_name": (ctypes.c_char_p, [c_i32]),

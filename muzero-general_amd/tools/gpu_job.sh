@@ -43,23 +43,22 @@ run_bench() {
   tail -c 1500 $OUT/bench_default.log
 }
 
-run_pmc() {   # one workload per profile directory: the search kernels' HBM traffic and matrix-pipe occupancy per launch
+run_pmc() {   # one workload per directory: HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes), matrix-pipe occupancy, L2 hit rate
   for w in "$@"; do
-    local CMD="python bench.py --workload $w --steps 2 --warmup 1 $Q"
+    local N=2
+    case $w in gomoku|atari|c4-large) N=1 ;; esac
+    local CMD="python bench.py --workload $w --steps $N --warmup 0 --repeats 1 $Q"
     local D=$OUT/pmc_$w
     mkdir -p $D
-    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -o run -- $CMD > $D/rocprof_stats.log 2>&1
-    timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -o run -- $CMD > $D/rocprof_fetch.log 2>&1
-    timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -o run -- $CMD > $D/rocprof_write.log 2>&1
-    timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $D/pmc_mfma -o run -- $CMD > $D/rocprof_mfma.log 2>&1
-    python muzero-general_amd/tools/rocprof_summary.py $D > $D/summary.txt 2>&1
+    timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -o run -- $CMD > $D/rocprof_fetch.log 2>&1
+    timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -o run -- $CMD > $D/rocprof_write.log 2>&1
+    timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $D/pmc_mfma -o run -- $CMD > $D/rocprof_mfma.log 2>&1
+    timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $D/pmc_l2 -o run -- $CMD > $D/rocprof_l2.log 2>&1
+    local TAG=$(timeout 200 $CMD 2>/dev/null | python -c "import sys, json; print(json.loads(sys.stdin.readline())['roofline']['kernel'].replace('whole step: ', ''))")
+    python muzero-general_amd/tools/pmc_traffic.py $w $N $D "$TAG" >> $OUT/pmc_entries.jsonl 2>> $OUT/pmc_err.log
+    python muzero-general_amd/tools/rocprof_summary.py $D mzx > $D/summary.txt 2>&1
   done
-}
-
-one() {   # label, bench arguments...: one line per run
-  local label=$1; shift
-  timeout 300 python bench.py --steps 3 --warmup 1 $Q "$@" 2>> $OUT/err.log |
-    python -c "import sys, json; d = json.loads(sys.stdin.readline()); print('%-40s %.4g sims/s, %.2f ms per step, %.4f of peak' % ('$label', d['value'], d['ms_per_step'], d['roofline']['frac']))"
+  cat $OUT/pmc_entries.jsonl
 }
 
 case $JOB in
@@ -275,8 +274,8 @@ case $JOB in
   c4-shards) shift; shift; c4_shards ${@:-512 768 1024 1536 2048 3072 4608 9216} > $OUT/c4_by_shard.txt 2>&1; cat $OUT/c4_by_shard.txt ;;
   tests) run_tests ;;
   bench) run_bench ;;
-  pmc) shift; shift; run_pmc ${@:-c2 c3 c4 c4-ws c4-large c5 gomoku atari} ;;
-  final) run_tests; run_bench; run_pmc c2 c3 c4 c4-ws c4-large c5 gomoku atari ;;
+  pmc) shift; shift; run_pmc ${@:-c2 c2-ckpt c3 c4 c4-ws c4-large c5 c5-512 gomoku atari} ;;
+  final) run_tests; run_bench; run_pmc c2 c2-ckpt c3 c4 c4-ws c4-large c5 c5-512 gomoku atari ;;
   *) echo "unknown job $JOB"; exit 2 ;;
 esac
 find $OUT -size +4M -delete

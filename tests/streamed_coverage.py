@@ -94,17 +94,55 @@ def gpu_tested_launches(lib):
     return out
 
 
-def bench_streamed_workloads(bench):
-    """bench.py's default workloads that run on the streamed engine: {name: (game, overrides, trees, network mode)}."""
+def net_route(lib, game, trees, overrides=None, simulations=None):
+    """mzx_net_search_route for a search of `trees` roots of configuration `game` (host-side planner, no GPU): the list
+    [route, trees per workgroup, row tiles per wave, workgroups, workgroups per CU, LDS bytes, threads | first half, second half]."""
+    cfg = configs.BY_NAME[game](**(overrides or {}))
+    h = _create(lib, cfg)
+    try:
+        out = (ctypes.c_int32 * 8)()
+        lib.check(lib.mzx_net_search_route(h, int(trees), int(simulations or cfg.num_simulations), ctypes.byref(out)))
+        return list(out)
+    finally:
+        lib.mzx_net_destroy(h)
+
+
+def bench_streamed_workloads(lib, bench):
+    """bench.py's default workloads whose SIMULATIONS run launch by launch on the streamed engine (route 2):
+    {name: (game, overrides, trees, network mode)}."""
     names = [bench.DEFAULT_WORKLOAD] + [w for w in bench.DEFAULT_ALSO.split(",") if w]
     out = {}
     for w in names:
         game, overrides, trees, _ = bench.WORKLOADS[w]
+        if configs.BY_NAME[game](**overrides).network != "resnet" or bench.WORKLOAD_TUNING.get(w, {}).get("wide_towers") == 0:
+            continue
         forced = bench.WORKLOAD_NET_MODE.get(w) == "streamed"
-        # (connect4 from 1024 trees: csrc/mzx_row_search.h row_search_preferred, unless the workload's environment says no)
-        routed = game == "connect4" and bench.WORKLOAD_TUNING.get(w, {}).get("rt_search") == 0      # (per-simulation launches)
-        if forced or routed or game in ("gomoku", "atari"):
+        if net_route(lib, game, trees, overrides)[0] == 2 or bench.WORKLOAD_TUNING.get(w, {}).get("rt_search") == 0:
             out[w] = (game, overrides, trees, 3 if forced else None)
+    return out
+
+
+# rt_search_kernel (csrc/mzx_tower_search.hip: every simulation in one launch) AT SIZE: (game, trees) -> the -m gpu test that
+# runs the planner's shape for that shard against the CPU oracle / the per-simulation launches
+RT_AT_SIZE = {
+    ("connect4", 512): "test_gpu_tower_search.py::test_tower_search_other_shards_against_oracle[512-1-32]",
+    ("connect4", 1024): "test_gpu_parity.py::test_full_size_residual_configs[connect4] + test_gpu_tower_search.py::test_tower_search_at_size_same_trees_as_launches",
+    ("connect4", 1536): "test_gpu_tower_search.py::test_tower_search_other_shards_against_oracle[1536-3-48]",
+    ("connect4", 9216): "test_gpu_tower_search.py::test_tower_search_other_shards_against_oracle[9216-3-48]",
+}
+
+
+def bench_rt_workloads(lib, bench):
+    """bench.py's default workloads the library runs on rt_search_kernel (route 3): {name: (game, overrides, trees, route list)}."""
+    names = [bench.DEFAULT_WORKLOAD] + [w for w in bench.DEFAULT_ALSO.split(",") if w]
+    out = {}
+    for w in names:
+        game, overrides, trees, _ = bench.WORKLOADS[w]
+        if configs.BY_NAME[game](**overrides).network != "resnet" or bench.WORKLOAD_TUNING.get(w):
+            continue
+        r = net_route(lib, game, trees, overrides)
+        if r[0] == 3:
+            out[w] = (game, overrides, trees, r)
     return out
 
 

@@ -47,9 +47,11 @@ def test_bench_single_rank_dry_run_with_second_workload():
     line = _run(["--dry-run", "--trees", "4", "--steps", "1", "--warmup", "0", "--selfplay-moves", "2",
                  "--also", "c3", "--also-steps", "1"])
     assert line["n_gpus"] == 1 and "per_rank" not in line
-    assert [w["workload"] for w in line["workloads"]] == ["c3"]      # compact entries: name, value, config, repeats, roofline
-    assert set(line["workloads"][0]) == {"workload", "value", "unit", "ms_per_step", "steps", "config", "repeats", "roofline"}
+    assert [w["w"] for w in line["workloads"]] == ["c3"]      # compact entries, short keys (bench.py docstring)
+    assert set(line["workloads"][0]) == {"w", "v", "ms", "B", "S", "L", "k", "min", "max", "n", "roofline"}
+    assert set(line["workloads"][0]["roofline"]) == {"bound", "achieved", "frac", "traffic", "launch_ms"}
     assert line["workloads"][0]["roofline"]["bound"] == "mfma"
+    assert "reference constructor" in line["config"]["weights"] or "synthetic" in line["config"]["weights"]
     assert line["selfplay_end_to_end"]["steps_per_sec"] > 0
     assert line["selfplay_end_to_end_batched_game"]["steps_per_sec"] > 0
 
@@ -63,21 +65,21 @@ def test_cpu_baseline_workers_reference_and_port():
 
     threads = torch.get_num_threads()     # the workers pin torch to one thread (one process per core in the bench):
     try:                                  # restore it, ATen's convolutions are not bit-reproducible across thread counts
-        sims, searches, wall = bench._cpu_worker_port(("c2", 0, 0.5))
+        sims, searches, wall = bench._cpu_worker_port(("c2", 0, 0.5, "reference"))
         assert searches >= 1 and sims == 50 * searches and wall > 0
         if not build_ref.available():
             pytest.skip("oracle/_ref not built (no /root/reference at build time)")
-        sims, searches, wall = bench._cpu_worker_reference(("c2", 0, 0.5))
+        sims, searches, wall = bench._cpu_worker_reference(("c2", 0, 0.5, "reference"))
         assert searches >= 1 and sims == 50 * searches and wall > 0
     finally:
         torch.set_num_threads(threads)
 
 
 def test_bench_large_shard_workload_labels_what_ran():
-    """`c4-large` chooses the layer-by-layer engine itself, and a `--trees` override shows in the line's label."""
+    """A `--trees` override shows in the line's label; the dry run (serial test double) names its path honestly."""
     line = _run(["--dry-run", "--workload", "c4-large", "--trees", "4", "--steps", "1", "--warmup", "0",
                  "--selfplay-moves", "0", "--also", "none"])
     cfg = line["config"]
     assert cfg["trees_per_gpu"] == 4 and "4 trees x 200 sims" in cfg["workload"] and "9216" not in cfg["workload"]
-    assert "streamed MFMA trunks / layers" in cfg["search_kernel"]
+    assert cfg["search_kernel"] == "one kernel per operator"      # (the test double has no tuned kernels)
     assert line["roofline"]["bound"] == "mfma" and line["roofline"]["traffic"] is None     # PMC entry is for the default shard

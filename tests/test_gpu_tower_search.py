@@ -179,7 +179,7 @@ def test_tower_search_at_size_same_trees_as_launches(backend):
     _assert_same(outs["rt"], outs["undivided"], "rt vs undivided launches")
 
 
-@pytest.mark.parametrize("B,trees_per_wg,n_sample", [(512, 1, 32), (1536, 3, 48)])
+@pytest.mark.parametrize("B,trees_per_wg,n_sample", [(512, 1, 32), (1536, 3, 48), (9216, 3, 48)])
 def test_tower_search_other_shards_against_oracle(backend, B, trees_per_wg, n_sample):
     """The other tilings the planner picks at full size (one tree per 256-thread workgroup = <3,1> at 512 trees, three = <8,1>
     at 1536; four per 512-thread workgroup = <6,1> at 1024 trees: test_full_size_residual_configs[connect4]) against the CPU

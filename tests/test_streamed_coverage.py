@@ -31,17 +31,32 @@ def bench():
     return mod
 
 
-def test_bench_streamed_workloads_are_the_expected_ones(bench):
-    # (if a workload joins or leaves the default line, the at-size table has to be looked at again)
-    assert sorted(sc.bench_streamed_workloads(bench)) == ["atari", "c4", "c4-large", "gomoku"]
-    assert bench.WORKLOAD_NET_MODE == {"c4-large": "streamed"}
+def test_bench_streamed_workloads_are_the_expected_ones(lib, bench):
+    # (if a workload joins or leaves the default line, the at-size tables have to be looked at again)
+    assert sorted(sc.bench_streamed_workloads(lib, bench)) == ["atari", "gomoku"]
+    assert sorted(sc.bench_rt_workloads(lib, bench)) == ["c4", "c4-large"]
+    assert bench.WORKLOAD_NET_MODE == {}
+
+
+def test_bench_whole_search_workloads_run_tested_shapes(lib, bench):
+    """The workloads the library runs as ONE launch of rt_search_kernel: the (game, shard) is one a -m gpu test runs on the
+    planner's own shape, and the root -- initial_inference at the shard size on the streamed engine -- launches only
+    GPU-tested shapes."""
+    tested = sc.gpu_tested_launches(lib)
+    tested_full = {models.launch_key(l) for l in tested}
+    for name, (game, overrides, trees, route) in sc.bench_rt_workloads(lib, bench).items():
+        assert (game, trees) in sc.RT_AT_SIZE, f"bench workload {name}: no at-size test of rt_search_kernel at {trees} trees"
+        assert route[2] <= 8 and route[6] in (256, 512) and route[5] <= 160 * 1024, (name, route)
+        initial = sc.inference_launches(lib, game, trees, 0, overrides, mode=3)
+        missing = [l for l in initial if models.launch_key(l) not in tested_full]
+        assert not missing, f"bench workload {name}: root launch shapes outside the GPU-tested set: {missing[:3]}"
 
 
 def test_every_bench_launch_is_gpu_parity_tested(lib, bench):
     tested = sc.gpu_tested_launches(lib)
     tested_full = {models.launch_key(l) for l in tested}
     tested_inst = {models.instantiation_key(l) for l in tested}
-    for name, (game, overrides, trees, mode) in sc.bench_streamed_workloads(bench).items():
+    for name, (game, overrides, trees, mode) in sc.bench_streamed_workloads(lib, bench).items():
         launches, parts = sc.search_launches(lib, game, trees, overrides, mode=mode)
         assert launches
         missing = sorted({models.instantiation_key(l) for l in launches} - tested_inst)
@@ -59,7 +74,7 @@ def test_bench_workloads_run_at_exactly_tested_sizes(lib, bench):
     for game, mode, trees, _, _ in sc.AT_SIZE_SEARCHES.values():
         tested |= {(game, towers_on(mode), l["program"], l["batch"])
                    for l in sc.search_launches(lib, game, trees, both_ways=True, mode=mode)[0]}
-    for name, (game, overrides, trees, mode) in sc.bench_streamed_workloads(bench).items():
+    for name, (game, overrides, trees, mode) in sc.bench_streamed_workloads(lib, bench).items():
         for l in sc.search_launches(lib, game, trees, overrides, mode=mode)[0]:
             assert (game, towers_on(mode), l["program"], l["batch"]) in tested, (name, l["program"], l["batch"])
 
