@@ -436,7 +436,7 @@ void rb_apply_shape(RbGemmArgs& a, const RbOp& o, const RbShape& sh) {
     a.magic_tw = rb_magic(o.wout); a.magic_phw = rb_magic(sh.PH * o.PW);
   }
   a.ntiles_wg = sh.ntiles_wg; a.WN = WN; a.WM = WM;
-  static const int dbg = getenv("MZX_RB_DBG") ? atoi(getenv("MZX_RB_DBG")) : 0;
+  static const int dbg = exp_int("MZX_RB_DBG", 0);
   a.dbg = dbg;
   a.grid_x = sh.groups; a.grid_y = sh.nsplit;
 }
@@ -453,7 +453,7 @@ int rb_launch_gemm(RbGemmArgs& a, const RbOp& o, int batch, stream_t stream) {
   const int groups_m = sh.groups, nsplit = sh.nsplit, NT = sh.NT, WN = sh.WN, WM = sh.WM, MT = sh.MT;
   // MZX_RB_STAMPS=<launch number>: phase clocks of that GEMM launch (counted from the first one of the process),
   // printed to stderr after a blocking copy -- a diagnostic, never set in production
-  static const int stamp_launch = getenv("MZX_RB_STAMPS") ? atoi(getenv("MZX_RB_STAMPS")) : -1;
+  static const int stamp_launch = exp_int("MZX_RB_STAMPS", -1);
   static std::atomic<int> launch_no{0};      // (two streams / host threads launch through here)
   static unsigned long long* d_stamps = nullptr;   // touched by the one stamped launch only
   const bool stamp = stamp_launch >= 0 && launch_no.fetch_add(1) == stamp_launch;
@@ -600,7 +600,7 @@ int rb_launch_tower(const mzx_net* net, const std::vector<OpDesc>& prog, const R
   a.batch = batch; a.cin0 = o0.cin; a.C = tw.C; a.H = tw.H; a.W = tw.W; a.PH = tw.H + 2; a.PW = tw.W + 2;
   a.Cs = sh.Cs; a.cchunks = tw.cchunks; a.T = sh.T; a.rows = sh.rows; a.mtiles = sh.mtiles; a.ntiles = tw.ntiles;
   a.WN = sh.WN; a.WM = sh.WM; a.layers = layers;
-  static const int dbg = getenv("MZX_RB_DBG") ? atoi(getenv("MZX_RB_DBG")) : 0;
+  static const int dbg = exp_int("MZX_RB_DBG", 0);
   a.dbg = dbg;
   a.y_vec = (tw.C % 4 == 0 && a.y_sstride % 4 == 0 && ((uintptr_t)y % 16) == 0) ? 1 : 0;
   a.rowskip = (a.PW - 3) * sh.Cs;

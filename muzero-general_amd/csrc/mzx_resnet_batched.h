@@ -37,8 +37,7 @@ inline int64_t rb_lds_bytes(int T, int mtiles, int cells, int Cs) {
 // (every workgroup streams the whole B matrix once: traffic per flop ~ 1 / rows).
 inline int rb_lds_budget() {   // MZX_RB_LDS: A/B knob (bytes), e.g. 159744 = one workgroup per CU
   static const int v = [] {
-    const char* e = getenv("MZX_RB_LDS");
-    const int x = e ? atoi(e) : RB_LDS_BUDGET;
+    const int x = exp_int("MZX_RB_LDS", RB_LDS_BUDGET);
     return std::min(std::max(x, 16 * 1024), RB_LDS_MAX);
   }();
   return v;
@@ -50,7 +49,7 @@ inline int rb_lds_budget() {   // MZX_RB_LDS: A/B knob (bytes), e.g. 159744 = on
 // fill -- are paid half as often; 0.615 -> 0.65 of the MFMA peak for the whole step at 9216 trees).
 // MZX_RB_ROWS_WIDE=0: nine row tiles per workgroup whatever the width (A/B).
 inline int rb_max_rows(const RbOp& o) {
-  static const int wide = getenv("MZX_RB_ROWS_WIDE") ? atoi(getenv("MZX_RB_ROWS_WIDE")) : 1;
+  static const int wide = exp_int("MZX_RB_ROWS_WIDE", 1);
   if (!wide || o.taps == 1 || o.ntiles < 2) return RB_MAX_ROWS;      // trunk convolutions only: head layers are tiny
   const int nt = o.ntiles > 8 ? 2 : 1, wn = std::min(8, (std::min(o.ntiles, 16) + nt - 1) / nt);
   return RB_MAX_ROWS * std::min(4, std::max(1, 8 / wn));
@@ -102,7 +101,7 @@ inline bool rb_choose_tile(RbOp& o) {
 struct RbShape { int T, rows, mtiles, lds, ntiles_wg, nsplit, NT, WN, WM, MT, groups, cpg, phases, Cs, rowsplit, splits, PH; };
 
 inline RbShape rb_choose_shape(const RbOp& o, int batch) {
-  static const int fixed = getenv("MZX_RB_SHAPE") ? atoi(getenv("MZX_RB_SHAPE")) : 0;   // 1: always the planned tile (A/B)
+  static const int fixed = exp_int("MZX_RB_SHAPE", 0);   // 1: always the planned tile (A/B)
   RbShape best{};
   double best_cost = 1e30;
   const int spatial = o.tiles_x * o.tiles_y;
@@ -119,7 +118,7 @@ inline RbShape rb_choose_shape(const RbOp& o, int batch) {
       c.nsplit = (o.ntiles + ntiles_wg - 1) / ntiles_wg;
       // two column tiles per wave when the workgroup has more than eight -- or, MZX_RB_NT=2 (experiment), whenever it has
       // an even number: half the A-fragment LDS reads per MFMA, the waves split the row tiles instead
-      static const int want_nt = getenv("MZX_RB_NT") ? atoi(getenv("MZX_RB_NT")) : 0;
+      static const int want_nt = exp_int("MZX_RB_NT", 0);
       c.NT = (ntiles_wg > 8 || (want_nt == 2 && ntiles_wg >= 2 && ntiles_wg % 2 == 0)) ? 2 : 1;
       c.WN = std::min(8, (ntiles_wg + c.NT - 1) / c.NT);
       c.WM = std::max(1, std::min(8 / c.WN, c.mtiles));
@@ -131,7 +130,7 @@ inline RbShape rb_choose_shape(const RbOp& o, int batch) {
       const int64_t rem = wgs % cap;
       const double ways = (double)(wgs / cap) * per_cu + (rem ? (double)std::min<int64_t>(per_cu, (rem + 255) / 256) : 0.0);
       const double cost = ways * (c.MT * c.NT) * (1.0 + 0.02 * (c.nsplit - 1)) + 1e-4 * (double)wgs;
-      static const int force_ntw = getenv("MZX_RB_NTILES_WG") ? atoi(getenv("MZX_RB_NTILES_WG")) : 0;   // experiment knob
+      static const int force_ntw = exp_int("MZX_RB_NTILES_WG", 0);   // experiment knob
       if (force_ntw > 0 && T == o.T && ntiles_wg == std::min(force_ntw, std::min(o.ntiles, 16))) { best_cost = -1.0; best = c; }
       if (cost < best_cost) { best_cost = cost; best = c; }
       if (ntiles_wg == 1 || fixed) break;
@@ -142,7 +141,7 @@ inline RbShape rb_choose_shape(const RbOp& o, int batch) {
   // keep two of them overlapping to the end of the launch (with ONE round of two the younger one, which loses the
   // matrix pipes to the older by age, runs alone for the last quarter: measured 115 / 165 us for the two of a CU).
   best.rowsplit = 0; best.splits = 1; best.PH = o.PH;
-  static const int want_splits = getenv("MZX_RB_ROWSPLIT") ? atoi(getenv("MZX_RB_ROWSPLIT")) : 0;
+  static const int want_splits = exp_int("MZX_RB_ROWSPLIT", 0);
   if (!fixed && want_splits > 1 && o.tiles_x * o.tiles_y == 1 && best.T == 1 && o.stride == 1 && o.ksize == 2 * o.pad + 1 &&
       best.mtiles >= 2 * want_splits) {
     const int per = (best.mtiles + want_splits - 1) / want_splits;
@@ -246,7 +245,7 @@ inline bool rb_tower_use(const RbTower& tw, int batch) {
 inline void rb_find_towers(const std::vector<OpDesc>& prog, RbProgram& R) {
   R.towers.clear();
   for (RbOp& o : R.ops) { o.tower = -1; o.tower_of_tail = -1; }
-  static const int enabled = getenv("MZX_RB_TOWER") ? atoi(getenv("MZX_RB_TOWER")) : 1;
+  static const int enabled = exp_int("MZX_RB_TOWER", 1);
   if (!enabled) return;
   const int n = (int)prog.size();
   auto trunk_conv = [&](int k) {

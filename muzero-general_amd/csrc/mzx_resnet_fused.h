@@ -1238,10 +1238,7 @@ inline int rz_launch_k(const RzArgs& a, unsigned grid, size_t lds_bytes, stream_
 
 struct RzLaunch { RzArgs a; bool wlds; bool eight; bool small; unsigned grid; size_t lds; };
 
-inline int rz_env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return (e && *e) ? atoi(e) : dflt;
-}
+inline int rz_env_int(const char* name, int dflt) { return exp_int(name, dflt); }   // (instrumented builds only: mzx_tuning.h)
 
 // Everything of a launch that depends on (network, program, batch); `extra_lds_floats` = LDS the caller
 // adds behind the engine's own image (search kernel).
@@ -1533,7 +1530,7 @@ inline int rz_run_stem(const mzx_net* net, const std::vector<OpDesc>& prog, int 
   // 16-byte staging and stores, no residual / write-back phases behind barriers) when the whole stem is planned
   // there and ends in a pooling, which then writes the NCHW tensor the LDS-resident engine gathers (MZX_RZ_STEM=rz:
   // the round-1 stem kernel, A/B).
-  static const bool rb_stem = !(getenv("MZX_RZ_STEM") && !strcmp(getenv("MZX_RZ_STEM"), "rz"));
+  static const bool rb_stem = exp_int("MZX_RZ_STEM_RZ", 0) == 0;      // (1: the LDS-resident engine's own stem kernel, the A/B)
   if (rb_stem && net->rz_mode == 1 && &prog == &net->prog_initial && net->rb.ok && net->rb.initial.ok && count > 0 &&
       prog[count - 1].kind == OP_POOL) {
     bool all = true;

@@ -6,6 +6,7 @@
 // makes them -- the same rule as for handles, mzx.h "Conventions").
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace mzx {
@@ -47,6 +48,19 @@ inline TuningEntry* tuning_table() {
 }
 
 inline int32_t tune(TuningKey k) { return tuning_table()[k].value; }
+
+// Latency / layout EXPERIMENTS of earlier rounds (knock-outs, forced tilings, phase stamps; profiles/r0*_experiments*.txt)
+// are environment variables -- in instrumented builds only (MZX_CXXFLAGS=-DMZX_EXPERIMENT, muzero-general_amd/build.py).  The
+// product library never reads the environment: every such knob is its default there.
+inline int exp_int(const char* name, int dflt) {
+#ifdef MZX_EXPERIMENT
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
 
 inline int tuning_find(const char* name) {
   if (!name) return -1;

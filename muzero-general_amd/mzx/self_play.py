@@ -29,6 +29,7 @@ the number of words the device consumed.
 import ctypes
 import math
 import time
+import warnings
 
 import numpy
 import torch
@@ -1124,7 +1125,9 @@ class SelfPlay:
         one group runs (a worker thread inside the C call / the stream synchronisation, both of which release the GIL),
         the host steps the other group's ``Game`` objects -- the Python work of the reference plugin surface (a third of
         the wall for connect4 at 1024 games) hides behind the other half's search.  Slots are independent actors (own
-        ``Game``, own numpy stream), so which ones share a launch does not change what any of them plays.
+        ``Game``, own numpy stream) and the library searches a network on ONE arithmetic whatever the shard size (wide
+        residual networks: csrc/mzx_row_search.h wide_search_route), so which slots share a launch does not change what any of
+        them plays -- bit for bit, on the device too (tests/test_gpu_parity.py: 1024 connect4 games, two groups against one).
         ``config.self_play_pipeline``: True / False; unset = from 1024 games on -- each half must still fill the chip: the
         residual whole-search kernels run a workgroup per tree or pair of trees, so a search of fewer than ~512 trees takes as
         long as one of 512 and two half searches would cost more than they hide.
@@ -1200,6 +1203,13 @@ class SelfPlay:
             if pipelined:
                 device = self.model.backend.device
                 stream = torch.cuda.current_stream(device) if device.type == "cuda" else None
+                # A search queued across the end of this call is consumed by the NEXT play_rounds call; should play_games /
+                # close_game come instead, its result is dropped -- and the root noise / tie words it drew are given back
+                # (_drain_searches), so that the slots' streams stay those of lone actors.  The states are only kept when
+                # this call can actually end before the result is consumed.
+                may_be_last = (len(finished) + sum(len(g["slots"]) for g in groups) >= min_games
+                               or (max_rounds is not None and rounds + 2 >= max_rounds))
+                group["streams_before"] = [self.bank.get_state(s) for s in slots] if may_be_last else None
                 group["pending"] = self._search_worker.submit(self._search_job, group, stacked, legal, to_play, stream)
             else:
                 group["pending"] = self._search_job(group, stacked, legal, to_play, None)
@@ -1417,14 +1427,25 @@ class SelfPlay:
         return store
 
     def _drain_searches(self):
-        """Waits for a search a pipelined ``play_rounds`` left on the worker thread (normally none: every call drains)."""
+        """
+        A search a pipelined ``play_rounds`` call queued for its next round and nobody will consume (``play_games`` or
+        ``close_game`` follows): waited for, dropped, and the draws it took from its slots' streams are undone.  A failure
+        of the worker thread surfaces here instead of disappearing.
+        """
         for group in (self._live or {}).get("groups", ()):
             pending = group.get("pending")
-            if pending is not None and hasattr(pending, "result"):
-                try:
-                    pending.result()
-                except Exception:
-                    pass
+            if pending is None or not hasattr(pending, "result"):
+                continue
+            group["pending"] = None
+            try:
+                pending.result()
+            except Exception as e:       # (the search is being discarded anyway; the failure is not)
+                warnings.warn(f"a queued self-play search failed on the worker thread: {e!r}")
+            before = group.get("streams_before")
+            if before is not None and self.bank is not None:
+                for s, state in zip(group["slots"], before):
+                    self.bank.set_state(s, state)
+            group["streams_before"] = None
 
     def close_game(self):
         self._drain_searches()

@@ -62,6 +62,13 @@ run_pmc() {   # one workload per directory: HBM traffic (separate FETCH_SIZE / W
 }
 
 case $JOB in
+  refweights)      # the at-size parity tests on the reference constructor's weights (strict gates) + the new pipelined-shard test
+    timeout 1400 python -m pytest tests/test_gpu_streamed_at_size.py -m gpu -q -s -k "reference" > $OUT/pytest_ref.log 2>&1
+    echo "pytest rc $?" >> $OUT/pytest_ref.log
+    grep -E "passed|failed|^FAILED|^ERROR|Error|identical to the oracle|loose rows|worst error|diverges" $OUT/pytest_ref.log | cut -c1-260 | tail -60
+    timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "pipelined_shard or routed_to_their or full_size_residual" > $OUT/pytest_par.log 2>&1
+    grep -E "passed|failed|^FAILED|^ERROR|Error|identical|trees on" $OUT/pytest_par.log | cut -c1-200 | tail -20
+    ;;
   rt-sweep)      # forced (trees per workgroup, waves) at the BASELINE shard and around it
     {
     for cfg in "4 8" "2 4" "2 8" "1 4" "3 8" "3 4"; do

@@ -130,6 +130,40 @@ def test_refilled_board_game_slots_equal_lone_actors_on_device(backend, name, pr
     refill.test_slot_games_equal_a_lone_actor_s_sequence(backend, name, protocol)
 
 
+def test_pipelined_shard_of_1024_connect4_games_plays_what_one_group_plays(backend):
+    """
+    1024 per-object connect4 games: two slot groups of 512 taking turns on the GPU against ONE group of 1024 (in
+    round 4 the two shard sizes were routed to different engines -- the LDS-resident whole-search kernel below 640 trees, the
+    streamed towers above -- whose convolutions sum in different orders, so the claim "which slots share a launch changes
+    nothing a slot plays" was not bit-true on the device).  The library now searches a wide network on ONE arithmetic at
+    every shard size (csrc/mzx_row_search.h wide_search_route): every game of every slot, field for field.
+    """
+    from mzx import games as board_games
+
+    def run(pipeline):
+        cfg = configs.connect4(num_simulations=12)
+        cfg.self_play_pipeline = pipeline
+        weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg).state_dict(), 5)
+        shard = self_play.SelfPlay({"weights": weights}, board_games.PER_OBJECT["connect4"], cfg, 3, num_games=1024)
+        by_slot = {}
+        for gh, slot in zip(shard.play_rounds(1.0, None, min_games=1 << 60, max_rounds=14), shard.finished_slots):
+            by_slot.setdefault(slot, []).append(gh)
+        groups = [g["engine"] for g in shard._live["groups"]]
+        kernels = sorted({e.kernel_name(len(g["slots"])) for e, g in zip(groups, shard._live["groups"])})
+        shard.close_game()
+        return by_slot, kernels
+
+    one, k1 = run(False)
+    two, k2 = run(True)
+    assert k1 == k2 == ["mzx::rt_search_kernel"], (k1, k2)
+    assert one.keys() == two.keys() and len(one) > 100
+    for slot in one:
+        assert len(one[slot]) == len(two[slot])
+        for a, b in zip(one[slot], two[slot]):
+            assert a.action_history == b.action_history and a.reward_history == b.reward_history, slot
+            assert a.child_visits == b.child_visits and a.root_values == b.root_values, slot
+
+
 def _tree_invariants(cfg, res, S):
     assert (res.visit_counts.sum(1) == S).all()          # every simulation passes the root once
     assert (res.visit_counts >= 0).all()

@@ -75,14 +75,33 @@ MUST_LAUNCH = {
 }
 
 
-def _network(game, mode, seed):
+def _network(game, mode, seed, weights="synthetic"):
+    """weights = "synthetic": mzx.synthetic.fill_state_dict(seed) -- large random weights, searches that dig single lines
+    a hundred plies deep, near-flat planes in front of the min-max scaling: the stress case.  "reference": what SURVEY.md
+    section 8(d) prescribes and bench.py times -- torch.manual_seed(0); models.MuZeroNetwork(config) of the UNMODIFIED
+    reference, from the oracle/_ref bytecode (skipped where that did not travel)."""
     cfg = configs.BY_NAME[game]()
     net = models.MuZeroNetwork(cfg)
-    sd = synthetic.fill_state_dict(net.state_dict(), seed)
+    if weights == "reference":
+        from oracle import build_ref
+        if not build_ref.available():
+            pytest.skip("oracle/_ref not built (no /root/reference at build time)")
+        ref_models, _ = build_ref.load()
+        torch.manual_seed(0)
+        sd = {k: v.clone() for k, v in ref_models.MuZeroNetwork(cfg).get_weights().items()}
+    else:
+        sd = synthetic.fill_state_dict(net.state_dict(), seed)
     net.set_weights(sd)
     if mode is not None:
         net.set_mode(mode)
     return cfg, net, sd
+
+
+# How far a row's logits may be from the oracle evaluated in binary64, in units of the oracle's OWN fp32 error on that
+# row, when it misses 1e-4 against the fp32 oracle (ill-conditioned rows: a near-flat plane in front of the min-max
+# scaling).  Synthetic weights: 32 x (observed up to 18 x: gomoku's 1 152-term fp32 chains against ATen's blocked sums);
+# the reference constructor's weights -- the case the north star's 1e-4 is stated for -- 4 x.
+OWN_ERROR_FACTOR = {"synthetic": 32.0, "reference": 4.0}
 
 
 def _device_rand(shape, seed):
@@ -91,7 +110,7 @@ def _device_rand(shape, seed):
     return torch.rand(shape, device="cuda", generator=g)
 
 
-def _rows_against_oracle(cfg, sd, rows, obs, hid, act, outs, label, loose=()):
+def _rows_against_oracle(cfg, sd, rows, obs, hid, act, outs, label, loose=(), factor=32.0):
     """
     Device heads of `rows` (initial_inference of obs, recurrent_inference of (hid, act)) against the oracle network.
     Bound: 1e-4 against the oracle's fp32 arithmetic -- or, where that fails (ill-conditioned rows: a near-flat plane
@@ -123,7 +142,7 @@ def _rows_against_oracle(cfg, sd, rows, obs, hid, act, outs, label, loose=()):
         err32 = numpy.abs(got - ref32).max(axis=1)
         err64 = numpy.abs(got - ref64).max(axis=1)
         own = numpy.abs(ref32 - ref64).max(axis=1)
-        ok = (err32 < TOL) | (err64 <= numpy.maximum(TOL, 32 * own))
+        ok = (err32 < TOL) | (err64 <= numpy.maximum(TOL, factor * own))
         worst = max(worst, float(err32[[r not in loose for r in rows]].max(initial=0.0)))
         assert ok.all(), (label, name, [(rows[i], err32[i], err64[i], own[i]) for i in numpy.nonzero(~ok)[0]])
         if k in (3, 7) or not len(loose):
@@ -135,10 +154,15 @@ def _rows_against_oracle(cfg, sd, rows, obs, hid, act, outs, label, loose=()):
     print(f"{label}: {len(rows)} rows against the oracle network: worst error of a well-conditioned row {worst:.2e}")
 
 
-@pytest.mark.parametrize("case", sorted(sc.AT_SIZE))
-def test_at_size_operators_and_heads(backend, case):
+# (the reference constructor's weights at one size per configuration: the launch shapes are those of the synthetic run)
+AT_SIZE_WEIGHTS = [(c, "synthetic") for c in sorted(sc.AT_SIZE)] + [(c, "reference") for c in ("gomoku-1024", "connect4-1024", "atari-512")]
+
+
+@pytest.mark.parametrize("case,weights", AT_SIZE_WEIGHTS)
+def test_at_size_operators_and_heads(backend, case, weights):
     game, mode, B = sc.AT_SIZE[case]
-    cfg, net, sd = _network(game, mode, seed=41)
+    cfg, net, sd = _network(game, mode, seed=41, weights=weights)
+    case = case if weights == "synthetic" else case + " (reference weights)"
     if mode in (None, 5):
         assert net.fused_supported() == 0 and net.streamed_supported() == 3
     launched = set()
@@ -148,7 +172,7 @@ def test_at_size_operators_and_heads(backend, case):
                                                             sc.inference_launches(backend.lib, game, B, recurrent, mode=mode)]
         launched |= {models.instantiation_key(l) for l in launches}
         print(f"{case} {'recurrent' if recurrent else 'initial'}: {models.summarize_launches(launches)}")
-    assert MUST_LAUNCH[case] <= launched, (case, sorted(MUST_LAUNCH[case] - launched))
+    assert MUST_LAUNCH[case.split(" ")[0]] <= launched, (case, sorted(MUST_LAUNCH[case.split(" ")[0]] - launched))
 
     obs = _device_rand((B,) + tuple(net.input_shape), 5)
     hid = _device_rand((B,) + tuple(net.hidden_shape), 6)
@@ -185,7 +209,7 @@ def test_at_size_operators_and_heads(backend, case):
     o = net.initial_inference(obs)
     r = net.recurrent_inference(hid, act)
     rows = sorted(set([0, 1, B // 3, B // 2 - 1, B // 2, (2 * B) // 3, B - 2, B - 1]) | set(sorted(loose_rows)[:8]))
-    _rows_against_oracle(cfg, sd, rows, obs, hid, act, list(o) + list(r), case, loose=loose_rows)
+    _rows_against_oracle(cfg, sd, rows, obs, hid, act, list(o) + list(r), case, loose=loose_rows, factor=OWN_ERROR_FACTOR[weights])
 
 
 def _first_scale_operator(net, recurrent):
@@ -212,10 +236,15 @@ def _traces(t, rows, legal):
 TREE_KEYS = ("visit", "value_sum", "reward", "prior", "child", "parent", "to_play", "minmax", "n_nodes")
 
 
-@pytest.mark.parametrize("case", sorted(sc.AT_SIZE_SEARCHES))
-def test_at_size_search_two_streams_and_oracle(backend, case, monkeypatch):
+AT_SIZE_SEARCH_WEIGHTS = ([(c, "synthetic") for c in sorted(sc.AT_SIZE_SEARCHES)] +
+                          [(c, "reference") for c in ("gomoku-1024", "connect4-1024", "atari-256")])
+
+
+@pytest.mark.parametrize("case,weights", AT_SIZE_SEARCH_WEIGHTS)
+def test_at_size_search_two_streams_and_oracle(backend, case, weights, monkeypatch):
     game, mode, B, sims, n_sample = sc.AT_SIZE_SEARCHES[case]
-    cfg, net, sd = _network(game, mode, seed=9)
+    cfg, net, sd = _network(game, mode, seed=9, weights=weights)
+    case = case if weights == "synthetic" else case + " (reference weights)"
     if sims is not None:
         cfg.num_simulations = sims
     S, A = cfg.num_simulations, len(cfg.action_space)
@@ -283,19 +312,24 @@ def test_at_size_search_two_streams_and_oracle(backend, case, monkeypatch):
             # fp32 and binary64 searches together (they part at simulations 54 ... 262, the device parts from the fp32
             # oracle at 77 ... 251, often at the very same simulation, profiles/r04_pytest_gpu_*.log), and the margin at
             # such a node (4e-3 at depth 94) measures the compounded error of BOTH fp32 evaluations, not a defect
-            if gap >= parity.MARGIN_GATE and not (k64 is not None and 2 * k >= k64):
+            # With the reference constructor's weights (the weights bench.py times) there is NO such waiver: every divergence
+            # must be a near-tie.  (Their searches go even deeper -- 110 to 400 plies for games/gomoku.py -- and the oracle's
+            # fp32 and binary64 searches part on every tree as well, but at margins of 1e-6 ... 1.2e-4: CPU probe, round 5.)
+            waived = weights == "synthetic" and k64 is not None and 2 * k >= k64
+            if gap >= parity.MARGIN_GATE and not waived:
                 failures.append((i, k, gap, depth, k64))
             continue
         identical += 1
         assert t32["root_visit_counts"] == list(res.visit_counts[i]), (case, i)
         assert res.max_tree_depth[i] == t32["max_depth"], (case, i)
-        # root value of a tree that agrees in every simulation: 3e-3, or 8 x the error the oracle's own fp32 has
-        # against binary64 on this very tree (the decode cancels ~3 digits; near-flat planes)
+        # root value of a tree that agrees in every simulation.  The yardstick is the tree itself: when the oracle's fp32 and
+        # binary64 searches agree on it too, the device must be within 8 x the oracle-fp32's own error of the binary64
+        # value (floor 1e-3: the decode cancels ~3 digits); otherwise within 3e-3 of the fp32 oracle
         rv32 = t32["root_value"]
         tol, ref = 30 * TOL, rv32
         if k64 is None:
             ref = t64["root_value"]
-            tol = max(tol, 8 * abs(rv32 - ref))
+            tol = max(10 * TOL, 8 * abs(rv32 - ref))
         if not abs(res.root_values[i] - ref) < tol * max(1.0, abs(ref)):
             failures.append((i, "root value", res.root_values[i], rv32, ref))
     n = len(sample)

@@ -175,3 +175,29 @@ def test_two_slot_groups_play_what_one_group_plays(backend):
         assert len(one[slot]) == len(two[slot])
         for a, b in zip(one[slot], two[slot]):
             _same(a, b, slot)
+
+
+def test_dropped_queued_search_gives_its_draws_back(backend):
+    """A pipelined play_rounds call that ends with a search queued for the next round, followed by play_games instead of
+    another play_rounds: the queued search is dropped and the root noise / tie words it drew go back to the slots' streams
+     -- the streams are then exactly those of a run that never queued it."""
+    def streams(pipeline):
+        cfg = configs.cartpole(num_simulations=5, max_moves=7)
+        cfg.self_play_pipeline = pipeline
+        Game = synthetic.make_synthetic_game(cfg.observation_shape, len(cfg.action_space), len(cfg.players))
+        weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 3)
+        shard = self_play.SelfPlay({"weights": weights}, Game, cfg, 11, num_games=8, _backend=backend)
+        # (fixed-length games: all eight end in one round; the first group's four leave the call short of five games, so its
+        # next search is queued before the second group's four end the call)
+        shard.play_rounds(1.0, None, min_games=5)
+        queued = any(g.get("pending") is not None for g in shard._live["groups"])
+        shard._drain_searches()
+        states = [shard.bank.get_state(s) for s in range(8)]
+        shard.close_game()
+        return states, queued
+
+    one, q1 = streams(False)
+    two, q2 = streams(True)
+    assert not q1 and q2
+    for a, b in zip(one, two):
+        assert a[2] == b[2] and (a[1] == b[1]).all() and a[3] == b[3]
