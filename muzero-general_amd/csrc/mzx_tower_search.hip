@@ -211,9 +211,11 @@ rt_search_kernel(const RtSearchArgs sa) {
       const RtTower& a = sa.tw[0];
 #define RB_TOWER_HAS_TAIL true
 #define RB_TOWER_ACTION(b, t) sel_action[t]
+#define RB_TOWER_LDS_BARRIER true
 #include "mzx_tower_layers.inc"
 #undef RB_TOWER_HAS_TAIL
 #undef RB_TOWER_ACTION
+#undef RB_TOWER_LDS_BARRIER
     }
     __syncthreads();                                     // the dynamics tower's output is in the tile's interior cells
     // ---- its tail, as rb_tower_kernel's: the reward head's 1x1 convolution and the per-plane (min, range) pairs read
@@ -280,9 +282,11 @@ rt_search_kernel(const RtSearchArgs sa) {
       const RtTower& a = sa.tw[1];
 #define RB_TOWER_HAS_TAIL true
 #define RB_TOWER_ACTION(b, t) 0
+#define RB_TOWER_LDS_BARRIER true
 #include "mzx_tower_layers.inc"
 #undef RB_TOWER_HAS_TAIL
 #undef RB_TOWER_ACTION
+#undef RB_TOWER_LDS_BARRIER
     }
     __syncthreads();
     for (int q = sa.n_conv[0]; q < ((sa.dbg & 8) ? 0 : sa.n_conv[0] + sa.n_conv[1]); ++q) {

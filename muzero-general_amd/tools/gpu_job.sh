@@ -61,7 +61,31 @@ run_pmc() {   # one workload per directory: HBM traffic (separate FETCH_SIZE / W
   cat $OUT/pmc_entries.jsonl
 }
 
+one() {   # label, bench arguments...: one line per run
+  local label=$1; shift
+  timeout 300 python bench.py --steps 3 --warmup 1 $Q "$@" 2>> $OUT/err.log |
+    python -c "import sys, json; d = json.loads(sys.stdin.readline()); print('%-40s %.4g sims/s, %.2f ms per step, %.4f of peak' % ('$label', d['value'], d['ms_per_step'], d['roofline']['frac']))"
+}
+
 case $JOB in
+  variants)      # library variants built beside the product one (mzx/libmzx_<v>.so): whole steps of the tower workloads
+    {
+    for v in "" _vA _vB; do
+      L=$PWD/muzero-general_amd/mzx/libmzx$v.so
+      MZX_LIB=$L one "lib$v: rt 1024" --workload c4
+      MZX_LIB=$L one "lib$v: rt 1024 K loops only" --workload c4 --tuning rt_dbg=30
+      MZX_LIB=$L one "lib$v: rt 1536" --workload c4 --trees 1536
+      MZX_LIB=$L one "lib$v: gomoku" --workload gomoku --steps 1
+      MZX_LIB=$L one "lib$v: atari" --workload atari --steps 1
+    done
+    } > $OUT/variants.txt 2>&1
+    cat $OUT/variants.txt
+    ;;
+  tests-host)      # the whole -m gpu suite + smoke, then the host profile of the batched self-play protocol
+    run_tests
+    timeout 300 python muzero-general_amd/tools/selfplay_host_profile.py > $OUT/host_profile_batched.txt 2>&1
+    head -45 $OUT/host_profile_batched.txt
+    ;;
   refweights)      # the at-size parity tests on the reference constructor's weights (strict gates) + the new pipelined-shard test
     timeout 1400 python -m pytest tests/test_gpu_streamed_at_size.py -m gpu -q -s -k "reference" > $OUT/pytest_ref.log 2>&1
     echo "pytest rc $?" >> $OUT/pytest_ref.log

@@ -31,15 +31,16 @@ def main():
     make = synthetic.make_synthetic_game if args.plugin else synthetic.make_synthetic_batched_game
     Game = make(cfg.observation_shape, len(cfg.action_space), len(cfg.players))
     sp = self_play.SelfPlay({"weights": net.get_weights()}, Game, cfg, 0, num_games=args.trees)
-    sp.play_games(1.0, None, False, "self", 0)
+    run = lambda: sp.play_rounds(1.0, None, min_games=1 << 60, max_rounds=args.moves)    # (what bench.py's self-play legs run)
+    run()
     t0 = time.perf_counter()
-    sp.play_games(1.0, None, False, "self", 0)
+    run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"{args.trees} games x {args.moves} moves: {dt / args.moves * 1e3:.3f} ms per move = {args.trees * args.moves / dt / 1e6:.3f} M steps/s")
+    print(f"{args.trees} games x {args.moves} rounds: {dt / args.moves * 1e3:.3f} ms per round = {args.trees * args.moves / dt / 1e6:.3f} M steps/s")
     pr = cProfile.Profile()
     pr.enable()
-    sp.play_games(1.0, None, False, "self", 0)
+    run()
     pr.disable()
     pstats.Stats(pr).sort_stats("tottime").print_stats(22)
 
