@@ -68,6 +68,18 @@ one() {   # label, bench arguments...: one line per run
 }
 
 case $JOB in
+  rt-quick)      # the rt tests and the planner's shapes around the BASELINE shard
+    timeout 600 python -m pytest tests/test_gpu_tower_search.py -m gpu -q -s -x -k "bit_identical or same_trees or routing" > $OUT/pytest_rt.log 2>&1
+    grep -E "passed|failed|^FAILED|^ERROR|Error" $OUT/pytest_rt.log | tail
+    {
+    for t in 512 768 1024 1536 2048; do
+      one "rt $t (planner)" --workload c4 --trees $t
+    done
+    one "rt 1024 K loops only" --workload c4 --tuning rt_dbg=30
+    one "rt 1024 no epilogues" --workload c4 --tuning rt_dbg=2
+    } > $OUT/rt_quick.txt 2>&1
+    cat $OUT/rt_quick.txt
+    ;;
   variants)      # library variants built beside the product one (mzx/libmzx_<v>.so): whole steps of the tower workloads
     {
     for v in "" _vA _vB; do

@@ -127,8 +127,8 @@ def bench_streamed_workloads(lib, bench):
 RT_AT_SIZE = {
     ("connect4", 512): "test_gpu_tower_search.py::test_tower_search_other_shards_against_oracle[512-1-32]",
     ("connect4", 1024): "test_gpu_parity.py::test_full_size_residual_configs[connect4] + test_gpu_tower_search.py::test_tower_search_at_size_same_trees_as_launches",
-    ("connect4", 1536): "test_gpu_tower_search.py::test_tower_search_other_shards_against_oracle[1536-3-48]",
-    ("connect4", 9216): "test_gpu_tower_search.py::test_tower_search_other_shards_against_oracle[9216-3-48]",
+    ("connect4", 1536): "test_gpu_tower_search.py::test_tower_search_other_shards_against_oracle[1536-6-48]",
+    ("connect4", 9216): "test_gpu_tower_search.py::test_tower_search_other_shards_against_oracle[9216-6-48]",
 }
 
 
