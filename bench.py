@@ -642,9 +642,9 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         assert (visits.sum(1) == S).all(), "a tree did not complete its simulations"
         assert (info[:, 1] == 0).all(), "search flagged an overflow"
     mean_leaf_depth = float(sets[0][1]["info"].cpu().numpy()[:, 3].mean() / S)
-    for k, v in tuning_saved.items():
-        lib.tuning_set(k, v)
     if rank != 0:
+        for k, v in tuning_saved.items():
+            lib.tuning_set(k, v)
         return None, cfg, net
 
     value = world * B * S * steps / elapsed
@@ -654,7 +654,9 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     ran = lib.mzx_search_kernel_name(handle)      # the search kernel the last step launched
     ran = ran.decode() if ran else ""
     route = (ctypes.c_int32 * 8)()
-    lib.check(lib.mzx_search_route(handle, route))
+    lib.check(lib.mzx_search_route(handle, route))      # (under the workload's tuning: restored right below)
+    for k, v in tuning_saved.items():
+        lib.tuning_set(k, v)
     # short tag of what ran: the search kernel (+ its shape where the library plans one per shard)
     if route[0] == 3:
         tag = f"mzx::rt_search_kernel<{route[2]},1> {route[1]} trees x {route[6]} threads, {route[4]} per CU"

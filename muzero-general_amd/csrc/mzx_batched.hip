@@ -568,10 +568,19 @@ RbTowerFn rb_pick_tower_mt(int mt) {
     case 4: return rb_tower_kernel<4, NT>;
     case 5: return rb_tower_kernel<5, NT>;
     case 6: return rb_tower_kernel<6, NT>;
-    case 7: return rb_tower_kernel<7, NT>;
-    case 8: return rb_tower_kernel<8, NT>;
-    default: return rb_tower_kernel<9, NT>;
+    default: break;
   }
+  // (two column tiles per wave: the planner stops at six row tiles, rb_tower_grid -- 7 .. 9 would not fit 256 registers with
+  // the saved residual beside the accumulators and are not instantiated)
+  if constexpr (NT == 1) {
+    switch (mt) {
+      case 7: return rb_tower_kernel<7, NT>;
+      case 8: return rb_tower_kernel<8, NT>;
+      case 9: return rb_tower_kernel<9, NT>;
+      default: break;
+    }
+  }
+  return nullptr;
 }
 
 // Launches layers [tw.first, tw.first + layers) of a tower (layers < tw.count: a diagnostic prefix; the last layer run
@@ -621,6 +630,7 @@ int rb_launch_tower(const mzx_net* net, const std::vector<OpDesc>& prog, const R
     if (l + 1 < tw.count && prog[tw.first + l + 1].res != -100) L.flags |= 2;
   }
   RbTowerFn fn = sh.NT == 2 ? rb_pick_tower_mt<2>(sh.MT) : rb_pick_tower_mt<1>(sh.MT);
+  if (!fn) { set_error("tower: no instantiation for %d x %d tiles per wave", sh.MT, sh.NT); return MZX_ERR_INVALID; }
   static std::atomic<uint64_t> lds_attr_done[2][RB_MT + 1];
   if (const int ae = allow_large_lds((const void*)fn, RB_LDS_MAX, lds_attr_done[sh.NT - 1][sh.MT])) {
     set_error("hipFuncSetAttribute: %s", runtime_error_string(ae));

@@ -68,6 +68,21 @@ one() {   # label, bench arguments...: one line per run
 }
 
 case $JOB in
+  bench-only)      # the default bench line as the driver runs it; size of the line
+    timeout 900 python bench.py > $OUT/bench_default.log 2> $OUT/bench_default.err
+    echo "bench rc $?" >> $OUT/bench_default.err
+    tail -3 $OUT/bench_default.err
+    wc -c $OUT/bench_default.log
+    python -c "
+import json
+d = json.loads(open('$OUT/bench_default.log').read().strip().splitlines()[-1])
+print('C2', d['value'], d['ms_per_step'], d['roofline']['frac'], d['config']['weights'], d['config']['mean_leaf_depth'])
+for w in d['workloads']: print(w['w'], w['v'], w['ms'], w['roofline']['frac'], w['L'], w['k'])
+for k in d:
+    if k.startswith('selfplay'): print(k, round(d[k]['steps_per_sec']), d[k].get('search_share'))
+print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['kind'], d['cpu_baseline']['cores'])
+"
+    ;;
   rt-quick)      # the rt tests and the planner's shapes around the BASELINE shard
     timeout 600 python -m pytest tests/test_gpu_tower_search.py -m gpu -q -s -x -k "bit_identical or same_trees or routing" > $OUT/pytest_rt.log 2>&1
     grep -E "passed|failed|^FAILED|^ERROR|Error" $OUT/pytest_rt.log | tail
