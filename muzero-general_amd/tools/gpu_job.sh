@@ -45,6 +45,7 @@ run_bench() {
 
 run_pmc() {   # one workload per directory: HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes), matrix-pipe occupancy, L2 hit rate
   for w in "$@"; do
+    if [ -n "$PMC_DEADLINE" ] && [ $(date +%s) -gt $PMC_DEADLINE ]; then echo "pmc: out of time before $w" >> $OUT/pmc_err.log; continue; fi
     local N=2
     case $w in gomoku|atari|c4-large) N=1 ;; esac
     local CMD="python bench.py --workload $w --steps $N --warmup 0 --repeats 1 $Q"
@@ -53,7 +54,9 @@ run_pmc() {   # one workload per directory: HBM traffic (separate FETCH_SIZE / W
     timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -o run -- $CMD > $D/rocprof_fetch.log 2>&1
     timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -o run -- $CMD > $D/rocprof_write.log 2>&1
     timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $D/pmc_mfma -o run -- $CMD > $D/rocprof_mfma.log 2>&1
-    timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $D/pmc_l2 -o run -- $CMD > $D/rocprof_l2.log 2>&1
+    case $w in c4|c4-large|gomoku|atari)     # the tower workloads: L2 hit rate of the weight-fragment stream
+      timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $D/pmc_l2 -o run -- $CMD > $D/rocprof_l2.log 2>&1 ;;
+    esac
     local TAG=$(timeout 200 $CMD 2>/dev/null | python -c "import sys, json; print(json.loads(sys.stdin.readline())['roofline']['kernel'].replace('whole step: ', ''))")
     python muzero-general_amd/tools/pmc_traffic.py $w $N $D "$TAG" >> $OUT/pmc_entries.jsonl 2>> $OUT/pmc_err.log
     python muzero-general_amd/tools/rocprof_summary.py $D mzx > $D/summary.txt 2>&1
@@ -333,7 +336,9 @@ print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['kind'], d['cpu_basel
   tests) run_tests ;;
   bench) run_bench ;;
   pmc) shift; shift; run_pmc ${@:-c2 c2-ckpt c3 c4 c4-ws c4-large c5 c5-512 gomoku atari} ;;
-  final) run_tests; run_bench; run_pmc c2 c2-ckpt c3 c4 c4-ws c4-large c5 c5-512 gomoku atari ;;
+  final)      # tests + bench + pmc; the PMC passes stop starting workloads FINAL_BUDGET_S (default 1500) after the job began
+    PMC_DEADLINE=$(( $(date +%s) + ${FINAL_BUDGET_S:-1500} ))
+    run_tests; run_bench; run_pmc c4 atari c2 c3 c5 c4-ws c2-ckpt c5-512 c4-large gomoku ;;
   *) echo "unknown job $JOB"; exit 2 ;;
 esac
 find $OUT -size +4M -delete
