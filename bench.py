@@ -372,7 +372,7 @@ def observation_stacker_leg(backend, games=64, stacked=32, iters=20):
             "algorithmic_bytes_per_launch": nbytes, "launch_ms": ms, "games": games, "stacked_observations": stacked}
 
 
-def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=False, pipeline=None):
+def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=False, pipeline=None, fused=True):
     """
     What a user of the drop-in engine sees per process -- game stepping, per-game numpy-compatible streams (native
     bank), temperature sampling and GameHistory records around one batched search per move.  Default:
@@ -401,6 +401,7 @@ def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=F
         Game = (board_games.BATCHED if batched else board_games.PER_OBJECT)[game]
         rounds = c.max_moves          # as many rounds as the longest possible game (connect4: 42)
     sp = self_play.SelfPlay({"weights": net.get_weights()}, Game, c, 0, num_games=B, _backend=net.backend)
+    sp.engine.fused_move = fused     # (False: the A/B of mzx_selfplay_search / mzx_selfplay_select, one slot group only)
     if lockstep:
         sp.play_games(1.0, None, False, "self", 0)          # warm-up (allocations, kernel attributes)
     else:
@@ -783,6 +784,13 @@ def main():
         if env.world == 1 and args.selfplay_moves > 0:
             line["selfplay_end_to_end"] = selfplay_leg(cfg, net, B, args.selfplay_moves)
             line["selfplay_end_to_end_batched_game"] = selfplay_leg(cfg, net, B, args.selfplay_moves, batched=True)
+            if not args.dry_run:
+                # A/B of round 5's host path: ONE slot group (no overlap of the host with the search), and one group on the
+                # separate calls of rounds 1-4 (root_draws / upload / mzx_search_run / download / advance / numpy action draw)
+                line["selfplay_end_to_end_batched_game"]["one_group_steps_per_sec"] = selfplay_leg(
+                    cfg, net, B, args.selfplay_moves, batched=True, pipeline=False)["steps_per_sec"]
+                line["selfplay_end_to_end_batched_game"]["separate_calls_steps_per_sec"] = selfplay_leg(
+                    cfg, net, B, args.selfplay_moves, batched=True, pipeline=False, fused=False)["steps_per_sec"]
             if c4_net is not None and not args.dry_run:
                 # the Connect4 half of BASELINE.json's "self-play steps/sec": whole games with the real rules
                 # (games/connect4.py:125-346 semantics, mzx.games), C4 network, 1024 games per process

@@ -393,6 +393,53 @@ int mzx_rng_randint(mzx_rng* r, const int32_t* idx, int32_t count, const int32_t
 int mzx_rng_choice_weighted(mzx_rng* r, const int32_t* idx, int32_t count, const double* weights,
                             int32_t row_stride, const int32_t* n, int32_t* out);
 
+/* ------------------------------------------------------------------------- *
+ * One self-play MOVE of a shard of games in two host calls (self_play.py:138-181 for B games at once): what an actor
+ * does around MCTS.run on the host -- root noise draw (:473), tie-break words, the upload of the move's inputs, the
+ * search, the download, the streams' advance, SelfPlay.select_action (:222-245) -- without a Python statement per
+ * field in between.  `mzx_move` describes a move: host arrays as the game plugin returns them, ONE pinned host
+ * block + ONE device block of the same layout for the inputs and for the outputs (io's device pointers point into
+ * d_in / d_out; a field's host copy is at the same offset of h_in / h_out; io.d_observation may point elsewhere when
+ * `observation` is NULL = the stacked observations are already on the device; h_in == d_in on a build without a
+ * device).  Same arithmetic, same draws in the same order as the calls it replaces (mzx_rng_root_draws,
+ * mzx_search_run, mzx_rng_advance, mzx_rng_choice_weighted / mzx_rng_randint), pinned by tests/test_selfplay_move.py.
+ * ------------------------------------------------------------------------- */
+typedef struct mzx_move {
+  int32_t num_games;               /* B */
+  int32_t action_space_size;       /* A */
+  int32_t tape_words;              /* raw words per game handed to the search for its tie breaks */
+  int32_t num_threads;             /* host threads for the per-game draws (persistent pool of the bank) */
+  const int32_t* streams;          /* [B] stream of game k in the bank */
+  const int32_t* legal_actions;    /* host [B][A], game.legal_actions() padded with -1 (validated: self_play.py:296-301) */
+  const int32_t* to_play;          /* host [B] */
+  const float* observation;        /* host [B][observation_floats], or NULL (io.d_observation holds them already) */
+  int64_t observation_floats;
+  double dirichlet_alpha;          /* config.root_dirichlet_alpha */
+  int32_t add_exploration_noise;   /* 0: no noise drawn (io.d_noise must be NULL) */
+  int32_t flags;                   /* MZX_MOVE_NO_SYNC: return once the download is queued; the caller waits for `stream`
+                                      (an event of its own behind the call) before it reads h_out */
+  void* h_in;  void* d_in;  int64_t in_bytes;
+  void* h_out; void* d_out; int64_t out_bytes;
+  mzx_search_io io;
+} mzx_move;
+#define MZX_MOVE_NO_SYNC 1
+/* Draws + upload + mzx_search_run + download + stream synchronisation.  n_legal [B] (out): legal actions per game.
+ * On return the outputs are in h_out; the streams have consumed the noise draws but NOT the tie-break words
+ * (info[k][2]): a caller that sees the tape-overflow flag (info[k][1] & 1) searches those games again on a longer
+ * tape before mzx_selfplay_select. */
+int mzx_selfplay_search(mzx_search* s, mzx_rng* r, const mzx_move* m, int32_t* n_legal, void* d_arena,
+                        int64_t arena_bytes, void* stream);
+/* mzx_rng_advance by words[k], then SelfPlay.select_action for every game: temperature[k] == 0 -> first maximum of
+ * the visit counts in legal order; +inf -> randint(0, n_legal[k]); else numpy.random.choice(p = dist / sum(dist)) with
+ * dist[j] = pow_table[row(temperature[k])][count_j] -- the caller fills pow_table [num_temperatures][table_stride]
+ * with numpy's own integer ** (1 / T) for the distinct finite non-zero temperatures `table_temperatures` (so that
+ * the power is the reference's, whatever libm this library was linked with).  visit_counts [B][A] by action (as the
+ * search wrote them), action [B] (out): the chosen action. */
+int mzx_selfplay_select(mzx_rng* r, const mzx_move* m, const int32_t* n_legal, const int32_t* words,
+                        const int32_t* visit_counts, const double* temperature, const double* pow_table,
+                        int32_t table_stride, const double* table_temperatures, int32_t num_temperatures,
+                        int64_t* action);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,11 @@ inline int copy_d2d(void* dst, const void* src, size_t bytes, stream_t) {
   memcpy(dst, src, bytes);
   return 0;
 }
+inline int copy_d2h(void* dst, const void* src, size_t bytes, stream_t) {
+  memcpy(dst, src, bytes);
+  return 0;
+}
+inline int stream_sync(stream_t) { return 0; }
 
 inline int device_alloc(void** out, size_t bytes) {
   *out = malloc(bytes);
@@ -74,6 +79,10 @@ inline int copy_h2d(void* dst, const void* src, size_t bytes, stream_t stream) {
 inline int copy_d2d(void* dst, const void* src, size_t bytes, stream_t stream) {
   return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
 }
+inline int copy_d2h(void* dst, const void* src, size_t bytes, stream_t stream) {
+  return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
+}
+inline int stream_sync(stream_t stream) { return (int)hipStreamSynchronize(stream); }
 
 // small library-owned device allocations (the search's pb_c / sqrt tables); every large buffer is the caller's
 inline int device_alloc(void** out, size_t bytes) { return (int)hipMalloc(out, bytes); }

@@ -753,6 +753,11 @@ int mzx_rng_root_draws(mzx_rng* r, const int32_t* idx, int32_t count, double alp
       if (n_legal[k] < 1 || n_legal[k] > action_space_size) { set_error("n_legal[%d] = %d out of range", k, n_legal[k]); return MZX_ERR_INVALID; }
   rng_parallel(r, count, n_threads, [=](int lo, int hi) {
     for (int k = lo; k < hi; ++k) {
+      if (k + 1 < hi) {   // the next game's generator state (2.5 KB each: a shard's bank does not stay in cache)
+        const Mt19937& nx = r->streams[idx[k + 1]];
+        __builtin_prefetch(&nx.pos);
+        __builtin_prefetch(&nx.key[nx.pos < 624 ? nx.pos : 0]);
+      }
       Mt19937& m = r->streams[idx[k]];
       if (noise) {  // RandomState.dirichlet([alpha] * n): gammas, then multiplication by 1 / sum
         double* out = noise + (size_t)k * action_space_size;
@@ -820,6 +825,158 @@ int mzx_rng_choice_weighted(mzx_rng* r, const int32_t* idx, int32_t count, const
     for (int j = 0; j < m; ++j) pos += (cdf[j] / last <= u) ? 1 : 0;
     out[k] = pos;
   }
+  return MZX_OK;
+}
+
+// ------------------------------------------------------------- a self-play move of a shard behind two calls
+
+static int move_check(const mzx_rng* r, const mzx_move* m) {
+  if (!m) { set_error("mzx_move: null"); return MZX_ERR_INVALID; }
+  if (m->num_games < 1 || m->action_space_size < 1 || m->tape_words < 0) { set_error("mzx_move: sizes"); return MZX_ERR_INVALID; }
+  if (!m->legal_actions) { set_error("mzx_move: legal_actions missing"); return MZX_ERR_INVALID; }
+  return rng_check(r, m->streams, m->num_games);
+}
+
+// host address of the field whose device address is `d` (NULL when the field lies outside the staged block)
+static void* move_host(const void* d, const void* d_block, void* h_block, int64_t bytes) {
+  if (!d) return nullptr;
+  const ptrdiff_t off = (const char*)d - (const char*)d_block;
+  if (off < 0 || off >= bytes) return nullptr;
+  return (char*)h_block + off;
+}
+
+int mzx_selfplay_search(mzx_search* s, mzx_rng* r, const mzx_move* m, int32_t* n_legal, void* d_arena,
+                        int64_t arena_bytes, void* stream) {
+  int rc = move_check(r, m);
+  if (rc) return rc;
+  if (!s || !n_legal || !m->to_play || !m->h_in || !m->d_in || !m->h_out || !m->d_out || m->in_bytes < 1 || m->out_bytes < 1) {
+    set_error("mzx_selfplay_search: missing buffer");
+    return MZX_ERR_INVALID;
+  }
+  const int B = m->num_games, A = m->action_space_size, W = m->tape_words;
+  const mzx_search_io& io = m->io;
+  double* h_noise = (double*)move_host(io.d_noise, m->d_in, m->h_in, m->in_bytes);
+  int32_t* h_legal = (int32_t*)move_host(io.d_legal_actions, m->d_in, m->h_in, m->in_bytes);
+  int32_t* h_to_play = (int32_t*)move_host(io.d_to_play, m->d_in, m->h_in, m->in_bytes);
+  uint32_t* h_tape = (uint32_t*)move_host(io.d_tape, m->d_in, m->h_in, m->in_bytes);
+  float* h_obs = (float*)move_host(io.d_observation, m->d_in, m->h_in, m->in_bytes);
+  if (!h_legal || !h_to_play || (W > 0 && !h_tape) || (m->observation && !h_obs) || (!m->observation && !io.d_observation) ||
+      (m->add_exploration_noise ? !h_noise : io.d_noise != nullptr)) {
+    set_error("mzx_selfplay_search: io fields must lie inside the staged input block");
+    return MZX_ERR_INVALID;
+  }
+  // self_play.py:296-301 on the padded lists
+  for (int k = 0; k < B; ++k) {
+    const int32_t* row = m->legal_actions + (size_t)k * A;
+    int n = 0;
+    while (n < A && row[n] >= 0) ++n;
+    if (n == 0) { set_error("Legal actions should not be an empty array. Got [] (game %d).", k); return MZX_ERR_INVALID; }
+    for (int j = 0; j < A; ++j)
+      if (j < n ? row[j] >= A : row[j] >= 0) {
+        set_error("Legal actions should be a subset of the action space (padded with -1 at the end); game %d.", k);
+        return MZX_ERR_INVALID;
+      }
+    n_legal[k] = n;
+  }
+  const double alpha = m->dirichlet_alpha;
+  const int32_t* idx = m->streams;
+  rng_parallel(r, B, m->num_threads, [=](int lo, int hi) {
+    for (int k = lo; k < hi; ++k) {
+      if (k + 1 < hi) {   // the next game's generator state (2.5 KB each, a shard's bank does not stay in cache)
+        const Mt19937& nx = r->streams[idx[k + 1]];
+        __builtin_prefetch(&nx.pos);
+        __builtin_prefetch(&nx.key[nx.pos < 624 ? nx.pos : 0]);
+      }
+      Mt19937& g = r->streams[idx[k]];
+      if (h_noise) {  // RandomState.dirichlet([alpha] * n): the statements of mzx_rng_root_draws
+        double* out = h_noise + (size_t)k * A;
+        const int n = n_legal[k];
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) { out[j] = g.standard_gamma(alpha); acc = acc + out[j]; }
+        const double invacc = 1 / acc;
+        for (int j = 0; j < n; ++j) out[j] = out[j] * invacc;
+        for (int j = n; j < A; ++j) out[j] = 0.0;
+      }
+      if (W > 0) g.peek(W, h_tape + (size_t)k * W);
+    }
+  });
+  memcpy(h_legal, m->legal_actions, sizeof(int32_t) * (size_t)B * A);
+  memcpy(h_to_play, m->to_play, sizeof(int32_t) * (size_t)B);
+  if (m->observation) memcpy(h_obs, m->observation, sizeof(float) * (size_t)B * m->observation_floats);
+  const bool staged = m->h_in != m->d_in;
+  if (staged) MZX_TRY_LAUNCH(copy_h2d(m->d_in, m->h_in, (size_t)m->in_bytes, (stream_t)stream));
+  // (instrumented builds only, -DMZX_EXPERIMENT: the host envelope of a move timed without the search)
+  if (!exp_int("MZX_MOVE_NO_SEARCH", 0)) {
+    rc = mzx_search_run(s, &io, d_arena, arena_bytes, stream);
+    if (rc) return rc;
+  }
+  if (m->h_out != m->d_out) MZX_TRY_LAUNCH(copy_d2h(m->h_out, m->d_out, (size_t)m->out_bytes, (stream_t)stream));
+  if (!(m->flags & MZX_MOVE_NO_SYNC)) MZX_TRY_LAUNCH(stream_sync((stream_t)stream));
+  return MZX_OK;
+}
+
+int mzx_selfplay_select(mzx_rng* r, const mzx_move* m, const int32_t* n_legal, const int32_t* words,
+                        const int32_t* visit_counts, const double* temperature, const double* pow_table,
+                        int32_t table_stride, const double* table_temperatures, int32_t num_temperatures,
+                        int64_t* action) {
+  int rc = move_check(r, m);
+  if (rc) return rc;
+  if (!n_legal || !visit_counts || !temperature || !action || num_temperatures < 0 ||
+      (num_temperatures > 0 && (!pow_table || !table_temperatures || table_stride < 1))) {
+    set_error("mzx_selfplay_select: missing argument");
+    return MZX_ERR_INVALID;
+  }
+  const int B = m->num_games, A = m->action_space_size;
+  if (A > 4096) { set_error("mzx_selfplay_select: more than 4096 actions"); return MZX_ERR_INVALID; }
+  for (int k = 0; k < B; ++k) {
+    if (n_legal[k] < 1 || n_legal[k] > A) { set_error("n_legal[%d] = %d out of range", k, n_legal[k]); return MZX_ERR_INVALID; }
+    const double t = temperature[k];
+    if (t == 0.0 || t == MZX_INF) continue;
+    int row = -1;
+    for (int q = 0; q < num_temperatures; ++q) if (table_temperatures[q] == t) row = q;
+    if (row < 0) { set_error("mzx_selfplay_select: no power table for temperature %g", t); return MZX_ERR_INVALID; }
+    const int32_t* legal = m->legal_actions + (size_t)k * A;
+    const int32_t* vis = visit_counts + (size_t)k * A;
+    for (int j = 0; j < n_legal[k]; ++j)
+      if (vis[legal[j]] < 0 || vis[legal[j]] >= table_stride) { set_error("visit count %d outside the power table", vis[legal[j]]); return MZX_ERR_INVALID; }
+  }
+  const int32_t* idx = m->streams;
+  const int32_t* legal_all = m->legal_actions;
+  rng_parallel(r, B, m->num_threads, [=](int lo, int hi) {
+    double cdf[4096];
+    for (int k = lo; k < hi; ++k) {
+      if (k + 1 < hi) {
+        const Mt19937& nx = r->streams[idx[k + 1]];
+        __builtin_prefetch(&nx.pos);
+        __builtin_prefetch(&nx.key[nx.pos < 624 ? nx.pos : 0]);
+      }
+      Mt19937& g = r->streams[idx[k]];
+      if (words) for (int32_t j = 0; j < words[k]; ++j) g.next32();        // what the search consumed (mzx_rng_advance)
+      const int32_t* legal = legal_all + (size_t)k * A;
+      const int32_t* vis = visit_counts + (size_t)k * A;
+      const int n = n_legal[k];
+      const double t = temperature[k];
+      int pos = 0;
+      if (t == 0.0) {                            // actions[numpy.argmax(visit_counts)]: the first maximum
+        int32_t best = vis[legal[0]];
+        for (int j = 1; j < n; ++j) if (vis[legal[j]] > best) { best = vis[legal[j]]; pos = j; }
+      } else if (t == MZX_INF) {                 // numpy.random.choice(actions)
+        pos = (int)g.bounded((uint32_t)n);
+      } else {                                   // numpy.random.choice(actions, p=dist / sum(dist)): mzx_rng_choice_weighted
+        int row = 0;
+        for (int q = 0; q < num_temperatures; ++q) if (table_temperatures[q] == t) row = q;
+        const double* tab = pow_table + (size_t)row * table_stride;
+        double total = 0.0;
+        for (int j = 0; j < n; ++j) total = total + tab[vis[legal[j]]];
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) { acc = acc + tab[vis[legal[j]]] / total; cdf[j] = acc; }
+        const double last = cdf[n - 1];
+        const double u = g.next_double();
+        for (int j = 0; j < n; ++j) pos += (cdf[j] / last <= u) ? 1 : 0;
+      }
+      action[k] = legal[pos < n ? pos : n - 1];
+    }
+  });
   return MZX_OK;
 }
 

@@ -15,6 +15,7 @@ import torch
 
 MZX_MAX_LAYERS = 8
 ABI_VERSION = 1
+MOVE_NO_SYNC = 1
 
 c_i32, c_i64, c_f64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
 
@@ -49,6 +50,17 @@ class SearchIO(ctypes.Structure):
     _fields_ = [
         ("d_observation", c_vp), ("d_legal_actions", c_vp), ("d_to_play", c_vp), ("d_noise", c_vp), ("d_tape", c_vp),
         ("d_visit_counts", c_vp), ("d_root_value", c_vp), ("d_root_predicted_value", c_vp), ("d_info", c_vp),
+    ]
+
+
+class Move(ctypes.Structure):
+    """``mzx_move`` (include/mzx.h): one self-play move of a shard behind mzx_selfplay_search / mzx_selfplay_select."""
+    _fields_ = [
+        ("num_games", c_i32), ("action_space_size", c_i32), ("tape_words", c_i32), ("num_threads", c_i32),
+        ("streams", c_vp), ("legal_actions", c_vp), ("to_play", c_vp), ("observation", c_vp),
+        ("observation_floats", c_i64), ("dirichlet_alpha", c_f64), ("add_exploration_noise", c_i32), ("flags", c_i32),
+        ("h_in", c_vp), ("d_in", c_vp), ("in_bytes", c_i64), ("h_out", c_vp), ("d_out", c_vp), ("out_bytes", c_i64),
+        ("io", SearchIO),
     ]
 
 
@@ -132,6 +144,9 @@ PROTOTYPES = {
     "mzx_rng_random_sample": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp]),
     "mzx_rng_randint": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_vp]),
     "mzx_rng_choice_weighted": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    "mzx_selfplay_search": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(Move), c_vp, c_vp, c_i64, c_vp]),
+    "mzx_selfplay_select": (ctypes.c_int, [c_vp, ctypes.POINTER(Move), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32,
+                                           c_vp]),
 }
 
 

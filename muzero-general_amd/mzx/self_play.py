@@ -187,7 +187,12 @@ class ShardGameHistory(GameHistory):
 class _ShardRecord:
     """Game-major arrays of one finished shard (what ShardGameHistory objects view)."""
 
-    def __init__(self, A, obs, acts, rews, tps, vis=None, vals=None, totals=None, ratios=None, simple=None, legal_mask=None):
+    def __init__(self, A, obs, acts, rews, tps, vis=None, vals=None, totals=None, ratios=None, simple=None, legal_mask=None,
+                 time_major=False):
+        if time_major:     # [move][game] arrays (the rows of a slot group's ring, copied out as they lie): views, no transposition
+            sw = lambda a: None if a is None else numpy.swapaxes(a, 0, 1)
+            obs, acts, rews, tps, vis, vals, totals, ratios, legal_mask = (sw(a) for a in (obs, acts, rews, tps, vis, vals, totals,
+                                                                                             ratios, legal_mask))
         self.A, self.obs, self.acts, self.rews, self.tps = A, obs, acts, rews, tps
         self.vis, self.vals, self.totals, self.ratios, self.simple, self.legal_mask = vis, vals, totals, ratios, simple, legal_mask
 
@@ -228,6 +233,8 @@ class SearchResult:
         self.sum_depth = info[:, 3]
         self.legal_actions = legal_actions
         self.shared_legal = None     # set when every root has the same legal-action list (list protocol)
+        self.legal_array = self.n_legal = self.streams = None    # bank searches: [B][A] padded lists, their lengths, the streams
+        self.pending_words = None    # tie-break words the streams have still to consume (run(..., _defer_advance=True))
 
     def root(self, i):
         """A ``Node`` whose children carry the visit counts of root i (self_play.py:222-245, :496-511)."""
@@ -242,6 +249,18 @@ class SearchResult:
         node._root_value = float(self.root_values[i])
         node.value = lambda: node._root_value if total else 0
         return node
+
+
+class PendingSearch:
+    """A search that may still be running on the device (``BatchedMCTS.run(..., _asynchronous=True)``)."""
+
+    def __init__(self, complete):
+        self._complete, self._result = complete, None
+
+    def result(self):
+        if self._complete is not None:
+            self._result, self._complete = self._complete(), None
+        return self._result
 
 
 def _validate(config):
@@ -260,6 +279,8 @@ class BatchedMCTS:
     MCTS.run (self_play.py:260-361) for B roots at once.  One instance owns the
     device arena for up to ``max_trees`` roots of a given network.
     """
+
+    fused_move = True     # A/B switch of the tests: False = the separate calls (root_draws, _launch, advance, numpy select)
 
     def __init__(self, config, model, max_trees, num_simulations=None, mode=None):
         _validate(config)
@@ -515,11 +536,77 @@ class BatchedMCTS:
         return (vout["visits"].reshape(B, A).copy(), vout["root_value"].copy(), vout["predicted"].copy(),
                 vout["info"].reshape(B, 4).copy())
 
-    def run(self, observations, legal_actions, to_play, add_exploration_noise, rngs, _override=None):
+    def _move_search(self, B, obs, legal, to_play, bank, bank_idx, with_noise, asynchronous=False):
+        """
+        ``mzx_selfplay_search``: root draws of the bank straight into the pinned staging block, ONE upload, the search,
+        ONE download, the stream synchronisation -- the statements of ``StreamBank.root_draws`` + ``_launch`` behind one
+        call.  Returns a function that hands out host copies of the outputs, n_legal [B] and the noise the roots got
+        ([B][A] view, or None).  ``asynchronous``: the call returns once the download is queued (MZX_MOVE_NO_SYNC) and
+        the returned function first waits for an event recorded behind it -- the host is free in between (the staging
+        block of this (B, tape) geometry is in use until then: one search in flight per engine).
+        """
+        lib, A = self.backend.lib, self.A
+        obs_dev = obs if isinstance(obs, torch.Tensor) else None
+        obs_floats = 0 if obs_dev is not None else int(obs.size // B)
+        st = self._staging(B, TAPE_WORDS, obs_floats, with_noise)
+        pin, pout = st["pin"], st["pout"]
+        mv = st.get("move")
+        if mv is None:
+            c_vp = ctypes.c_void_p
+            mv = st["move"] = _lib.Move()
+            mv.num_games, mv.action_space_size, mv.tape_words = B, A, TAPE_WORDS
+            mv.h_in, mv.d_in, mv.in_bytes = st["h_in"].data_ptr(), st["d_in"].data_ptr(), st["h_in"].numel()
+            mv.h_out, mv.d_out, mv.out_bytes = st["h_out"].data_ptr(), st["d_out"].data_ptr(), st["h_out"].numel()
+            mv.io = _lib.SearchIO(c_vp(pin["obs"]), c_vp(pin["legal"]), c_vp(pin["to_play"]),
+                                  c_vp(pin["noise"]) if with_noise else c_vp(0), c_vp(pin["tape"]), c_vp(pout["visits"]),
+                                  c_vp(pout["root_value"]), c_vp(pout["predicted"]), c_vp(pout["info"]))
+        asynchronous = bool(asynchronous) and st["on_gpu"]
+        mv.num_threads = bank.threads
+        mv.flags = _lib.MOVE_NO_SYNC if asynchronous else 0
+        mv.streams, mv.legal_actions, mv.to_play = bank_idx.ctypes.data, legal.ctypes.data, to_play.ctypes.data
+        mv.dirichlet_alpha, mv.add_exploration_noise = float(self.config.root_dirichlet_alpha), int(with_noise)
+        if obs_dev is not None:
+            mv.observation, mv.observation_floats = None, 0
+            mv.io.d_observation = obs_dev.data_ptr()
+        else:
+            mv.observation, mv.observation_floats = obs.ctypes.data, obs_floats
+        n_legal = numpy.empty(B, numpy.int32)
+        arena = self.arena(B)
+        rc = lib.mzx_selfplay_search(self.handle(B, TAPE_WORDS), bank.handle, ctypes.byref(mv), n_legal.ctypes.data,
+                                     self.backend.ptr(arena), arena.numel(), self.backend.stream())
+        if rc != 0:
+            message = lib.mzx_last_error().decode()
+            if message.startswith("Legal actions"):       # self_play.py:296-301 raise AssertionError
+                raise AssertionError(message)
+            lib.check(rc)
+        done = None
+        if asynchronous:
+            done = st.get("event")
+            if done is None:
+                done = st["event"] = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.backend.device))
+        keep = (obs, legal, to_play, bank_idx)      # the library read them during the call; the caller may reuse them after
+
+        def outputs():
+            if done is not None:
+                done.synchronize()
+            vout = st["vout"]
+            return (vout["visits"].reshape(B, A).copy(), vout["root_value"].copy(), vout["predicted"].copy(),
+                    vout["info"].reshape(B, 4).copy(), n_legal, st["vin"]["noise"].reshape(B, A) if with_noise else None)
+        outputs.keep = keep
+        return outputs
+
+    def run(self, observations, legal_actions, to_play, add_exploration_noise, rngs, _override=None, _defer_advance=False,
+            _asynchronous=False):
         """
         observations: B stacked observations; legal_actions: B lists; to_play: B ints;
         rngs: B numpy RandomState-like objects (dirichlet / randint / get_state / set_state), or a pair
-        ``(StreamBank, stream indices)`` -- the native bank serves all B games with one call.
+        ``(StreamBank, stream indices)`` -- the native bank serves all B games, and the whole host side of the
+        move (draws, staging, upload, search, download) is ONE call into the library (``mzx_selfplay_search``).
+        ``_defer_advance``: leave the consumption of the tie-break words to ``SelfPlay._select_actions_bank``
+        (``mzx_selfplay_select`` does it in the same pass as the action draw); ``result.pending_words`` holds them.
+        ``_asynchronous`` (bank searches): returns a ``PendingSearch`` as soon as the search is queued on the device;
+        its ``result()`` waits and completes the call -- the host steps another group of games in between.
         """
         cfg, A = self.config, self.A
         B = len(legal_actions)
@@ -534,13 +621,15 @@ class BatchedMCTS:
         legal = numpy.full((B, A), -1, numpy.int32)
         n_legal = numpy.empty(B, numpy.int32)
         action_set = set(cfg.action_space)
+        fused = self.fused_move and bank is not None and _override is None     # the move's host side behind one library call
         if isinstance(legal_actions, numpy.ndarray):   # batched protocol: [B][A] int32, lists padded with -1
             legal = numpy.ascontiguousarray(legal_actions, dtype=numpy.int32)
             assert legal.shape == (B, A), "legal_actions array must be [num_trees][len(action_space)]"
-            n_legal = (legal >= 0).sum(1).astype(numpy.int32)
-            assert (n_legal > 0).all(), "Legal actions should not be an empty array."
-            assert (legal < A).all() and ((legal >= 0) == (numpy.arange(A)[None, :] < n_legal[:, None])).all(), \
-                "Legal actions should be a subset of the action space (padded with -1 at the end)."
+            if not fused:                              # (mzx_selfplay_search validates the rows itself)
+                n_legal = (legal >= 0).sum(1).astype(numpy.int32)
+                assert (n_legal > 0).all(), "Legal actions should not be an empty array."
+                assert (legal < A).all() and ((legal >= 0) == (numpy.arange(A)[None, :] < n_legal[:, None])).all(), \
+                    "Legal actions should be a subset of the action space (padded with -1 at the end)."
             legal_actions = legal
         if not isinstance(legal_actions, numpy.ndarray) and B > 1 and legal_actions.count(legal_actions[0]) == B:
             # every game offers the same list (the common case): validate it once (self_play.py:296-301)
@@ -560,7 +649,9 @@ class BatchedMCTS:
             assert len(set(acts)) == len(acts), "Legal actions must not repeat."
             legal[i, : len(acts)] = acts
             n_legal[i] = len(acts)
-        if bank is not None:
+        if fused:
+            noise = tape = None
+        elif bank is not None:
             noise, tape = bank.root_draws(bank_idx, cfg.root_dirichlet_alpha, n_legal, A, TAPE_WORDS,
                                           with_noise=bool(add_exploration_noise))
         else:
@@ -579,8 +670,23 @@ class BatchedMCTS:
             obs = observations.reshape(B, -1)
         else:
             obs = numpy.ascontiguousarray(numpy.asarray(observations, dtype=numpy.float32).reshape(B, -1))
-        to_play = numpy.asarray(to_play, numpy.int32)
-        visits, root_values, predicted, info = self._launch(B, obs, legal, to_play, noise, tape, TAPE_WORDS, _override)
+        to_play = numpy.ascontiguousarray(to_play, dtype=numpy.int32)
+        outputs = None
+        if fused:
+            outputs = self._move_search(B, obs, legal, to_play, bank, bank_idx, bool(add_exploration_noise), _asynchronous)
+        pending = PendingSearch(lambda: self._complete_run(
+            outputs, B, obs, legal, legal_actions, shared, to_play, n_legal, noise, tape, bank, bank_idx if bank is not None else None,
+            rngs, states if bank is None else None, _override, _defer_advance))
+        return pending if _asynchronous else pending.result()
+
+    def _complete_run(self, outputs, B, obs, legal, legal_actions, shared, to_play, n_legal, noise, tape, bank, bank_idx, rngs,
+                      states, _override, _defer_advance):
+        """The second half of ``run``: outputs of the (possibly still running) search, tape retries, the result record."""
+        cfg, A = self.config, self.A
+        if outputs is not None:
+            visits, root_values, predicted, info, n_legal, noise = outputs()
+        else:
+            visits, root_values, predicted, info = self._launch(B, obs, legal, to_play, noise, tape, TAPE_WORDS, _override)
         # A tree that exhausted its tie-break tape (a network with equal priors ties at every level) is searched
         # again with a longer tape: same roots, same noise, the stream peeked further -- the reference never
         # fails here (numpy.random.choice at self_play.py:371 simply keeps drawing).
@@ -612,7 +718,11 @@ class BatchedMCTS:
             raise _lib.MzxError(f"search flagged trees {numpy.nonzero(info[:, 1])[0][:8]} (flags {set(info[:, 1])}): "
                                 "node arena exhausted")
         if bank is not None:
-            bank.advance(bank_idx, info[:, 2])   # consume exactly what the device consumed
+            result.legal_array, result.n_legal, result.streams = legal, n_legal, bank_idx
+            if _defer_advance and self.fused_move:     # (the numpy action draw of the A/B switch does not advance)
+                result.pending_words = numpy.ascontiguousarray(info[:, 2], dtype=numpy.int32)
+            else:
+                bank.advance(bank_idx, info[:, 2])   # consume exactly what the device consumed
         else:
             for i in range(B):  # rewind, then consume exactly what the device consumed
                 rngs[i].set_state(states[i])
@@ -659,6 +769,148 @@ def _remote(method, *args):
     return method(*args)
 
 
+class _BatchedGroup(dict):
+    """
+    A group of slots of a shard behind the batched plugin protocol (``SelfPlay._rounds_batched``): its game object,
+    engine, streams, frame store and the LOG of the games in progress -- ring arrays [row][slot], row = round % capacity,
+    a move is one contiguous row per field (a game lasts at most ``max_moves`` rounds, so its rows never collide; the
+    ring starts small and grows to that bound when a game outlasts it); a finished game's rows are copied out as they
+    lie (move-major) and viewed game by game -- no transposition on the actor's path.  A dict for the few fields the
+    actor's other methods read (``pending``, ``n``, ``slots``).
+    """
+
+    def __init__(self, actor, game, first, n, engine, temperature):
+        cfg = actor.config
+        obs = numpy.asarray(game.reset())
+        assert obs.shape == (n,) + tuple(cfg.observation_shape), \
+            f"Observation should match the observation_shape defined in MuZeroConfig. Expected {(n,) + tuple(cfg.observation_shape)} but got {obs.shape}."
+        super().__init__(game=game, first=first, n=n, engine=engine, slots=list(range(first, first + n)),
+                         streams=numpy.arange(first, first + n, dtype=numpy.int32), everyone=numpy.arange(n), obs=obs,
+                         tp=numpy.asarray(game.to_play()).astype(numpy.int64), start=numpy.zeros(n, numpy.int64),
+                         temps=numpy.full(n, float(temperature)), round=0, store=None, pending=None, legal=None)
+        self.A, self.max_moves = len(cfg.action_space), int(cfg.max_moves)
+        self.ring, self.cap = None, 0
+        if cfg.stacked_observations > 0:   # frames stay in HBM; the stacked inputs are assembled there (csrc/mzx_obs.h)
+            whole = n == actor.num_games
+            self["store"] = actor._frame_store(n) if whole else observations_mod.FrameStore(cfg, n, actor.model.backend)
+            self["store"].push(obs, None)
+
+    def _row(self, r, obs, reward):
+        """Ring row of round ``r``; allocates / grows the ring so that the rounds of every running game keep their own."""
+        need = r - int(self["start"].min()) + 1
+        if need > self.cap:
+            cap = min(max(2 * self.cap, need, 16), self.max_moves + 1)
+            n, A = self["n"], self.A
+            ring = dict(obs=numpy.empty((cap, n) + obs.shape[1:], obs.dtype), tp=numpy.empty((cap, n), numpy.int64),
+                        act=numpy.empty((cap, n), numpy.int64), rew=numpy.empty((cap, n), reward.dtype),
+                        vis=numpy.empty((cap, n, A), numpy.int32), val=numpy.empty((cap, n), numpy.float64), mask=None)
+            if self.ring is not None:
+                if self.ring["mask"] is not None:
+                    ring["mask"] = numpy.ones((cap, n, A), bool)
+                for q in range(int(self["start"].min()), r):
+                    for name, arr in ring.items():
+                        if arr is not None:
+                            arr[q % cap] = self.ring[name][q % self.cap]
+            self.ring, self.cap = ring, cap
+        return r % self.cap
+
+    def play(self, actor, result, temperature, temperature_threshold):
+        """One move of every slot after its search: action draw, game step, log, finished games out, slots refilled."""
+        cfg, g, n, A = actor.config, self["game"], self["n"], self.A
+        r, start, store, everyone = self["round"], self["start"], self["store"], self["everyone"]
+        legal = self["legal"]
+        moves_before = r - start                      # len(action_history) - 1 of every slot's game
+        temps = self["temps"]
+        if temperature_threshold:                     # self_play.py:151-157
+            temps = numpy.where(moves_before + 1 < temperature_threshold, temps, 0.0)
+        actions = numpy.asarray(actor._select_actions_bank(result, self["streams"], temps), numpy.int64)
+        obs2, reward, done = g.step(actions, None)
+        obs2, reward = numpy.asarray(obs2), numpy.asarray(reward)
+        c = self._row(r, self["obs"], reward)
+        ring = self.ring
+        ring["obs"][c], ring["tp"][c], ring["act"][c], ring["rew"][c] = self["obs"], self["tp"], actions, reward
+        ring["vis"][c], ring["val"][c] = result.visit_counts, result.root_values
+        if isinstance(legal, numpy.ndarray) and (legal >= 0).all():
+            if ring["mask"] is not None:              # every action legal for every game
+                ring["mask"][c] = True
+        else:
+            if ring["mask"] is None:
+                ring["mask"] = numpy.ones((self.cap, n, A), bool)
+            mask = numpy.zeros((n, A), bool)
+            if isinstance(legal, numpy.ndarray):
+                mask[numpy.repeat(everyone, (legal >= 0).sum(1)), legal[legal >= 0]] = True
+            else:
+                for i, acts in enumerate(legal):
+                    mask[i, acts] = True
+            ring["mask"][c] = mask
+        tp2 = numpy.asarray(g.to_play()).astype(numpy.int64)
+        over = numpy.asarray(done, bool) | (moves_before + 2 > cfg.max_moves)     # len(action_history) <= max_moves, :129
+        pushed = actions
+        finished, slots = [], []
+        if over.any():
+            idx = numpy.nonzero(over)[0]
+            finished = self._harvest(idx, r, obs2[idx], tp2[idx])
+            slots = (idx + self["first"]).tolist()
+            if not obs2.flags.writeable or obs2 is self["obs"]:
+                obs2 = obs2.copy()
+            obs2[idx] = numpy.asarray(g.reset_games(idx))       # the slots' next games begin (self_play.py:31-52)
+            tp2 = numpy.asarray(g.to_play()).astype(numpy.int64)
+            start[idx] = r + 1
+            self["temps"][idx] = float(temperature)
+            pushed = actions.copy()
+            pushed[idx] = 0
+            if store is not None:
+                store.clear_history(idx)
+        if store is not None:
+            store.push(obs2, pushed)
+        self["obs"], self["tp"] = obs2, tp2
+        self["round"] = r + 1
+        return finished, slots
+
+    def _harvest(self, idx, r, final_obs, final_tp):
+        """GameHistory views of the games of slots ``idx`` that ended with round ``r`` (self_play.py:479-511)."""
+        A, ring, cap = self.A, self.ring, self.cap
+        out = [None] * len(idx)
+        starts = self["start"][idx]
+        for st in numpy.unique(starts):
+            where = numpy.nonzero(starts == st)[0]
+            slots = idx[where]
+            n = r - int(st) + 1
+            rows = numpy.arange(int(st), r + 1) % cap
+            everyone = slots.size == self["n"]
+            contiguous = rows[-1] - rows[0] == n - 1               # the game's rounds did not wrap around the ring
+            if everyone and contiguous:
+                take = lambda a, lead=0: a[rows[0]: rows[0] + n]   # (a view: copied into the record's arrays below)
+            elif everyone:
+                take = lambda a: a[rows]
+            else:
+                take = lambda a: a[rows[:, None], slots[None, :]]
+            k = slots.size
+            obs_all = numpy.empty((n + 1, k) + ring["obs"].shape[2:], ring["obs"].dtype)
+            obs_all[:n], obs_all[n] = take(ring["obs"]), final_obs[where]
+            acts = numpy.zeros((n + 1, k), numpy.int64)
+            acts[1:] = take(ring["act"])
+            rews = numpy.zeros((n + 1, k), ring["rew"].dtype)
+            rews[1:] = take(ring["rew"])
+            tps = numpy.empty((n + 1, k), numpy.int64)
+            tps[:n], tps[n] = take(ring["tp"]), final_tp[where]
+            vis, vals = numpy.array(take(ring["vis"])), numpy.array(take(ring["val"]))      # [n][games][A], [n][games] (copies)
+            totals = vis.sum(2)
+            ratios = vis / numpy.maximum(totals, 1)[:, :, None]       # true division of small integers == Python's int / int
+            plain = totals > 0
+            legal_mask = None
+            if ring["mask"] is not None:
+                legal_mask = numpy.array(take(ring["mask"]))
+                plain = plain & legal_mask.all(2)
+            record = _ShardRecord(A, obs_all, acts, rews, tps, vis, vals, totals, ratios, plain.all(0), legal_mask, time_major=True)
+            views = [ShardGameHistory(record, j, n) for j in range(k)]
+            if k == len(idx):
+                return views
+            for j, w in enumerate(where):
+                out[w] = views[j]
+        return out
+
+
 class SelfPlay:
     """
     self_play.py:11-245.  ``num_games`` (new, default 1) is the number of games
@@ -673,7 +925,8 @@ class SelfPlay:
         if getattr(Game, "batched", False):
             # optional batched plugin protocol (mzx.synthetic.make_synthetic_batched_game documents it): ONE
             # object steps the whole shard, the per-move host work is a handful of numpy calls
-            self.batched_game = Game([seed + i for i in range(self.num_games)])
+            self._game_seeds = [seed + i for i in range(self.num_games)]
+            self.batched_game = Game(self._game_seeds)
             self.games = []
             self.game = self.batched_game
         else:
@@ -1288,114 +1541,82 @@ class SelfPlay:
 
     def _rounds_batched(self, temperature, temperature_threshold, min_games, max_rounds):
         """
-        ``play_rounds`` behind the batched plugin protocol: per round ONE game call, ONE search, ONE action draw for
-        the whole shard.  A round is logged as a handful of arrays over all slots; a finished game is the column of its
-        slot over the rounds it lasted, handed out as a ``ShardGameHistory`` view (games that started and ended together
-        share one game-major record).
+        ``play_rounds`` behind the batched plugin protocol: per round and slot group ONE game call, ONE library call for
+        the host side of the search (``mzx_selfplay_search``: draws, staging, upload, launch, download), ONE for the
+        streams' advance and the action draw (``mzx_selfplay_select``).  A move is logged as one column of a handful
+        of game-major arrays (``_BatchedGroup``); a finished game is a gather of its slot's columns, handed out as a
+        ``ShardGameHistory`` view (games that started and ended together share one record).
+
+        Slot groups (``_batched_spans``): a large shard of a cheaply searched network runs as two groups with their own
+        game object, engine and staging that take turns on the GPU -- the search of one group is queued, the host
+        draws / steps / logs the other group, then waits for the first (an event behind the asynchronous library call;
+        no worker thread).  Slots are independent actors with their own stream: which of them share a launch changes
+        nothing any of them plays (tests/test_selfplay_refill.py, tests/test_selfplay_move.py); games finish in the
+        order (round, slot) either way.  A search is only queued ahead when the call cannot end before it is consumed,
+        so nothing is in flight between calls (weights may change there).
         """
-        cfg, g, B = self.config, self.batched_game, self.num_games
-        A, k = len(cfg.action_space), int(cfg.stacked_observations)
+        cfg, B = self.config, self.num_games
         live = self._live
         if live is None:
-            obs = numpy.asarray(g.reset())
-            assert obs.shape == (B,) + tuple(cfg.observation_shape), \
-                f"Observation should match the observation_shape defined in MuZeroConfig. Expected {(B,) + tuple(cfg.observation_shape)} but got {obs.shape}."
-            live = self._live = dict(obs=obs, tp=numpy.asarray(g.to_play()).astype(numpy.int64), start=numpy.zeros(B, numpy.int64),
-                                     temps=numpy.full(B, float(temperature)), log=[], base=0, round=0, store=None,
-                                     everyone=numpy.arange(B))
-            if k > 0:   # frames stay in HBM; the stacked inputs are assembled there (csrc/mzx_obs.h)
-                live["store"] = self._frame_store(B)
-                live["store"].push(obs, None)
-        store, everyone, start, log = live["store"], live["everyone"], live["start"], live["log"]
+            spans = self._batched_spans(B)
+            groups = []
+            for first, last in spans:
+                game = self.batched_game if len(spans) == 1 else type(self.batched_game)(self._game_seeds[first:last])
+                engine = self.engine if len(spans) == 1 else BatchedMCTS(cfg, self.model, last - first)
+                groups.append(_BatchedGroup(self, game, first, last - first, engine, temperature))
+            live = self._live = dict(groups=groups)
+        groups = live["groups"]
+        pipelined = len(groups) > 1
         finished, rounds = [], 0
-        while len(finished) < min_games and (max_rounds is None or rounds < max_rounds):
-            r = live["round"]
-            legal = g.legal_actions()
-            stacked = store.stacked(None) if store is not None else live["obs"]
+
+        def begin(group):
             t0 = time.perf_counter()
-            result = self.engine.run(stacked, legal, live["tp"], True, (self.bank, everyone))
+            legal = group["game"].legal_actions()
+            stacked = group["store"].stacked(None) if group["store"] is not None else group["obs"]
+            group["legal"] = legal
+            group["pending"] = group["engine"].run(stacked, legal, group["tp"], True, (self.bank, group["streams"]),
+                                                   _defer_advance=True, _asynchronous=True)
             self.stats["search_seconds"] += time.perf_counter() - t0
-            self.stats["searches"] += B
-            self.stats["simulations"] += B * self.engine.num_simulations
-            moves_before = r - start                      # len(action_history) - 1 of every slot's game
-            temps = live["temps"]
-            if temperature_threshold:                     # self_play.py:151-157
-                temps = numpy.where(moves_before + 1 < temperature_threshold, temps, 0.0)
-            t = float(temps[0]) if (temps == temps[0]).all() else temps
-            actions = numpy.asarray(self._select_actions_bank(result, everyone, t), numpy.int64)
-            obs2, reward, done = g.step(actions, None)
-            obs2 = numpy.asarray(obs2)
-            if isinstance(legal, numpy.ndarray) and (legal >= 0).all():
-                mask = None                               # every action legal for every game
-            else:
-                mask = numpy.zeros((B, A), bool)
-                if isinstance(legal, numpy.ndarray):
-                    mask[numpy.repeat(everyone, (legal >= 0).sum(1)), legal[legal >= 0]] = True
-                else:
-                    for i, acts in enumerate(legal):
-                        mask[i, acts] = True
-            log.append(dict(obs=live["obs"], tp=live["tp"], act=actions, rew=numpy.asarray(reward), vis=result.visit_counts,
-                            val=result.root_values, mask=mask))
-            tp2 = numpy.asarray(g.to_play()).astype(numpy.int64)
-            over = numpy.asarray(done, bool) | (moves_before + 2 > cfg.max_moves)     # len(action_history) <= max_moves, :129
-            pushed = actions
-            if over.any():
-                idx = numpy.nonzero(over)[0]
-                finished += self._harvest(live, idx, r, obs2[idx], tp2[idx])
-                self.finished_slots += idx.tolist()
-                if not obs2.flags.writeable or obs2 is live["obs"]:
-                    obs2 = obs2.copy()
-                obs2[idx] = numpy.asarray(g.reset_games(idx))       # the slots' next games begin (self_play.py:31-52)
-                tp2 = numpy.asarray(g.to_play()).astype(numpy.int64)
-                start[idx] = r + 1
-                live["temps"][idx] = float(temperature)
-                pushed = actions.copy()
-                pushed[idx] = 0
-                if store is not None:
-                    store.clear_history(idx)
-                keep = int(start.min()) - live["base"]              # rounds no running game reaches back to
-                if keep > 0:
-                    del log[:keep]
-                    live["base"] += keep
-            if store is not None:
-                store.push(obs2, pushed)
-            live["obs"], live["tp"] = obs2, tp2
-            live["round"] = r + 1
+
+        def consume(group):
+            t0 = time.perf_counter()
+            pending, group["pending"] = group["pending"], None
+            result = pending.result()
+            self.stats["search_seconds"] += time.perf_counter() - t0
+            n = group["n"]
+            self.stats["searches"] += n
+            self.stats["simulations"] += n * group["engine"].num_simulations
+            done_games, slots = group.play(self, result, temperature, temperature_threshold)
+            finished.extend(done_games)
+            self.finished_slots += slots
+
+        while len(finished) < min_games and (max_rounds is None or rounds < max_rounds):
+            for group in groups:
+                if group["pending"] is None:
+                    begin(group)
+            for k, group in enumerate(groups):
+                consume(group)
+                later = sum(g["n"] for g in groups[k + 1:])
+                if (pipelined and k + 1 < len(groups) and len(finished) + later < min_games
+                        and (max_rounds is None or rounds + 1 < max_rounds)):
+                    begin(group)      # certain to be consumed by this call: runs while the host plays the groups after it
             rounds += 1
         return finished
 
-    def _harvest(self, live, idx, r, final_obs, final_tp):
-        """GameHistory views of the games of slots ``idx`` that ended with round ``r`` (self_play.py:479-511)."""
-        A = len(self.config.action_space)
-        log, base, start = live["log"], live["base"], live["start"]
-        out = [None] * len(idx)
-        starts = start[idx]
-        for st in numpy.unique(starts):
-            where = numpy.nonzero(starts == st)[0]
-            slots = idx[where]
-            entries = log[int(st) - base: r - base + 1]
-            n = len(entries)
-            whole = slots.size == self.num_games
-            col = (lambda a: a) if whole else (lambda a: a[slots])
-            by_game = lambda seq: numpy.ascontiguousarray(numpy.swapaxes(numpy.stack(seq), 0, 1))
-            zeros = numpy.zeros(slots.size, numpy.int64)
-            obs_all = by_game([col(e["obs"]) for e in entries] + [final_obs[where]])
-            acts = by_game([zeros] + [col(e["act"]) for e in entries])
-            rews = by_game([zeros.astype(entries[0]["rew"].dtype)] + [col(e["rew"]) for e in entries])
-            tps = by_game([col(e["tp"]) for e in entries] + [final_tp[where]])
-            vis = by_game([col(e["vis"]) for e in entries])          # [games][n][A]
-            vals = by_game([col(e["val"]) for e in entries])
-            totals = vis.sum(2)
-            ratios = vis / numpy.maximum(totals, 1)[:, :, None]       # true division of small integers == Python's int / int
-            plain = totals > 0
-            legal_mask = None
-            if any(e["mask"] is not None for e in entries):
-                legal_mask = by_game([numpy.ones((slots.size, A), bool) if e["mask"] is None else col(e["mask"]) for e in entries])
-                plain = plain & legal_mask.all(2)
-            record = _ShardRecord(A, obs_all, acts, rews, tps, vis, vals, totals, ratios, plain.all(1), legal_mask)
-            for j, w in enumerate(where):
-                out[w] = ShardGameHistory(record, j, n)
-        return out
+    def _batched_spans(self, B):
+        """
+        Slot groups of a shard behind the batched protocol.  ``config.self_play_pipeline`` True / False; unset: two groups
+        when the host side of a move weighs as much as its search -- a fully connected network (one whole-search launch
+        of a fraction of a millisecond) from 2048 games on.  Residual networks are search-bound (connect4 at 1024 games:
+        98 % of the wall is the search, and two searches of 512 trees cost 14 % more than one of 1024): one group.
+        """
+        want = getattr(self.config, "self_play_pipeline", None)
+        if want is None:
+            want = self.config.network == "fullyconnected" and B >= 2048
+        if not want or B < 2 or not hasattr(self, "_game_seeds"):
+            return [(0, B)]
+        half = (B + 1) // 2
+        return [(0, half), (half, B)]
 
     @staticmethod
     def _stacked_batch(obs_hist, act_hist, k, A):
@@ -1454,6 +1675,9 @@ class SelfPlay:
             worker.shutdown(wait=True)
             self._search_worker = None
         if self.batched_game is not None:
+            for group in (self._live or {}).get("groups", ()):
+                if group.get("game") is not None and group["game"] is not self.batched_game:
+                    group["game"].close()
             self.batched_game.close()
         for g in self.games:
             g.close()
@@ -1488,6 +1712,8 @@ class SelfPlay:
         """
         k = len(searching)
         A = self.engine.A
+        if self.engine.fused_move and getattr(result, "legal_array", None) is not None and A <= 4096:
+            return self._select_actions_native(result, temps)
         counts = numpy.zeros((k, A), numpy.int32)     # in CHILD order (= legal-action order), zero padded
         n = numpy.empty(k, numpy.int32)
         if isinstance(result.legal_actions, numpy.ndarray):
@@ -1526,6 +1752,46 @@ class SelfPlay:
         if result.shared_legal is not None:
             return [result.shared_legal[a] for a in actions.tolist()]
         return [result.legal_actions[r][int(actions[r])] for r in range(k)]
+
+    def _select_actions_native(self, result, temps):
+        """
+        ``mzx_selfplay_select``: the streams consume the search's tie-break words (when ``run`` deferred that), then
+        every game's action is drawn -- one pass over the bank on the library's host threads.  The power
+        ``visit_count ** (1 / T)`` stays numpy's own: a table over 0 .. num_simulations per temperature, computed
+        with the reference's expression (int32 array ** float) and indexed by the library.
+        """
+        lib, bank = self.model.backend.lib, self.bank
+        B, A = result.legal_array.shape
+        temps = numpy.full(B, float(temps)) if numpy.isscalar(temps) else numpy.ascontiguousarray(temps, dtype=numpy.float64)
+        finite = temps[(temps != 0) & ~numpy.isinf(temps)]
+        distinct = numpy.unique(finite) if finite.size else numpy.zeros(0)
+        stride = int(result.visit_counts.max()) + 1 if distinct.size else 1
+        tables = getattr(self, "_pow_tables", None)
+        if tables is None:
+            tables = self._pow_tables = {}
+        rows = []
+        for t in distinct.tolist():
+            tab = tables.get(t)
+            if tab is None or tab.size < stride:
+                tab = tables[t] = numpy.arange(max(stride, self.engine.num_simulations + 2), dtype="int32") ** (1 / t)
+            rows.append(tab)
+        stride = min((r.size for r in rows), default=1)
+        table = numpy.ascontiguousarray(numpy.stack([r[:stride] for r in rows])) if rows else None
+        mv = _lib.Move()
+        mv.num_games, mv.action_space_size, mv.num_threads = B, A, bank.threads
+        mv.streams, mv.legal_actions = result.streams.ctypes.data, result.legal_array.ctypes.data
+        visits = numpy.ascontiguousarray(result.visit_counts, dtype=numpy.int32)
+        actions = numpy.empty(B, numpy.int64)
+        words = result.pending_words
+        result.pending_words = None
+        lib.check(lib.mzx_selfplay_select(bank.handle, ctypes.byref(mv), result.n_legal.ctypes.data,
+                                          None if words is None else words.ctypes.data, visits.ctypes.data,
+                                          temps.ctypes.data, None if table is None else table.ctypes.data, stride,
+                                          distinct.ctypes.data if distinct.size else None, int(distinct.size),
+                                          actions.ctypes.data))
+        if isinstance(result.legal_actions, numpy.ndarray):
+            return actions
+        return actions.tolist()
 
     @staticmethod
     def _select_action(node, temperature, rng):

@@ -110,7 +110,7 @@ def test_whole_game_matches_reference(backend, name):
     common.test_whole_game_matches_reference(backend, name)
 
 
-@pytest.mark.parametrize("protocol", ["per-object", "per-object-pipelined", "batched"])
+@pytest.mark.parametrize("protocol", ["per-object", "per-object-pipelined", "batched", "batched-pipelined"])
 def test_refilled_slots_equal_lone_actors_on_device(backend, protocol):
     """SelfPlay.play_rounds on the device (tests/test_selfplay_refill.py runs the host logic on the CPU double): slot s's
     games = a lone actor's seeded seed + s, also when two slot groups take turns on the GPU (a worker thread launches the
@@ -120,7 +120,7 @@ def test_refilled_slots_equal_lone_actors_on_device(backend, protocol):
     refill.test_refill_with_stacked_observations_and_fixed_length_games(backend, protocol)
 
 
-@pytest.mark.parametrize("protocol", ["per-object", "per-object-pipelined", "batched"])
+@pytest.mark.parametrize("protocol", ["per-object", "per-object-pipelined", "batched", "batched-pipelined"])
 @pytest.mark.parametrize("name", ["tictactoe", "tictactoe-threshold", "connect4"])
 def test_refilled_board_game_slots_equal_lone_actors_on_device(backend, name, protocol):
     """The same contract with the real rules and residual networks (ragged game lengths, temperature threshold): a
@@ -128,6 +128,48 @@ def test_refilled_board_game_slots_equal_lone_actors_on_device(backend, name, pr
     import test_selfplay_refill as refill
 
     refill.test_slot_games_equal_a_lone_actor_s_sequence(backend, name, protocol)
+
+
+def test_batched_shard_of_4096_cartpole_games_two_groups_against_one_and_against_the_separate_calls(backend):
+    """
+    BASELINE C2's shard behind the batched protocol (4096 games, 50 simulations, games of 6 moves, three rounds of
+    games): (a) the move behind two library calls (mzx_selfplay_search asynchronous + mzx_selfplay_select, two slot
+    groups of 2048 taking turns on the GPU -- the default at this size), (b) one group, (c) one group on the SEPARATE
+    calls of rounds 1 - 4 (root_draws, upload, mzx_search_run, download, advance, numpy action draw): the same games,
+    slot by slot and field by field, in the same order.
+    """
+    import copy
+
+    cfg = copy.copy(configs.cartpole())
+    cfg.max_moves = 6
+    Batched = synthetic.make_synthetic_batched_game(cfg.observation_shape, len(cfg.action_space), len(cfg.players))
+    weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg).state_dict(), 4)
+    B, seed = 4096, 1000
+
+    def play(pipeline, fused):
+        c = copy.copy(cfg)
+        c.self_play_pipeline = pipeline
+        sp = self_play.SelfPlay({"weights": weights}, Batched, c, seed, num_games=B)
+        sp.engine.fused_move = fused
+        out, slots = [], []
+        for _ in range(3):
+            out += sp.play_rounds(1.0, None)
+            slots += sp.finished_slots
+        groups = len(sp._live["groups"])
+        sp.close_game()
+        return out, slots, groups
+
+    a, slots_a, groups_a = play(None, True)
+    b, slots_b, groups_b = play(False, True)
+    c, slots_c, _ = play(False, False)
+    assert groups_a == 2 and groups_b == 1 and len(a) == len(b) == len(c) == 3 * B
+    assert slots_a == slots_b == slots_c
+    for k in range(0, 3 * B, 7):
+        for other in (b, c):
+            assert a[k].action_history == other[k].action_history, k
+            assert a[k].child_visits == other[k].child_visits and a[k].reward_history == other[k].reward_history, k
+            assert numpy.array_equal(numpy.array(a[k].root_values).view(numpy.int64), numpy.array(other[k].root_values).view(numpy.int64)), k
+            assert all(numpy.array_equal(x, y) for x, y in zip(a[k].observation_history, other[k].observation_history)), k
 
 
 def test_pipelined_shard_of_1024_connect4_games_plays_what_one_group_plays(backend):

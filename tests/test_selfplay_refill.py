@@ -47,17 +47,19 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("protocol", ["per-object", "per-object-pipelined", "batched"])
+@pytest.mark.parametrize("protocol", ["per-object", "per-object-pipelined", "batched", "batched-pipelined"])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_slot_games_equal_a_lone_actor_s_sequence(backend, name, protocol):
     make_cfg, make_game, make_batched, temperature = CASES[name]
     cfg = make_cfg()
-    if protocol == "per-object-pipelined":      # two slot groups take turns: one is searched while the other is stepped
+    if protocol.endswith("pipelined"):      # two slot groups take turns: one is searched while the other is stepped
         cfg.self_play_pipeline = True
+    elif protocol == "batched":
+        cfg.self_play_pipeline = False
     Game = make_game()
     weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 21)
     B, seed, per_slot = 5, 70, 3
-    shard = self_play.SelfPlay({"weights": weights}, make_batched() if protocol == "batched" else Game, cfg, seed,
+    shard = self_play.SelfPlay({"weights": weights}, make_batched() if protocol.startswith("batched") else Game, cfg, seed,
                                num_games=B, _backend=backend)
     by_slot = {s: [] for s in range(B)}
     rounds_played = 0
@@ -78,13 +80,18 @@ def test_slot_games_equal_a_lone_actor_s_sequence(backend, name, protocol):
             _same(by_slot[s][k], want[k], (name, protocol, s, k))
             lengths.add(len(want[k].action_history))
     assert len(lengths) > 1, "games should end at different moves for this test to mean anything"
-    if protocol == "per-object-pipelined":
+    if protocol.endswith("pipelined"):
         assert len(shard._live["groups"]) == 2 and [len(g["slots"]) for g in shard._live["groups"]] == [3, 2]
+    if protocol == "per-object-pipelined":
         assert all(g["pending"] is None or g["pending"].done() for g in shard._live["groups"])   # nothing runs between calls
+    if protocol == "batched-pipelined":      # the batched protocol never leaves a search queued across calls
+        assert all(g["pending"] is None for g in shard._live["groups"])
+    if protocol == "batched":
+        assert len(shard._live["groups"]) == 1
     shard.close_game()
 
 
-@pytest.mark.parametrize("protocol", ["per-object", "per-object-pipelined", "batched"])
+@pytest.mark.parametrize("protocol", ["per-object", "per-object-pipelined", "batched", "batched-pipelined"])
 def test_refill_with_stacked_observations_and_fixed_length_games(backend, protocol):
     """Synthetic game (never ends on its own: max_moves does), stacked observations through the device frame store:
     a restarted slot must see zeros in front of its first frame, not the previous game's frames."""
@@ -94,8 +101,8 @@ def test_refill_with_stacked_observations_and_fixed_length_games(backend, protoc
     Batched = synthetic.make_synthetic_batched_game(cfg.observation_shape, 3, 2)
     weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 5)
     B, seed = 4, 11
-    cfg.self_play_pipeline = protocol == "per-object-pipelined"    # (two groups of two slots, a frame store each)
-    shard = self_play.SelfPlay({"weights": weights}, Batched if protocol == "batched" else Game, cfg, seed, num_games=B,
+    cfg.self_play_pipeline = protocol.endswith("pipelined")    # (two groups of two slots, a frame store each)
+    shard = self_play.SelfPlay({"weights": weights}, Batched if protocol.startswith("batched") else Game, cfg, seed, num_games=B,
                                _backend=backend)
     first = shard.play_rounds(0.5, None)              # one shard's worth: all four games end with round 4
     first_slots = list(shard.finished_slots)
