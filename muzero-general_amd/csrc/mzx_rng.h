@@ -232,6 +232,8 @@ struct mzx_rng {
   std::vector<mzx::Mt19937> streams;
   std::unique_ptr<mzx::RngPool> pool;   // created on the first large parallel call
   long pool_pid = 0;                    // process that created it: worker threads do not survive fork()
+  std::mutex pool_owner;                // ONE caller at a time drives the pool (two slot groups of a shard call into the
+                                        // bank from two threads: the search's draws on a worker, the action draw on the main one)
 };
 
 namespace mzx {
@@ -239,6 +241,10 @@ namespace mzx {
 template <class Fn>
 inline void rng_parallel(mzx_rng* r, int count, int n_threads, Fn fn) {
   if (n_threads <= 1 || count < 256) { fn(0, count); return; }
+  // the pool serves one call at a time; a caller that finds it busy (another thread's call on OTHER streams of the bank)
+  // does its own range itself instead of waiting -- disjoint streams, no shared state
+  std::unique_lock<std::mutex> owner(r->pool_owner, std::try_to_lock);
+  if (!owner.owns_lock()) { fn(0, count); return; }
   if (n_threads > 64) n_threads = 64;
   const long pid = (long)getpid();
   if (r->pool && r->pool_pid != pid) (void)r->pool.release();   // forked child: the parent's threads are not here; never join them

@@ -334,10 +334,10 @@ print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['kind'], d['cpu_basel
     ;;
   c4-shards) shift; shift; c4_shards ${@:-512 768 1024 1536 2048 3072 4608 9216} > $OUT/c4_by_shard.txt 2>&1; cat $OUT/c4_by_shard.txt ;;
   move)      # round 5: the self-play move behind two library calls -- device tests, then the self-play legs of the bench line
-    timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "refilled or batched_shard_of_4096 or whole_game or pipelined_shard" > $OUT/pytest_move.log 2>&1
+    timeout ${MOVE_TEST_S:-300} python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "${MOVE_TESTS:-refilled or batched_shard_of_4096 or whole_game or pipelined_shard}" > $OUT/pytest_move.log 2>&1
     echo "pytest rc $?" >> $OUT/pytest_move.log
     grep -E "passed|failed|^FAILED|^ERROR|Error|rc " $OUT/pytest_move.log | tail -12
-    timeout 600 python bench.py --also c4 --cpu-seconds 0 > $OUT/bench_selfplay.log 2> $OUT/bench_selfplay.err
+    timeout 400 python bench.py ${MOVE_BENCH_ARGS---also c4 --cpu-seconds 0} > $OUT/bench_selfplay.log 2> $OUT/bench_selfplay.err
     echo "bench rc $?" >> $OUT/bench_selfplay.err
     tail -3 $OUT/bench_selfplay.err
     python -c "
@@ -347,8 +347,10 @@ print('C2', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['
 for k in d:
     if k.startswith('selfplay'): print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in d[k].items() if a in ('steps_per_sec', 'search_share', 'slot_groups', 'one_group_steps_per_sec', 'separate_calls_steps_per_sec', 'steps_per_sec_with_all_histories_as_lists', 'lockstep_steps_per_sec')})
 "
-    timeout 300 python muzero-general_amd/tools/selfplay_host_profile.py > $OUT/host_profile_batched.txt 2>&1
-    head -40 $OUT/host_profile_batched.txt
+    if [ -z "$MOVE_SKIP_PROFILE" ]; then
+      timeout 300 python muzero-general_amd/tools/selfplay_host_profile.py > $OUT/host_profile_batched.txt 2>&1
+      head -40 $OUT/host_profile_batched.txt
+    fi
     ;;
   tests) run_tests ;;
   bench) run_bench ;;

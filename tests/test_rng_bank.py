@@ -81,3 +81,56 @@ def test_no_noise_draws_nothing(lib):
     assert noise is None
     ref = numpy.random.RandomState(11)
     assert numpy.array_equal(tape[0], ref.randint(0, 2 ** 32, size=8, dtype=numpy.uint32))
+
+
+@pytest.mark.timeout(120)
+def test_two_threads_call_into_one_bank(lib):
+    """
+    The pipelined per-object shard calls into the bank from TWO threads at once (the queued search's root draws on the
+    worker, the other group's action draw on the main thread), both large enough for the bank's thread pool: the pool
+    serves one caller, the other does its range itself -- no deadlock (round 5 found one on the device), and every
+    stream produces what it produces alone.
+    """
+    import ctypes
+    import threading
+
+    from mzx import _lib as lib_mod
+
+    B, A, rounds = 1024, 7, 200
+    half = B // 2
+    banks = [_rng.StreamBank(lib, list(range(B))) for _ in range(2)]
+    for b in banks:
+        b.threads = 4
+    idx_a, idx_b = numpy.arange(half, dtype=numpy.int32), numpy.arange(half, B, dtype=numpy.int32)
+    n = numpy.full(half, A, numpy.int32)
+    legal = numpy.ascontiguousarray(numpy.tile(numpy.arange(A, dtype=numpy.int32), (half, 1)))
+    visits = numpy.random.RandomState(0).randint(0, 30, size=(half, A)).astype(numpy.int32)
+    temps, table, table_t = numpy.ones(half), numpy.arange(64, dtype="int32") ** 1.0, numpy.array([1.0])
+
+    def draws(bank, out):
+        for _ in range(rounds):
+            out.append(bank.root_draws(idx_a, 0.3, n, A, 16, True))
+
+    def selects(bank, out):
+        mv = lib_mod.Move()
+        mv.num_games, mv.action_space_size, mv.num_threads = half, A, 4
+        mv.streams, mv.legal_actions = idx_b.ctypes.data, legal.ctypes.data
+        for _ in range(rounds):
+            act = numpy.empty(half, numpy.int64)
+            lib.check(lib.mzx_selfplay_select(bank.handle, ctypes.byref(mv), n.ctypes.data, None, visits.ctypes.data,
+                                              temps.ctypes.data, table.ctypes.data, 64, table_t.ctypes.data, 1, act.ctypes.data))
+            out.append(act)
+
+    together, alone = ([], []), ([], [])
+    threads = [threading.Thread(target=draws, args=(banks[0], together[0])),
+               threading.Thread(target=selects, args=(banks[0], together[1]))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    draws(banks[1], alone[0])
+    selects(banks[1], alone[1])
+    for (na, ta), (nb, tb) in zip(together[0], alone[0]):
+        assert numpy.array_equal(na.view(numpy.int64), nb.view(numpy.int64)) and numpy.array_equal(ta, tb)
+    for x, y in zip(together[1], alone[1]):
+        assert numpy.array_equal(x, y)
