@@ -64,6 +64,22 @@ def _hash_u32(x):
     return x
 
 
+def _hash_u32_wrapping(x):
+    """``_hash_u32`` on a uint32 array, IN PLACE: unsigned 32-bit arithmetic wraps by itself, so the masks go and the
+    temporaries are half as wide -- the same values (the batched game's step is on the per-round path of the bench)."""
+    assert x.dtype == numpy.uint32
+    t = x >> numpy.uint32(16)
+    x ^= numpy.uint32(61)
+    x ^= t
+    x *= numpy.uint32(9)
+    numpy.right_shift(x, numpy.uint32(4), out=t)
+    x ^= t
+    x *= numpy.uint32(0x27D4EB2D)
+    numpy.right_shift(x, numpy.uint32(15), out=t)
+    x ^= t
+    return x
+
+
 def _hash_u32_int(x):
     """``_hash_u32`` on one Python int (same 32-bit mix, no numpy): the per-object game's step is on the
     per-move path of the plugin-surface benchmark, where a numpy call on a 4-element array costs 20x the work."""
@@ -146,7 +162,8 @@ def make_synthetic_batched_game(observation_shape, num_actions, num_players=1):
     """
     shape = tuple(observation_shape)
     size = int(numpy.prod(shape))
-    lane = numpy.arange(size, dtype=numpy.uint64) * numpy.uint64(2654435761)
+    lane = (numpy.arange(size, dtype=numpy.uint64) * numpy.uint64(2654435761)).astype(numpy.uint32)     # (mod 2**32)
+    u32 = numpy.uint32
 
     class SyntheticBatchedGame:
         batched = True
@@ -155,19 +172,25 @@ def make_synthetic_batched_game(observation_shape, num_actions, num_players=1):
             self.seeds = numpy.asarray([0 if s is None else int(s) for s in seeds], dtype=numpy.uint64)
             self.num_games = int(self.seeds.size)
             self._legal = numpy.tile(numpy.arange(num_actions, dtype=numpy.int32), (self.num_games, 1))
-            self.t = numpy.zeros(self.num_games, numpy.uint64)       # per game: refilled slots restart at 0
+            self._never_done = numpy.zeros(self.num_games, bool)
+            self.t = numpy.zeros(self.num_games, numpy.uint32)       # per game: refilled slots restart at 0
             self.player = numpy.zeros(self.num_games, numpy.int64)
-            self.key = self.seeds & numpy.uint64(0xFFFFFFFF)
+            self.key = self.seeds.astype(numpy.uint32)
+
+        # all arithmetic is the per-object game's (Python ints masked to 32 bits) modulo 2**32: uint32 arrays wrap
 
         def _observation(self, key=None):
             key = self.key if key is None else key
-            h = _hash_u32(lane[None, :] + key[:, None])
+            h = _hash_u32_wrapping(lane[None, :] + key[:, None])
             return (h.astype(numpy.float64) / 4294967296.0).astype(numpy.float32).reshape((key.size,) + shape)
+
+        def _first_key(self, seeds):
+            return _hash_u32_wrapping((seeds * numpy.uint64(7919) + numpy.uint64(17)).astype(numpy.uint32))
 
         def reset(self):
             self.t[:] = 0
             self.player[:] = 0
-            self.key = _hash_u32(self.seeds * numpy.uint64(7919) + numpy.uint64(17))
+            self.key = self._first_key(self.seeds)
             return self._observation()
 
         def reset_games(self, games):
@@ -175,16 +198,18 @@ def make_synthetic_batched_game(observation_shape, num_actions, num_players=1):
             g = numpy.asarray(games, numpy.int64)
             self.t[g] = 0
             self.player[g] = 0
-            self.key[g] = _hash_u32(self.seeds[g] * numpy.uint64(7919) + numpy.uint64(17))
+            self.key[g] = self._first_key(self.seeds[g])
             return self._observation(self.key[g])
 
         def step(self, actions, active=None):
-            self.t += numpy.uint64(1)
-            a = numpy.asarray(actions).astype(numpy.uint64)
-            self.key = _hash_u32(self.key * numpy.uint64(31) + a * numpy.uint64(131) + self.t)
-            self.player = (self.player + 1) % num_players
-            reward = (self.key & numpy.uint64(1)).astype(numpy.int64)
-            return self._observation(), reward, numpy.zeros(self.num_games, bool)
+            self.t += u32(1)
+            key = self.key * u32(31)
+            key += numpy.asarray(actions).astype(numpy.uint32) * u32(131)
+            key += self.t
+            self.key = _hash_u32_wrapping(key)
+            self.player = (self.player + 1) % num_players if num_players > 1 else self.player
+            reward = (self.key & u32(1)).astype(numpy.int64)
+            return self._observation(), reward, self._never_done
 
         def to_play(self):
             return self.player
