@@ -27,10 +27,10 @@ c4_shards() {   # trees...
 }
 
 run_tests() {
-  timeout 1700 python -m pytest tests -m gpu -q -s -x > $OUT/pytest_gpu.log 2>&1
-  echo "pytest rc $?" >> $OUT/pytest_gpu.log
-  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+  timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
   echo "smoke rc $?" >> $OUT/smoke.log
+  timeout ${SUITE_S:-1700} python -m pytest tests -m gpu -q -s -x > $OUT/pytest_gpu.log 2>&1
+  echo "pytest rc $?" >> $OUT/pytest_gpu.log
   grep -E "passed|failed|^FAILED|^ERROR|rc " $OUT/pytest_gpu.log | tail -20
   tail -3 $OUT/smoke.log
 }
@@ -351,6 +351,12 @@ for k in d:
       timeout 300 python muzero-general_amd/tools/selfplay_host_profile.py > $OUT/host_profile_batched.txt 2>&1
       head -40 $OUT/host_profile_batched.txt
     fi
+    ;;
+  last)      # HEAD's evidence in one short call: the default bench line, then smoke + the whole -m gpu suite
+    timeout 300 python bench.py > $OUT/bench_default.log 2> $OUT/bench_default.err
+    echo "bench rc $?" >> $OUT/bench_default.err
+    wc -c $OUT/bench_default.log
+    run_tests
     ;;
   tests) run_tests ;;
   bench) run_bench ;;
