@@ -143,3 +143,74 @@ def test_batched_shard_two_groups_against_one_and_against_the_separate_calls(bac
             assert a[k].child_visits == other[k].child_visits and a[k].reward_history == other[k].reward_history, k
             assert numpy.array_equal(numpy.array(a[k].root_values).view(numpy.int64), numpy.array(other[k].root_values).view(numpy.int64)), k
             assert all(numpy.array_equal(x, y) for x, y in zip(a[k].observation_history, other[k].observation_history)), k
+
+
+def test_move_entry_points_reject_bad_arguments(backend):
+    """Error behaviour of the two entry points through the C ABI: codes + messages, nothing drawn on a rejected call."""
+    import ctypes
+
+    from mzx import _lib
+
+    cfg, sp = _shard(backend, 4, 3, 5)
+    lib, bank, engine = backend.lib, sp.bank, sp.engine
+    B, A = 3, 4
+    obs = numpy.zeros((B, 4), numpy.float32)
+    legal = numpy.tile(numpy.arange(A, dtype=numpy.int32), (B, 1))
+    to_play = numpy.zeros(B, numpy.int32)
+    streams = numpy.arange(B, dtype=numpy.int32)
+    before = [bank.get_state(i) for i in range(B)]
+    outputs = engine._move_search(B, obs, legal, to_play, bank, streams, True)      # a valid move: fills the cached struct
+    outputs()
+    for i in range(B):
+        bank.set_state(i, before[i])
+    st = engine._staging(B, self_play.TAPE_WORDS, 4, True)
+    good = st["move"]
+    n_legal = numpy.empty(B, numpy.int32)
+    arena = engine.arena(B)
+
+    def call(mv, n=n_legal, bank_handle=bank.handle):
+        return lib.mzx_selfplay_search(engine.handle(B, self_play.TAPE_WORDS), bank_handle, ctypes.byref(mv),
+                                       None if n is None else n.ctypes.data, backend.ptr(arena), arena.numel(), backend.stream())
+
+    def variant(**fields):
+        mv = _lib.Move()
+        ctypes.memmove(ctypes.byref(mv), ctypes.byref(good), ctypes.sizeof(_lib.Move))
+        for k, v in fields.items():
+            setattr(mv, k, v)
+        return mv
+
+    assert call(good) == 0
+    for i in range(B):
+        bank.set_state(i, before[i])
+    assert call(variant(num_games=0)) != 0 and b"sizes" in lib.mzx_last_error()
+    assert call(variant(legal_actions=None)) != 0 and b"legal_actions" in lib.mzx_last_error()
+    assert call(good, n=None) != 0 and b"missing buffer" in lib.mzx_last_error()
+    assert call(variant(h_in=None)) != 0 and b"missing buffer" in lib.mzx_last_error()
+    bad_streams = numpy.array([0, 1, 99], numpy.int32)
+    assert call(variant(streams=bad_streams.ctypes.data)) != 0 and b"out of range" in lib.mzx_last_error()
+    outside = variant()
+    outside.io.d_tape = 12345                      # a field of the staged block that does not lie inside it
+    assert call(outside) != 0 and b"inside the staged input block" in lib.mzx_last_error()
+    no_noise = variant(add_exploration_noise=0)    # io.d_noise still set: contradiction
+    assert call(no_noise) != 0 and b"inside the staged input block" in lib.mzx_last_error()
+    for i in range(B):                             # nothing was drawn by any rejected call
+        state = bank.get_state(i)
+        assert state[2:] == before[i][2:] and numpy.array_equal(state[1], before[i][1]), i
+    # select
+    visits = numpy.array([[3, 1, 0, 2]] * B, numpy.int32)
+    temps = numpy.ones(B)
+    table, table_t = numpy.arange(8, dtype="int32") ** 1.0, numpy.array([1.0])
+    act = numpy.empty(B, numpy.int64)
+    nl = numpy.full(B, A, numpy.int32)
+
+    def select(mv, n=nl, vis=visits, t=temps, tab=table, stride=8, tt=table_t, nt=1):
+        return lib.mzx_selfplay_select(bank.handle, ctypes.byref(mv), n.ctypes.data, None, vis.ctypes.data, t.ctypes.data,
+                                       None if tab is None else tab.ctypes.data, stride, None if tt is None else tt.ctypes.data, nt,
+                                       act.ctypes.data)
+
+    assert select(good) == 0 and set(act.tolist()) <= set(range(A))
+    assert select(good, t=numpy.full(B, 0.5)) != 0 and b"no power table" in lib.mzx_last_error()
+    assert select(good, vis=numpy.array([[9, 1, 0, 2]] * B, numpy.int32)) != 0 and b"outside the power table" in lib.mzx_last_error()
+    assert select(good, n=numpy.array([4, 0, 4], numpy.int32)) != 0 and b"n_legal" in lib.mzx_last_error()
+    assert select(good, tab=None) != 0 and b"missing argument" in lib.mzx_last_error()
+    assert select(good, t=numpy.zeros(B), tab=None, tt=None, nt=0) == 0 and act.tolist() == [0, 0, 0]      # arg-max needs no table
