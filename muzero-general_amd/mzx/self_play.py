@@ -812,6 +812,10 @@ class _BatchedGroup(dict):
                         if arr is not None:
                             arr[q % cap] = self.ring[name][q % self.cap]
             self.ring, self.cap = ring, cap
+        for name, value in (("obs", obs), ("rew", reward)):      # a plugin may return ints in one round and floats in another
+            have = self.ring[name].dtype
+            if value.dtype != have and numpy.result_type(value.dtype, have) != have:
+                self.ring[name] = self.ring[name].astype(numpy.result_type(value.dtype, have))
         return r % self.cap
 
     def play(self, actor, result, temperature, temperature_threshold):

@@ -214,3 +214,28 @@ def test_move_entry_points_reject_bad_arguments(backend):
     assert select(good, n=numpy.array([4, 0, 4], numpy.int32)) != 0 and b"n_legal" in lib.mzx_last_error()
     assert select(good, tab=None) != 0 and b"missing argument" in lib.mzx_last_error()
     assert select(good, t=numpy.zeros(B), tab=None, tt=None, nt=0) == 0 and act.tolist() == [0, 0, 0]      # arg-max needs no table
+
+
+def test_ring_log_keeps_rewards_a_plugin_returns_as_ints_first_and_floats_later(backend):
+    """The log's reward rows take the wider dtype when a later round brings one (numpy.stack of round 4 promoted too)."""
+    cfg = configs.cartpole(num_simulations=5, max_moves=6)
+    Base = synthetic.make_synthetic_batched_game(cfg.observation_shape, len(cfg.action_space), 1)
+
+    class Mixed(Base):
+        def step(self, actions, active=None):
+            obs, reward, done = super().step(actions, active)
+            if int(self.t[0]) >= 3:
+                reward = reward * 0.5            # floats from the third move on
+            return obs, reward, done
+
+    weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 4)
+    sp = self_play.SelfPlay({"weights": weights}, Mixed, cfg, 9, num_games=4, _backend=backend)
+    games_played = sp.play_rounds(1.0, None)
+    assert len(games_played) == 4
+    halves = 0
+    for gh in games_played:
+        assert len(gh.reward_history) == 7 and gh.reward_history[0] == 0
+        assert all(float(x) in (0.0, 1.0) for x in gh.reward_history[1:3])
+        assert all(float(x) in (0.0, 0.5) for x in gh.reward_history[3:])
+        halves += sum(1 for x in gh.reward_history[3:] if float(x) == 0.5)
+    assert halves > 0
