@@ -143,6 +143,14 @@ def _actor_worker(rank, world, port, out_dir, pipeline=False):
             made.append(seed)
             super().__init__(seed)
 
+    if pipeline == "batched":      # the batched game protocol, two slot groups that take turns (SelfPlay._rounds_batched)
+        from mzx import games as board_games
+
+        class Game(board_games.TicTacToeBatched):      # noqa: F811
+            def __init__(self, seeds):
+                made.extend(s for s in seeds if s not in made)      # (each slot group builds its own object over its seeds)
+                super().__init__(seeds)
+
     # every rank starts from its OWN junk weights: what it plays with must come through the broadcast
     start = synthetic.fill_state_dict(template, 50 + rank)
     actor = self_play.SelfPlay({"weights": start}, Game, cfg, seeds[0], num_games=G, _backend=be)
@@ -167,7 +175,7 @@ def _actor_worker(rank, world, port, out_dir, pipeline=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("pipeline", [False, True])
+@pytest.mark.parametrize("pipeline", [False, True, "batched"])
 def test_continuous_self_play_two_ranks_with_midrun_weight_update(tmp_path, pipeline):
     world, port = 2, _free_port()
     mp.spawn(_actor_worker, args=(world, port, str(tmp_path), pipeline), nprocs=world, join=True)
