@@ -799,7 +799,9 @@ class _BatchedGroup(dict):
         """Ring row of round ``r``; allocates / grows the ring so that the rounds of every running game keep their own."""
         need = r - int(self["start"].min()) + 1
         if need > self.cap:
-            cap = min(max(2 * self.cap, need, 16), self.max_moves + 1)
+            row_bytes = max(1, obs.nbytes)      # (large observations: start with a ring of at most ~256 MB of frames)
+            first = max(2, min(16, (256 << 20) // row_bytes))
+            cap = min(max(2 * self.cap, need, first), self.max_moves + 1)
             n, A = self["n"], self.A
             ring = dict(obs=numpy.empty((cap, n) + obs.shape[1:], obs.dtype), tp=numpy.empty((cap, n), numpy.int64),
                         act=numpy.empty((cap, n), numpy.int64), rew=numpy.empty((cap, n), reward.dtype),
