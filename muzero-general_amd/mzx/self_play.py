@@ -27,6 +27,7 @@ words (numpy's masked rejection, exactly); the host then advances the stream by
 the number of words the device consumed.
 """
 import ctypes
+import gc
 import math
 import time
 import warnings
@@ -195,20 +196,45 @@ class _ShardRecord:
                                                                                              ratios, legal_mask))
         self.A, self.obs, self.acts, self.rews, self.tps = A, obs, acts, rews, tps
         self.vis, self.vals, self.totals, self.ratios, self.simple, self.legal_mask = vis, vals, totals, ratios, simple, legal_mask
+        self._lists = {}        # field -> the whole record as nested Python lists, one row per game (first touch)
+
+    _ARRAY_OF = {"action_history": "acts", "reward_history": "rews", "to_play_history": "tps", "child_visits": "ratios",
+                 "root_values": "vals"}
+
+    def _row(self, name, i, length):
+        """
+        Game i's list of a list-typed field.  The FIRST touch of a field converts the whole record -- one contiguous
+        game-major copy + one ``tolist()`` for all its games -- because the consumers touch every game (the actor's own
+        ``fill_initial_priorities``, pickling for the Ray object store): per game that is a list hand-over instead of a
+        strided gather of its moves.  Each row is handed out once (the history keeps it), so nothing is shared.
+        """
+        rows = self._lists.get(name)
+        if rows is None:
+            # (a million small objects at once: the cyclic collector would re-scan the heap again and again for nothing)
+            collecting = gc.isenabled()
+            gc.disable()
+            try:
+                rows = self._lists[name] = numpy.ascontiguousarray(getattr(self, self._ARRAY_OF[name])).tolist()
+            finally:
+                if collecting:
+                    gc.enable()
+        row = rows[i]
+        if row is None:         # (handed out before: a second request goes to the arrays)
+            return getattr(self, self._ARRAY_OF[name])[i, :length].tolist()
+        rows[i] = None
+        return row if len(row) == length else row[:length]
 
     def field(self, name, i, n):
         if name == "observation_history":
+            if not self.obs.flags.c_contiguous:      # move-major rows of a slot group's ring: game-major once, for all games
+                self.obs = numpy.ascontiguousarray(self.obs)
             return list(self.obs[i, : n + 1])
-        if name == "action_history":
-            return self.acts[i, : n + 1].tolist()
-        if name == "reward_history":
-            return self.rews[i, : n + 1].tolist()
-        if name == "to_play_history":
-            return self.tps[i, : n + 1].tolist()
+        if name in ("action_history", "reward_history", "to_play_history"):
+            return self._row(name, i, n + 1)
         if n == 0:
             return []
-        if self.simple[i]:      # every row "all actions legal, root visited": two array slices
-            return (self.ratios if name == "child_visits" else self.vals)[i, :n].tolist()
+        if self.simple[i]:      # every row "all actions legal, root visited": the record's own rows
+            return self._row(name, i, n)
         out = []                 # illegal actions get 0, an unvisited root reports value 0 (self_play.py:496-511)
         for t in range(n):
             total = int(self.totals[i, t])
