@@ -78,6 +78,53 @@ def fill_initial_priorities(game_history, config):
     return True
 
 
+def fill_initial_priorities_many(histories, config):
+    """
+    ``fill_initial_priorities`` for the games a self-play shard hands out together.  Games that are still VIEWS of one
+    shard record with the same length (``mzx.self_play.ShardGameHistory``: the batched protocol's finished games) are
+    computed in one pass over the record's arrays -- the loop over the reward horizon (``td_steps`` iterations of a
+    dozen numpy statements) runs once per record instead of once per game: 4096 cartpole games cost one game's worth of
+    interpreter time (per game it was 0.4 ms, twenty times what playing the game's 32 moves costs).  Same binary64
+    operations in the same order per position, the power through the same scalar ``pow``, the same float32 rounding:
+    bit-identical to the per-game function (tests/test_replay_handoff.py).  Everything else goes through
+    ``fill_initial_priorities`` one by one.  Returns the number of games that got priorities.
+    """
+    if not getattr(config, "PER", False):
+        return 0
+    filled, groups = 0, {}
+    for h in histories:
+        view = h.__dict__.get("_view") if hasattr(h, "__dict__") else None
+        if (view is None or h.priorities is not None or h.reanalysed_predicted_root_values is not None or view[2] == 0
+                or any(name in h.__dict__ for name in ("root_values", "reward_history", "to_play_history"))):
+            filled += bool(fill_initial_priorities(h, config))
+        else:
+            groups.setdefault((id(view[0]), view[2]), (view[0], view[2], []))[2].append((h, view[1]))
+    td, discount, alpha = int(config.td_steps), config.discount, config.PER_alpha
+    for record, T, members in groups.values():
+        rows = numpy.array([i for _, i in members])
+        rv = numpy.where(record.totals[rows, :T] > 0, record.vals[rows, :T], 0.0).astype(numpy.float64)   # root.value() or 0
+        tp = numpy.asarray(record.tps[rows, : T + 1])
+        rewards = numpy.asarray(record.rews[rows, : T + 1]).astype(numpy.float64)
+        value = numpy.zeros((len(members), T), numpy.float64)
+        m = T - td
+        if m > 0:          # bootstrap: +-root_values[index + td] * discount ** td
+            value[:, :m] = numpy.where(tp[:, td:td + m] == tp[:, :m], rv[:, td:td + m], -rv[:, td:td + m]) * (discount ** td)
+        for i in range(td):      # rewards index + 1 + i, truncated at the end of the game
+            m = T - i
+            if m <= 0:
+                break
+            r = rewards[:, 1 + i: 1 + i + m]
+            value[:, :m] = value[:, :m] + numpy.where(tp[:, :m] == tp[:, i:i + m], r, -r) * (discount ** i)
+        gaps = numpy.abs(rv - value).ravel().tolist()
+        priorities = numpy.array([g ** alpha for g in gaps], dtype="float32").reshape(len(members), T)   # the scalar pow, as :44
+        top = priorities.max(axis=1)
+        for j, (h, _) in enumerate(members):
+            h.priorities = priorities[j].copy()
+            h.game_priority = top[j]
+        filled += len(members)
+    return filled
+
+
 def _stock_replay_buffer_class():
     """
     The user's own ``ReplayBuffer`` (the reference's replay_buffer.py:11-303, importable wherever its trainer runs):

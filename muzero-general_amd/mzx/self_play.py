@@ -1013,10 +1013,11 @@ class SelfPlay:
                     lambda t, th: self.play_games(t, th, False, "self", 0))
                 histories = play(self.config.visit_softmax_temperature_fn(trained_steps=get("training_step")),
                                  self.config.temperature_threshold)
+                # initial PER priorities, vectorised (replay_buffer.py:39-51 would loop in Python) -- the games a shard
+                # hands out together in ONE pass over their record; save_game then takes its "priorities already
+                # present" branch
+                replay.fill_initial_priorities_many(histories, self.config)
                 for game_history in histories:
-                    # initial PER priorities, vectorised (replay_buffer.py:39-51 would loop in Python);
-                    # save_game then takes its "priorities already present" branch
-                    replay.fill_initial_priorities(game_history, self.config)
                     _remote(replay_buffer.save_game, game_history, shared_storage)
             else:
                 game_history = self.play_game(

@@ -73,3 +73,60 @@ def test_against_reference():
             assert gh.game_priority == theirs.game_priority
             # and the stock buffer accepts a pre-filled game through its "already present" branch
             rb.save_game(copy.deepcopy(gh))
+
+
+def _record_views(rs, k, T, players, float_rewards, time_major, holes):
+    """k ShardGameHistory views of one record of T-move games (random statistics; ``holes``: unvisited roots + illegal actions)."""
+    A = 4
+    vis = rs.randint(0, 20, size=(k, T, A)).astype(numpy.int32)
+    mask = None
+    if holes:
+        vis[rs.rand(k, T) < 0.15] = 0                       # roots that were never visited report value 0
+        mask = rs.rand(k, T, A) < 0.8
+        vis = numpy.where(mask, vis, 0).astype(numpy.int32)
+    totals = vis.sum(2)
+    ratios = vis / numpy.maximum(totals, 1)[:, :, None]
+    vals = rs.standard_normal((k, T))
+    rews = numpy.zeros((k, T + 1), numpy.float64 if float_rewards else numpy.int64)
+    rews[:, 1:] = rs.standard_normal((k, T)) if float_rewards else rs.randint(0, 2, size=(k, T))
+    tps = numpy.tile(numpy.arange(T + 1) % players, (k, 1)).astype(numpy.int64)
+    if players == 2:
+        tps[rs.rand(k) < 0.5] ^= 1                          # half of the games start with the other player
+    acts = rs.randint(0, A, size=(k, T + 1)).astype(numpy.int64)
+    obs = rs.rand(k, T + 1, 1, 1, 2).astype(numpy.float32)
+    plain = totals > 0 if mask is None else (totals > 0) & mask.all(2)
+    arrays = [obs, acts, rews, tps, vis, vals, totals, ratios]
+    if time_major:
+        arrays = [numpy.ascontiguousarray(numpy.swapaxes(a, 0, 1)) for a in arrays]
+        mask = None if mask is None else numpy.ascontiguousarray(numpy.swapaxes(mask, 0, 1))
+    record = self_play._ShardRecord(A, *arrays[:4], arrays[4], arrays[5], arrays[6], arrays[7], plain.all(1), mask, time_major=time_major)
+    return [self_play.ShardGameHistory(record, j, T) for j in range(k)]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_a_shard_s_games_in_one_pass_equal_the_per_game_function(cfg):
+    """fill_initial_priorities_many on the views of shard records == fill_initial_priorities game by game, bit for bit."""
+    config = types.SimpleNamespace(PER=True, **cfg)
+    rs = numpy.random.RandomState(7 + cfg["td_steps"])
+    for k, T, players, fl, tm, holes in [(5, 1, 1, False, True, False), (17, 9, 2, False, True, False), (6, 57, 1, True, False, False),
+                                         (9, 42, 2, True, True, True), (3, 300, 1, False, True, False), (4, 12, 2, False, False, True)]:
+        state = rs.get_state()
+        bulk = _record_views(rs, k, T, players, fl, tm, holes)
+        rs.set_state(state)
+        single = _record_views(rs, k, T, players, fl, tm, holes)
+        extra = _game(rs, 11, 2, True)                       # an ordinary GameHistory rides along
+        extra_twin = copy.deepcopy(extra)
+        touched = bulk[0]
+        touched.root_values                                  # a view whose field was already materialised: per-game path
+        assert replay.fill_initial_priorities_many(bulk + [extra], config) == k + 1
+        assert replay.fill_initial_priorities(extra_twin, config)
+        assert numpy.array_equal(extra.priorities, extra_twin.priorities)
+        for a, b in zip(bulk, single):
+            assert replay.fill_initial_priorities(b, config)
+            assert a.priorities.dtype == numpy.float32 and a.priorities.shape == (T,)
+            assert numpy.array_equal(a.priorities.view(numpy.int32), b.priorities.view(numpy.int32)), (cfg, k, T)
+            assert type(a.game_priority) is type(b.game_priority) and a.game_priority == b.game_priority
+            assert a.root_values == b.root_values and a.reward_history == b.reward_history
+        assert replay.fill_initial_priorities_many(bulk, config) == 0      # already present: untouched
+    config.PER = False
+    assert replay.fill_initial_priorities_many(_record_views(rs, 3, 5, 1, False, True, False), config) == 0
