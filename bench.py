@@ -28,6 +28,8 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                   (TFLOP/s | GB/s), frac, traffic (PMC HBM bytes per step | null), launch_ms}
   "per_rank" / "single_gpu_reference"   N > 1: every rank's own rate, and rank 0 timed alone just before
   "selfplay_end_to_end*"  self-play steps/s through the plugin surface (N = 1)
+  "selfplay_actor_loop"   continuous_self_play itself, batched protocol: play_rounds + initial PER priorities (td_steps 50) +
+                          save_game of every finished game, in-process storage (N = 1)
   "observation_stacker"   the path's HBM-bound kernel (mzx_obs_stack, atari geometry) against the HBM peak
   "cpu_baseline"  kind "reference": the UNMODIFIED reference MCTS(config).run + models.py (oracle/_ref, compiled
                   from /root/reference by oracle/build_ref.py) on this box's host cores, bounded sample (kind "port": the
@@ -433,6 +435,54 @@ def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=F
     }
 
 
+def actor_loop_leg(cfg, net, B, moves, shards=3):
+    """
+    ``SelfPlay.continuous_self_play`` itself (self_play.py:31-108) through the batched game protocol: rounds of searches,
+    finished games refilled, and the HAND-OFF the self-play legs above do not time -- initial PER priorities of every
+    finished game (replay_buffer.py:39-51; games/cartpole.py:99-101: td_steps 50, PER_alpha 0.5), ``save_game`` of a
+    buffer that does what the stock one does on that branch (replay_buffer.py:33-65: keep the game, count games /
+    steps, report them to the storage) -- until ``shards`` x B games are saved.  In-process storage, no Ray.
+    """
+    import copy
+
+    from mzx import self_play, shared_storage, synthetic
+
+    c = copy.copy(cfg)
+    c.max_moves = moves
+    c.PER, c.PER_alpha, c.td_steps = True, 0.5, 50
+    c.training_steps, c.ratio, c.self_play_delay = 1 << 60, None, 0
+    Game = synthetic.make_synthetic_batched_game(c.observation_shape, len(c.action_space), len(c.players))
+    sp = self_play.SelfPlay({"weights": net.get_weights()}, Game, c, 0, num_games=B, _backend=net.backend)
+    sp.play_rounds(1.0, None, min_games=1 << 60, max_rounds=2)          # warm-up (allocations, kernel attributes)
+    storage = shared_storage.LocalStorage(training_step=0, terminate=False, weights=net.get_weights(),
+                                          num_played_games=0, num_played_steps=0)
+
+    class Buffer:
+        def __init__(self):
+            self.buffer, self.games, self.steps, self.with_priorities = {}, 0, 0, 0
+
+        def save_game(self, game_history, shared_storage=None):
+            self.with_priorities += game_history.priorities is not None
+            self.buffer[self.games] = game_history
+            self.games += 1
+            self.steps += len(game_history.root_values)
+            if shared_storage:
+                shared_storage.set_info("num_played_games", self.games)
+                shared_storage.set_info("num_played_steps", self.steps)
+                if self.games >= shards * B:
+                    shared_storage.set_info("terminate", True)
+
+    buffer = Buffer()
+    sp.stats = {"searches": 0, "simulations": 0, "search_seconds": 0.0}
+    t0 = time.perf_counter()
+    sp.continuous_self_play(storage, buffer)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return {"steps_per_sec": sp.stats["searches"] / wall, "games_saved": buffer.games, "with_priorities": buffer.with_priorities,
+            "steps_saved": buffer.steps, "search_share": sp.stats["search_seconds"] / wall}
+
+
 # ----------------------------------------------------------------------------- weights
 def bench_weights(cfg, net, workload, kind):
     """(state_dict, label).  SURVEY.md section 8(d): the weights of the reference's own constructor under
@@ -784,6 +834,10 @@ def main():
         if env.world == 1 and args.selfplay_moves > 0:
             line["selfplay_end_to_end"] = selfplay_leg(cfg, net, B, args.selfplay_moves)
             line["selfplay_end_to_end_batched_game"] = selfplay_leg(cfg, net, B, args.selfplay_moves, batched=True)
+            try:       # the actor loop with the replay hand-off (its failure must not cost the line)
+                line["selfplay_actor_loop"] = actor_loop_leg(cfg, net, B, args.selfplay_moves)
+            except Exception as e:      # noqa: BLE001
+                line["selfplay_actor_loop"] = {"error": repr(e)[:200]}
             if not args.dry_run:
                 # A/B of round 5's host path: ONE slot group (no overlap of the host with the search), and one group on the
                 # separate calls of rounds 1-4 (root_draws / upload / mzx_search_run / download / advance / numpy action draw)

@@ -100,6 +100,7 @@ def fill_initial_priorities_many(histories, config):
         else:
             groups.setdefault((id(view[0]), view[2]), (view[0], view[2], []))[2].append((h, view[1]))
     td, discount, alpha = int(config.td_steps), config.discount, config.PER_alpha
+    from .self_play import gc_paused       # (self_play imports this module)
     for record, T, members in groups.values():
         rows = numpy.array([i for _, i in members])
         rv = numpy.where(record.totals[rows, :T] > 0, record.vals[rows, :T], 0.0).astype(numpy.float64)   # root.value() or 0
@@ -109,18 +110,26 @@ def fill_initial_priorities_many(histories, config):
         m = T - td
         if m > 0:          # bootstrap: +-root_values[index + td] * discount ** td
             value[:, :m] = numpy.where(tp[:, td:td + m] == tp[:, :m], rv[:, td:td + m], -rv[:, td:td + m]) * (discount ** td)
+        same, term = numpy.empty((len(members), T), bool), numpy.empty((len(members), T), numpy.float64)
         for i in range(td):      # rewards index + 1 + i, truncated at the end of the game
             m = T - i
             if m <= 0:
                 break
-            r = rewards[:, 1 + i: 1 + i + m]
-            value[:, :m] = value[:, :m] + numpy.where(tp[:, :m] == tp[:, i:i + m], r, -r) * (discount ** i)
-        gaps = numpy.abs(rv - value).ravel().tolist()
-        priorities = numpy.array([g ** alpha for g in gaps], dtype="float32").reshape(len(members), T)   # the scalar pow, as :44
-        top = priorities.max(axis=1)
-        for j, (h, _) in enumerate(members):
-            h.priorities = priorities[j].copy()
-            h.game_priority = top[j]
+            # value[:m] + where(to_play[k] == to_play[k + i], r, -r) * discount ** i, in two reused buffers (a dozen
+            # half-megabyte temporaries per iteration cost more in page faults than the arithmetic)
+            r, sg = rewards[:, 1 + i: 1 + i + m], term[:, :m]
+            numpy.equal(tp[:, :m], tp[:, i:i + m], out=same[:, :m])
+            numpy.negative(r, out=sg)
+            numpy.copyto(sg, r, where=same[:, :m])
+            sg *= (discount ** i)
+            value[:, :m] += sg
+        with gc_paused():
+            gaps = numpy.abs(rv - value).ravel().tolist()
+            priorities = numpy.array([g ** alpha for g in gaps], dtype="float32").reshape(len(members), T)   # the scalar pow, as :44
+            top = priorities.max(axis=1)
+            for j, (h, _) in enumerate(members):
+                h.priorities = priorities[j].copy()
+                h.game_priority = top[j]
         filled += len(members)
     return filled
 

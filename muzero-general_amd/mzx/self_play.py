@@ -26,6 +26,7 @@ draw.  Tie draws happen on the device from a tape of the stream's next raw
 words (numpy's masked rejection, exactly); the host then advances the stream by
 the number of words the device consumed.
 """
+import contextlib
 import ctypes
 import gc
 import math
@@ -210,14 +211,8 @@ class _ShardRecord:
         """
         rows = self._lists.get(name)
         if rows is None:
-            # (a million small objects at once: the cyclic collector would re-scan the heap again and again for nothing)
-            collecting = gc.isenabled()
-            gc.disable()
-            try:
+            with gc_paused():      # (a million small objects at once)
                 rows = self._lists[name] = numpy.ascontiguousarray(getattr(self, self._ARRAY_OF[name])).tolist()
-            finally:
-                if collecting:
-                    gc.enable()
         row = rows[i]
         if row is None:         # (handed out before: a second request goes to the arrays)
             return getattr(self, self._ARRAY_OF[name])[i, :length].tolist()
@@ -275,6 +270,23 @@ class SearchResult:
         node._root_value = float(self.root_values[i])
         node.value = lambda: node._root_value if total else 0
         return node
+
+
+@contextlib.contextmanager
+def gc_paused():
+    """
+    Bulk allocation of small acyclic objects (thousands of history views, a record's nested lists, per-game priority
+    arrays): with the cyclic collector on, every 700 allocations start a young-generation pass and the older
+    generations -- everything the replay buffer keeps alive -- are re-scanned again and again for nothing.  Collection is
+    only deferred to the end of the block.
+    """
+    collecting = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if collecting:
+            gc.enable()
 
 
 class PendingSearch:
@@ -935,7 +947,8 @@ class _BatchedGroup(dict):
                 legal_mask = numpy.array(take(ring["mask"]))
                 plain = plain & legal_mask.all(2)
             record = _ShardRecord(A, obs_all, acts, rews, tps, vis, vals, totals, ratios, plain.all(0), legal_mask, time_major=True)
-            views = [ShardGameHistory(record, j, n) for j in range(k)]
+            with gc_paused():
+                views = [ShardGameHistory(record, j, n) for j in range(k)]
             if k == len(idx):
                 return views
             for j, w in enumerate(where):

@@ -54,6 +54,9 @@ def test_bench_single_rank_dry_run_with_second_workload():
     assert "reference constructor" in line["config"]["weights"] or "synthetic" in line["config"]["weights"]
     assert line["selfplay_end_to_end"]["steps_per_sec"] > 0
     assert line["selfplay_end_to_end_batched_game"]["steps_per_sec"] > 0
+    loop = line["selfplay_actor_loop"]         # continuous_self_play with the replay hand-off: 3 shards of 4 games, all with priorities
+    assert "error" not in loop and loop["games_saved"] >= 12 and loop["with_priorities"] == loop["games_saved"]
+    assert loop["steps_saved"] == 2 * loop["games_saved"] and loop["steps_per_sec"] > 0
 
 
 def test_cpu_baseline_workers_reference_and_port():
