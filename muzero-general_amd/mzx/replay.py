@@ -80,37 +80,66 @@ def fill_initial_priorities(game_history, config):
 
 def fill_initial_priorities_many(histories, config):
     """
-    ``fill_initial_priorities`` for the games a self-play shard hands out together.  Games that are still VIEWS of one
-    shard record with the same length (``mzx.self_play.ShardGameHistory``: the batched protocol's finished games) are
-    computed in one pass over the record's arrays -- the loop over the reward horizon (``td_steps`` iterations of a
-    dozen numpy statements) runs once per record instead of once per game: 4096 cartpole games cost one game's worth of
-    interpreter time (per game it was 0.4 ms, twenty times what playing the game's 32 moves costs).  Same binary64
+    ``fill_initial_priorities`` for the games a self-play shard hands out together, in ONE pass per group of games of the
+    same length: the loop over the reward horizon (``td_steps`` iterations of a dozen numpy statements) runs once per
+    group instead of once per game -- 4096 cartpole games cost one game's worth of interpreter time (per game it was
+    0.4 ms, twenty times what playing the game's 32 moves costs).  Groups: games that are still VIEWS of one shard record
+    (``mzx.self_play.ShardGameHistory``, the batched protocol: the record's arrays are used as they are), and ordinary
+    ``GameHistory`` objects of equal length (the per-object plugin surface: their lists are stacked).  Same binary64
     operations in the same order per position, the power through the same scalar ``pow``, the same float32 rounding:
-    bit-identical to the per-game function (tests/test_replay_handoff.py).  Everything else goes through
-    ``fill_initial_priorities`` one by one.  Returns the number of games that got priorities.
+    bit-identical to the per-game function (tests/test_replay_handoff.py).  Games the per-game function would skip
+    (priorities present, a missing root value) or treat differently (reanalysed values) go through it one by one.
+    Returns the number of games that got priorities.
     """
     if not getattr(config, "PER", False):
         return 0
-    filled, groups = 0, {}
-    for h in histories:
-        view = h.__dict__.get("_view") if hasattr(h, "__dict__") else None
-        if (view is None or h.priorities is not None or h.reanalysed_predicted_root_values is not None or view[2] == 0
-                or any(name in h.__dict__ for name in ("root_values", "reward_history", "to_play_history"))):
-            filled += bool(fill_initial_priorities(h, config))
-        else:
-            groups.setdefault((id(view[0]), view[2]), (view[0], view[2], []))[2].append((h, view[1]))
-    td, discount, alpha = int(config.td_steps), config.discount, config.PER_alpha
     from .self_play import gc_paused       # (self_play imports this module)
-    for record, T, members in groups.values():
+
+    filled, views, plain = 0, {}, {}
+    for h in histories:
+        if h.priorities is not None:
+            continue
+        view = h.__dict__.get("_view")
+        if h.reanalysed_predicted_root_values is not None:
+            filled += bool(fill_initial_priorities(h, config))
+        elif view is not None and view[2] > 0 and not any(name in h.__dict__ for name in ("root_values", "reward_history",
+                                                                                           "to_play_history")):
+            views.setdefault((id(view[0]), view[2]), (view[0], view[2], []))[2].append((h, view[1]))
+        else:
+            roots = h.root_values
+            if len(roots) == 0 or len(h.reward_history) != len(roots) + 1 or len(h.to_play_history) != len(roots) + 1:
+                filled += bool(fill_initial_priorities(h, config))      # (empty, or not a finished game's shape)
+            else:
+                plain.setdefault(len(roots), []).append(h)
+    jobs = []
+    for record, T, members in views.values():
         rows = numpy.array([i for _, i in members])
         rv = numpy.where(record.totals[rows, :T] > 0, record.vals[rows, :T], 0.0).astype(numpy.float64)   # root.value() or 0
-        tp = numpy.asarray(record.tps[rows, : T + 1])
-        rewards = numpy.asarray(record.rews[rows, : T + 1]).astype(numpy.float64)
-        value = numpy.zeros((len(members), T), numpy.float64)
+        jobs.append((rv, numpy.asarray(record.tps[rows, : T + 1]), numpy.asarray(record.rews[rows, : T + 1]).astype(numpy.float64),
+                     [h for h, _ in members]))
+    for T, members in plain.items():
+        if len(members) < 4:       # (nothing to share)
+            for h in members:
+                filled += bool(fill_initial_priorities(h, config))
+            continue
+        with gc_paused():
+            roots = [h.root_values for h in members]
+            if any(v is None for row in roots for v in row):      # opponent moves carry None (self_play.py:509-511)
+                keep = [h for h, row in zip(members, roots) if not any(v is None for v in row)]
+                roots = [h.root_values for h in keep]
+                members = keep
+            if not members:
+                continue
+            jobs.append((numpy.array(roots, dtype=numpy.float64), numpy.array([h.to_play_history for h in members]),
+                         numpy.array([h.reward_history for h in members], dtype=numpy.float64), members))
+    td, discount, alpha = int(config.td_steps), config.discount, config.PER_alpha
+    for rv, tp, rewards, members in jobs:
+        k, T = rv.shape
+        value = numpy.zeros((k, T), numpy.float64)
         m = T - td
         if m > 0:          # bootstrap: +-root_values[index + td] * discount ** td
             value[:, :m] = numpy.where(tp[:, td:td + m] == tp[:, :m], rv[:, td:td + m], -rv[:, td:td + m]) * (discount ** td)
-        same, term = numpy.empty((len(members), T), bool), numpy.empty((len(members), T), numpy.float64)
+        same, term = numpy.empty((k, T), bool), numpy.empty((k, T), numpy.float64)
         for i in range(td):      # rewards index + 1 + i, truncated at the end of the game
             m = T - i
             if m <= 0:
@@ -125,12 +154,12 @@ def fill_initial_priorities_many(histories, config):
             value[:, :m] += sg
         with gc_paused():
             gaps = numpy.abs(rv - value).ravel().tolist()
-            priorities = numpy.array([g ** alpha for g in gaps], dtype="float32").reshape(len(members), T)   # the scalar pow, as :44
+            priorities = numpy.array([g ** alpha for g in gaps], dtype="float32").reshape(k, T)   # the scalar pow, as :44
             top = priorities.max(axis=1)
-            for j, (h, _) in enumerate(members):
+            for j, h in enumerate(members):
                 h.priorities = priorities[j].copy()
                 h.game_priority = top[j]
-        filled += len(members)
+        filled += k
     return filled
 
 

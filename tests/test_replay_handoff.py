@@ -130,3 +130,28 @@ def test_a_shard_s_games_in_one_pass_equal_the_per_game_function(cfg):
         assert replay.fill_initial_priorities_many(bulk, config) == 0      # already present: untouched
     config.PER = False
     assert replay.fill_initial_priorities_many(_record_views(rs, 3, 5, 1, False, True, False), config) == 0
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_plain_game_histories_of_equal_length_in_one_pass(cfg):
+    """The per-object plugin surface hands out ordinary GameHistory objects: equal lengths are stacked and computed together."""
+    config = types.SimpleNamespace(PER=True, **cfg)
+    rs = numpy.random.RandomState(3 + cfg["td_steps"])
+    games = []
+    for length, players, fl, count in [(9, 2, False, 7), (32, 1, False, 12), (32, 1, True, 5), (57, 2, True, 4), (5, 1, False, 2)]:
+        games += [_game(rs, length, players, fl) for _ in range(count)]
+    games[3].root_values[2] = None                       # an opponent's move: the per-game function skips this game
+    games[8].root_values[0] = 0                          # an unvisited root reports the integer 0
+    games[20].reanalysed_predicted_root_values = [float(v) for v in rs.standard_normal(32)]
+    games[21].priorities = numpy.ones(32, numpy.float32)  # already present: untouched
+    rs.shuffle(games)
+    twins = copy.deepcopy(games)
+    want = sum(bool(replay.fill_initial_priorities(t, config)) for t in twins)
+    assert replay.fill_initial_priorities_many(games, config) == want == len(games) - 2
+    for a, b in zip(games, twins):
+        if b.priorities is None:
+            assert a.priorities is None
+            continue
+        assert a.priorities.dtype == numpy.float32
+        assert numpy.array_equal(a.priorities.view(numpy.int32), b.priorities.view(numpy.int32))
+        assert a.game_priority == b.game_priority and type(a.game_priority) is type(b.game_priority)
