@@ -924,7 +924,7 @@ class _BatchedGroup(dict):
             everyone = slots.size == self["n"]
             contiguous = rows[-1] - rows[0] == n - 1               # the game's rounds did not wrap around the ring
             if everyone and contiguous:
-                take = lambda a, lead=0: a[rows[0]: rows[0] + n]   # (a view: copied into the record's arrays below)
+                take = lambda a: a[rows[0]: rows[0] + n]           # (a view: copied into the record's arrays below)
             elif everyone:
                 take = lambda a: a[rows]
             else:
