@@ -1808,21 +1808,30 @@ class SelfPlay:
         """
         lib, bank = self.model.backend.lib, self.bank
         B, A = result.legal_array.shape
-        temps = numpy.full(B, float(temps)) if numpy.isscalar(temps) else numpy.ascontiguousarray(temps, dtype=numpy.float64)
-        finite = temps[(temps != 0) & ~numpy.isinf(temps)]
-        distinct = numpy.unique(finite) if finite.size else numpy.zeros(0)
-        stride = int(result.visit_counts.max()) + 1 if distinct.size else 1
-        tables = getattr(self, "_pow_tables", None)
-        if tables is None:
-            tables = self._pow_tables = {}
-        rows = []
-        for t in distinct.tolist():
-            tab = tables.get(t)
-            if tab is None or tab.size < stride:
-                tab = tables[t] = numpy.arange(max(stride, self.engine.num_simulations + 2), dtype="int32") ** (1 / t)
-            rows.append(tab)
-        stride = min((r.size for r in rows), default=1)
-        table = numpy.ascontiguousarray(numpy.stack([r[:stride] for r in rows])) if rows else None
+        if numpy.isscalar(temps):
+            single, temps = float(temps), numpy.full(B, float(temps))
+        else:
+            temps = numpy.ascontiguousarray(temps, dtype=numpy.float64)
+            first = temps[0]
+            single = float(first) if (temps == first).all() else None       # the common case: one temperature for the shard
+        if single is not None:
+            key = () if single == 0 or math.isinf(single) else (single,)
+        else:
+            finite = temps[(temps != 0) & ~numpy.isinf(temps)]
+            key = tuple(numpy.unique(finite).tolist())
+        # power tables (visit_count ** (1 / T) over 0 .. num_simulations + 1, numpy's own pow) per set of temperatures, kept
+        stride = self.engine.num_simulations + 2
+        peak = int(result.visit_counts.max()) if key else 0
+        if peak >= stride:
+            stride = peak + 1
+        cache = self.__dict__.setdefault("_pow_tables", {})
+        entry = cache.get((key, stride))
+        if entry is None:
+            distinct = numpy.array(key, numpy.float64)
+            table = (numpy.ascontiguousarray(numpy.stack([numpy.arange(stride, dtype="int32") ** (1 / t) for t in key]))
+                     if key else None)
+            entry = cache[(key, stride)] = (table, distinct)
+        table, distinct = entry
         mv = _lib.Move()
         mv.num_games, mv.action_space_size, mv.num_threads = B, A, bank.threads
         mv.streams, mv.legal_actions = result.streams.ctypes.data, result.legal_array.ctypes.data
