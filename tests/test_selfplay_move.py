@@ -4,6 +4,7 @@ against the separate calls they replace (StreamBank.root_draws, BatchedMCTS._lau
 statements of SelfPlay._select_actions_bank) and against the reference's own statements on numpy RandomState streams
 (self_play.py:222-245 select_action, :473 dirichlet).  CPU, through tests/hostcheck: host logic is under test.
 """
+import copy
 import types
 
 import numpy
@@ -239,3 +240,51 @@ def test_ring_log_keeps_rewards_a_plugin_returns_as_ints_first_and_floats_later(
         assert all(float(x) in (0.0, 0.5) for x in gh.reward_history[3:])
         halves += sum(1 for x in gh.reward_history[3:] if float(x) == 0.5)
     assert halves > 0
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fused_move_equals_the_separate_calls_on_random_shards(backend, seed):
+    """
+    Random shard shapes (1 - 40 games, 2 - 9 actions, one / two players), RAGGED legal lists that change every round
+    (a batched game whose legal_actions() offers a random subset in a random order), random per-game temperatures
+    (0, inf, 1, 0.5, 0.25, 0.7) that change every round, noise on / off: play_rounds through the two library calls
+    against play_rounds through the separate calls -- the same games, slot by slot.
+    """
+    rs = numpy.random.RandomState(1000 + seed)
+    A, players, B = int(rs.randint(2, 10)), int(rs.randint(1, 3)), int(rs.randint(1, 41))
+    cfg = configs.cartpole(num_simulations=int(rs.randint(3, 12)), max_moves=int(rs.randint(3, 9)), action_space=list(range(A)),
+                           players=list(range(players)), temperature_threshold=[None, 2, 4][seed % 3])
+    Base = synthetic.make_synthetic_batched_game(cfg.observation_shape, A, players)
+
+    class Ragged(Base):
+        def legal_actions(self):
+            out = numpy.full((self.num_games, A), -1, numpy.int32)
+            for i in range(self.num_games):           # a function of (game seed, move): the same for both actors
+                r = numpy.random.RandomState(int(self.seeds[i]) * 131 + int(self.t[i]))
+                acts = r.permutation(A)[: r.randint(1, A + 1)]
+                out[i, : acts.size] = acts
+            return out
+
+    weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 40 + seed)
+    temperature = [1.0, 0.5, 0.25, 0.7, 0.0, float("inf")][seed % 6]
+    played = []
+    for fused, pipeline in ((True, True), (False, False)):
+        c = copy.copy(cfg)
+        c.self_play_pipeline = pipeline and B > 1
+        sp = self_play.SelfPlay({"weights": weights}, Ragged, c, 500 + seed, num_games=B, _backend=backend)
+        sp.engine.fused_move = fused
+        by_slot = {}
+        for _ in range(3):
+            for gh, slot in zip(sp.play_rounds(temperature, c.temperature_threshold), sp.finished_slots):
+                by_slot.setdefault(slot, []).append(gh)
+        played.append(by_slot)
+        sp.close_game()
+    a, b = played
+    assert a.keys() == b.keys() and len(a) == B
+    for slot in a:
+        assert len(a[slot]) == len(b[slot]) >= 3
+        for x, y in zip(a[slot], b[slot]):
+            assert x.action_history == y.action_history and x.to_play_history == y.to_play_history, (seed, slot)
+            assert x.child_visits == y.child_visits and x.reward_history == y.reward_history, (seed, slot)
+            assert numpy.array_equal(numpy.array(x.root_values, numpy.float64).view(numpy.int64),
+                                     numpy.array(y.root_values, numpy.float64).view(numpy.int64)), (seed, slot)
