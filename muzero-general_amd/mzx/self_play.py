@@ -1072,6 +1072,9 @@ class SelfPlay:
     def play_games(self, temperature, temperature_threshold, render, opponent, muzero_player):
         """All ``num_games`` games of this shard in lock-step; returns their GameHistory list."""
         self._drain_searches()
+        for group in (self._live or {}).get("groups", ()):      # (slot groups of the batched protocol own their game objects)
+            if group.get("game") is not None and group["game"] is not self.batched_game:
+                group["game"].close()
         self._live = None       # (games in progress under play_rounds end here: every game object is reset)
         if self.batched_game is not None:
             if opponent != "self" or render:
