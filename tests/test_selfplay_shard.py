@@ -154,3 +154,32 @@ def test_action_draws_with_mixed_temperatures_follow_each_game_s_own_stream(back
         assert int(got[r]) == int(want), (r, temps[r])
         state = sp.bank.get_state(r)
         assert state[2] == ref.get_state()[2] and numpy.array_equal(state[1], ref.get_state()[1]), r
+
+
+@pytest.mark.parametrize("shape,actions,players", [((1, 1, 4), 2, 1), ((3, 5, 5), 6, 2), ((2, 1, 3), 3, 2)])
+def test_synthetic_batched_game_steps_like_the_per_object_game(shape, actions, players):
+    """
+    The batched synthetic environment (uint32 arrays that wrap) against the per-object one (Python ints masked to 32
+    bits): observations (values and dtype), rewards, side to move over 300 moves with restarts, seeds up to 2**32 - 1.
+    """
+    Single = synthetic.make_synthetic_game(shape, actions, players)
+    Batched = synthetic.make_synthetic_batched_game(shape, actions, players)
+    seeds = [0, 1, 7, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1, 123456789, 4000000000]
+    singles, shard = [Single(s) for s in seeds], Batched(seeds)
+    obs, want = shard.reset(), [g.reset() for g in singles]
+    rs = numpy.random.RandomState(0)
+    for move in range(300):
+        for i in range(len(seeds)):
+            assert obs[i].dtype == want[i].dtype and numpy.array_equal(obs[i], want[i]), (move, i)
+        acts = rs.randint(0, actions, size=len(seeds))
+        obs, reward, done = shard.step(acts)
+        stepped = [g.step(int(a)) for g, a in zip(singles, acts)]
+        want = [s[0] for s in stepped]
+        assert [int(r) for r in reward] == [s[1] for s in stepped] and not numpy.asarray(done).any()
+        assert [int(p) for p in shard.to_play()] == [g.to_play() for g in singles]
+        if move % 50 == 49:                    # the refill hook restarts some games
+            idx = [1, 4]
+            obs = obs.copy()
+            obs[idx] = shard.reset_games(idx)
+            for i in idx:
+                want[i] = singles[i].reset()
