@@ -291,6 +291,41 @@ def _cpu_worker_reference(args):
     return sims, searches, time.perf_counter() - t0
 
 
+def _cpu_worker_reference_play_game(args):
+    """One host core: the UNMODIFIED reference's SelfPlay.play_game (self_play.py:110-183: search, select_action, Game.step,
+    GameHistory per move) -- self-play STEPS per second.  Games: the synthetic fixed-shape game of the
+    GPU legs with its max_moves (C2), or the real connect4 rules (mzx.games.Connect4: the per-object plugin class, identical
+    to games/connect4.py observation for observation) on the C4 network, whole games.  Counts the moves of FINISHED games and
+    the time at which the last of them finished."""
+    what, worker, seconds, moves = args
+    torch.set_num_threads(1)
+    import copy
+
+    from mzx import configs, games as board_games, synthetic
+    from oracle import build_ref
+
+    ref_models, ref_self_play = build_ref.load()
+    if what == "c2":
+        cfg = copy.copy(configs.cartpole())
+        cfg.max_moves = moves
+        Game = synthetic.make_synthetic_game(cfg.observation_shape, len(cfg.action_space), len(cfg.players))
+    else:
+        cfg = configs.connect4()
+        Game = board_games.PER_OBJECT["connect4"]
+    cfg.selfplay_on_gpu = False         # the CPU baseline: the reference actor's own switch (self_play.py:28)
+    torch.manual_seed(0)
+    weights = ref_models.MuZeroNetwork(cfg).get_weights()
+    actor = ref_self_play.SelfPlay({"weights": weights}, Game, cfg, 1000 + worker)     # (seeds numpy + torch, builds the model)
+    steps, games, t0, t_last = 0, 0, time.perf_counter(), None
+    with torch.no_grad():
+        while t_last is None or time.perf_counter() - t0 < seconds:
+            h = actor.play_game(1.0, cfg.temperature_threshold, False, "self", 0)
+            steps += len(h.action_history) - 1
+            games += 1
+            t_last = time.perf_counter() - t0
+    return steps, games, t_last
+
+
 def _state_dict_template(cfg):
     """{key: zero tensor} in reference state_dict order, from the library's host-side weight table (no GPU)."""
     from mzx import _lib, models
@@ -309,26 +344,28 @@ def _state_dict_template(cfg):
     return out
 
 
-def cpu_baseline(workload, seconds, cores, kind, weights_kind="reference"):
+def _cpu_pool_map(pool_cores, jobs):
+    """Runs (worker function, argument list) jobs one after the other in ONE pool of spawned single-thread processes that do
+    not see the GPU (the reference wraps its networks in torch.nn.DataParallel, models.py:98-126, which would route batch-1
+    inferences through cuda:0).  Returns the per-job result lists."""
     import multiprocessing as mp
 
-    cores = cores or min(os.cpu_count() or 1, 64)
     ctx = mp.get_context("spawn")
-    worker = _cpu_worker_reference if kind == "reference" else _cpu_worker_port
-    # CPU baseline: the workers must not see the GPU (the reference wraps its networks in
-    # torch.nn.DataParallel, models.py:98-126, which would route batch-1 inferences through cuda:0)
     hidden = {k: os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")}
     hidden["MZX_BENCH_CPU_WORKER"] = os.environ.get("MZX_BENCH_CPU_WORKER")
     os.environ.update({"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": "", "MZX_BENCH_CPU_WORKER": "1"})
     try:
-        with ctx.Pool(cores) as pool:
-            res = pool.map(worker, [(workload, w, seconds, weights_kind) for w in range(cores)])
+        with ctx.Pool(pool_cores) as pool:
+            return [pool.map(fn, argl) for fn, argl in jobs]
     finally:
         for k, v in hidden.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def _search_baseline_entry(res, cores, seconds, kind):
     sims = sum(r[0] for r in res)
     wall = max(r[2] for r in res)
     rates = [r[0] / r[2] for r in res]
@@ -342,6 +379,49 @@ def cpu_baseline(workload, seconds, cores, kind, weights_kind="reference"):
         # busy host; the aggregate above is sum(sims) / max(wall)
         "per_core_min_median_max": [float(numpy.min(rates)), float(numpy.median(rates)), float(numpy.max(rates))],
     }
+
+
+def cpu_baselines(workload, seconds, cores, kind, weights_kind="reference", c4=False, steps_moves=0):
+    """
+    The CPU legs BASELINE.md section 3 names, timed on this box's host cores in one pool: `workload`'s MCTS.run (the line's
+    cpu_baseline), and -- when the unmodified reference travelled (kind "reference") -- the Connect4 half of the metric
+    (MCTS(config).run on games/connect4.py's network, S = 200) and self-play STEPS per second (SelfPlay.play_game on the
+    synthetic C2 game and on whole connect4 games).  Baselines only (a large GPU / CPU ratio says nothing about kernel
+    quality).  Returns {"cpu_baseline": ..., "cpu_baseline_c4": ..., "cpu_baseline_steps": ...}.
+    """
+    cores = cores or min(os.cpu_count() or 1, 64)
+    worker = _cpu_worker_reference if kind == "reference" else _cpu_worker_port
+    jobs = [(worker, [(workload, w, seconds, weights_kind) for w in range(cores)])]
+    extra = kind == "reference"
+    if extra and c4:
+        jobs.append((worker, [("c4", w, seconds, weights_kind) for w in range(cores)]))
+    if extra and steps_moves > 0:
+        jobs.append((_cpu_worker_reference_play_game, [("c2", w, seconds, steps_moves) for w in range(cores)]))
+        if c4:
+            jobs.append((_cpu_worker_reference_play_game, [("connect4", w, seconds, 0) for w in range(cores)]))
+    res = _cpu_pool_map(cores, jobs)
+    out = {"cpu_baseline": _search_baseline_entry(res[0], cores, seconds, kind)}
+    k = 1
+    if extra and c4:
+        e = _search_baseline_entry(res[k], cores, seconds, kind)
+        e["workload"] = "C4 Connect4 ResNet (games/connect4.py), MCTS.run of one tree at a time, 200 sims"
+        out["cpu_baseline_c4"] = e
+        k += 1
+    if extra and steps_moves > 0:
+        legs = {}
+        for name in (["c2_synthetic_game"] + (["connect4_whole_games"] if c4 else [])):
+            r = res[k]
+            k += 1
+            rates = [x[0] / x[2] for x in r]
+            legs[name] = {"value": sum(x[0] for x in r) / max(x[2] for x in r), "unit": "steps/s", "cores": cores,
+                          "games_finished": sum(x[1] for x in r), "moves_per_game": sum(x[0] for x in r) / max(1, sum(x[1] for x in r)),
+                          "per_core_min_median_max": [float(numpy.min(rates)), float(numpy.median(rates)), float(numpy.max(rates))]}
+        legs["kind"] = "reference"
+        legs["sample"] = (f"unmodified reference SelfPlay.play_game (oracle/_ref), {cores} processes, 1 thread each, whole games until "
+                          f"{seconds:.0f} s have passed (at least one per process); C2: the synthetic game of the GPU legs, "
+                          f"{steps_moves} moves per game; connect4: mzx.games.Connect4 (= games/connect4.py) on the C4 network")
+        out["cpu_baseline_steps"] = legs
+    return out
 
 
 # ----------------------------------------------------------------------------- side legs (N = 1)
@@ -717,17 +797,22 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         tag = ran
     else:
         tag = "one kernel per operator"
-    traffic = None
+    traffic, traffic_source = None, None
     try:  # PMC-measured HBM bytes per STEP of this workload (muzero-general_amd/tools/pmc_traffic.py from separate rocprofv3 --pmc passes)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            entry = json.load(f).get(workload)
+            table = json.load(f)
+        entry = table.get(workload)
         if entry and B == default_trees and entry.get("kernel_tag", tag).split(" ")[0] == tag.split(" ")[0]:
             traffic = entry["bytes_per_step"]
+            # NOT an observation of this run: PMC counters need their own rocprofv3 --pmc passes, so the figure is the one
+            # the builder collected for this workload and kernel on the commit named here
+            traffic_source = {"file": "profiles/pmc_traffic.json", "commit": table.get("_collected_at_commit", "755c514"),
+                              "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (gpu_job.sh pmc), not this run"}
     except (OSError, ValueError):
         pass
     roofline = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": bytes_per_sim * B * S,
         "kernel": tag, "launch_ms": launch_ms, "algorithmic_bytes_per_sim": bytes_per_sim,
     }
@@ -738,7 +823,7 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
         tf = flops / (launch_ms * 1e-3) / 1e12
         roofline = {
             "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "kernel": "whole step: " + tag,
+            "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "kernel": "whole step: " + tag,
             "launch_ms": launch_ms, "flops_per_simulation": f_rec, "flops_initial_inference": f_init, "flops_per_step": flops,
         }
     instantiations = None
@@ -827,6 +912,8 @@ def main():
     if env.rank == 0:
         if others:
             line["workloads"] = others
+            # (every workloads[*].roofline.traffic comes from the same file as the main roofline's: see roofline.traffic_source)
+            line["workloads_traffic_source"] = "profiles/pmc_traffic.json, as roofline.traffic_source"
         if args.dry_run:
             line["dry_run"] = True
             line["data"] = "DRY RUN on the CPU test double (gloo): plumbing check, NOT a measurement"
@@ -863,9 +950,11 @@ def main():
         line["cpu_baseline"] = None
         if env.world == 1 and args.cpu_seconds > 0 and not args.dry_run:
             from oracle import build_ref
-            # the UNMODIFIED reference when its bytecode travelled (oracle/_ref), else the oracle's restatement stands in
-            line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds, args.cpu_cores,
-                                                "reference" if build_ref.available() else "port", args.weights)
+            # the UNMODIFIED reference when its bytecode travelled (oracle/_ref), else the oracle's restatement stands in;
+            # with it also the Connect4 half of the metric and self-play steps/s
+            line.update(cpu_baselines(args.workload, args.cpu_seconds, args.cpu_cores,
+                                      "reference" if build_ref.available() else "port", args.weights,
+                                      c4=c4_net is not None, steps_moves=args.selfplay_moves))
         print(json.dumps(line), flush=True)
     env.barrier()
     env.close()

@@ -56,7 +56,7 @@ int mzx_is_device_build(void);
  *                  tower arithmetic at EVERY shard size (a tree's result must not depend on the shard it is searched
  *                  in); 0: mzx::rz_search_kernel (the A/B)
  *   rt_search      the tower whole-search kernel (every simulation in one launch): -1 automatic, 0 never, 1 whenever
- *                  the network fits;  rt_trees > 0: trees per workgroup;  rt_waves 8 | 16: waves per workgroup (0: cost
+ *                  the network fits;  rt_trees > 0: trees per workgroup;  rt_waves 4 | 8: waves per workgroup (0: cost
  *                  model);  rt_max_trees: largest shard routed to it;  rt_dbg: timing knock-outs (wrong results)
  * mzx_tuning_set / _get return MZX_ERR_INVALID for an unknown name or a value out of range; mzx_tuning_name /
  * _help enumerate the table (NULL past its end).

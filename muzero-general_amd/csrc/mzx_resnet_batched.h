@@ -228,14 +228,25 @@ inline RbTowerShape rb_tower_shape(const RbTower& tw, int batch) {
   return best;
 }
 
-// Does the tower run as one launch at THIS batch?  Not when the shape the batch leaves it wastes more than a fifth of the
-// MFMA rows (games/atari.py at 256 trees: one 6 x 6 sample per workgroup = 36 rows in three 16-row tiles; the layer
-// kernel packs four samples into nine full tiles and wins, 0.62 against 0.58) -- the layers then launch one by one.
-inline bool rb_tower_use(const RbTower& tw, int batch) {
-  const RbTowerShape sh = rb_tower_shape(tw, batch);
-  if (sh.T < 1) return false;
+// Does the tower run as one launch?  A property of the NETWORK, not of the batch (a tower and the layer kernels
+// sum a convolution in different orders -- the layer kernel stages its channels in groups --, and the LDS-resident engine in a
+// third; whichever runs must not depend on how many trees share the launch, or a tree's result would depend on its shard
+// and the two slot groups of a pipelined self-play shard would play other games than the undivided shard).  Usable: SOME
+// samples-per-workgroup count the LDS admits wastes at most a fifth of the MFMA rows (connect4: 42 of 48 rows with one
+// board; a 5 x 5 board: 75 of 80 with three; games/atari.py: 72 of 80 with two 6 x 6 samples).  The shape for a given batch
+// is still rb_tower_shape's (a small batch may take fewer samples per workgroup to fill the chip: games/atari.py at 256
+// trees runs one sample per workgroup at 36 of 48 rows, measured 0.58 of the peak against 0.62 layer by layer -- the price
+// of one arithmetic per network).
+inline bool rb_tower_rows_ok(const RbTowerShape& c) { return c.rows * 5 >= c.mtiles * 16 * 4; }
+
+inline bool rb_tower_use(const RbTower& tw, int /*batch*/ = 0) {
+  if (tw.t_max < 1) return false;
   if (tune(TUNE_RB_TOWER_T) > 0) return true;     // a forced shape (tests, A/B) is taken as given
-  return sh.rows * 5 >= sh.mtiles * 16 * 4;
+  for (int T = 1; T <= tw.t_max; ++T) {
+    RbTowerShape c;
+    if (rb_tower_grid(tw, T, c) && rb_tower_rows_ok(c)) return true;
+  }
+  return false;
 }
 
 // Finds the towers of a planned program.  A layer joins the tower of its predecessor when it is a stride-1 3x3 GEMM of

@@ -31,7 +31,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <assert.h>
+
 #include <atomic>
+#include <memory>
 
 #include "mzx_row_search.h"
 #include "mzx_tower.h"
@@ -485,6 +488,7 @@ bool rt_grid(const RbTower& tw, int T, int waves, RbTowerShape& c) {
 // positions are DEALT: eight residues to every half tile, boards shifted by a few cells so that the residues of the
 // workgroup's positions are evenly filled.  Rows without a position read a cell of a residue their half tile lacks.
 void rt_row_order(RtSearchArgs& a, int mtiles) {
+  assert(16 * mtiles <= RT_MAX_ROWS && a.T <= RT_MAX_T);      // (rt_plan rejects such candidates before carving)
   const int T = a.T, HW = a.H * a.W, phw = a.PH * a.PW, halves = 2 * mtiles;
   const bool deal = (a.Cs / 4) % 2 == 0 && (a.Cs / 4) % 4 != 0 && T <= RT_MAX_T && 16 * mtiles <= RT_MAX_ROWS;   // slot stride 2 (mod 4)
   int count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -658,7 +662,7 @@ struct RtPlan {
   RtSearchArgs a;
 };
 
-RtPlan rt_plan(const mzx_search* s) {
+RtPlan rt_plan_compute(const mzx_search* s) {
   RtPlan best;
   if (!rt_structure(s->net, nullptr) || !row_search_supported(s->p)) return best;
   const RbProgram& R = s->net->rb.recurrent;
@@ -672,6 +676,9 @@ RtPlan rt_plan(const mzx_search* s) {
       if (force_t > 0 && T != force_t) continue;
       RbTowerShape sh;
       if (!rt_grid(R.towers[0], T, waves, sh) || sh.MT > RT_MT_MAX) continue;
+      // (RtSearchArgs::perm / ::shift are sized for these: narrow towers in forced modes reach 64 row tiles otherwise, and
+      // rt_row_order's raster fallback would write past perm[] -- ADVICE r5)
+      if (16 * sh.mtiles > RT_MAX_ROWS || T > RT_MAX_T) continue;
       if (T * 16 > waves * 64) continue;                     // a 16-lane row per tree
       RtPlan c;
       memset(&c.a, 0, sizeof(c.a));
@@ -699,6 +706,20 @@ RtPlan rt_plan(const mzx_search* s) {
   return best;
 }
 
+// The plan of a handle is a function of its shard size, the two forcing knobs and the network's structure (fixed at
+// mzx_net_create): about 32 (waves, trees) candidates through rt_carve / rt_row_order, several kilobytes of argument struct
+// each.  mzx_selfplay_search runs it on every move (route check + launch), so it is computed once per handle and key
+// (ADVICE r5).  Pointers into the arena / weight buffers are filled per launch (rt_search_simulations works on a copy).
+const RtPlan& rt_plan(const mzx_search* s) {
+  const int64_t key[4] = {s->p.num_trees, tune(TUNE_RT_TREES), tune(TUNE_RT_WAVES),
+                          ((int64_t)s->p.num_nodes << 8) | (s->net ? (s->net->rb_no_towers ? 1 : 0) | (s->net->rb_force ? 2 : 0) : 4)};
+  if (!s->rt_plan_cache || memcmp(key, s->rt_plan_key, sizeof(key)) != 0) {
+    s->rt_plan_cache = std::make_shared<RtPlan>(rt_plan_compute(s));
+    memcpy(s->rt_plan_key, key, sizeof(key));
+  }
+  return *static_cast<const RtPlan*>(s->rt_plan_cache.get());
+}
+
 }  // namespace
 
 bool rt_search_supported(const mzx_search* s) { return s && s->net && rt_plan(s).ok; }
@@ -706,7 +727,7 @@ bool rt_search_supported(const mzx_search* s) { return s && s->net && rt_plan(s)
 // {trees per workgroup, row tiles per wave, workgroups, workgroups per CU, LDS bytes, threads per workgroup}; zeros when the
 // kernel does not take the search
 void rt_search_shape(const mzx_search* s, int32_t out[6]) {
-  const RtPlan P = rt_plan(s);
+  const RtPlan& P = rt_plan(s);
   out[0] = P.ok ? P.T : 0; out[1] = P.ok ? P.MT : 0; out[2] = P.ok ? P.groups : 0; out[3] = P.ok ? P.per_cu : 0;
   out[4] = P.ok ? (int32_t)P.lds : 0; out[5] = P.ok ? P.waves * 64 : 0;
 }

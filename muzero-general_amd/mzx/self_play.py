@@ -841,8 +841,13 @@ class _BatchedGroup(dict):
             first = max(2, min(16, (256 << 20) // row_bytes))
             cap = min(max(2 * self.cap, need, first), self.max_moves + 1)
             n, A = self["n"], self.A
-            ring = dict(obs=numpy.empty((cap, n) + obs.shape[1:], obs.dtype), tp=numpy.empty((cap, n), numpy.int64),
-                        act=numpy.empty((cap, n), numpy.int64), rew=numpy.empty((cap, n), reward.dtype),
+            obs_dtype, rew_dtype = obs.dtype, reward.dtype
+            if self.ring is not None:        # rows already logged keep their precision (a plugin may return floats in
+                # one round and ints in the next: the copy below must not truncate the earlier rows -- ADVICE r5)
+                obs_dtype = numpy.result_type(self.ring["obs"].dtype, obs_dtype)
+                rew_dtype = numpy.result_type(self.ring["rew"].dtype, rew_dtype)
+            ring = dict(obs=numpy.empty((cap, n) + obs.shape[1:], obs_dtype), tp=numpy.empty((cap, n), numpy.int64),
+                        act=numpy.empty((cap, n), numpy.int64), rew=numpy.empty((cap, n), rew_dtype),
                         vis=numpy.empty((cap, n, A), numpy.int32), val=numpy.empty((cap, n), numpy.float64), mask=None)
             if self.ring is not None:
                 if self.ring["mask"] is not None:

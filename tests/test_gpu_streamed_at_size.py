@@ -27,6 +27,7 @@ import numpy
 import pytest
 import torch
 
+import at_size
 import streamed_coverage as sc
 import test_gpu_parity as parity
 from mzx import _lib, configs, models, self_play, synthetic
@@ -62,9 +63,10 @@ MUST_LAUNCH = {
     "connect4-1024": {(6, 1, 1, "tower in-place"), (1, 1, 1, "ring grouped")},
     "connect4-4608": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring grouped")},
     "connect4-9216": {(8, 1, 1, "tower in-place"), (1, 1, 1, "ring grouped")},
-    # 256 trees leave a tower three-quarter-empty row tiles: its layers launch one by one
-    "atari-256": {(5, 1, 1, "two-sets"), (9, 1, 2, "in-place"), (9, 2, 2, "in-place"), (6, 2, 4, "in-place"),
-                  (6, 2, 2, "in-place"), (4, 1, 3, "ring"), (1, 1, 4, "ring")},
+    # 256 trees: one 6 x 6 sample per workgroup (36 of 48 rows) so that the chip is filled -- towers all the same (round 6:
+    # whether a trunk runs as a tower is a property of the network, not of the batch; round 5 launched these layer by layer)
+    "atari-256": {(3, 2, 1, "tower two-sets"), (5, 1, 1, "two-sets"), (9, 1, 2, "in-place"), (9, 2, 2, "in-place"),
+                  (6, 2, 4, "in-place"), (6, 2, 2, "in-place"), (4, 1, 3, "ring"), (1, 1, 4, "ring")},
     "atari-512": {(5, 2, 1, "tower in-place"), (9, 1, 1, "in-place"), (9, 2, 4, "in-place"), (6, 2, 4, "in-place"),
                   (6, 2, 2, "in-place"), (4, 1, 3, "ring"), (1, 1, 4, "ring")},
     "atari-1024": {(5, 2, 1, "tower in-place"), (9, 2, 1, "in-place"), (9, 2, 4, "in-place"), (9, 1, 2, "in-place"),
@@ -332,9 +334,9 @@ def test_at_size_search_two_streams_and_oracle(backend, case, weights, monkeypat
             tol = max(10 * TOL, 8 * abs(rv32 - ref))
         if not abs(res.root_values[i] - ref) < tol * max(1.0, abs(ref)):
             failures.append((i, "root value", res.root_values[i], rv32, ref))
-    n = len(sample)
-    print(f"{case}: {identical}/{n} sampled trees identical to the oracle (fp32) in EVERY simulation; the oracle's own fp32 "
-          f"search is identical to its binary64 evaluation on {own_identical}/{n} of the same trees")
     assert not failures, (case, failures)
-    # the device may diverge from the oracle's fp32 about as often as the oracle's fp32 diverges from exact arithmetic
-    assert n - identical <= math.ceil(1.5 * (n - own_identical)) + max(2, n // 16), (case, identical, own_identical, n)
+    # the visit statistics the replay buffer consumes (root child_visits, root value) on ALL sampled trees, diverged ones
+    # included, against absolute per-case bounds (tests/at_size.py; round 5's bound was relative to the oracle's own
+    # fp32-vs-binary64 divergence count, which is total for games/gomoku.py and could not fail)
+    at_size.gate(case, at_size.statistics(S, [res.visit_counts[i] for i in sample], [res.root_values[i] for i in sample],
+                                          s32, s64, identical))

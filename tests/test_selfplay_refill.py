@@ -208,3 +208,31 @@ def test_dropped_queued_search_gives_its_draws_back(backend):
     assert not q1 and q2
     for a, b in zip(one, two):
         assert a[2] == b[2] and (a[1] == b[1]).all() and a[3] == b[3]
+
+
+def test_reward_dtype_change_across_a_ring_growth_keeps_earlier_rows(backend):
+    """a batched plugin that returns float rewards for its first rounds and integer arrays afterwards (numpy.asarray
+    of an all-integer list).  The move log is a ring that grows while a game outlasts it; the grown ring must take the wider of
+    the old and the new dtype, or the float rewards already logged are truncated by the copy (they then flow into the PER
+    priorities).  max_moves 40 > the ring's first 16 rows, so the growth happens in an integer round."""
+    cfg = configs.cartpole(num_simulations=4, max_moves=40)
+    Base = synthetic.make_synthetic_batched_game(cfg.observation_shape, len(cfg.action_space), len(cfg.players))
+
+    class HalfStepRewards(Base):
+        def step(self, actions, active=None):
+            obs, reward, done = super().step(actions, active)
+            early = self.t <= 10               # (per game: refilled slots restart at 0)
+            if early.all():
+                return obs, reward * 0.5 + 0.25, done
+            assert not early.any()
+            return obs, numpy.asarray([int(x) for x in reward]), done
+
+    weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 9)
+    shard = self_play.SelfPlay({"weights": weights}, HalfStepRewards, cfg, 3, num_games=3, _backend=backend)
+    games_out = shard.play_rounds(1.0, None)
+    assert len(games_out) == 3
+    for gh in games_out:
+        rewards = [float(x) for x in gh.reward_history]
+        assert len(rewards) == 41 and rewards[0] == 0.0
+        assert all(x in (0.25, 0.75) for x in rewards[1:11]), rewards[:12]
+        assert all(x in (0.0, 1.0) for x in rewards[11:])

@@ -225,7 +225,13 @@ def test_tower_shapes_follow_the_calibrated_cost_model(lib):
         assert t["WM"] * t["WN"] <= 8 and t["WM"] * t["MT"] * 16 >= t["T"] * 42
     lib.mzx_net_destroy(h)
     h = _create(lib, configs.atari())
-    assert [t["groups"] for t in _towers(lib, h, 1, 256)] == [0, 0]        # 36 rows in three tiles: layer by layer
+    # whether a tower runs as one launch is a property of the NETWORK (towers and layer launches sum in different
+    # orders, so the choice must not move with the batch): two 6 x 6 samples fill 72 of 80 rows -> towers at every batch;
+    # 256 trees take one sample per workgroup (36 of 48 rows) to fill the chip
+    small = _towers(lib, h, 1, 256)
+    assert [(t["T"], t["MT"], t["NT"], t["groups"]) for t in small] == [(1, 3, 2, 256), (1, 3, 2, 256)]
+    for batch in (1, 2, 7, 64, 100, 256, 300, 512, 1024, 4096):
+        assert all(t["groups"] > 0 for t in _towers(lib, h, 1, batch)), batch
     big = _towers(lib, h, 1, 512)
     assert [(t["T"], t["MT"], t["NT"]) for t in big] == [(2, 5, 2), (2, 5, 2)] and all(t["groups"] == 256 for t in big)
     lib.mzx_net_destroy(h)
@@ -233,6 +239,43 @@ def test_tower_shapes_follow_the_calibrated_cost_model(lib):
     t = _towers(lib, h, 1, 512)[0]
     assert (t["T"], t["MT"], t["NT"], t["WN"], t["groups"]) == (1, 8, 1, 8, 512)    # one 11 x 11 board per workgroup
     lib.mzx_net_destroy(h)
+
+
+def test_route_and_tower_use_do_not_depend_on_the_shard_size(lib):
+    """
+    ADVICE r5: mzx_net_search_route for 64-channel networks on several boards, swept over the shard size.  The ARITHMETIC a
+    search runs on (route 1: the LDS-resident engine of rz_search_kernel; routes 2 / 3: the towers, launch by launch or
+    inside rt_search_kernel -- bit-identical to each other, tests/test_gpu_tower_search.py) must be the same at every shard
+    size: in round 5 a 5 x 5 board took the LDS-resident engine up to 512 trees and the towers from 1024 on, so a 1024-game
+    shard pipelined as two groups of 512 played other games than the undivided shard.  Also: the towers of every shipped
+    streamed configuration are in use at every batch or at none.
+    """
+    import streamed_coverage as sc
+
+    boards = {
+        "connect4 6x7": dict(),
+        "5x5": dict(observation_shape=(3, 5, 5), action_space=list(range(25))),
+        "5x7": dict(observation_shape=(3, 5, 7), action_space=list(range(7))),
+        "4x4": dict(observation_shape=(3, 4, 4), action_space=list(range(16))),
+        "8x8": dict(observation_shape=(3, 8, 8), action_space=list(range(64))),
+        "3x3 wide": dict(observation_shape=(3, 3, 3), action_space=list(range(9))),
+        "9x9 48ch": dict(observation_shape=(3, 9, 9), action_space=list(range(81)), channels=48),
+    }
+    sizes = (1, 2, 3, 16, 64, 100, 255, 256, 512, 640, 768, 1024, 1536, 2048, 4096, 9216)
+    for name, overrides in boards.items():
+        kinds = {}
+        for B in sizes:
+            route = sc.net_route(lib, "connect4", B, overrides, simulations=8)[0]
+            kinds[B] = "towers" if route in (2, 3) else {1: "lds-resident", 0: "generic", 4: "fc"}[route]
+        assert len(set(kinds.values())) == 1, (name, kinds)
+    for game in ("connect4", "gomoku", "atari"):
+        h = _create(lib, configs.BY_NAME[game]())
+        if game == "connect4":
+            lib.check(lib.mzx_net_set_mode(h, 3))
+        for recurrent in (0, 1):
+            used = {B: tuple(t["groups"] > 0 for t in _towers(lib, h, recurrent, B)) for B in sizes}
+            assert len(set(used.values())) == 1, (game, recurrent, used)
+        lib.mzx_net_destroy(h)
 
 
 def test_head_chains_run_level_by_level_in_grouped_launches(lib):
