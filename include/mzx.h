@@ -440,6 +440,96 @@ int mzx_selfplay_select(mzx_rng* r, const mzx_move* m, const int32_t* n_legal, c
                         int32_t table_stride, const double* table_temperatures, int32_t num_temperatures,
                         int64_t* action);
 
+/* ------------------------------------------------------------------------- *
+ * Replay hand-off: the INITIAL prioritised-replay priorities of finished games on the device --
+ * ReplayBuffer.save_game, replay_buffer.py:39-51, with compute_target_value (:230-262) -- for G games of T searched
+ * positions each (a shard record: games that started and ended together).  Device arrays:
+ *   d_root_values [G][T] f64 (root.value(), 0 for an unvisited root), d_rewards [G][T+1] f64 (reward_history, leading 0),
+ *   d_to_play [G][T+1] i32, d_discount_pow [td_steps+1] f64 = config.discount ** i computed by the CALLER with the host
+ *   language's own pow (the reference's `self.config.discount**i`);
+ *   out: d_targets [G][T] f64 (nullable) = compute_target_value, bit for bit (binary64 multiply / add in the reference's
+ *   order); d_priorities [G][T] f32 = float32(|root - target| ** per_alpha) (binary64 sqrt for 0.5, identity for 1, device
+ *   pow otherwise); d_game_priority [G] f32 (nullable) = numpy.max(priorities).
+ * ------------------------------------------------------------------------- */
+int mzx_replay_priorities(const double* d_root_values, const double* d_rewards, const int32_t* d_to_play, int32_t num_games,
+                          int32_t moves, int32_t td_steps, const double* d_discount_pow, double per_alpha, double* d_targets,
+                          float* d_priorities, float* d_game_priority, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Games that step NATIVELY for a whole shard (host side, no GPU; csrc/mzx_games.h): the plugin surface of
+ * games/abstract_game.py:9-105 -- reset / step / legal_actions / to_play -- for num_games games at once, so that a
+ * self-play shard need not return to the interpreter per move (mzx_selfplay_rounds below).  kind: "synthetic" (the
+ * fixed-shape environment of the metric, mzx/synthetic.py: observation_shape [C,H,W], action_space_size and num_players
+ * are read), "tictactoe" / "connect4" / "gomoku" (games/tictactoe.py:125-310, games/connect4.py:125-300,
+ * games/gomoku.py:130-300: geometry fixed, the three size arguments are ignored).  seeds [num_games] (nullable = 0).
+ * Observations are float32 [num_games][C*H*W] (what torch.tensor(obs).float() makes of the reference game's arrays);
+ * mzx_game_info: out[0..7] = C, H, W, actions, players, dtype of the reference game's observation arrays (0 float32,
+ * 1 int32, 2 float64), rewards are integers (1 / 0), every action always legal (1 / 0).  legal_actions: int32
+ * [num_games][actions], increasing, padded with -1.  mzx_game_reset(games = NULL): every game.
+ * ------------------------------------------------------------------------- */
+typedef struct mzx_game mzx_game;
+int mzx_game_create(const char* kind, int32_t num_games, const uint32_t* seeds, const int32_t* observation_shape,
+                    int32_t action_space_size, int32_t num_players, mzx_game** out);
+void mzx_game_destroy(mzx_game* g);
+int mzx_game_info(const mzx_game* g, int32_t out[8]);
+int mzx_game_reset(mzx_game* g, const int32_t* games, int32_t count);
+int mzx_game_observe(const mzx_game* g, float* out);
+int mzx_game_legal_actions(const mzx_game* g, int32_t* out);
+int mzx_game_to_play(const mzx_game* g, int32_t* out);
+int mzx_game_step(mzx_game* g, const int64_t* actions, const uint8_t* active /* nullable: games with 0 stay untouched */,
+                  double* reward, uint8_t* done);
+
+/* ------------------------------------------------------------------------- *
+ * The self-play ROUND LOOP of a shard of natively stepped games in one call (self_play.py:110-183 for every slot of the
+ * shard + the actor loop :31-52; csrc/mzx_actor.h).  An `mzx_actor` is one SLOT GROUP: its game object, search handle,
+ * streams of the bank, staging blocks (`move`: as for mzx_selfplay_search; the host-array fields are the actor's own)
+ * and the log of its games in progress.  mzx_selfplay_rounds plays rounds -- one move of every slot: search
+ * (mzx_selfplay_search), action draw (mzx_selfplay_select, temperature_threshold gate self_play.py:151-157), Game.step,
+ * GameHistory row -- until at least `min_games` games have finished or `max_rounds` (< 0: unbounded) rounds were played;
+ * a finished game (done, or max_moves moves) is queued for mzx_actor_take and its slot restarts at once on the same
+ * stream.  Two groups take turns on the GPU (one searched while the host consumes the other); nothing is in flight when
+ * the call returns.  Temperature: `temperature` applies to the games that START during the call; pow_table as for
+ * mzx_selfplay_select (every finite non-zero temperature a running game may carry must have a row).  `retry`: called with
+ * the games of a group whose search exhausted its tie-break tape (info flag 1); it must search them again on a longer
+ * tape and write visit counts / root value / info into the group's output block (rare; NULL: such a search is an error).
+ * In / out: `sequence` numbers finished games in the order they finish (across groups and calls).
+ * mzx_actor_take hands out and forgets the finished games of a group, game-major and ragged: game j has length[j] moves;
+ * observations / actions / rewards / to_play hold length[j] + 1 entries per game (action_history / reward_history with
+ * their leading 0, the final position's observation and side to move), visit_counts / root_values / legal_mask length[j];
+ * sizes from mzx_actor_finished (out[0] games, out[1] sum of lengths).  legal_mask [sum][A] u8 is needed when
+ * mzx_actor_has_masks.
+ * ------------------------------------------------------------------------- */
+typedef struct mzx_actor mzx_actor;
+typedef struct mzx_actor_config {
+  mzx_game* game; mzx_search* search; mzx_rng* bank;
+  const int32_t* streams;          /* [num_games] stream of game k in the bank (copied) */
+  int32_t first_slot;              /* slot of game 0 in the shard (finished games are reported by shard slot) */
+  int32_t max_moves;               /* config.max_moves */
+  double temperature;              /* of the games that start with the actor */
+  void* d_arena; int64_t arena_bytes;
+  mzx_move move;                   /* num_games, action_space_size, tape_words, num_threads, dirichlet_alpha, staging blocks, io */
+} mzx_actor_config;
+int mzx_actor_create(const mzx_actor_config* config, mzx_actor** out);
+void mzx_actor_destroy(mzx_actor* a);
+typedef int (*mzx_retry_fn)(void* ctx, int32_t group, int32_t count, const int32_t* games);
+typedef struct mzx_rounds {
+  double temperature;
+  int32_t temperature_threshold;   /* config.temperature_threshold, 0 = none */
+  int32_t table_stride;
+  const double* pow_table; const double* table_temperatures; int32_t num_temperatures; int32_t reserved;
+  int64_t min_games, max_rounds;
+  int64_t sequence;                /* in / out */
+  mzx_retry_fn retry; void* retry_ctx;
+  int64_t rounds, games, searches; /* out: rounds played, games finished, searches run (one per slot and round) */
+  double search_seconds;           /* out: host time queueing searches + waiting for them */
+} mzx_rounds;
+int mzx_selfplay_rounds(mzx_actor* const* groups, int32_t num_groups, mzx_rounds* io, void* stream);
+int mzx_actor_finished(const mzx_actor* a, int64_t out[2]);
+int mzx_actor_has_masks(const mzx_actor* a);
+int mzx_actor_take(mzx_actor* a, int32_t* slot, int32_t* length, int64_t* sequence, float* observations, int64_t* actions,
+                   double* rewards, int64_t* to_play, int32_t* visit_counts, double* root_values, uint8_t* legal_mask,
+                   int32_t* any_illegal);
+
 #ifdef __cplusplus
 }
 #endif

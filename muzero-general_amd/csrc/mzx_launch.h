@@ -39,6 +39,10 @@ inline int copy_d2h(void* dst, const void* src, size_t bytes, stream_t) {
   return 0;
 }
 inline int stream_sync(stream_t) { return 0; }
+// an event recorded behind the work queued on a stream so far (mzx_actor.h: one search in flight per slot group)
+inline int event_record(void** ev, stream_t) { *ev = (void*)1; return 0; }
+inline int event_wait(void*) { return 0; }
+inline void event_destroy(void*) {}
 
 inline int device_alloc(void** out, size_t bytes) {
   *out = malloc(bytes);
@@ -83,6 +87,19 @@ inline int copy_d2h(void* dst, const void* src, size_t bytes, stream_t stream) {
   return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
 }
 inline int stream_sync(stream_t stream) { return (int)hipStreamSynchronize(stream); }
+// an event recorded behind the work queued on a stream so far (mzx_actor.h: one search in flight per slot group, both
+// groups on the caller's stream -- waiting for the stream would wait for the OTHER group's search queued behind)
+inline int event_record(void** ev, stream_t stream) {
+  if (!*ev) {
+    hipEvent_t e = nullptr;
+    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (rc != hipSuccess) return (int)rc;
+    *ev = (void*)e;
+  }
+  return (int)hipEventRecord((hipEvent_t)*ev, stream);
+}
+inline int event_wait(void* ev) { return ev ? (int)hipEventSynchronize((hipEvent_t)ev) : 0; }
+inline void event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
 
 // small library-owned device allocations (the search's pb_c / sqrt tables); every large buffer is the caller's
 inline int device_alloc(void** out, size_t bytes) { return (int)hipMalloc(out, bytes); }

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "mzx_obs.h"
+#include "mzx_replay.h"
 #include "mzx_rng.h"
 #include "mzx_search.h"
 #ifndef MZX_HOSTCHECK
@@ -978,6 +979,213 @@ int mzx_selfplay_select(mzx_rng* r, const mzx_move* m, const int32_t* n_legal, c
     }
   });
   return MZX_OK;
+}
+
+// ------------------------------------------------------------- replay hand-off: initial PER priorities on the device
+
+int mzx_replay_priorities(const double* d_root_values, const double* d_rewards, const int32_t* d_to_play, int32_t num_games,
+                          int32_t moves, int32_t td_steps, const double* d_discount_pow, double per_alpha, double* d_targets,
+                          float* d_priorities, float* d_game_priority, void* stream) {
+  if (num_games < 0 || moves < 0 || td_steps < 0) { set_error("mzx_replay_priorities: negative argument"); return MZX_ERR_INVALID; }
+  if (num_games == 0 || moves == 0) return MZX_OK;
+  if (!d_root_values || !d_rewards || !d_to_play || !d_discount_pow || !d_priorities) { set_error("mzx_replay_priorities: missing buffer"); return MZX_ERR_INVALID; }
+  ReplayPriorityOp op;
+  op.root_values = d_root_values; op.rewards = d_rewards; op.to_play = d_to_play; op.discount_pow = d_discount_pow;
+  op.targets = d_targets; op.priorities = d_priorities; op.per_alpha = per_alpha;
+  op.num_games = num_games; op.moves = moves; op.td_steps = td_steps;
+  MZX_TRY_LAUNCH(launch<256>(op, (stream_t)stream));
+  if (d_game_priority) {
+    ReplayGameMaxOp mx;
+    mx.priorities = d_priorities; mx.game_priority = d_game_priority; mx.num_games = num_games; mx.moves = moves;
+    MZX_TRY_LAUNCH(launch<64>(mx, (stream_t)stream));
+  }
+  return MZX_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------- natively stepped games + the round loop of a shard
+#include "mzx_actor.h"
+
+extern "C" {
+
+int mzx_game_create(const char* kind, int32_t num_games, const uint32_t* seeds, const int32_t* observation_shape,
+                    int32_t action_space_size, int32_t num_players, mzx_game** out) {
+  if (!out) { set_error("mzx_game_create: null out"); return MZX_ERR_INVALID; }
+  std::string err;
+  mzx_game* g = game_make(kind, num_games, seeds, observation_shape, action_space_size, num_players, err);
+  if (!g) { set_error("%s", err.c_str()); return MZX_ERR_INVALID; }
+  *out = g;
+  return MZX_OK;
+}
+
+void mzx_game_destroy(mzx_game* g) { delete g; }
+
+int mzx_game_info(const mzx_game* g, int32_t out[8]) {
+  if (!g || !out) { set_error("mzx_game_info: null"); return MZX_ERR_INVALID; }
+  out[0] = g->shape[0]; out[1] = g->shape[1]; out[2] = g->shape[2]; out[3] = g->num_actions; out[4] = g->num_players;
+  out[5] = g->obs_dtype; out[6] = g->reward_is_int; out[7] = g->always_all_legal;
+  return MZX_OK;
+}
+
+int mzx_game_reset(mzx_game* g, const int32_t* games, int32_t count) {
+  if (!g || count < 0) { set_error("mzx_game_reset: argument"); return MZX_ERR_INVALID; }
+  if (!games) { g->reset(nullptr, g->num_games); return MZX_OK; }
+  for (int32_t k = 0; k < count; ++k)
+    if (games[k] < 0 || games[k] >= g->num_games) { set_error("mzx_game_reset: game %d out of range", games[k]); return MZX_ERR_INVALID; }
+  g->reset(games, count);
+  return MZX_OK;
+}
+
+int mzx_game_observe(const mzx_game* g, float* out) {
+  if (!g || !out) { set_error("mzx_game_observe: null"); return MZX_ERR_INVALID; }
+  g->observe(0, g->num_games, out);
+  return MZX_OK;
+}
+
+int mzx_game_legal_actions(const mzx_game* g, int32_t* out) {
+  if (!g || !out) { set_error("mzx_game_legal_actions: null"); return MZX_ERR_INVALID; }
+  g->legal_actions(0, g->num_games, out);
+  return MZX_OK;
+}
+
+int mzx_game_to_play(const mzx_game* g, int32_t* out) {
+  if (!g || !out) { set_error("mzx_game_to_play: null"); return MZX_ERR_INVALID; }
+  g->to_play(0, g->num_games, out);
+  return MZX_OK;
+}
+
+int mzx_game_step(mzx_game* g, const int64_t* actions, const uint8_t* active, double* reward, uint8_t* done) {
+  if (!g || !actions || !reward || !done) { set_error("mzx_game_step: null"); return MZX_ERR_INVALID; }
+  for (int32_t k = 0; k < g->num_games; ++k)
+    if ((!active || active[k]) && (actions[k] < 0 || actions[k] >= g->num_actions)) {
+      set_error("mzx_game_step: action %lld of game %d outside the action space", (long long)actions[k], k);
+      return MZX_ERR_INVALID;
+    }
+  g->step(0, g->num_games, actions, active, reward, done);
+  return MZX_OK;
+}
+
+int mzx_actor_create(const mzx_actor_config* c, mzx_actor** out) {
+  if (!c || !out || !c->game || !c->search || !c->bank || !c->streams || !c->d_arena) { set_error("mzx_actor_create: missing argument"); return MZX_ERR_INVALID; }
+  const mzx_game* g = c->game;
+  const mzx_move& m = c->move;
+  if (m.num_games != g->num_games || m.action_space_size != g->num_actions || c->max_moves < 1 ||
+      !m.h_in || !m.d_in || !m.h_out || !m.d_out || !m.io.d_noise) {
+    set_error("mzx_actor_create: the move block does not fit the game (%d games x %d actions) or lacks a staging block / root noise",
+              g->num_games, g->num_actions);
+    return MZX_ERR_INVALID;
+  }
+  int rc = rng_check(c->bank, c->streams, g->num_games);
+  if (rc) return rc;
+  mzx_actor* a = new (std::nothrow) mzx_actor();
+  if (!a) { set_error("out of host memory"); return MZX_ERR_RUNTIME; }
+  a->game = c->game; a->search = c->search; a->bank = c->bank; a->d_arena = c->d_arena; a->arena_bytes = c->arena_bytes;
+  a->move = c->move;
+  a->move.add_exploration_noise = 1;
+  a->B = g->num_games; a->A = g->num_actions; a->E = g->obs_elems(); a->max_moves = c->max_moves; a->first_slot = c->first_slot;
+  const size_t B = (size_t)a->B, A = (size_t)a->A;
+  a->streams.assign(c->streams, c->streams + B);
+  a->legal.resize(B * A); a->to_play.resize(B); a->n_legal.resize(B); a->words.resize(B);
+  a->cur_obs.resize(B * (size_t)a->E); a->next_obs.resize(B * (size_t)a->E);
+  a->actions.resize(B); a->start.assign(B, 0);
+  a->temps.assign(B, c->temperature); a->move_temps.resize(B); a->reward.resize(B); a->done.resize(B);
+  a->game->reset(nullptr, a->B);
+  a->game->observe(0, a->B, a->cur_obs.data());
+  actor_refresh(a);
+  *out = a;
+  return MZX_OK;
+}
+
+void mzx_actor_destroy(mzx_actor* a) {
+  if (!a) return;
+  if (a->pending) (void)event_wait(a->event);
+  event_destroy(a->event);
+  delete a;
+}
+
+int mzx_selfplay_rounds(mzx_actor* const* groups, int32_t num_groups, mzx_rounds* io, void* stream) {
+  if (!groups || num_groups < 1 || !io) { set_error("mzx_selfplay_rounds: missing argument"); return MZX_ERR_INVALID; }
+  for (int k = 0; k < num_groups; ++k)
+    if (!groups[k]) { set_error("mzx_selfplay_rounds: null group"); return MZX_ERR_INVALID; }
+  RoundsArgs args;
+  args.temperature = io->temperature; args.temperature_threshold = io->temperature_threshold;
+  args.pow_table = io->pow_table; args.table_stride = io->table_stride; args.table_temperatures = io->table_temperatures;
+  args.num_temperatures = io->num_temperatures; args.retry = io->retry; args.retry_ctx = io->retry_ctx;
+  int64_t finished = 0, rounds = 0, searches = 0, sequence = io->sequence;
+  double search_seconds = 0.0;
+  int rc = MZX_OK;
+  const bool pipelined = num_groups > 1;
+  // SelfPlay._rounds_batched, statement for statement
+  while (rc == MZX_OK && finished < io->min_games && (io->max_rounds < 0 || rounds < io->max_rounds)) {
+    for (int k = 0; k < num_groups && rc == MZX_OK; ++k)
+      if (!groups[k]->pending) rc = actor_begin(groups[k], stream, &search_seconds);
+    for (int k = 0; k < num_groups && rc == MZX_OK; ++k) {
+      rc = actor_consume(groups[k], k, args, &sequence, &finished, &search_seconds);
+      if (rc) break;
+      searches += groups[k]->B;
+      int64_t later = 0;
+      for (int j = k + 1; j < num_groups; ++j) later += groups[j]->B;
+      // certain to be consumed by this call: runs while the host plays the groups after it
+      if (pipelined && k + 1 < num_groups && finished + later < io->min_games && (io->max_rounds < 0 || rounds + 1 < io->max_rounds))
+        rc = actor_begin(groups[k], stream, &search_seconds);
+    }
+    ++rounds;
+  }
+  if (rc != MZX_OK) {          // nothing stays in flight behind a failure
+    (void)stream_sync((stream_t)stream);
+    for (int k = 0; k < num_groups; ++k) groups[k]->pending = false;
+  }
+  io->rounds = rounds; io->games = finished; io->searches = searches; io->search_seconds = search_seconds; io->sequence = sequence;
+  return rc;
+}
+
+int mzx_actor_finished(const mzx_actor* a, int64_t out[2]) {
+  if (!a || !out) { set_error("mzx_actor_finished: null"); return MZX_ERR_INVALID; }
+  out[0] = a->finished_games; out[1] = a->finished_moves;
+  return MZX_OK;
+}
+
+int mzx_actor_take(mzx_actor* a, int32_t* slot, int32_t* length, int64_t* sequence, float* observations, int64_t* actions,
+                   double* rewards, int64_t* to_play, int32_t* visit_counts, double* root_values, uint8_t* legal_mask,
+                   int32_t* any_illegal) {
+  if (!a || !slot || !length || !sequence || !observations || !actions || !rewards || !to_play || !visit_counts || !root_values) {
+    set_error("mzx_actor_take: missing buffer");
+    return MZX_ERR_INVALID;
+  }
+  const size_t A = (size_t)a->A, E = (size_t)a->E;
+  size_t g = 0, q1 = 0, q0 = 0;
+  int32_t illegal = 0;
+  for (const mzx_actor::Batch& b : a->finished) {
+    const size_t k = b.slot.size(), n1 = b.act.size(), n0 = b.val.size();
+    memcpy(slot + g, b.slot.data(), sizeof(int32_t) * k);
+    memcpy(length + g, b.n.data(), sizeof(int32_t) * k);
+    memcpy(sequence + g, b.seq.data(), sizeof(int64_t) * k);
+    memcpy(observations + q1 * E, b.obs.data(), sizeof(float) * n1 * E);
+    memcpy(actions + q1, b.act.data(), sizeof(int64_t) * n1);
+    memcpy(rewards + q1, b.rew.data(), sizeof(double) * n1);
+    memcpy(to_play + q1, b.tp.data(), sizeof(int64_t) * n1);
+    memcpy(visit_counts + q0 * A, b.vis.data(), sizeof(int32_t) * n0 * A);
+    memcpy(root_values + q0, b.val.data(), sizeof(double) * n0);
+    if (legal_mask) {
+      if (b.mask.empty()) memset(legal_mask + q0 * A, 1, n0 * A);
+      else { memcpy(legal_mask + q0 * A, b.mask.data(), n0 * A); illegal = 1; }
+    } else if (!b.mask.empty()) {
+      illegal = 1;
+    }
+    g += k; q1 += n1; q0 += n0;
+  }
+  if (any_illegal) *any_illegal = illegal;
+  if (illegal && !legal_mask) { set_error("mzx_actor_take: games with restricted legal sets need the legal_mask buffer"); return MZX_ERR_INVALID; }
+  a->finished.clear();
+  a->finished_games = 0; a->finished_moves = 0;
+  return MZX_OK;
+}
+
+int mzx_actor_has_masks(const mzx_actor* a) {
+  if (!a) return 0;
+  for (const mzx_actor::Batch& b : a->finished) if (!b.mask.empty()) return 1;
+  return 0;
 }
 
 }  // extern "C"

@@ -64,6 +64,27 @@ class Move(ctypes.Structure):
     ]
 
 
+class ActorConfig(ctypes.Structure):
+    """``mzx_actor_config``: one slot group of a shard of natively stepped games (mzx_selfplay_rounds)."""
+    _fields_ = [
+        ("game", c_vp), ("search", c_vp), ("bank", c_vp), ("streams", c_vp), ("first_slot", c_i32), ("max_moves", c_i32),
+        ("temperature", c_f64), ("d_arena", c_vp), ("arena_bytes", c_i64), ("move", Move),
+    ]
+
+
+RETRY_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_vp, c_i32, c_i32, ctypes.POINTER(c_i32))
+
+
+class Rounds(ctypes.Structure):
+    """``mzx_rounds``: arguments and results of one mzx_selfplay_rounds call."""
+    _fields_ = [
+        ("temperature", c_f64), ("temperature_threshold", c_i32), ("table_stride", c_i32), ("pow_table", c_vp),
+        ("table_temperatures", c_vp), ("num_temperatures", c_i32), ("reserved", c_i32), ("min_games", c_i64),
+        ("max_rounds", c_i64), ("sequence", c_i64), ("retry", RETRY_FN), ("retry_ctx", c_vp), ("rounds", c_i64),
+        ("games", c_i64), ("searches", c_i64), ("search_seconds", c_f64),
+    ]
+
+
 class TreeDump(ctypes.Structure):
     _fields_ = [
         ("d_visit", c_vp), ("d_value_sum", c_vp), ("d_reward", c_vp), ("d_to_play", c_vp), ("d_parent", c_vp),
@@ -145,6 +166,21 @@ PROTOTYPES = {
     "mzx_rng_randint": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_vp]),
     "mzx_rng_choice_weighted": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "mzx_selfplay_search": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(Move), c_vp, c_vp, c_i64, c_vp]),
+    "mzx_replay_priorities": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_f64, c_vp, c_vp, c_vp, c_vp]),
+    "mzx_game_create": (ctypes.c_int, [ctypes.c_char_p, c_i32, c_vp, c_vp, c_i32, c_i32, ctypes.POINTER(c_vp)]),
+    "mzx_game_destroy": (None, [c_vp]),
+    "mzx_game_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32 * 8)]),
+    "mzx_game_reset": (ctypes.c_int, [c_vp, c_vp, c_i32]),
+    "mzx_game_observe": (ctypes.c_int, [c_vp, c_vp]),
+    "mzx_game_legal_actions": (ctypes.c_int, [c_vp, c_vp]),
+    "mzx_game_to_play": (ctypes.c_int, [c_vp, c_vp]),
+    "mzx_game_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mzx_actor_create": (ctypes.c_int, [ctypes.POINTER(ActorConfig), ctypes.POINTER(c_vp)]),
+    "mzx_actor_destroy": (None, [c_vp]),
+    "mzx_selfplay_rounds": (ctypes.c_int, [ctypes.POINTER(c_vp), c_i32, ctypes.POINTER(Rounds), c_vp]),
+    "mzx_actor_finished": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64 * 2)]),
+    "mzx_actor_has_masks": (ctypes.c_int, [c_vp]),
+    "mzx_actor_take": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i32)]),
     "mzx_selfplay_select": (ctypes.c_int, [c_vp, ctypes.POINTER(Move), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32,
                                            c_vp]),
 }

@@ -237,3 +237,113 @@ class GomokuBatched(_KInARowBatched):
 
 
 BATCHED = {"tictactoe": TicTacToeBatched, "connect4": Connect4Batched, "gomoku": GomokuBatched}
+
+
+# ---- natively stepped games (include/mzx.h "Games that step NATIVELY", csrc/mzx_games.h) --------------------------------
+class NativeBatchedGame:
+    """
+    A shard of games stepped inside the library (``mzx_game_*``): the batched plugin protocol above on a native game
+    object -- and, because it carries ``native_handle``, a game ``SelfPlay.play_rounds`` plays WITHOUT returning to the
+    interpreter per move (``mzx_selfplay_rounds``: search, action draw, step, history row and slot refill of every round in
+    one call; ``config.native_rounds = False`` keeps the Python loop, the A/B and the parity reference of
+    tests/test_native_rounds.py).  Game i equals game i of the Python class of the same name, observation for
+    observation (values and dtype) and reward for reward (tests/test_native_games.py).  Subclasses fix ``kind``; the
+    synthetic environment takes its geometry from ``make_native_synthetic_game``.
+    """
+    batched = True
+    native = True
+    kind = None
+    observation_shape = (0, 0, 0)
+    num_actions = num_players = 0
+    _DTYPES = ("float32", "int32", "float64")
+
+    def __init__(self, seeds, _backend=None):
+        import ctypes
+
+        from . import _lib
+
+        backend = _backend or getattr(type(self), "backend", None) or _lib.default_backend()
+        self.lib = backend.lib
+        seeds = numpy.asarray([0 if s is None else int(s) & 0xFFFFFFFF for s in seeds], numpy.uint32)
+        self.num_games = int(seeds.size)
+        shape = numpy.asarray(self.observation_shape, numpy.int32)
+        self.native_handle = ctypes.c_void_p()
+        self.lib.check(self.lib.mzx_game_create(self.kind.encode(), self.num_games, seeds.ctypes.data, shape.ctypes.data,
+                                                int(self.num_actions), int(self.num_players), ctypes.byref(self.native_handle)))
+        info = (ctypes.c_int32 * 8)()
+        self.lib.check(self.lib.mzx_game_info(self.native_handle, ctypes.byref(info)))
+        self.shape, self.A = tuple(info[0:3]), int(info[3])
+        self.obs_dtype = numpy.dtype(self._DTYPES[info[5]])
+        self.reward_dtype = numpy.int64 if info[6] else numpy.float64
+        self._reward = numpy.empty(self.num_games, numpy.float64)
+        self._done = numpy.empty(self.num_games, numpy.uint8)
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        handle, self.native_handle = getattr(self, "native_handle", None), None
+        if handle:
+            try:
+                self.lib.mzx_game_destroy(handle)
+            except Exception:
+                pass
+
+    def _observation(self):
+        out = numpy.empty((self.num_games,) + self.shape, numpy.float32)
+        self.lib.check(self.lib.mzx_game_observe(self.native_handle, out.ctypes.data))
+        return out if self.obs_dtype == numpy.float32 else out.astype(self.obs_dtype)
+
+    def reset(self):
+        self.lib.check(self.lib.mzx_game_reset(self.native_handle, None, 0))
+        return self._observation()
+
+    def reset_games(self, games):
+        g = numpy.ascontiguousarray(games, numpy.int32)
+        self.lib.check(self.lib.mzx_game_reset(self.native_handle, g.ctypes.data, int(g.size)))
+        return self._observation()[g]
+
+    def step(self, actions, active=None):
+        a = numpy.ascontiguousarray(actions, numpy.int64)
+        act = None if active is None else numpy.ascontiguousarray(active, numpy.uint8)
+        self.lib.check(self.lib.mzx_game_step(self.native_handle, a.ctypes.data, None if act is None else act.ctypes.data,
+                                              self._reward.ctypes.data, self._done.ctypes.data))
+        return self._observation(), self._reward.astype(self.reward_dtype), self._done.astype(bool)
+
+    def legal_actions(self):
+        out = numpy.empty((self.num_games, self.A), numpy.int32)
+        self.lib.check(self.lib.mzx_game_legal_actions(self.native_handle, out.ctypes.data))
+        return out
+
+    def to_play(self):
+        out = numpy.empty(self.num_games, numpy.int32)
+        self.lib.check(self.lib.mzx_game_to_play(self.native_handle, out.ctypes.data))
+        return out.astype(numpy.int64)
+
+
+class TicTacToeNative(NativeBatchedGame):
+    """games/tictactoe.py:125-310 for a shard, stepped natively."""
+    kind = "tictactoe"
+
+
+class Connect4Native(NativeBatchedGame):
+    """games/connect4.py:125-300 for a shard, stepped natively."""
+    kind = "connect4"
+
+
+class GomokuNative(NativeBatchedGame):
+    """games/gomoku.py:130-300 for a shard, stepped natively."""
+    kind = "gomoku"
+
+
+def make_native_synthetic_game(observation_shape, num_actions, num_players=1):
+    """``mzx.synthetic.make_synthetic_batched_game`` stepped natively: the fixed-shape environment of the metric."""
+    class SyntheticNative(NativeBatchedGame):
+        kind = "synthetic"
+
+    SyntheticNative.observation_shape = tuple(int(x) for x in observation_shape)
+    SyntheticNative.num_actions, SyntheticNative.num_players = int(num_actions), int(num_players)
+    return SyntheticNative
+
+
+NATIVE = {"tictactoe": TicTacToeNative, "connect4": Connect4Native, "gomoku": GomokuNative}

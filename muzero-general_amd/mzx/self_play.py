@@ -36,7 +36,7 @@ import warnings
 import numpy
 import torch
 
-from . import _lib, _rng, models, replay
+from . import _lib, _rng, models, native_rounds, replay
 from . import observations as observations_mod
 
 # raw MT19937 words per tree handed to a search for its tie draws: a search normally consumes ONE (the all-zero
@@ -976,7 +976,9 @@ class SelfPlay:
             # optional batched plugin protocol (mzx.synthetic.make_synthetic_batched_game documents it): ONE
             # object steps the whole shard, the per-move host work is a handful of numpy calls
             self._game_seeds = [seed + i for i in range(self.num_games)]
-            self.batched_game = Game(self._game_seeds)
+            # (a natively stepped game -- mzx.games.NativeBatchedGame -- lives in the library this actor's model runs on)
+            self.batched_game = (Game(self._game_seeds, _backend=_backend) if getattr(Game, "native", False)
+                                 else Game(self._game_seeds))
             self.games = []
             self.game = self.batched_game
         else:
@@ -1076,11 +1078,7 @@ class SelfPlay:
 
     def play_games(self, temperature, temperature_threshold, render, opponent, muzero_player):
         """All ``num_games`` games of this shard in lock-step; returns their GameHistory list."""
-        self._drain_searches()
-        for group in (self._live or {}).get("groups", ()):      # (slot groups of the batched protocol own their game objects)
-            if group.get("game") is not None and group["game"] is not self.batched_game:
-                group["game"].close()
-        self._live = None       # (games in progress under play_rounds end here: every game object is reset)
+        self._end_live()        # (games in progress under play_rounds end here: every game object is reset)
         if self.batched_game is not None:
             if opponent != "self" or render:
                 raise NotImplementedError("the batched game protocol covers self-play without rendering")
@@ -1089,6 +1087,17 @@ class SelfPlay:
             return self._play_shard(temperature, temperature_threshold)
         return self._play(list(range(self.num_games)), temperature, temperature_threshold, render, opponent,
                           muzero_player)
+
+    def _end_live(self):
+        """Ends the games in progress under ``play_rounds``: queued searches drained, the slot groups' own game objects
+        (and native actors) released."""
+        self._drain_searches()
+        live, self._live = self._live, None
+        for group in (live or {}).get("groups", ()):      # (slot groups of the batched protocol own their game objects)
+            if group.get("game") is not None and group["game"] is not self.batched_game:
+                group["game"].close()
+        if live and live.get("native") is not None:
+            live["native"].close()
 
     def _check_observation(self, observation):
         # self_play.py:132-137 (same messages); ndarray observations of the right shape take the fast exit
@@ -1610,6 +1619,16 @@ class SelfPlay:
         so nothing is in flight between calls (weights may change there).
         """
         cfg, B = self.config, self.num_games
+        if native_rounds.usable(self):
+            # the game steps inside the library: the whole loop below runs there (mzx_selfplay_rounds), same schedule, same
+            # draws, same games (mzx/native_rounds.py; config.native_rounds = False keeps this loop on such a game)
+            live = self._live
+            if live is None:
+                shard = native_rounds.NativeShard(self, temperature)
+                live = self._live = dict(groups=shard.groups, native=shard)
+            finished, slots = live["native"].play(temperature, temperature_threshold, min_games, max_rounds)
+            self.finished_slots += slots
+            return finished
         live = self._live
         if live is None:
             spans = self._batched_spans(B)
@@ -1724,6 +1743,8 @@ class SelfPlay:
 
     def close_game(self):
         self._drain_searches()
+        if self._live and self._live.get("native") is not None:
+            self._live["native"].close()
         worker = getattr(self, "_search_worker", None)
         if worker is not None:
             worker.shutdown(wait=True)

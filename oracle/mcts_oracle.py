@@ -47,7 +47,7 @@ class Tree:
     __slots__ = (
         "actions", "visit", "value_sum", "reward", "to_play", "hidden",
         "prior", "child", "parent", "parent_slot", "minimum", "maximum",
-        "trace", "max_depth", "root_predicted_value", "tie_draws", "margins", "_sim_margin",
+        "trace", "max_depth", "root_predicted_value", "tie_draws", "margins", "_sim_margin", "value_margins", "_sim_value_margin",
     )
 
     def __init__(self):
@@ -72,6 +72,13 @@ class Tree:
         # close the simulation came to taking another branch under a perturbation of the network outputs
         self.margins = []
         self._sim_margin = (float("inf"), 0)
+        # the same gap in units of the backed-up values r + gamma v, relative to their magnitude: a UCB score contains
+        # normalize(q) = (q - min) / (max - min) (MinMaxStats, self_play.py:562-570), so a perturbation eps of a decoded value
+        # moves a score by eps / (max - min) -- early in a search, when the tree-wide range is a few hundredths, a score gap
+        # of 2e-3 is a value gap of 1e-4.  value_margins[k] = margins[k][0] * (max - min) / max(1, |min|, |max|) (range 1 while
+        # max <= min: nothing is normalised then)
+        self.value_margins = []
+        self._sim_value_margin = float("inf")
 
     def root_visit_counts(self, action_space):
         """Visit count per action of ``action_space`` (0 for non-children)."""
@@ -157,6 +164,9 @@ def _select_slot(tree, cfg, parent, rng):
         second = sorted(scores)[-2]
         if best - second < tree._sim_margin[0]:
             tree._sim_margin = (best - second, tree._sim_margin[1])
+            spread = tree.maximum - tree.minimum if tree.maximum > tree.minimum else 1.0
+            scale = max(1.0, abs(tree.minimum), abs(tree.maximum)) if tree.maximum > tree.minimum else 1.0
+            tree._sim_value_margin = (best - second) * spread / scale
     ties = [s for s, v in enumerate(scores) if v == best]
     if len(ties) > 1:
         tree.tie_draws += 1
@@ -219,6 +229,7 @@ def run_search(cfg, evaluator, observation, legal_actions, to_play,
         path = [node]
         depth = 0
         tree._sim_margin = (float("inf"), 0)
+        tree._sim_value_margin = float("inf")
         while True:
             depth += 1
             before = tree._sim_margin[0]
@@ -248,6 +259,7 @@ def run_search(cfg, evaluator, observation, legal_actions, to_play,
         tree.max_depth = max(tree.max_depth, depth)
         tree.trace.append((parent, int(action), depth))
         tree.margins.append(tree._sim_margin)
+        tree.value_margins.append(tree._sim_value_margin)
     return tree
 
 

@@ -33,7 +33,7 @@ def _one(job):
     cfg = _STATE["cfg"]
     ev = net_oracle.NetworkEvaluator(_STATE["net"], cfg.support_size)
     tree = mcts_oracle.run_search(cfg, ev, obs, legal, to_play, True, numpy.random.RandomState(seed))
-    return dict(trace=[(p, a) for p, a, _ in tree.trace], margins=list(tree.margins),
+    return dict(trace=[(p, a) for p, a, _ in tree.trace], margins=list(tree.margins), value_margins=list(tree.value_margins),
                 root_visit_counts=tree.root_visit_counts(cfg.action_space), root_value=tree.node_value(0),
                 max_depth=tree.max_depth)
 

@@ -268,10 +268,12 @@ def _compare_sample_with_oracle(cfg, sd, res, obs, legal, to_play, seeds, sample
             assert res.max_tree_depth[i] == tree["max_depth"], (label, i)
             continue
         gap, depth = tree["margins"][k]
+        vgap = tree["value_margins"][k]
         print(f"{label}: tree {i} diverges at simulation {k} of {len(want)} (oracle {want[k]}, device "
-              f"{got[k] if k < len(got) else None}); oracle UCB top-2 margin on that walk {gap:.3e} at depth {depth}")
+              f"{got[k] if k < len(got) else None}); oracle UCB top-2 margin on that walk {gap:.3e} at depth {depth}"
+              f" (in units of the backed-up values: {vgap:.3e})")
         # observed margins of diverging trees: <= 8e-5 (profiles/r02_pytest_gpu_full_v2.log); the gate leaves 6x
-        assert gap < MARGIN_GATE, (label, i, k, gap, "divergence with a comfortable UCB margin: not fp32 noise")
+        assert near_tie(gap, vgap), (label, i, k, gap, vgap, "divergence with a comfortable UCB margin: not fp32 noise")
     # what the replay buffer consumes (root child_visits, root value) on ALL sampled trees, diverged ones included, with
     # ABSOLUTE per-case bounds (tests/at_size.py; round 5 gated the divergence count relative to the oracle's own fp32-vs-
     # binary64 instability, which cannot fail where that is total)
@@ -310,6 +312,17 @@ def weights_for(cfg, net, kind, seed):
 MARGIN_GATE = 5e-4
 
 
+def near_tie(gap, value_gap):
+    """A divergence from the fp32 oracle is fp32 noise when the oracle's best and second-best UCB scores on that walk were a
+    near-tie: closer than MARGIN_GATE in score units -- or in units of the backed-up values r + gamma v relative to their
+    magnitude (oracle/mcts_oracle.py ``value_margins``).  A score contains (q - min) / (max - min) over the TREE-WIDE range
+    (MinMaxStats): in the first simulations of a search that range is a few hundredths, and the 1e-4 round-off of the
+    decoded values (fp32 inverse transform) is a 1e-2 step in score units.  Found with the reference
+    constructor's breakout weights (round 6): the oracle's OWN fp32 and binary64 searches part at simulation 2 of a tree
+    with a score margin of 2.2e-3 -- and the device follows the binary64 line (profiles/r06_at_size_breakout_probe.txt)."""
+    return gap < MARGIN_GATE or value_gap < MARGIN_GATE
+
+
 @pytest.mark.parametrize("mode,weights", [(0, "synthetic"), (1, "synthetic"), (1, "reference"), (1, "checkpoint")])
 def test_full_size_c2_cartpole(backend, mode, weights):
     """BASELINE config C2: CartPole-FC, 4096 trees x 50 simulations on one GPU -- on synthetic stress weights (both
@@ -342,7 +355,10 @@ def test_full_size_c2_cartpole(backend, mode, weights):
     label = f"C2 mode {mode}" + ("" if weights == "synthetic" else f" ({weights} weights)")
     # fp32 network arithmetic is not bit-reproducible across implementations; a near-tie may flip one simulation on rare
     # trees: each such tree's margin is printed and bounded (MARGIN_GATE), the visit statistics are gated in at_size.GATES
-    _compare_sample_with_oracle(cfg, sd, res, obs, legal, [0] * B, seeds, sample, factory, TOL, label)
+    # (root value of a tree identical in every simulation: 1e-4 on the synthetic weights; the trained checkpoint's values
+    # are larger and its decoded scalars carry the 3e-4 of DESIGN.md section 2 -- measured 1.4e-4 on tree 664)
+    _compare_sample_with_oracle(cfg, sd, res, obs, legal, [0] * B, seeds, sample, factory,
+                                TOL if weights == "synthetic" else 3 * TOL, label)
 
 
 @pytest.mark.parametrize("players", [1, 2])

@@ -318,7 +318,7 @@ def test_at_size_search_two_streams_and_oracle(backend, case, weights, monkeypat
             # must be a near-tie.  (Their searches go even deeper -- 110 to 400 plies for games/gomoku.py -- and the oracle's
             # fp32 and binary64 searches part on every tree as well, but at margins of 1e-6 ... 1.2e-4: CPU probe, round 5.)
             waived = weights == "synthetic" and k64 is not None and 2 * k >= k64
-            if gap >= parity.MARGIN_GATE and not waived:
+            if not parity.near_tie(gap, t32["value_margins"][k]) and not waived:
                 failures.append((i, k, gap, depth, k64))
             continue
         identical += 1

@@ -225,7 +225,7 @@ def test_tower_search_other_shards_against_oracle(backend, B, trees_per_wg, n_sa
             continue
         gap, depth = t32["margins"][k]
         print(f"connect4 x {B}: tree {i} diverges at simulation {k}; oracle UCB top-2 margin {gap:.3e} at depth {depth}")
-        assert gap < parity.MARGIN_GATE, (i, k, gap)
+        assert parity.near_tie(gap, t32["value_margins"][k]), (i, k, gap)
     # the visit statistics the replay buffer consumes, on all sampled trees, against absolute bounds (tests/at_size.py)
     at_size.gate(f"connect4 x {B} on rt_search_kernel", at_size.statistics(
         S, [res.visit_counts[i] for i in sample], [res.root_values[i] for i in sample], s32, s64, identical))
