@@ -454,7 +454,7 @@ def observation_stacker_leg(backend, games=64, stacked=32, iters=20):
             "algorithmic_bytes_per_launch": nbytes, "launch_ms": ms, "games": games, "stacked_observations": stacked}
 
 
-def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=False, pipeline=None, fused=True):
+def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=False, pipeline=None, fused=True, native=False):
     """
     What a user of the drop-in engine sees per process -- game stepping, per-game numpy-compatible streams (native
     bank), temperature sampling and GameHistory records around one batched search per move.  Default:
@@ -466,6 +466,8 @@ def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=F
     the batched protocol), whole games to their natural end.  pipeline: config.self_play_pipeline (None = the engine's
     default: per-object shards from 1024 games on run as two slot groups that take turns on the GPU, one searched while the
     host steps the other's Game objects; `search_share` is then search time / wall with the two overlapping).
+    native=True (round 6): the game steps inside the library (mzx.games.NativeBatchedGame) and play_rounds is ONE call of
+    mzx_selfplay_rounds per shard's worth of games -- no interpreter statement per move.
     """
     import copy
 
@@ -476,11 +478,12 @@ def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=F
     c.self_play_pipeline = pipeline
     if game == "synthetic":
         c.max_moves = moves
-        make = synthetic.make_synthetic_batched_game if batched else synthetic.make_synthetic_game
+        make = (board_games.make_native_synthetic_game if native else
+                synthetic.make_synthetic_batched_game if batched else synthetic.make_synthetic_game)
         Game = make(c.observation_shape, len(c.action_space), len(c.players))
         rounds = moves
     else:
-        Game = (board_games.BATCHED if batched else board_games.PER_OBJECT)[game]
+        Game = (board_games.NATIVE if native else board_games.BATCHED if batched else board_games.PER_OBJECT)[game]
         rounds = c.max_moves          # as many rounds as the longest possible game (connect4: 42)
     sp = self_play.SelfPlay({"weights": net.get_weights()}, Game, c, 0, num_games=B, _backend=net.backend)
     sp.engine.fused_move = fused     # (False: the A/B of mzx_selfplay_search / mzx_selfplay_select, one slot group only)
@@ -510,12 +513,12 @@ def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=F
         "game": game, "mode": "play_games (lock-step)" if lockstep else "play_rounds (slots refilled)",
         "wall_s": wall, "search_share": sp.stats["search_seconds"] / wall,
         "steps_per_sec_with_all_histories_as_lists": steps / (wall + (materialize if batched else 0.0)),
-        "game_protocol": "batched" if batched else "B Game objects",
+        "game_protocol": "native rounds (mzx_selfplay_rounds)" if native else "batched" if batched else "B Game objects",
         "slot_groups": len((sp._live or {}).get("groups", ())) or 1,
     }
 
 
-def actor_loop_leg(cfg, net, B, moves, shards=3):
+def actor_loop_leg(cfg, net, B, moves, shards=3, native=True):
     """
     ``SelfPlay.continuous_self_play`` itself (self_play.py:31-108) through the batched game protocol: rounds of searches,
     finished games refilled, and the HAND-OFF the self-play legs above do not time -- initial PER priorities of every
@@ -531,7 +534,9 @@ def actor_loop_leg(cfg, net, B, moves, shards=3):
     c.max_moves = moves
     c.PER, c.PER_alpha, c.td_steps = True, 0.5, 50
     c.training_steps, c.ratio, c.self_play_delay = 1 << 60, None, 0
-    Game = synthetic.make_synthetic_batched_game(c.observation_shape, len(c.action_space), len(c.players))
+    from mzx import games as board_games
+    make = board_games.make_native_synthetic_game if native else synthetic.make_synthetic_batched_game
+    Game = make(c.observation_shape, len(c.action_space), len(c.players))
     sp = self_play.SelfPlay({"weights": net.get_weights()}, Game, c, 0, num_games=B, _backend=net.backend)
     sp.play_rounds(1.0, None, min_games=1 << 60, max_rounds=2)          # warm-up (allocations, kernel attributes)
     storage = shared_storage.LocalStorage(training_step=0, terminate=False, weights=net.get_weights(),
@@ -560,7 +565,8 @@ def actor_loop_leg(cfg, net, B, moves, shards=3):
         torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     return {"steps_per_sec": sp.stats["searches"] / wall, "games_saved": buffer.games, "with_priorities": buffer.with_priorities,
-            "steps_saved": buffer.steps, "search_share": sp.stats["search_seconds"] / wall}
+            "steps_saved": buffer.steps, "search_share": sp.stats["search_seconds"] / wall,
+            "game_protocol": "native rounds (mzx_selfplay_rounds) + device priorities" if native else "batched (Python game) + device priorities"}
 
 
 # ----------------------------------------------------------------------------- weights
@@ -921,9 +927,12 @@ def main():
         if env.world == 1 and args.selfplay_moves > 0:
             line["selfplay_end_to_end"] = selfplay_leg(cfg, net, B, args.selfplay_moves)
             line["selfplay_end_to_end_batched_game"] = selfplay_leg(cfg, net, B, args.selfplay_moves, batched=True)
-            try:       # the actor loop with the replay hand-off (its failure must not cost the line)
+            try:       # the round loop inside the library (natively stepped game), and the actor loop with the replay hand-off
+                line["selfplay_end_to_end_native_rounds"] = selfplay_leg(cfg, net, B, args.selfplay_moves, batched=True, native=True)
                 line["selfplay_actor_loop"] = actor_loop_leg(cfg, net, B, args.selfplay_moves)
-            except Exception as e:      # noqa: BLE001
+                line["selfplay_actor_loop"]["python_game_steps_per_sec"] = actor_loop_leg(cfg, net, B, args.selfplay_moves,
+                                                                                           native=False)["steps_per_sec"]
+            except Exception as e:      # noqa: BLE001  (a failure here must not cost the line)
                 line["selfplay_actor_loop"] = {"error": repr(e)[:200]}
             if not args.dry_run:
                 # A/B of round 5's host path: ONE slot group (no overlap of the host with the search), and one group on the
@@ -945,6 +954,8 @@ def main():
                 # rounds 1-3 played whole shards in lock-step (the batch thins out while the longest game ends): the A/B
                 line["selfplay_end_to_end_connect4_batched_game"]["lockstep_steps_per_sec"] = selfplay_leg(
                     c4_cfg, c4_model, WORKLOADS["c4"][2], 0, batched=True, game="connect4", lockstep=True)["steps_per_sec"]
+                line["selfplay_end_to_end_connect4_batched_game"]["native_rounds_steps_per_sec"] = selfplay_leg(
+                    c4_cfg, c4_model, WORKLOADS["c4"][2], 0, batched=True, game="connect4", native=True)["steps_per_sec"]
             if not args.dry_run:
                 line["observation_stacker"] = observation_stacker_leg(net.backend)
         line["cpu_baseline"] = None

@@ -78,7 +78,35 @@ def fill_initial_priorities(game_history, config):
     return True
 
 
-def fill_initial_priorities_many(histories, config):
+def device_priorities(backend, root_values, to_play, rewards, config, want_targets=False):
+    """
+    ``mzx_replay_priorities`` (include/mzx.h, csrc/mzx_replay.h): the initial priorities of G games of T positions each
+    ON THE DEVICE -- root_values [G][T] binary64 (0 for an unvisited root), to_play / rewards [G][T + 1] as the histories
+    hold them.  Returns (priorities float32 [G][T], game_priority float32 [G][, targets binary64 [G][T]]) as host arrays.
+    The target values are the reference's bit for bit (binary64 multiply / add in its order, ``discount ** i`` from a
+    table filled HERE with Python's own float pow -- the reference's expression, replay_buffer.py:247, :260); the final
+    ``** PER_alpha`` is a binary64 sqrt for 0.5 (every shipped configuration), the identity for 1.
+    """
+    lib, dev = backend.lib, backend.device
+    rv = numpy.ascontiguousarray(root_values, dtype=numpy.float64)
+    G, T = rv.shape
+    td = int(config.td_steps)
+    up = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
+    d_rv = up(rv)
+    d_rw = up(numpy.ascontiguousarray(rewards, dtype=numpy.float64))
+    d_tp = up(numpy.ascontiguousarray(to_play, dtype=numpy.int32))
+    d_pw = up(numpy.array([config.discount ** i for i in range(td + 1)], dtype=numpy.float64))
+    assert d_rw.shape == (G, T + 1) and d_tp.shape == (G, T + 1)
+    d_pri, d_top = backend.empty((G, T), torch.float32), backend.empty((G,), torch.float32)
+    d_tg = backend.empty((G, T), torch.float64) if want_targets else None
+    lib.check(lib.mzx_replay_priorities(backend.ptr(d_rv), backend.ptr(d_rw), backend.ptr(d_tp), G, T, td, backend.ptr(d_pw),
+                                        float(config.PER_alpha), backend.ptr(d_tg), backend.ptr(d_pri), backend.ptr(d_top),
+                                        backend.stream()))
+    out = (d_pri.cpu().numpy(), d_top.cpu().numpy())
+    return out + (d_tg.cpu().numpy(),) if want_targets else out
+
+
+def fill_initial_priorities_many(histories, config, backend=None):
     """
     ``fill_initial_priorities`` for the games a self-play shard hands out together, in ONE pass per group of games of the
     same length: the loop over the reward horizon (``td_steps`` iterations of a dozen numpy statements) runs once per
@@ -90,6 +118,12 @@ def fill_initial_priorities_many(histories, config):
     bit-identical to the per-game function (tests/test_replay_handoff.py).  Games the per-game function would skip
     (priorities present, a missing root value) or treat differently (reanalysed values) go through it one by one.
     Returns the number of games that got priorities.
+
+    ``backend`` (a ``mzx._lib.Backend``: what ``SelfPlay.continuous_self_play`` passes): the groups are computed ON THE
+    DEVICE (``device_priorities``: one upload of a group's root values / rewards / to_play, one kernel, one download) --
+    the horizon loop and the power leave the interpreter altogether; same float32 priorities
+    (tests/test_replay_handoff.py on the serial build, tests/test_gpu_parity.py on the device against the reference's
+    own save_game outputs).
     """
     if not getattr(config, "PER", False):
         return 0
@@ -135,6 +169,14 @@ def fill_initial_priorities_many(histories, config):
     td, discount, alpha = int(config.td_steps), config.discount, config.PER_alpha
     for rv, tp, rewards, members in jobs:
         k, T = rv.shape
+        if backend is not None:
+            priorities, top = device_priorities(backend, rv, tp, rewards, config)
+            with gc_paused():
+                for j, h in enumerate(members):
+                    h.priorities = priorities[j]        # (a row of the downloaded array: nothing else refers to it)
+                    h.game_priority = top[j]
+            filled += k
+            continue
         value = numpy.zeros((k, T), numpy.float64)
         m = T - td
         if m > 0:          # bootstrap: +-root_values[index + td] * discount ** td

@@ -1036,7 +1036,7 @@ class SelfPlay:
                 # initial PER priorities, vectorised (replay_buffer.py:39-51 would loop in Python) -- the games a shard
                 # hands out together in ONE pass over their record; save_game then takes its "priorities already
                 # present" branch
-                replay.fill_initial_priorities_many(histories, self.config)
+                replay.fill_initial_priorities_many(histories, self.config, backend=self.model.backend)
                 for game_history in histories:
                     _remote(replay_buffer.save_game, game_history, shared_storage)
             else:

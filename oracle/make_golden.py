@@ -426,6 +426,57 @@ def make_replay_batch_fixture():
     print("replay batch cases", len(cases))
 
 
+def make_replay_priorities_fixture():
+    """
+    Initial PER priorities as the UNMODIFIED ``ReplayBuffer.save_game`` computes them (replay_buffer.py:39-51, :230-262) for
+    records of seeded games -- G games of T moves each per case: root values, reward / to_play histories in, float32
+    priorities + game priorities out.  tests/test_gpu_parity.py::test_replay_priorities_on_device_match_the_reference
+    runs mzx_replay_priorities on the same arrays ON THE DEVICE and compares bit for bit.
+    """
+    import copy
+    import types
+
+    ref_shim.load()
+    import replay_buffer as ref_rb
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "muzero-general_amd"))
+    from mzx import self_play as mzx_self_play
+
+    cases, data = [], {}
+    shapes = [(7, 1, 1, False), (33, 9, 2, False), (64, 32, 1, False), (12, 57, 2, True), (5, 300, 1, True), (40, 42, 2, False)]
+    configs_ = [dict(td_steps=50, discount=0.997, PER_alpha=0.5), dict(td_steps=10, discount=0.997, PER_alpha=0.5),
+                dict(td_steps=9, discount=1, PER_alpha=0.5), dict(td_steps=3, discount=0.9, PER_alpha=1)]
+    for c, cfg in enumerate(configs_):
+        config = types.SimpleNamespace(PER=True, seed=0, replay_buffer_size=10 ** 6, **cfg)
+        rb = ref_rb.ReplayBuffer({"num_played_games": 0, "num_played_steps": 0}, {}, config)
+        for q, (G, T, players, float_rewards) in enumerate(shapes):
+            rs = numpy.random.RandomState(1000 * c + q)
+            rv = rs.standard_normal((G, T)) * (1.0 + 4.0 * (q % 2))
+            rv[rs.rand(G, T) < 0.05] = 0.0                               # unvisited roots report 0
+            rew = numpy.zeros((G, T + 1))
+            rew[:, 1:] = rs.standard_normal((G, T)) if float_rewards else rs.randint(0, 2, size=(G, T))
+            tp = numpy.tile(numpy.arange(T + 1) % players, (G, 1))
+            if players == 2:
+                tp[rs.rand(G) < 0.5] ^= 1
+            pri, top = numpy.zeros((G, T), numpy.float32), numpy.zeros(G, numpy.float32)
+            for g in range(G):
+                gh = mzx_self_play.GameHistory()
+                gh.root_values = [float(v) for v in rv[g]]
+                gh.reward_history = [float(r) if float_rewards else int(r) for r in rew[g]]
+                gh.to_play_history = [int(x) for x in tp[g]]
+                gh.action_history = [0] * (T + 1)
+                gh.child_visits = [[1.0]] * T
+                gh.observation_history = [numpy.zeros((1, 1, 1))] * (T + 1)
+                rb.save_game(gh)                                          # the reference computes and stores the priorities
+                pri[g], top[g] = gh.priorities, gh.game_priority
+            key = f"c{c}_q{q}"
+            data[key + "_root_values"], data[key + "_rewards"], data[key + "_to_play"] = rv, rew, tp.astype(numpy.int32)
+            data[key + "_priorities"], data[key + "_game_priority"] = pri, top
+        cases.append(cfg)
+    data["meta"] = numpy.array(json.dumps(dict(configs=cases, shapes=[list(s) for s in shapes])))
+    numpy.savez_compressed(os.path.join(OUT, "replay_priorities.npz"), **data)
+    print("replay priority cases", len(cases) * len(shapes))
+
+
 def make_large_residual_fixtures():
     """
     The reference's two large residual configurations AS SHIPPED (games/gomoku.py:56-64: 128 channels x 6 blocks
@@ -452,6 +503,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if "--large-residual" in sys.argv or "--large-trees-only" in sys.argv:
         make_large_residual_fixtures()
+        return
+    if "--replay-priorities" in sys.argv:
+        make_replay_priorities_fixture()
         return
     full = lambda c, cfg: list(cfg.action_space)
 
@@ -524,6 +578,7 @@ def main():
     make_virtual_fixture("cartpole", "cartpole", 41, 3, 4)
     make_virtual_fixture("tictactoe", "tictactoe", 42, 4, 3)
     make_replay_batch_fixture()
+    make_replay_priorities_fixture()
     make_large_residual_fixtures()
 
 

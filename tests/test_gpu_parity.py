@@ -968,6 +968,74 @@ def test_reanalyse_long_game_matches_oracle(backend):
     assert numpy.allclose(got, want, atol=3 * TOL, rtol=3 * TOL), numpy.abs(got - want).max()
 
 
+# ---- replay hand-off: initial PER priorities on the device
+
+def test_replay_priorities_on_device_match_the_reference(backend):
+    """
+    mzx_replay_priorities (csrc/mzx_replay.h) on the device against what the UNMODIFIED ReplayBuffer.save_game computed
+    (replay_buffer.py:39-51, :230-262) for records of seeded games -- tests/golden/replay_priorities.npz, written by
+    oracle/make_golden.py --replay-priorities from the imported reference: float32 priorities and game priorities BIT FOR BIT
+    (PER_alpha 0.5 / 1: binary64 sqrt / identity behind bit-exact binary64 targets); one / two players, integer and float
+    rewards, unvisited roots, horizons longer and shorter than the games, discount 1.
+    """
+    from mzx import replay
+    import types
+
+    z = numpy.load(os.path.join(GOLDEN, "replay_priorities.npz"))
+    meta = json.loads(str(z["meta"]))
+    checked = 0
+    for c, cfg in enumerate(meta["configs"]):
+        config = types.SimpleNamespace(PER=True, **cfg)
+        for q in range(len(meta["shapes"])):
+            key = f"c{c}_q{q}"
+            pri, top, targets = replay.device_priorities(backend, z[key + "_root_values"], z[key + "_to_play"], z[key + "_rewards"],
+                                                         config, want_targets=True)
+            want, want_top = z[key + "_priorities"], z[key + "_game_priority"]
+            assert pri.dtype == numpy.float32 and pri.shape == want.shape
+            assert numpy.array_equal(pri.view(numpy.int32), want.view(numpy.int32)), (cfg, q, float(numpy.abs(pri - want).max()))
+            assert numpy.array_equal(top.view(numpy.int32), want_top.view(numpy.int32)), (cfg, q)
+            checked += pri.size
+    assert checked > 20000
+
+
+@pytest.mark.parametrize("alpha", [0.5, 1, 0.7])
+def test_replay_hand_off_of_shard_records_on_device(backend, alpha):
+    """fill_initial_priorities_many(..., backend) on shard records and plain histories ON THE DEVICE against the per-game host
+    function (itself bit-identical to the reference, tests/test_replay_handoff.py); targets against the restatement of
+    compute_target_value as binary64 bit patterns.  PER_alpha = 0.7 (no shipped configuration): the device's pow, held to
+    one float32 ulp."""
+    import test_replay_handoff as handoff
+
+    handoff.check_device_priorities(backend, dict(td_steps=50, discount=0.997, PER_alpha=alpha), exact_pow=False)
+    handoff.check_device_priorities(backend, dict(td_steps=5, discount=0.9, PER_alpha=alpha), exact_pow=False)
+
+
+def test_native_rounds_on_device_equal_the_python_loop(backend):
+    """mzx_selfplay_rounds (csrc/mzx_actor.h) on the device: BASELINE C2's shard shape in small (512 synthetic games, two slot
+    groups, asynchronous searches behind events) and 96 connect4 games on the residual engine against SelfPlay._rounds_batched
+    on the same game objects -- every game field for field, same order, same stream states."""
+    import test_native_rounds as native
+
+    from mzx import games
+
+    games.NativeBatchedGame.backend = backend
+    cfg = configs.cartpole(max_moves=6)
+    weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg).state_dict(), 4)
+    Native = games.make_native_synthetic_game(cfg.observation_shape, len(cfg.action_space), len(cfg.players))
+    calls = [(1.0, {}), (0.5, dict(max_rounds=4, min_games=1 << 60)), (1.0, dict(min_games=1500))]
+    a = native._run(backend, Native, cfg, weights, 512, 1000, calls, True, True)
+    b = native._run(backend, Native, cfg, weights, 512, 1000, calls, False, True)
+    assert a[4] and not b[4] and a[3] == b[3] == 2
+    native._assert_equal_runs(a, b)
+    cfg = configs.connect4(num_simulations=10)
+    weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg).state_dict(), 5)
+    calls = [(1.0, dict(min_games=40)), (0.25, dict(min_games=100))]
+    a = native._run(backend, games.Connect4Native, cfg, weights, 96, 3, calls, True, False)
+    b = native._run(backend, games.Connect4Batched, cfg, weights, 96, 3, calls, False, False)
+    assert a[4] and not b[4]
+    native._assert_equal_runs(a, b)
+
+
 # ---- reference-compat facade (SURVEY.md 8f row 4): Node graph + override_root_with on the device
 
 import test_virtual_trajectory as virtual_common  # noqa: E402

@@ -155,3 +155,43 @@ def test_plain_game_histories_of_equal_length_in_one_pass(cfg):
         assert a.priorities.dtype == numpy.float32
         assert numpy.array_equal(a.priorities.view(numpy.int32), b.priorities.view(numpy.int32))
         assert a.game_priority == b.game_priority and type(a.game_priority) is type(b.game_priority)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_device_kernel_path_equals_the_per_game_function(cfg):
+    """``fill_initial_priorities_many(..., backend=...)``: the groups go through mzx_replay_priorities (csrc/mzx_replay.h; here
+    the serial build of the same functor, on the device in tests/test_gpu_parity.py) -- target values bit for bit the
+    reference's (binary64), priorities the same float32."""
+    import hostcheck
+
+    check_device_priorities(hostcheck.backend(), cfg, exact_pow=True)
+
+
+def check_device_priorities(backend, cfg, exact_pow):
+    config = types.SimpleNamespace(PER=True, **cfg)
+    rs = numpy.random.RandomState(11 + cfg["td_steps"])
+    for k, T, players, fl, tm, holes in [(5, 1, 1, False, True, False), (17, 9, 2, False, True, False), (6, 57, 1, True, False, False),
+                                         (9, 42, 2, True, True, True), (3, 300, 1, False, True, False), (130, 32, 1, False, False, False)]:
+        state = rs.get_state()
+        bulk = _record_views(rs, k, T, players, fl, tm, holes)
+        rs.set_state(state)
+        single = _record_views(rs, k, T, players, fl, tm, holes)
+        plain = [_game(rs, 21, 2, True) for _ in range(6)]          # ordinary GameHistory objects of one length ride along
+        twins = copy.deepcopy(plain)
+        assert replay.fill_initial_priorities_many(bulk + plain, config, backend=backend) == k + 6
+        for a, b in zip(bulk + plain, single + twins):
+            assert replay.fill_initial_priorities(b, config)
+            assert a.priorities.dtype == numpy.float32 and a.priorities.shape == b.priorities.shape
+            if exact_pow or cfg["PER_alpha"] in (0.5, 1):
+                assert numpy.array_equal(a.priorities.view(numpy.int32), b.priorities.view(numpy.int32)), (cfg, k, T)
+                assert a.game_priority == b.game_priority
+            else:       # the device's pow against libm's: one float32 ulp (csrc/mzx_replay.h)
+                assert (numpy.abs(a.priorities.view(numpy.int32).astype(numpy.int64) - b.priorities.view(numpy.int32)) <= 1).all()
+            assert type(a.game_priority) is type(b.game_priority)
+        # compute_target_value itself, binary64 bit patterns, against the reference restatement
+        record, T0 = single[0].__dict__["_view"][0], T
+        rv = numpy.where(record.totals[:, :T0] > 0, record.vals[:, :T0], 0.0)
+        _, _, targets = replay.device_priorities(backend, rv, record.tps[:, : T0 + 1], record.rews[:, : T0 + 1], config, want_targets=True)
+        for j in (0, k - 1):
+            want = [replay_oracle.compute_target_value(single[j], i, config) for i in range(T0)]
+            assert numpy.array_equal(targets[j].view(numpy.int64), numpy.array(want, numpy.float64).view(numpy.int64)), (cfg, k, T, j)
