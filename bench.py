@@ -515,6 +515,7 @@ def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=F
         "steps_per_sec_with_all_histories_as_lists": steps / (wall + (materialize if batched else 0.0)),
         "game_protocol": "native rounds (mzx_selfplay_rounds)" if native else "batched" if batched else "B Game objects",
         "slot_groups": len((sp._live or {}).get("groups", ())) or 1,
+        **({"native_phase_ms": [round(x * 1e3, 2) for x in sp.stats["native_phase_seconds"]]} if "native_phase_seconds" in sp.stats else {}),
     }
 
 

@@ -58,6 +58,8 @@ int mzx_is_device_build(void);
  *   rt_search      the tower whole-search kernel (every simulation in one launch): -1 automatic, 0 never, 1 whenever
  *                  the network fits;  rt_trees > 0: trees per workgroup;  rt_waves 4 | 8: waves per workgroup (0: cost
  *                  model);  rt_max_trees: largest shard routed to it;  rt_dbg: timing knock-outs (wrong results)
+ *   rounds_streams mzx_selfplay_rounds: 1 = every slot group behind the first searches on a stream of its own (two half-shard
+ *                  searches of a small network run side by side); 0 = all on the caller's stream (the A/B)
  * mzx_tuning_set / _get return MZX_ERR_INVALID for an unknown name or a value out of range; mzx_tuning_name /
  * _help enumerate the table (NULL past its end).
  * ------------------------------------------------------------------------- */
@@ -522,6 +524,10 @@ typedef struct mzx_rounds {
   mzx_retry_fn retry; void* retry_ctx;
   int64_t rounds, games, searches; /* out: rounds played, games finished, searches run (one per slot and round) */
   double search_seconds;           /* out: host time queueing searches + waiting for them */
+  double phase_seconds[6];         /* out: where the host time went -- 0 mzx_selfplay_search (draws, staging, upload, launch,
+                                      download queued), 1 waiting for a search's event, 2 the per-move region (action draws, log
+                                      row, Game.step, next position), 3 finished games copied out + slots restarted, 4 tape
+                                      retries, 5 the rest of the call */
 } mzx_rounds;
 int mzx_selfplay_rounds(mzx_actor* const* groups, int32_t num_groups, mzx_rounds* io, void* stream);
 int mzx_actor_finished(const mzx_actor* a, int64_t out[2]);

@@ -45,6 +45,8 @@ struct mzx_actor {
   int64_t round = 0;
   bool pending = false;
   void* event = nullptr;                 // recorded behind the queued download of the search in flight
+  void* own_stream = nullptr;            // groups behind the first search on a stream of their own (created on first use)
+  void* start_event = nullptr;           // orders that stream behind what the caller queued before the call
   // the log of the games in progress: ring rows [round % cap][slot]
   int64_t cap = 0;
   std::vector<float> r_obs;
@@ -112,7 +114,7 @@ inline void actor_refresh(mzx_actor* a) {
   });
 }
 
-inline int actor_begin(mzx_actor* a, void* stream, double* search_seconds) {
+inline int actor_begin(mzx_actor* a, void* stream, double* search_seconds, double* phase) {
   const double t0 = actor_now();
   mzx_move& m = a->move;
   m.streams = a->streams.data();
@@ -126,7 +128,9 @@ inline int actor_begin(mzx_actor* a, void* stream, double* search_seconds) {
   rc = event_record(&a->event, (stream_t)stream);
   if (rc) { set_error("mzx_selfplay_rounds: event record failed: %s", runtime_error_string(rc)); return MZX_ERR_RUNTIME; }
   a->pending = true;
-  *search_seconds += actor_now() - t0;
+  const double dt = actor_now() - t0;
+  *search_seconds += dt;
+  phase[0] += dt;
   return MZX_OK;
 }
 
@@ -194,6 +198,7 @@ inline void actor_harvest(mzx_actor* a, const std::vector<int32_t>& idx, int64_t
 typedef int (*actor_retry_fn)(void* ctx, int32_t group, int32_t count, const int32_t* games);
 
 struct RoundsArgs {
+  double* phase;               // [6] accumulators (mzx_rounds::phase_seconds)
   double temperature;
   int32_t temperature_threshold;
   const double* pow_table; int32_t table_stride; const double* table_temperatures; int32_t num_temperatures;
@@ -207,7 +212,9 @@ inline int actor_consume(mzx_actor* a, int group, const RoundsArgs& args, int64_
   int rc = event_wait(a->event);
   if (rc) { set_error("mzx_selfplay_rounds: waiting for the search failed: %s", runtime_error_string(rc)); return MZX_ERR_RUNTIME; }
   a->pending = false;
-  *search_seconds += actor_now() - t0;
+  double t1 = actor_now();
+  *search_seconds += t1 - t0;
+  args.phase[1] += t1 - t0;
   const int B = a->B, A = a->A;
   const int64_t E = a->E;
   const mzx_move& m = a->move;
@@ -224,6 +231,9 @@ inline int actor_consume(mzx_actor* a, int group, const RoundsArgs& args, int64_
     if (!args.retry) { set_error("mzx_selfplay_rounds: a search exhausted its tie-break tape and no retry callback was given"); return MZX_ERR_RUNTIME; }
     rc = args.retry(args.retry_ctx, group, (int32_t)redo.size(), redo.data());
     if (rc) { set_error("mzx_selfplay_rounds: the tape-retry callback failed (%d)", rc); return MZX_ERR_RUNTIME; }
+    const double t2 = actor_now();
+    args.phase[4] += t2 - t1;
+    t1 = t2;
   }
   for (int k = 0; k < B; ++k)
     if (info[4 * k + 1] != 0) { set_error("search flagged tree %d (flags %d): node arena exhausted", k, info[4 * k + 1]); return MZX_ERR_RUNTIME; }
@@ -233,49 +243,75 @@ inline int actor_consume(mzx_actor* a, int group, const RoundsArgs& args, int64_
     const int64_t moves_before = r - a->start[k];
     a->move_temps[k] = (args.temperature_threshold && moves_before + 1 >= args.temperature_threshold) ? 0.0 : a->temps[k];   // self_play.py:151-157
   }
-  mzx_move sel = m;
-  sel.streams = a->streams.data(); sel.legal_actions = a->legal.data();
-  rc = mzx_selfplay_select(a->bank, &sel, a->n_legal.data(), a->words.data(), visits, a->move_temps.data(), args.pow_table,
-                           args.table_stride, args.table_temperatures, args.num_temperatures, a->actions.data());
+  if (A > 4096) { set_error("mzx_selfplay_rounds: more than 4096 actions"); return MZX_ERR_INVALID; }
+  rc = select_check(a->legal.data(), a->n_legal.data(), visits, a->move_temps.data(), B, A, args.table_stride, args.table_temperatures,
+                    args.num_temperatures);
   if (rc) return rc;
   int64_t lo_start = r;
   for (int k = 0; k < B; ++k) lo_start = std::min(lo_start, a->start[k]);
   actor_grow_ring(a, r - lo_start + 1);
   const int64_t c = r % a->cap;
-  // the move's row: position searched (observation, side to move), action, search statistics; the reward follows the step
-  memcpy(&a->r_obs[(size_t)(c * B * E)], a->cur_obs.data(), sizeof(float) * (size_t)(B * E));
-  memcpy(&a->r_tp[(size_t)(c * B)], a->to_play.data(), sizeof(int32_t) * (size_t)B);
-  memcpy(&a->r_act[(size_t)(c * B)], a->actions.data(), sizeof(int64_t) * (size_t)B);
-  memcpy(&a->r_vis[(size_t)(c * B * A)], visits, sizeof(int32_t) * (size_t)(B * A));
-  memcpy(&a->r_val[(size_t)(c * B)], root_value, sizeof(double) * (size_t)B);
-  if (!a->r_mask.empty()) {
-    uint8_t* mk = &a->r_mask[(size_t)(c * B * A)];
-    memset(mk, 0, (size_t)(B * A));
-    for (int k = 0; k < B; ++k)
-      for (int j = 0; j < a->n_legal[k]; ++j) mk[(size_t)k * A + a->legal[(size_t)k * A + j]] = 1;
-  }
+  SelectArgs sa;
+  sa.r = a->bank; sa.idx = a->streams.data(); sa.legal_all = a->legal.data(); sa.n_legal = a->n_legal.data(); sa.words = a->words.data();
+  sa.visit_counts = visits; sa.temperature = a->move_temps.data(); sa.pow_table = args.pow_table; sa.table_stride = args.table_stride;
+  sa.table_temperatures = args.table_temperatures; sa.num_temperatures = args.num_temperatures; sa.action = a->actions.data(); sa.A = A;
   mzx_game* g = a->game;
+  const bool masks = !a->r_mask.empty();
+  const int max_moves = a->max_moves;
+  // ONE region per move and slot group: per game [lo, hi) the action draw (the stream consumes the search's tie words first),
+  // the move's row of the log -- position searched (observation, side to move), action, search statistics, legal set --,
+  // Game.step, the reward, and the next position (observation, side to move, legal actions) for the next search
   rng_parallel(a->bank, B, m.num_threads, [=](int lo, int hi) {
+    select_range(sa, lo, hi);
+    const size_t n = (size_t)(hi - lo);
+    memcpy(&a->r_obs[(size_t)((c * B + lo) * E)], &a->cur_obs[(size_t)lo * E], sizeof(float) * n * (size_t)E);
+    memcpy(&a->r_tp[(size_t)(c * B + lo)], &a->to_play[lo], sizeof(int32_t) * n);
+    memcpy(&a->r_act[(size_t)(c * B + lo)], &a->actions[lo], sizeof(int64_t) * n);
+    memcpy(&a->r_vis[(size_t)((c * B + lo) * A)], visits + (size_t)lo * A, sizeof(int32_t) * n * (size_t)A);
+    memcpy(&a->r_val[(size_t)(c * B + lo)], root_value + lo, sizeof(double) * n);
+    if (masks) {
+      uint8_t* mk = &a->r_mask[(size_t)((c * B + lo) * A)];
+      memset(mk, 0, n * (size_t)A);
+      for (int k = lo; k < hi; ++k)
+        for (int j = 0; j < a->n_legal[k]; ++j) mk[(size_t)(k - lo) * A + a->legal[(size_t)k * A + j]] = 1;
+    }
     g->step(lo, hi, a->actions.data(), nullptr, a->reward.data(), a->done.data());
+    memcpy(&a->r_rew[(size_t)(c * B + lo)], &a->reward[lo], sizeof(double) * n);
     g->observe(lo, hi, a->next_obs.data());
     g->to_play(lo, hi, a->to_play.data());
+    g->legal_actions(lo, hi, a->legal.data());
+    for (int k = lo; k < hi; ++k)
+      if ((r - a->start[k]) + 2 > max_moves) a->done[k] = 1;        // len(action_history) <= max_moves, self_play.py:129
   });
-  memcpy(&a->r_rew[(size_t)(c * B)], a->reward.data(), sizeof(double) * (size_t)B);
+  {
+    const double t2 = actor_now();
+    args.phase[2] += t2 - t1;
+    t1 = t2;
+  }
   std::vector<int32_t> over;
   for (int k = 0; k < B; ++k)
-    if (a->done[k] || (r - a->start[k]) + 2 > a->max_moves) over.push_back(k);        // len(action_history) <= max_moves, :129
+    if (a->done[k]) over.push_back(k);
   if (!over.empty()) {
     actor_harvest(a, over, r, sequence);
     *games_done += (int64_t)over.size();
     g->reset(over.data(), (int32_t)over.size());          // the slots' next games begin (self_play.py:31-52)
+    // first positions of the restarted slots, run by run of consecutive slots
+    for (size_t q = 0; q < over.size();) {
+      size_t e = q + 1;
+      while (e < over.size() && over[e] == over[e - 1] + 1) ++e;
+      const int lo = over[q], hi = over[e - 1] + 1;
+      g->observe(lo, hi, a->next_obs.data());
+      g->to_play(lo, hi, a->to_play.data());
+      g->legal_actions(lo, hi, a->legal.data());
+      q = e;
+    }
     for (int32_t s : over) {
-      g->observe(s, s + 1, a->next_obs.data());
       a->start[s] = r + 1;
       a->temps[s] = args.temperature;
     }
   }
   a->cur_obs.swap(a->next_obs);
-  actor_refresh(a);
+  args.phase[3] += actor_now() - t1;
   a->round = r + 1;
   return MZX_OK;
 }

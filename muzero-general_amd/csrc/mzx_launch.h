@@ -43,6 +43,9 @@ inline int stream_sync(stream_t) { return 0; }
 inline int event_record(void** ev, stream_t) { *ev = (void*)1; return 0; }
 inline int event_wait(void*) { return 0; }
 inline void event_destroy(void*) {}
+inline int stream_create(void** out) { *out = nullptr; return 0; }
+inline void stream_destroy(void*) {}
+inline int stream_wait_event(stream_t, void*) { return 0; }
 
 inline int device_alloc(void** out, size_t bytes) {
   *out = malloc(bytes);
@@ -100,6 +103,16 @@ inline int event_record(void** ev, stream_t stream) {
 }
 inline int event_wait(void* ev) { return ev ? (int)hipEventSynchronize((hipEvent_t)ev) : 0; }
 inline void event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+// a library-owned stream (the second slot group of a natively played shard searches on its own: two searches of half a shard
+// each fill half the chip -- they run side by side instead of one after the other)
+inline int stream_create(void** out) {
+  hipStream_t st = nullptr;
+  const hipError_t rc = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  *out = (void*)st;
+  return (int)rc;
+}
+inline void stream_destroy(void* st) { if (st) (void)hipStreamDestroy((hipStream_t)st); }
+inline int stream_wait_event(stream_t stream, void* ev) { return ev ? (int)hipStreamWaitEvent(stream, (hipEvent_t)ev, 0) : 0; }
 
 // small library-owned device allocations (the search's pb_c / sqrt tables); every large buffer is the caller's
 inline int device_alloc(void** out, size_t bytes) { return (int)hipMalloc(out, bytes); }

@@ -829,6 +829,80 @@ int mzx_rng_choice_weighted(mzx_rng* r, const int32_t* idx, int32_t count, const
   return MZX_OK;
 }
 
+}  // extern "C"
+
+namespace mzx {
+
+// SelfPlay.select_action (self_play.py:222-245) for the games [lo, hi) of a move: the streams first consume the tie-break
+// words the search used (mzx_rng_advance), then every game's action is drawn.  Shared by mzx_selfplay_select and the round
+// loop of mzx_actor.h (where it runs inside the per-move region together with the game step).
+struct SelectArgs {
+  mzx_rng* r; const int32_t* idx; const int32_t* legal_all; const int32_t* n_legal; const int32_t* words; const int32_t* visit_counts;
+  const double* temperature; const double* pow_table; int32_t table_stride; const double* table_temperatures; int32_t num_temperatures;
+  int64_t* action; int32_t A;
+};
+
+inline void select_range(const SelectArgs& s, int lo, int hi) {
+  mzx_rng* r = s.r;
+  const int32_t* idx = s.idx;
+  const int A = s.A;
+  double cdf[4096];
+  for (int k = lo; k < hi; ++k) {
+    if (k + 1 < hi) {
+      const Mt19937& nx = r->streams[idx[k + 1]];
+      __builtin_prefetch(&nx.pos);
+      __builtin_prefetch(&nx.key[nx.pos < 624 ? nx.pos : 0]);
+    }
+    Mt19937& g = r->streams[idx[k]];
+    if (s.words) for (int32_t j = 0; j < s.words[k]; ++j) g.next32();        // what the search consumed (mzx_rng_advance)
+    const int32_t* legal = s.legal_all + (size_t)k * A;
+    const int32_t* vis = s.visit_counts + (size_t)k * A;
+    const int n = s.n_legal[k];
+    const double t = s.temperature[k];
+    int pos = 0;
+    if (t == 0.0) {                            // actions[numpy.argmax(visit_counts)]: the first maximum
+      int32_t best = vis[legal[0]];
+      for (int j = 1; j < n; ++j) if (vis[legal[j]] > best) { best = vis[legal[j]]; pos = j; }
+    } else if (t == MZX_INF) {                 // numpy.random.choice(actions)
+      pos = (int)g.bounded((uint32_t)n);
+    } else {                                   // numpy.random.choice(actions, p=dist / sum(dist)): mzx_rng_choice_weighted
+      int row = 0;
+      for (int q = 0; q < s.num_temperatures; ++q) if (s.table_temperatures[q] == t) row = q;
+      const double* tab = s.pow_table + (size_t)row * s.table_stride;
+      double total = 0.0;
+      for (int j = 0; j < n; ++j) total = total + tab[vis[legal[j]]];
+      double acc = 0.0;
+      for (int j = 0; j < n; ++j) { acc = acc + tab[vis[legal[j]]] / total; cdf[j] = acc; }
+      const double last = cdf[n - 1];
+      const double u = g.next_double();
+      for (int j = 0; j < n; ++j) pos += (cdf[j] / last <= u) ? 1 : 0;
+    }
+    s.action[k] = legal[pos < n ? pos : n - 1];
+  }
+}
+
+// the argument checks of mzx_selfplay_select (temperatures have a power table row, visit counts lie inside it)
+inline int select_check(const int32_t* legal_all, const int32_t* n_legal, const int32_t* visit_counts, const double* temperature,
+                        int B, int A, int32_t table_stride, const double* table_temperatures, int32_t num_temperatures) {
+  for (int k = 0; k < B; ++k) {
+    if (n_legal[k] < 1 || n_legal[k] > A) { set_error("n_legal[%d] = %d out of range", k, n_legal[k]); return MZX_ERR_INVALID; }
+    const double t = temperature[k];
+    if (t == 0.0 || t == MZX_INF) continue;
+    int row = -1;
+    for (int q = 0; q < num_temperatures; ++q) if (table_temperatures[q] == t) row = q;
+    if (row < 0) { set_error("mzx_selfplay_select: no power table for temperature %g", t); return MZX_ERR_INVALID; }
+    const int32_t* legal = legal_all + (size_t)k * A;
+    const int32_t* vis = visit_counts + (size_t)k * A;
+    for (int j = 0; j < n_legal[k]; ++j)
+      if (vis[legal[j]] < 0 || vis[legal[j]] >= table_stride) { set_error("visit count %d outside the power table", vis[legal[j]]); return MZX_ERR_INVALID; }
+  }
+  return MZX_OK;
+}
+
+}  // namespace mzx
+
+extern "C" {
+
 // ------------------------------------------------------------- a self-play move of a shard behind two calls
 
 static int move_check(const mzx_rng* r, const mzx_move* m) {
@@ -929,55 +1003,13 @@ int mzx_selfplay_select(mzx_rng* r, const mzx_move* m, const int32_t* n_legal, c
   }
   const int B = m->num_games, A = m->action_space_size;
   if (A > 4096) { set_error("mzx_selfplay_select: more than 4096 actions"); return MZX_ERR_INVALID; }
-  for (int k = 0; k < B; ++k) {
-    if (n_legal[k] < 1 || n_legal[k] > A) { set_error("n_legal[%d] = %d out of range", k, n_legal[k]); return MZX_ERR_INVALID; }
-    const double t = temperature[k];
-    if (t == 0.0 || t == MZX_INF) continue;
-    int row = -1;
-    for (int q = 0; q < num_temperatures; ++q) if (table_temperatures[q] == t) row = q;
-    if (row < 0) { set_error("mzx_selfplay_select: no power table for temperature %g", t); return MZX_ERR_INVALID; }
-    const int32_t* legal = m->legal_actions + (size_t)k * A;
-    const int32_t* vis = visit_counts + (size_t)k * A;
-    for (int j = 0; j < n_legal[k]; ++j)
-      if (vis[legal[j]] < 0 || vis[legal[j]] >= table_stride) { set_error("visit count %d outside the power table", vis[legal[j]]); return MZX_ERR_INVALID; }
-  }
-  const int32_t* idx = m->streams;
-  const int32_t* legal_all = m->legal_actions;
-  rng_parallel(r, B, m->num_threads, [=](int lo, int hi) {
-    double cdf[4096];
-    for (int k = lo; k < hi; ++k) {
-      if (k + 1 < hi) {
-        const Mt19937& nx = r->streams[idx[k + 1]];
-        __builtin_prefetch(&nx.pos);
-        __builtin_prefetch(&nx.key[nx.pos < 624 ? nx.pos : 0]);
-      }
-      Mt19937& g = r->streams[idx[k]];
-      if (words) for (int32_t j = 0; j < words[k]; ++j) g.next32();        // what the search consumed (mzx_rng_advance)
-      const int32_t* legal = legal_all + (size_t)k * A;
-      const int32_t* vis = visit_counts + (size_t)k * A;
-      const int n = n_legal[k];
-      const double t = temperature[k];
-      int pos = 0;
-      if (t == 0.0) {                            // actions[numpy.argmax(visit_counts)]: the first maximum
-        int32_t best = vis[legal[0]];
-        for (int j = 1; j < n; ++j) if (vis[legal[j]] > best) { best = vis[legal[j]]; pos = j; }
-      } else if (t == MZX_INF) {                 // numpy.random.choice(actions)
-        pos = (int)g.bounded((uint32_t)n);
-      } else {                                   // numpy.random.choice(actions, p=dist / sum(dist)): mzx_rng_choice_weighted
-        int row = 0;
-        for (int q = 0; q < num_temperatures; ++q) if (table_temperatures[q] == t) row = q;
-        const double* tab = pow_table + (size_t)row * table_stride;
-        double total = 0.0;
-        for (int j = 0; j < n; ++j) total = total + tab[vis[legal[j]]];
-        double acc = 0.0;
-        for (int j = 0; j < n; ++j) { acc = acc + tab[vis[legal[j]]] / total; cdf[j] = acc; }
-        const double last = cdf[n - 1];
-        const double u = g.next_double();
-        for (int j = 0; j < n; ++j) pos += (cdf[j] / last <= u) ? 1 : 0;
-      }
-      action[k] = legal[pos < n ? pos : n - 1];
-    }
-  });
+  rc = select_check(m->legal_actions, n_legal, visit_counts, temperature, B, A, table_stride, table_temperatures, num_temperatures);
+  if (rc) return rc;
+  SelectArgs sa;
+  sa.r = r; sa.idx = m->streams; sa.legal_all = m->legal_actions; sa.n_legal = n_legal; sa.words = words; sa.visit_counts = visit_counts;
+  sa.temperature = temperature; sa.pow_table = pow_table; sa.table_stride = table_stride; sa.table_temperatures = table_temperatures;
+  sa.num_temperatures = num_temperatures; sa.action = action; sa.A = A;
+  rng_parallel(r, B, m->num_threads, [=](int lo, int hi) { select_range(sa, lo, hi); });
   return MZX_OK;
 }
 
@@ -1101,6 +1133,8 @@ void mzx_actor_destroy(mzx_actor* a) {
   if (!a) return;
   if (a->pending) (void)event_wait(a->event);
   event_destroy(a->event);
+  event_destroy(a->start_event);
+  stream_destroy(a->own_stream);
   delete a;
 }
 
@@ -1108,7 +1142,10 @@ int mzx_selfplay_rounds(mzx_actor* const* groups, int32_t num_groups, mzx_rounds
   if (!groups || num_groups < 1 || !io) { set_error("mzx_selfplay_rounds: missing argument"); return MZX_ERR_INVALID; }
   for (int k = 0; k < num_groups; ++k)
     if (!groups[k]) { set_error("mzx_selfplay_rounds: null group"); return MZX_ERR_INVALID; }
+  const double t_call = actor_now();
+  for (double& x : io->phase_seconds) x = 0.0;
   RoundsArgs args;
+  args.phase = io->phase_seconds;
   args.temperature = io->temperature; args.temperature_threshold = io->temperature_threshold;
   args.pow_table = io->pow_table; args.table_stride = io->table_stride; args.table_temperatures = io->table_temperatures;
   args.num_temperatures = io->num_temperatures; args.retry = io->retry; args.retry_ctx = io->retry_ctx;
@@ -1116,10 +1153,28 @@ int mzx_selfplay_rounds(mzx_actor* const* groups, int32_t num_groups, mzx_rounds
   double search_seconds = 0.0;
   int rc = MZX_OK;
   const bool pipelined = num_groups > 1;
+  // Streams: the first group searches on the caller's stream, every further group on a stream of its own, ordered behind
+  // whatever the caller queued before this call (a weight upload).  Half a shard of a small network fills half the chip
+  // (C2: 2048 trees = two waves per CU), and such a search is latency-bound -- it takes as long as the whole shard's -- so
+  // the two groups' searches must run SIDE BY SIDE, not one behind the other, for the pipelining to pay.  Every search is
+  // waited for on the host before its results are read and nothing is in flight when the call returns.
+  std::vector<void*> streams((size_t)num_groups, stream);
+  for (int k = 1; k < num_groups && rc == MZX_OK; ++k) {
+    mzx_actor* a = groups[k];
+    if (tune(TUNE_ROUNDS_STREAMS) == 0) break;
+    if (!a->own_stream && stream_create(&a->own_stream) != 0) { a->own_stream = nullptr; continue; }
+    if (!a->own_stream) continue;          // (a build without streams: the caller's)
+    if (event_record(&a->start_event, (stream_t)stream) != 0 || stream_wait_event((stream_t)a->own_stream, a->start_event) != 0) {
+      set_error("mzx_selfplay_rounds: ordering the group's stream behind the caller's failed");
+      rc = MZX_ERR_RUNTIME;
+      break;
+    }
+    streams[(size_t)k] = a->own_stream;
+  }
   // SelfPlay._rounds_batched, statement for statement
   while (rc == MZX_OK && finished < io->min_games && (io->max_rounds < 0 || rounds < io->max_rounds)) {
     for (int k = 0; k < num_groups && rc == MZX_OK; ++k)
-      if (!groups[k]->pending) rc = actor_begin(groups[k], stream, &search_seconds);
+      if (!groups[k]->pending) rc = actor_begin(groups[k], streams[(size_t)k], &search_seconds, io->phase_seconds);
     for (int k = 0; k < num_groups && rc == MZX_OK; ++k) {
       rc = actor_consume(groups[k], k, args, &sequence, &finished, &search_seconds);
       if (rc) break;
@@ -1128,14 +1183,16 @@ int mzx_selfplay_rounds(mzx_actor* const* groups, int32_t num_groups, mzx_rounds
       for (int j = k + 1; j < num_groups; ++j) later += groups[j]->B;
       // certain to be consumed by this call: runs while the host plays the groups after it
       if (pipelined && k + 1 < num_groups && finished + later < io->min_games && (io->max_rounds < 0 || rounds + 1 < io->max_rounds))
-        rc = actor_begin(groups[k], stream, &search_seconds);
+        rc = actor_begin(groups[k], streams[(size_t)k], &search_seconds, io->phase_seconds);
     }
     ++rounds;
   }
   if (rc != MZX_OK) {          // nothing stays in flight behind a failure
-    (void)stream_sync((stream_t)stream);
+    for (int k = 0; k < num_groups; ++k) (void)stream_sync((stream_t)streams[(size_t)k]);
     for (int k = 0; k < num_groups; ++k) groups[k]->pending = false;
   }
+  io->phase_seconds[5] = (actor_now() - t_call) - (io->phase_seconds[0] + io->phase_seconds[1] + io->phase_seconds[2] +
+                                                   io->phase_seconds[3] + io->phase_seconds[4]);
   io->rounds = rounds; io->games = finished; io->searches = searches; io->search_seconds = search_seconds; io->sequence = sequence;
   return rc;
 }

@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -165,18 +166,20 @@ namespace mzx {
 
 // A few persistent worker threads: the per-move draws of a shard (4 096 Dirichlet samples, ~2 us each) are worth
 // spreading over cores, but creating and joining std::threads on every move costs more than the draws themselves
-// (~30 us per thread).  Workers sleep on a condition variable between moves.
+// (~30 us per thread).  A self-play round is two or three such regions of 20 - 100 us each, a fraction of a millisecond
+// apart (mzx_actor.h), so a worker that finished its piece SPINS on the generation counter for a short while before it goes
+// to sleep on the condition variable: waking sixteen sleepers through the futex cost more than the region they were woken
+// for (round 6: the native round loop measured 0.5 ms of a 0.69 ms round in pool hand-offs).  Between calls (no region for
+// ~100 us) the workers sleep.
 class RngPool {
  public:
-  explicit RngPool(int n) : stop_(false), generation_(0), pending_(0) {
+  explicit RngPool(int n) {
     for (int t = 0; t < n; ++t) workers_.emplace_back([this, t]() { loop(t); });
   }
   ~RngPool() {
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      stop_ = true;
-      ++generation_;
-    }
+    stop_.store(true, std::memory_order_seq_cst);
+    generation_.fetch_add(1, std::memory_order_seq_cst);
+    { std::lock_guard<std::mutex> lk(m_); }
     cv_.notify_all();
     for (std::thread& th : workers_) th.join();
   }
@@ -184,45 +187,49 @@ class RngPool {
   // fn(lo, hi) over [0, count) split into size() + 1 pieces (the caller's thread takes one)
   void run(int count, const std::function<void(int, int)>& fn) {
     const int parts = size() + 1, per = (count + parts - 1) / parts;
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      fn_ = &fn; count_ = count; per_ = per; pending_ = size();
-      ++generation_;
-    }
+    fn_ = &fn; count_ = count; per_ = per;
+    pending_.store(size(), std::memory_order_relaxed);
+    generation_.fetch_add(1, std::memory_order_seq_cst);       // publishes fn_ / count_ / per_
+    { std::lock_guard<std::mutex> lk(m_); }                      // (a worker between its last check and its wait holds m_)
     cv_.notify_all();
     const int lo = size() * per;
     if (lo < count) fn(lo, count);
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [this]() { return pending_ == 0; });
+    for (int spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins) {
+      if (spins < 4096) cpu_relax();
+      else std::this_thread::yield();
+    }
   }
 
  private:
+  static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+  }
   void loop(int t) {
     uint64_t seen = 0;
     for (;;) {
-      const std::function<void(int, int)>* fn;
-      int lo, hi;
-      {
+      // wait for the next region: spin first, then sleep
+      int spins = 0;
+      while (generation_.load(std::memory_order_acquire) == seen) {
+        if (++spins < 20000) { cpu_relax(); continue; }
         std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&]() { return generation_ != seen; });
-        seen = generation_;
-        if (stop_) return;
-        fn = fn_;
-        lo = t * per_; hi = lo + per_ < count_ ? lo + per_ : count_;
+        cv_.wait(lk, [&]() { return generation_.load(std::memory_order_seq_cst) != seen; });
       }
-      if (lo < hi) (*fn)(lo, hi);
-      {
-        std::lock_guard<std::mutex> lk(m_);
-        if (--pending_ == 0) done_.notify_one();
-      }
+      seen = generation_.load(std::memory_order_acquire);
+      if (stop_.load(std::memory_order_acquire)) return;
+      const int lo = t * per_, hi = lo + per_ < count_ ? lo + per_ : count_;
+      if (lo < hi) (*fn_)(lo, hi);
+      pending_.fetch_sub(1, std::memory_order_acq_rel);
     }
   }
   std::vector<std::thread> workers_;
   std::mutex m_;
-  std::condition_variable cv_, done_;
-  bool stop_;
-  uint64_t generation_;
-  int pending_, count_ = 0, per_ = 0;
+  std::condition_variable cv_;
+  std::atomic<bool> stop_{false};
+  std::atomic<uint64_t> generation_{0};
+  std::atomic<int> pending_{0};
+  int count_ = 0, per_ = 0;
   const std::function<void(int, int)>* fn_ = nullptr;
 };
 

@@ -81,7 +81,7 @@ class Rounds(ctypes.Structure):
         ("temperature", c_f64), ("temperature_threshold", c_i32), ("table_stride", c_i32), ("pow_table", c_vp),
         ("table_temperatures", c_vp), ("num_temperatures", c_i32), ("reserved", c_i32), ("min_games", c_i64),
         ("max_rounds", c_i64), ("sequence", c_i64), ("retry", RETRY_FN), ("retry_ctx", c_vp), ("rounds", c_i64),
-        ("games", c_i64), ("searches", c_i64), ("search_seconds", c_f64),
+        ("games", c_i64), ("searches", c_i64), ("search_seconds", c_f64), ("phase_seconds", c_f64 * 6),
     ]
 
 

@@ -167,17 +167,25 @@ class NativeShard:
         actor.stats["searches"] += int(io.searches)
         actor.stats["simulations"] += int(io.searches) * engine.num_simulations
         actor.stats["search_seconds"] += float(io.search_seconds)
-        return self.collect()
+        phases = actor.stats.setdefault("native_phase_seconds", [0.0] * 7)      # (diagnostics: where the host time of the calls went)
+        for k in range(6):
+            phases[k] += float(io.phase_seconds[k])
+        import time
+
+        t0 = time.perf_counter()
+        out = self.collect()
+        phases[6] += time.perf_counter() - t0          # the finished games wrapped into GameHistory views (Python)
+        return out
 
     def collect(self):
         """The finished games of every group as ``ShardGameHistory`` views, in the order they finished; their slots."""
-        from .self_play import ShardGameHistory, _ShardRecord, gc_paused
+        from .self_play import ShardGameHistory, ShardGames, _ShardRecord, gc_paused
 
         actor = self._actor
         lib, A = actor.model.backend.lib, len(actor.config.action_space)
         shape = tuple(actor.config.observation_shape)
         E = int(numpy.prod(shape))
-        out = []
+        views_all, seq_all, slot_all, records = [], [], [], []
         for g in self.groups:
             counts = (ctypes.c_int64 * 2)()
             lib.check(lib.mzx_actor_finished(g.handle, ctypes.byref(counts)))
@@ -222,7 +230,18 @@ class NativeShard:
                 record = _ShardRecord(A, take1(obs).reshape((k, n + 1) + shape), take1(acts), take1(rews), take1(tps), v, vl,
                                       totals, ratios, plain.all(1), legal_mask)
                 with gc_paused():
-                    views = [ShardGameHistory(record, j, n) for j in range(k)]
-                out.extend(zip(seq[rows_n].tolist(), views, slot[rows_n].tolist()))
-        out.sort(key=lambda e: e[0])
-        return [e[1] for e in out], [e[2] for e in out]
+                    views = ShardGameHistory.make_many(record, k, n)
+                views_all += views
+                seq_all.append(seq if k == G else seq[rows_n])
+                slot_all.append(slot if k == G else slot[rows_n])
+                records.append((record, n, views))
+        if not views_all:
+            return ShardGames(), []
+        seq, slot = numpy.concatenate(seq_all), numpy.concatenate(slot_all)
+        if (seq[1:] > seq[:-1]).all():          # one group, one length: already in finishing order
+            out, slots = ShardGames(views_all), slot.tolist()
+        else:
+            order = numpy.argsort(seq, kind="stable")
+            out, slots = ShardGames([views_all[i] for i in order.tolist()]), slot[order].tolist()
+        out.records = records
+        return out, slots

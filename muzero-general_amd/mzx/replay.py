@@ -130,6 +130,22 @@ def fill_initial_priorities_many(histories, config, backend=None):
     from .self_play import gc_paused       # (self_play imports this module)
 
     filled, views, plain = 0, {}, {}
+    jobs = []
+    grouped = getattr(histories, "records", None)
+    if grouped and backend is not None and all(len(h.__dict__) == 4 and h.__dict__["priorities"] is None
+                                              for _, _, members in grouped for h in members):
+        # the shard's own grouping (mzx.self_play.ShardGames): fresh views of whole records, in record order -- the record's
+        # arrays as they lie, no per-game discovery
+        for record, T, members in grouped:
+            if T > 0:
+                k = len(members)
+                rv = numpy.where(record.totals[:k, :T] > 0, record.vals[:k, :T], 0.0)        # root.value() or 0
+                jobs.append((rv, record.tps[:k, : T + 1], record.rews[:k, : T + 1], members))
+        if sum(len(m) for _, _, m in grouped) == len(histories):
+            histories = ()
+        else:
+            done = {id(h) for _, _, members in grouped for h in members}
+            histories = [h for h in histories if id(h) not in done]
     for h in histories:
         if h.priorities is not None:
             continue
@@ -145,7 +161,6 @@ def fill_initial_priorities_many(histories, config, backend=None):
                 filled += bool(fill_initial_priorities(h, config))      # (empty, or not a finished game's shape)
             else:
                 plain.setdefault(len(roots), []).append(h)
-    jobs = []
     for record, T, members in views.values():
         rows = numpy.array([i for _, i in members])
         rv = numpy.where(record.totals[rows, :T] > 0, record.vals[rows, :T], 0.0).astype(numpy.float64)   # root.value() or 0
@@ -172,9 +187,10 @@ def fill_initial_priorities_many(histories, config, backend=None):
         if backend is not None:
             priorities, top = device_priorities(backend, rv, tp, rewards, config)
             with gc_paused():
-                for j, h in enumerate(members):
-                    h.priorities = priorities[j]        # (a row of the downloaded array: nothing else refers to it)
-                    h.game_priority = top[j]
+                for h, p, t in zip(members, priorities, top):      # (rows of the downloaded array: nothing else refers to it)
+                    d = h.__dict__
+                    d["priorities"] = p
+                    d["game_priority"] = t
             filled += k
             continue
         value = numpy.zeros((k, T), numpy.float64)

@@ -164,6 +164,17 @@ class ShardGameHistory(GameHistory):
         self.priorities = None
         self.game_priority = None
 
+    @classmethod
+    def make_many(cls, source, k, n):
+        """k views of one record (games 0 .. k - 1, n moves each): what ``__init__`` sets, without 4 attribute stores per
+        object through the interpreter (a shard hands out thousands of games per call)."""
+        new = cls.__new__
+        out = [new(cls) for _ in range(k)]
+        for j, h in enumerate(out):
+            h.__dict__ = {"_view": (source, j, n), "reanalysed_predicted_root_values": None, "priorities": None,
+                          "game_priority": None}
+        return out
+
     def __getattr__(self, name):          # reached only while the field has not been materialised
         if name in ShardGameHistory._LAZY:
             source, i, n = self.__dict__["_view"]
@@ -239,6 +250,13 @@ class _ShardRecord:
             else:
                 out.append(float(self.vals[i, t]) if total else 0)
         return out
+
+
+class ShardGames(list):
+    """The finished games a shard hands out in one call (a plain list of GameHistory objects) + ``records``: for the games
+    that are fresh views of shard records, [(record, moves, [views in record order])] -- consumers that treat a record's
+    games together (``mzx.replay.fill_initial_priorities_many``) need not rediscover the grouping game by game."""
+    records = ()
 
 
 class SearchResult:
@@ -1023,22 +1041,52 @@ class SelfPlay:
             if getattr(shared_storage, "checkpoint_interval", 0) is None:
                 shared_storage.checkpoint_interval = getattr(self.config, "checkpoint_interval", 10)
             shared_storage.refresh(self.model, block=True)     # the trainer's weights before the first game
+        def hand_off(histories):
+            # initial PER priorities, on the device (replay_buffer.py:39-51 would loop in Python) -- the games a shard
+            # hands out together in ONE pass over their record; save_game then takes its "priorities already present" branch
+            replay.fill_initial_priorities_many(histories, self.config, backend=self.model.backend)
+            for game_history in histories:
+                _remote(replay_buffer.save_game, game_history, shared_storage)
+
+        # A natively played shard (mzx/native_rounds.py) spends its rounds inside ONE library call that needs no
+        # interpreter: the hand-off of the games call k returned -- priorities, save_game of every game: Python per game, as
+        # much wall time as playing them -- runs on this thread WHILE a worker thread is inside call k + 1.  Weights are
+        # only set between calls, with no call in flight; a game reaches the buffer one call later than it would otherwise
+        # (``config.self_play_overlap_handoff = False``: strictly in turn).
+        overlap = (not test_mode and native_rounds.usable(self) and getattr(self.config, "refill_finished_games", True)
+                   and getattr(self.config, "self_play_overlap_handoff", True))
+        waiting, executor = None, None
+        if overlap:
+            import concurrent.futures
+            executor = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+            on_gpu = self.model.backend.device.type == "cuda"
+            stream = torch.cuda.current_stream(self.model.backend.device) if on_gpu else None
+
+            def rounds_on_worker(temperature, threshold):
+                if stream is None:
+                    return self.play_rounds(temperature, threshold), list(self.finished_slots)
+                torch.cuda.set_device(self.model.backend.device)      # (device and stream are thread-local in torch)
+                with torch.cuda.stream(stream):
+                    return self.play_rounds(temperature, threshold), list(self.finished_slots)
+
         while get("training_step") < self.config.training_steps and not get("terminate"):
             if not sharded:
                 self.model.set_weights(get("weights"))
-            if not test_mode:
+            if overlap:
+                future = executor.submit(rounds_on_worker, self.config.visit_softmax_temperature_fn(trained_steps=get("training_step")),
+                                         self.config.temperature_threshold)
+                try:
+                    if waiting is not None:
+                        hand_off(waiting)
+                finally:
+                    waiting, _ = future.result()
+            elif not test_mode:
                 # every slot of the shard is one reference actor: its next game starts the moment one ends (:31-52), so
                 # every search runs at full width (``refill_finished_games = False``: whole shards in lock-step)
                 play = self.play_rounds if getattr(self.config, "refill_finished_games", True) else (
                     lambda t, th: self.play_games(t, th, False, "self", 0))
-                histories = play(self.config.visit_softmax_temperature_fn(trained_steps=get("training_step")),
-                                 self.config.temperature_threshold)
-                # initial PER priorities, vectorised (replay_buffer.py:39-51 would loop in Python) -- the games a shard
-                # hands out together in ONE pass over their record; save_game then takes its "priorities already
-                # present" branch
-                replay.fill_initial_priorities_many(histories, self.config, backend=self.model.backend)
-                for game_history in histories:
-                    _remote(replay_buffer.save_game, game_history, shared_storage)
+                hand_off(play(self.config.visit_softmax_temperature_fn(trained_steps=get("training_step")),
+                              self.config.temperature_threshold))
             else:
                 game_history = self.play_game(
                     0, self.config.temperature_threshold, False,
@@ -1068,6 +1116,10 @@ class SelfPlay:
                     time.sleep(0.5)
                     if sharded:
                         shared_storage.refresh(self.model)
+        if executor is not None:
+            executor.shutdown(wait=True)
+            if waiting is not None:          # the games of the last call
+                hand_off(waiting)
         if sharded and hasattr(shared_storage, "finish"):
             shared_storage.finish(self.model)
         self.close_game()

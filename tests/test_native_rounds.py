@@ -121,3 +121,77 @@ def test_play_games_after_native_rounds_starts_over(backend):
     assert len(out) == 3 and shard._live is None
     assert all(len(h.action_history) >= 6 for h in out)
     shard.close_game()
+
+
+@pytest.mark.parametrize("game", ["synthetic", "connect4"])
+def test_hand_off_of_native_games_fills_the_per_game_priorities(backend, game):
+    """The list play_rounds returns for a natively played shard carries its records (ShardGames.records);
+    fill_initial_priorities_many takes them as they are (no per-game discovery) and computes on the device functor -- the
+    priorities of every game must be the per-game host function's (= the reference's, tests/test_replay_handoff.py)."""
+    import pickle
+
+    from mzx import replay
+
+    if game == "synthetic":
+        cfg = configs.cartpole(num_simulations=6, max_moves=7, players=list(range(2)))
+        Game = games.make_native_synthetic_game(cfg.observation_shape, len(cfg.action_space), 2)
+    else:
+        cfg = configs.connect4(num_simulations=6, blocks=1, channels=8)
+        Game = games.Connect4Native
+    cfg.PER, cfg.PER_alpha, cfg.td_steps = True, 0.5, 5
+    weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 3)
+    shard = self_play.SelfPlay({"weights": weights}, Game, cfg, 9, num_games=9, _backend=backend)
+    out = shard.play_rounds(1.0, None, min_games=30)
+    assert isinstance(out, self_play.ShardGames) and out.records and sum(len(m) for _, _, m in out.records) == len(out)
+    twins = pickle.loads(pickle.dumps(list(out)))            # materialised copies: the per-game path
+    assert replay.fill_initial_priorities_many(out, cfg, backend=backend) == len(out)
+    for a, b in zip(out, twins):
+        assert replay.fill_initial_priorities(b, cfg)
+        assert a.priorities.dtype == numpy.float32
+        assert numpy.array_equal(a.priorities.view(numpy.int32), b.priorities.view(numpy.int32))
+        assert a.game_priority == b.game_priority and type(a.game_priority) is type(b.game_priority)
+    shard.close_game()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_continuous_self_play_hands_native_games_off_while_the_next_call_plays(backend, overlap):
+    """continuous_self_play on a natively played shard: the hand-off of call k's games (device priorities + save_game) runs
+    on the main thread while a worker is inside call k + 1.  The SAME games reach the buffer in the same order with the same
+    priorities as with the hand-off strictly in turn; only when they arrive differs (one call later), so the overlapped
+    run plays one call more before it sees the stop flag -- and still hands every finished game over."""
+    from mzx import shared_storage
+
+    def run(flag):
+        cfg = configs.tictactoe(num_simulations=5, training_steps=10, ratio=None, self_play_delay=0)
+        cfg.PER, cfg.PER_alpha, cfg.td_steps = True, 0.5, 4
+        cfg.self_play_overlap_handoff = flag
+        weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 4)
+        storage = shared_storage.LocalStorage(weights=weights, training_step=0, terminate=False, num_played_games=0,
+                                              num_played_steps=0)
+
+        class Buffer:
+            def __init__(self):
+                self.games = []
+
+            def save_game(self, game_history, shared_storage=None):
+                assert game_history.priorities is not None
+                self.games.append(game_history)
+                if len(self.games) >= 20:
+                    storage.set_info("terminate", True)
+
+        buf = Buffer()
+        actor = self_play.SelfPlay({"weights": weights}, games.TicTacToeNative, cfg, 1, num_games=6, _backend=backend)
+        actor.continuous_self_play(storage, buf)
+        actor.close_game()
+        return buf.games, actor.stats["searches"]
+
+    games_a, searches = run(overlap)
+    assert len(games_a) >= 20
+    if not overlap:
+        return
+    games_b, _ = run(False)
+    n = min(len(games_a), len(games_b))
+    assert n >= 20 and len(games_a) >= len(games_b)
+    for a, b in zip(games_a[:n], games_b[:n]):
+        _same(a, b, "overlapped hand-off")
+        assert numpy.array_equal(a.priorities.view(numpy.int32), b.priorities.view(numpy.int32))
