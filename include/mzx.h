@@ -498,8 +498,10 @@ int mzx_game_step(mzx_game* g, const int64_t* actions, const uint8_t* active /* 
  * mzx_actor_take hands out and forgets the finished games of a group, game-major and ragged: game j has length[j] moves;
  * observations / actions / rewards / to_play hold length[j] + 1 entries per game (action_history / reward_history with
  * their leading 0, the final position's observation and side to move), visit_counts / root_values / legal_mask length[j];
- * sizes from mzx_actor_finished (out[0] games, out[1] sum of lengths).  legal_mask [sum][A] u8 is needed when
- * mzx_actor_has_masks.
+ * sizes from mzx_actor_finished (out[0] games, out[1] sum of lengths, out[2] = 1 when a game had a restricted legal set:
+ * the legal_mask [sum][A] u8 buffer is then required).  `before_sequence` >= 0 restricts both to the games numbered below it
+ * (whole rounds: what the call that returned that `sequence` had finished) -- a caller may take the games of call k from
+ * one thread while call k + 1 is running on another (mzx.self_play.SelfPlay.continuous_self_play does).
  * ------------------------------------------------------------------------- */
 typedef struct mzx_actor mzx_actor;
 typedef struct mzx_actor_config {
@@ -530,9 +532,8 @@ typedef struct mzx_rounds {
                                       retries, 5 the rest of the call */
 } mzx_rounds;
 int mzx_selfplay_rounds(mzx_actor* const* groups, int32_t num_groups, mzx_rounds* io, void* stream);
-int mzx_actor_finished(const mzx_actor* a, int64_t out[2]);
-int mzx_actor_has_masks(const mzx_actor* a);
-int mzx_actor_take(mzx_actor* a, int32_t* slot, int32_t* length, int64_t* sequence, float* observations, int64_t* actions,
+int mzx_actor_finished(mzx_actor* a, int64_t before_sequence, int64_t out[3]);
+int mzx_actor_take(mzx_actor* a, int64_t before_sequence, int32_t* slot, int32_t* length, int64_t* sequence, float* observations, int64_t* actions,
                    double* rewards, int64_t* to_play, int32_t* visit_counts, double* root_values, uint8_t* legal_mask,
                    int32_t* any_illegal);
 

@@ -23,6 +23,7 @@
 #include <chrono>
 #include <deque>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "mzx_games.h"
@@ -65,8 +66,9 @@ struct mzx_actor {
     std::vector<double> val;             // sum(n)
     std::vector<uint8_t> mask;           // sum(n) x A, empty when every action was legal throughout
   };
+  // (taken by mzx_actor_take, possibly from another thread while a rounds call is appending: the queue has its own lock)
   std::deque<Batch> finished;
-  int64_t finished_games = 0, finished_moves = 0;
+  std::mutex finished_lock;
 };
 
 namespace mzx {
@@ -137,8 +139,7 @@ inline int actor_begin(mzx_actor* a, void* stream, double* search_seconds, doubl
 // copies the games of slots idx (ascending) that ended with round r out of the ring
 inline void actor_harvest(mzx_actor* a, const std::vector<int32_t>& idx, int64_t r, int64_t* sequence) {
   const int64_t B = a->B, A = a->A, E = a->E, cap = a->cap;
-  a->finished.emplace_back();
-  mzx_actor::Batch& b = a->finished.back();
+  mzx_actor::Batch b;
   int64_t rows = 0;
   for (int32_t s : idx) rows += r - a->start[s] + 1;
   const int64_t k = (int64_t)idx.size();
@@ -191,8 +192,8 @@ inline void actor_harvest(mzx_actor* a, const std::vector<int32_t>& idx, int64_t
   for (int64_t j = 0; j < k; ++j) any_illegal = any_illegal || flag[(size_t)j];
   (void)illegal;
   if (masks && !any_illegal) { b.mask.clear(); b.mask.shrink_to_fit(); }
-  a->finished_games += k;
-  a->finished_moves += rows;
+  std::lock_guard<std::mutex> lk(a->finished_lock);
+  a->finished.push_back(std::move(b));
 }
 
 typedef int (*actor_retry_fn)(void* ctx, int32_t group, int32_t count, const int32_t* games);

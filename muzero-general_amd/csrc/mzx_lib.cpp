@@ -1197,23 +1197,42 @@ int mzx_selfplay_rounds(mzx_actor* const* groups, int32_t num_groups, mzx_rounds
   return rc;
 }
 
-int mzx_actor_finished(const mzx_actor* a, int64_t out[2]) {
+int mzx_actor_finished(mzx_actor* a, int64_t before_sequence, int64_t out[3]) {
   if (!a || !out) { set_error("mzx_actor_finished: null"); return MZX_ERR_INVALID; }
-  out[0] = a->finished_games; out[1] = a->finished_moves;
+  std::lock_guard<std::mutex> lk(a->finished_lock);
+  out[0] = out[1] = out[2] = 0;
+  for (const mzx_actor::Batch& b : a->finished) {
+    if (before_sequence >= 0 && !b.seq.empty() && b.seq[0] >= before_sequence) break;
+    out[0] += (int64_t)b.slot.size(); out[1] += (int64_t)b.val.size();
+    if (!b.mask.empty()) out[2] = 1;
+  }
   return MZX_OK;
 }
 
-int mzx_actor_take(mzx_actor* a, int32_t* slot, int32_t* length, int64_t* sequence, float* observations, int64_t* actions,
-                   double* rewards, int64_t* to_play, int32_t* visit_counts, double* root_values, uint8_t* legal_mask,
-                   int32_t* any_illegal) {
+int mzx_actor_take(mzx_actor* a, int64_t before_sequence, int32_t* slot, int32_t* length, int64_t* sequence, float* observations,
+                   int64_t* actions, double* rewards, int64_t* to_play, int32_t* visit_counts, double* root_values,
+                   uint8_t* legal_mask, int32_t* any_illegal) {
   if (!a || !slot || !length || !sequence || !observations || !actions || !rewards || !to_play || !visit_counts || !root_values) {
     set_error("mzx_actor_take: missing buffer");
     return MZX_ERR_INVALID;
   }
+  // the batches to hand out leave the queue under its lock (a rounds call on another thread may be appending); the copies
+  // run outside it
+  std::deque<mzx_actor::Batch> mine;
+  {
+    std::lock_guard<std::mutex> lk(a->finished_lock);
+    while (!a->finished.empty()) {
+      mzx_actor::Batch& b = a->finished.front();
+      if (before_sequence >= 0 && !b.seq.empty() && b.seq[0] >= before_sequence) break;
+      if (!b.mask.empty() && !legal_mask) { set_error("mzx_actor_take: games with restricted legal sets need the legal_mask buffer"); return MZX_ERR_INVALID; }
+      mine.push_back(std::move(b));
+      a->finished.pop_front();
+    }
+  }
   const size_t A = (size_t)a->A, E = (size_t)a->E;
   size_t g = 0, q1 = 0, q0 = 0;
   int32_t illegal = 0;
-  for (const mzx_actor::Batch& b : a->finished) {
+  for (const mzx_actor::Batch& b : mine) {
     const size_t k = b.slot.size(), n1 = b.act.size(), n0 = b.val.size();
     memcpy(slot + g, b.slot.data(), sizeof(int32_t) * k);
     memcpy(length + g, b.n.data(), sizeof(int32_t) * k);
@@ -1227,22 +1246,11 @@ int mzx_actor_take(mzx_actor* a, int32_t* slot, int32_t* length, int64_t* sequen
     if (legal_mask) {
       if (b.mask.empty()) memset(legal_mask + q0 * A, 1, n0 * A);
       else { memcpy(legal_mask + q0 * A, b.mask.data(), n0 * A); illegal = 1; }
-    } else if (!b.mask.empty()) {
-      illegal = 1;
     }
     g += k; q1 += n1; q0 += n0;
   }
   if (any_illegal) *any_illegal = illegal;
-  if (illegal && !legal_mask) { set_error("mzx_actor_take: games with restricted legal sets need the legal_mask buffer"); return MZX_ERR_INVALID; }
-  a->finished.clear();
-  a->finished_games = 0; a->finished_moves = 0;
   return MZX_OK;
-}
-
-int mzx_actor_has_masks(const mzx_actor* a) {
-  if (!a) return 0;
-  for (const mzx_actor::Batch& b : a->finished) if (!b.mask.empty()) return 1;
-  return 0;
 }
 
 }  // extern "C"

@@ -178,9 +178,8 @@ PROTOTYPES = {
     "mzx_actor_create": (ctypes.c_int, [ctypes.POINTER(ActorConfig), ctypes.POINTER(c_vp)]),
     "mzx_actor_destroy": (None, [c_vp]),
     "mzx_selfplay_rounds": (ctypes.c_int, [ctypes.POINTER(c_vp), c_i32, ctypes.POINTER(Rounds), c_vp]),
-    "mzx_actor_finished": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64 * 2)]),
-    "mzx_actor_has_masks": (ctypes.c_int, [c_vp]),
-    "mzx_actor_take": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i32)]),
+    "mzx_actor_finished": (ctypes.c_int, [c_vp, c_i64, ctypes.POINTER(c_i64 * 3)]),
+    "mzx_actor_take": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i32)]),
     "mzx_selfplay_select": (ctypes.c_int, [c_vp, ctypes.POINTER(Move), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32,
                                            c_vp]),
 }

@@ -135,6 +135,18 @@ class NativeShard:
 
     # ---- one play_rounds call -------------------------------------------------------------------------------------------
     def play(self, temperature, temperature_threshold, min_games, max_rounds):
+        import time
+
+        before = self.rounds(temperature, temperature_threshold, min_games, max_rounds)
+        t0 = time.perf_counter()
+        out = self.collect(before)
+        self._actor.stats["native_phase_seconds"][6] += time.perf_counter() - t0      # the finished games wrapped into GameHistory views (Python)
+        return out
+
+    def rounds(self, temperature, temperature_threshold, min_games, max_rounds):
+        """The library call alone (it holds no interpreter lock: ``continuous_self_play`` runs it on a worker thread while
+        the main thread hands the previous call's games over).  Returns the sequence number behind the last game this call
+        finished: ``collect(before)`` hands out exactly the games finished so far."""
         actor = self._actor
         lib, engine = actor.model.backend.lib, actor.engine
         t = float(temperature)
@@ -170,15 +182,13 @@ class NativeShard:
         phases = actor.stats.setdefault("native_phase_seconds", [0.0] * 7)      # (diagnostics: where the host time of the calls went)
         for k in range(6):
             phases[k] += float(io.phase_seconds[k])
-        import time
+        return self.sequence
 
-        t0 = time.perf_counter()
-        out = self.collect()
-        phases[6] += time.perf_counter() - t0          # the finished games wrapped into GameHistory views (Python)
-        return out
-
-    def collect(self):
-        """The finished games of every group as ``ShardGameHistory`` views, in the order they finished; their slots."""
+    def collect(self, before=-1, priorities_for=None):
+        """The finished games of every group (numbered below ``before``; -1: all) as ``ShardGameHistory`` views, in the order
+        they finished; their slots.  ``priorities_for`` (a configuration with PER on; ``continuous_self_play``'s hand-off):
+        the initial PER priorities of every record are computed on the device right here and every view is created with its
+        row -- the buffer's save_game reads them for every game."""
         from .self_play import ShardGameHistory, ShardGames, _ShardRecord, gc_paused
 
         actor = self._actor
@@ -187,8 +197,8 @@ class NativeShard:
         E = int(numpy.prod(shape))
         views_all, seq_all, slot_all, records = [], [], [], []
         for g in self.groups:
-            counts = (ctypes.c_int64 * 2)()
-            lib.check(lib.mzx_actor_finished(g.handle, ctypes.byref(counts)))
+            counts = (ctypes.c_int64 * 3)()
+            lib.check(lib.mzx_actor_finished(g.handle, int(before), ctypes.byref(counts)))
             G, rows = int(counts[0]), int(counts[1])
             if G == 0:
                 continue
@@ -197,9 +207,9 @@ class NativeShard:
             acts, tps = numpy.empty(rows + G, numpy.int64), numpy.empty(rows + G, numpy.int64)
             rews = numpy.empty(rows + G, numpy.float64)
             vis, vals = numpy.empty((rows, A), numpy.int32), numpy.empty(rows, numpy.float64)
-            mask = numpy.empty((rows, A), numpy.uint8) if lib.mzx_actor_has_masks(g.handle) else None
+            mask = numpy.empty((rows, A), numpy.uint8) if counts[2] else None
             illegal = ctypes.c_int32()
-            lib.check(lib.mzx_actor_take(g.handle, slot.ctypes.data, length.ctypes.data, seq.ctypes.data, obs.ctypes.data,
+            lib.check(lib.mzx_actor_take(g.handle, int(before), slot.ctypes.data, length.ctypes.data, seq.ctypes.data, obs.ctypes.data,
                                          acts.ctypes.data, rews.ctypes.data, tps.ctypes.data, vis.ctypes.data, vals.ctypes.data,
                                          None if mask is None else mask.ctypes.data, ctypes.byref(illegal)))
             game = g.game
@@ -220,7 +230,12 @@ class NativeShard:
                     i0 = (off0[rows_n][:, None] + numpy.arange(n)[None, :])
                     take1, take0 = (lambda a: a[i1]), (lambda a: a[i0])
                 v, vl = take0(vis), take0(vals)
-                totals = v.sum(2)
+                if A <= 8:          # (numpy's reduction over a short last axis is slow: a few strided adds instead)
+                    totals = v[:, :, 0].astype(numpy.int64)
+                    for x in range(1, A):
+                        totals += v[:, :, x]
+                else:
+                    totals = v.sum(2)
                 ratios = v / numpy.maximum(totals, 1)[:, :, None]       # true division of small integers == Python's int / int
                 plain = totals > 0
                 legal_mask = None
@@ -229,6 +244,10 @@ class NativeShard:
                     plain = plain & legal_mask.all(2)
                 record = _ShardRecord(A, take1(obs).reshape((k, n + 1) + shape), take1(acts), take1(rews), take1(tps), v, vl,
                                       totals, ratios, plain.all(1), legal_mask)
+                if priorities_for is not None and getattr(priorities_for, "PER", False) and n > 0:
+                    from . import replay
+                    record.priorities, record.game_priority = replay.device_priorities(
+                        actor.model.backend, numpy.where(totals > 0, vl, 0.0), record.tps, record.rews, priorities_for)
                 with gc_paused():
                     views = ShardGameHistory.make_many(record, k, n)
                 views_all += views

@@ -132,15 +132,21 @@ def fill_initial_priorities_many(histories, config, backend=None):
     filled, views, plain = 0, {}, {}
     jobs = []
     grouped = getattr(histories, "records", None)
-    if grouped and backend is not None and all(len(h.__dict__) == 4 and h.__dict__["priorities"] is None
-                                              for _, _, members in grouped for h in members):
-        # the shard's own grouping (mzx.self_play.ShardGames): fresh views of whole records, in record order -- the record's
-        # arrays as they lie, no per-game discovery
+    if (grouped and all(record.priorities is not None for record, _, _ in grouped)
+            and sum(len(members) for _, _, members in grouped) == len(histories)):
+        return 0        # (every record came with its priorities: the views were created with their rows)
+    if grouped and backend is not None and all(len(h.__dict__) == 2 for _, _, members in grouped for h in members) and all(
+            record.priorities is None for record, _, _ in grouped):
+        # the shard's own grouping (mzx.self_play.ShardGames): fresh views of whole records, in record order (nothing of them
+        # materialised or assigned yet) -- the record's arrays as they lie, the result stored ON the record: a view
+        # resolves its row of it on first access (ShardGameHistory._PER); nothing is done per game
         for record, T, members in grouped:
             if T > 0:
                 k = len(members)
                 rv = numpy.where(record.totals[:k, :T] > 0, record.vals[:k, :T], 0.0)        # root.value() or 0
-                jobs.append((rv, record.tps[:k, : T + 1], record.rews[:k, : T + 1], members))
+                record.priorities, record.game_priority = device_priorities(backend, rv, record.tps[:k, : T + 1],
+                                                                            record.rews[:k, : T + 1], config)
+                filled += k
         if sum(len(m) for _, _, m in grouped) == len(histories):
             histories = ()
         else:

@@ -157,35 +157,63 @@ class ShardGameHistory(GameHistory):
     sampled games); pickling (Ray object store) materialises everything.
     """
     _LAZY = ("observation_history", "action_history", "reward_history", "to_play_history", "child_visits", "root_values")
+    # The PER fields (self_play.py:488-489) are lazy as well: ``mzx.replay.fill_initial_priorities_many`` stores the
+    # priorities of a whole record ON the record ([games][moves] float32 + [games]); a view resolves its row on first
+    # access (None while the record has none) -- handing 4096 games to the buffer sets nothing per game.  Assigning the
+    # attribute (the stock ``save_game`` copies it, the trainer updates it) makes it an ordinary instance attribute.
+    _PER = ("priorities", "game_priority")
+    _WITH_LEADING_ENTRY = frozenset(("action_history", "reward_history", "to_play_history"))     # n + 1 entries (self_play.py:118-120)
 
     def __init__(self, source, i, n):
         self.__dict__["_view"] = (source, i, n)
         self.reanalysed_predicted_root_values = None
-        self.priorities = None
-        self.game_priority = None
 
     @classmethod
     def make_many(cls, source, k, n):
-        """k views of one record (games 0 .. k - 1, n moves each): what ``__init__`` sets, without 4 attribute stores per
-        object through the interpreter (a shard hands out thousands of games per call)."""
+        """k views of one record (games 0 .. k - 1, n moves each): what ``__init__`` sets, without attribute stores per
+        object through the interpreter (a shard hands out thousands of games per call).  A record that already carries its
+        PER priorities (``SelfPlay.continuous_self_play`` computes them while it collects a call's games) hands every view
+        its row at once: the buffer reads them for every game, and an instance attribute costs nothing to read."""
         new = cls.__new__
         out = [new(cls) for _ in range(k)]
+        if source.priorities is not None:
+            for j, (h, p, t) in enumerate(zip(out, source.priorities, source.game_priority)):
+                h.__dict__ = {"_view": (source, j, n), "reanalysed_predicted_root_values": None, "priorities": p, "game_priority": t}
+            return out
         for j, h in enumerate(out):
-            h.__dict__ = {"_view": (source, j, n), "reanalysed_predicted_root_values": None, "priorities": None,
-                          "game_priority": None}
+            h.__dict__ = {"_view": (source, j, n), "reanalysed_predicted_root_values": None}
         return out
 
     def __getattr__(self, name):          # reached only while the field has not been materialised
         if name in ShardGameHistory._LAZY:
             source, i, n = self.__dict__["_view"]
+            rows = source._lists.get(name)
+            if rows is not None:          # the record's rows are lists already (_ShardRecord._row): hand this game's over
+                plus = name in ShardGameHistory._WITH_LEADING_ENTRY
+                if plus or source.simple[i]:
+                    value = rows[i]
+                    if value is not None and len(value) == n + plus:
+                        rows[i] = None
+                        self.__dict__[name] = value
+                        return value
             value = source.field(name, i, n)
+            self.__dict__[name] = value
+            return value
+        if name in ShardGameHistory._PER:
+            source, i, _ = self.__dict__["_view"]
+            rows = source.priorities if name == "priorities" else source.game_priority
+            if rows is None:
+                return None               # (not cached: the record may get its priorities later)
+            value = rows[i]
             self.__dict__[name] = value
             return value
         raise AttributeError(name)
 
     def materialize(self):
-        for name in ShardGameHistory._LAZY:
-            getattr(self, name)
+        for name in ShardGameHistory._LAZY + ShardGameHistory._PER:
+            value = getattr(self, name)
+            if name in ShardGameHistory._PER:
+                self.__dict__[name] = value
         return self
 
     def __getstate__(self):
@@ -209,6 +237,7 @@ class _ShardRecord:
         self.A, self.obs, self.acts, self.rews, self.tps = A, obs, acts, rews, tps
         self.vis, self.vals, self.totals, self.ratios, self.simple, self.legal_mask = vis, vals, totals, ratios, simple, legal_mask
         self._lists = {}        # field -> the whole record as nested Python lists, one row per game (first touch)
+        self.priorities = self.game_priority = None      # [games][moves] float32, [games]: set for the whole record at once
 
     _ARRAY_OF = {"action_history": "acts", "reward_history": "rews", "to_play_history": "tps", "child_visits": "ratios",
                  "root_values": "vals"}
@@ -1041,12 +1070,19 @@ class SelfPlay:
             if getattr(shared_storage, "checkpoint_interval", 0) is None:
                 shared_storage.checkpoint_interval = getattr(self.config, "checkpoint_interval", 10)
             shared_storage.refresh(self.model, block=True)     # the trainer's weights before the first game
+        save_game = replay_buffer.save_game
+        save_is_remote = hasattr(save_game, "remote")
+
         def hand_off(histories):
             # initial PER priorities, on the device (replay_buffer.py:39-51 would loop in Python) -- the games a shard
             # hands out together in ONE pass over their record; save_game then takes its "priorities already present" branch
             replay.fill_initial_priorities_many(histories, self.config, backend=self.model.backend)
-            for game_history in histories:
-                _remote(replay_buffer.save_game, game_history, shared_storage)
+            if save_is_remote:
+                for game_history in histories:
+                    _remote(save_game, game_history, shared_storage)
+            else:
+                for game_history in histories:
+                    save_game(game_history, shared_storage)
 
         # A natively played shard (mzx/native_rounds.py) spends its rounds inside ONE library call that needs no
         # interpreter: the hand-off of the games call k returned -- priorities, save_game of every game: Python per game, as
@@ -1063,11 +1099,14 @@ class SelfPlay:
             stream = torch.cuda.current_stream(self.model.backend.device) if on_gpu else None
 
             def rounds_on_worker(temperature, threshold):
+                # ONLY the library call runs here (no interpreter lock held inside it); wrapping the finished games into
+                # GameHistory views is Python and stays on the main thread, inside the hand-off the call overlaps with
+                shard = self._native_shard(temperature)
                 if stream is None:
-                    return self.play_rounds(temperature, threshold), list(self.finished_slots)
+                    return shard.rounds(temperature, threshold, self.num_games, None)
                 torch.cuda.set_device(self.model.backend.device)      # (device and stream are thread-local in torch)
                 with torch.cuda.stream(stream):
-                    return self.play_rounds(temperature, threshold), list(self.finished_slots)
+                    return shard.rounds(temperature, threshold, self.num_games, None)
 
         while get("training_step") < self.config.training_steps and not get("terminate"):
             if not sharded:
@@ -1076,10 +1115,12 @@ class SelfPlay:
                 future = executor.submit(rounds_on_worker, self.config.visit_softmax_temperature_fn(trained_steps=get("training_step")),
                                          self.config.temperature_threshold)
                 try:
-                    if waiting is not None:
-                        hand_off(waiting)
+                    if waiting is not None:          # the games the previous call finished (numbered below `waiting`)
+                        histories, slots = self._live["native"].collect(waiting, priorities_for=self.config)
+                        self.finished_slots = slots
+                        hand_off(histories)
                 finally:
-                    waiting, _ = future.result()
+                    waiting = future.result()
             elif not test_mode:
                 # every slot of the shard is one reference actor: its next game starts the moment one ends (:31-52), so
                 # every search runs at full width (``refill_finished_games = False``: whole shards in lock-step)
@@ -1119,7 +1160,9 @@ class SelfPlay:
         if executor is not None:
             executor.shutdown(wait=True)
             if waiting is not None:          # the games of the last call
-                hand_off(waiting)
+                histories, slots = self._live["native"].collect(waiting, priorities_for=self.config)
+                self.finished_slots = slots
+                hand_off(histories)
         if sharded and hasattr(shared_storage, "finish"):
             shared_storage.finish(self.model)
         self.close_game()
@@ -1674,11 +1717,7 @@ class SelfPlay:
         if native_rounds.usable(self):
             # the game steps inside the library: the whole loop below runs there (mzx_selfplay_rounds), same schedule, same
             # draws, same games (mzx/native_rounds.py; config.native_rounds = False keeps this loop on such a game)
-            live = self._live
-            if live is None:
-                shard = native_rounds.NativeShard(self, temperature)
-                live = self._live = dict(groups=shard.groups, native=shard)
-            finished, slots = live["native"].play(temperature, temperature_threshold, min_games, max_rounds)
+            finished, slots = self._native_shard(temperature).play(temperature, temperature_threshold, min_games, max_rounds)
             self.finished_slots += slots
             return finished
         live = self._live
@@ -1727,6 +1766,13 @@ class SelfPlay:
                     begin(group)      # certain to be consumed by this call: runs while the host plays the groups after it
             rounds += 1
         return finished
+
+    def _native_shard(self, temperature):
+        """The actors of a natively played shard (created with the first round; ``temperature``: of the games that start then)."""
+        if self._live is None:
+            shard = native_rounds.NativeShard(self, temperature)
+            self._live = dict(groups=shard.groups, native=shard)
+        return self._live["native"]
 
     def _batched_spans(self, B):
         """
