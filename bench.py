@@ -871,6 +871,8 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
             "roofline": {"bound": roofline["bound"], "achieved": round(roofline["achieved"], 3), "frac": round(roofline["frac"], 4),
                          "traffic": traffic, "launch_ms": round(launch_ms, 4)},
         }
+        if world > 1:        # every rank's own time per step of the median block (the first multi-GPU run yields the scaling of every workload)
+            result["per_rank_ms"] = [round(t / steps * 1e3, 4) for t in gathered]
         if WORKLOAD_WEIGHTS.get(workload):
             result["weights"] = weights_label
         if instantiations:
@@ -879,7 +881,8 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     elif instantiations:
         result["config"]["instantiations"] = instantiations
     if world > 1:
-        result["per_rank"] = {"sims_per_sec": per_rank, "min": min(per_rank), "max": max(per_rank)}
+        result["per_rank"] = {"sims_per_sec": per_rank, "min": min(per_rank), "max": max(per_rank),
+                              "ms_per_step": [t / steps * 1e3 for t in gathered]}
         if solo is not None:
             result["single_gpu_reference"] = {
                 "sims_per_sec": solo, "weak_scaling_efficiency": value / (world * solo),   # rank 0 timed alone on the same box

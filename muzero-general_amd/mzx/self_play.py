@@ -1786,8 +1786,13 @@ class SelfPlay:
             want = self.config.network == "fullyconnected" and B >= 2048
         if not want or B < 2 or not hasattr(self, "_game_seeds"):
             return [(0, B)]
-        half = (B + 1) // 2
-        return [(0, half), (half, B)]
+        # ``config.self_play_groups``: how many groups take turns (default two).  A round of k groups lasts max(search + host
+        # work of ONE group, k x host work of a group), so a latency-bound search (C2: 0.2 ms for 1024 trees as for 4096)
+        # would want more, smaller groups -- measured on the natively played C2 shard (profiles/r06_native_rounds.txt): four
+        # groups of 1024 on four streams 5.1 M steps/s against 10.3 M with two (queueing a search took 97 us instead of 40)
+        groups = max(2, min(int(getattr(self.config, "self_play_groups", None) or 2), B))
+        edges = [(B * g + groups - 1) // groups for g in range(groups + 1)]
+        return [(edges[g], edges[g + 1]) for g in range(groups) if edges[g + 1] > edges[g]]
 
     @staticmethod
     def _stacked_batch(obs_hist, act_hist, k, A):

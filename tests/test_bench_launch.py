@@ -29,7 +29,12 @@ def _run(argv, env_extra=None):
 
 
 def test_bench_self_launches_two_ranks():
-    line = _run(["--gpus", "2", "--dry-run", "--trees", "8", "--steps", "2", "--warmup", "1", "--selfplay-moves", "0"])
+    line = _run(["--gpus", "2", "--dry-run", "--trees", "8", "--steps", "2", "--warmup", "1", "--selfplay-moves", "0",
+                 "--also", "c3", "--also-steps", "1"])
+    # every workload of a multi-GPU run reports every rank's own time per step (the first real 8-GPU run yields the scaling
+    # of the CartPole AND the residual workloads in one go)
+    assert len(line["per_rank"]["ms_per_step"]) == 2 and all(t > 0 for t in line["per_rank"]["ms_per_step"])
+    assert [w["w"] for w in line["workloads"]] == ["c3"] and len(line["workloads"][0]["per_rank_ms"]) == 2
     assert line["dry_run"] is True and "NOT a measurement" in line["data"]
     assert line["n_gpus"] == 2 and line["collective_world_size"] == 2 and line["scaling"] == "weak"
     assert line["steps"] == 2 and line["warmup"] == 1

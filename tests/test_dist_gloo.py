@@ -293,3 +293,122 @@ def test_uneven_game_lengths_do_not_lock_step_the_ranks(tmp_path):
     assert r[0]["rounds"] >= 2 * r[1]["rounds"] >= 2, (r[0]["rounds"], r[1]["rounds"])   # ... at each rank's own pace
     assert r[0]["stalls"] > 0                                           # polls that found the exchange incomplete and moved on
     assert r[0]["games"] + r[1]["games"] >= 40
+
+
+class _VersionedStorage:
+    """Rank 0's real storage playing the trainer for the world-4 case: publishes NEW weights once the job has reported
+    ``update_at`` games, terminates at ``target`` games."""
+
+    def __init__(self, weights_a, weights_b, update_at, target):
+        from mzx import shared_storage
+        self.inner = shared_storage.LocalStorage(training_step=0, terminate=False, weights=weights_a,
+                                                 num_played_games=0, num_played_steps=0)
+        self.weights_b, self.update_at, self.target, self.updated = weights_b, update_at, target, False
+
+    def get_info(self, keys):
+        return self.inner.get_info(keys)
+
+    def set_info(self, keys, values=None):
+        self.inner.set_info(keys, values)
+        if isinstance(keys, dict):
+            played = keys.get("num_played_games", 0)
+            if played >= self.update_at and not self.updated:
+                self.updated = True
+                self.inner.set_info({"weights": self.weights_b, "training_step": 11})
+            if played >= self.target:
+                self.inner.set_info("terminate", True)
+
+
+def _world4_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "muzero-general_amd"), ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+
+    import games_fixture
+    import hostcheck
+    from mzx import configs, games as board_games, models, self_play, shared_storage, synthetic
+
+    torch.set_num_threads(1)
+    be = hostcheck.backend()
+    cfg = configs.tictactoe()
+    cfg.num_simulations = 4
+    cfg.training_steps = 100
+    cfg.ratio = None
+    cfg.self_play_delay = 0
+    cfg.PER, cfg.PER_alpha, cfg.td_steps = True, 0.5, 9
+    G = 4
+    template = models.MuZeroNetwork(cfg, _backend=be).state_dict()
+    wa, wb = synthetic.fill_state_dict(template, 1), synthetic.fill_state_dict(template, 2)
+    delay = (0.0, 0.004, 0.0, 0.02)[rank]
+
+    class Slow(games_fixture.GAMES["tictactoe"]):
+        def step(self, action):
+            if delay:
+                time.sleep(delay)
+            return super().step(action)
+
+    if rank == 2:       # a natively played shard: rounds inside the library on a worker thread, the hand-off overlapped
+        board_games.NativeBatchedGame.backend = be
+        Game = board_games.TicTacToeNative
+    else:               # per-object plugin games as two slot groups: a search of one group is queued across calls
+        Game = Slow
+        cfg.self_play_pipeline = True
+    seeds = shared_storage.shard_seeds(cfg.seed, G)
+    actor = self_play.SelfPlay({"weights": synthetic.fill_state_dict(template, 70 + rank)}, Game, cfg, seeds[0],
+                               num_games=G, _backend=be)
+    storage = shared_storage.ShardedStorage(_VersionedStorage(wa, wb, 12, 60) if rank == 0 else None, src=0)
+    buffer = _ListBuffer()
+    seen, queued_at_refresh = [], []
+    refresh = storage.refresh
+
+    def recording_refresh(model, *a, **kw):
+        live = actor._live or {}
+        queued_at_refresh.append(any(g.get("pending") is not None for g in live.get("groups", ())))
+        before = model.flat_weights().clone()
+        out = refresh(model, *a, **kw)
+        if not torch.equal(before, model.flat_weights()):
+            seen.append((len(queued_at_refresh), queued_at_refresh[-1]))     # a refresh that changed the weights
+        return out
+
+    storage.refresh = recording_refresh
+    t0 = time.perf_counter()
+    actor.continuous_self_play(storage, buffer)
+    final = actor.model.flat_weights().clone()
+    torch.save(dict(games=len(buffer.games), steps=buffer.steps, wall=time.perf_counter() - t0, refreshes=storage.refreshes,
+                    broadcasts=storage.weight_broadcasts, control=storage.control, changed=seen,
+                    queued_at_refresh=queued_at_refresh, final=final, searches=actor.stats["searches"],
+                    native=bool(actor._live and actor._live.get("native"))),
+               os.path.join(out_dir, f"w4_{rank}.pt"))
+    actor.close_game()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world4_unequal_ranks_midrun_update_with_searches_queued_across_calls(tmp_path):
+    """
+    Four ranks at four speeds (rank 3's environment is 5 x slower than rank 1's, ranks 0 and 2 do not wait at all; rank 2
+    plays a NATIVE shard whose rounds run on a worker thread with the hand-off overlapped), a weight update published in
+    the middle of the run, per-object shards pipelined as two slot groups -- so that a refresh can land while a rank holds a
+    search it queued before ("weight staleness of a pipelined shard": that search runs on the old
+    weights, everything after it on the new ones).  What must hold whatever the timing: every rank consumed the same
+    sequence of control exchanges and stopped on the same one; exactly two broadcasts (the initial weights, the update);
+    every rank ends on the trainer's SECOND weights; the job reached its target; the fast ranks were not held back.
+    """
+    world, port = 4, _free_port()
+    mp.spawn(_world4_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"w4_{k}.pt", weights_only=False) for k in range(world)]
+    assert len({x["refreshes"] for x in r}) == 1 and r[0]["refreshes"] >= 3
+    assert all(x["control"] == r[0]["control"] for x in r) and r[0]["control"]["terminate"] is True
+    assert all(x["broadcasts"] == 2 for x in r)
+    assert all(torch.equal(x["final"], r[0]["final"]) for x in r)
+    # the weights changed exactly twice on every rank (junk -> first version -> update)
+    assert all(len(x["changed"]) == 2 for x in r), [x["changed"] for x in r]
+    assert sum(x["games"] for x in r) >= 60
+    assert r[2]["native"] and not r[0]["native"]
+    assert r[0]["searches"] > 2 * r[3]["searches"] > 0, [x["searches"] for x in r]     # nobody waits for the slow rank
+    # the staleness path was exercised: some refresh of a pipelined rank ran with a search queued from the call before
+    assert any(any(x["queued_at_refresh"]) for k, x in enumerate(r) if k != 2), [sum(x["queued_at_refresh"]) for x in r]

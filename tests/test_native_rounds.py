@@ -96,6 +96,19 @@ def test_native_rounds_on_the_synthetic_game(backend, pipeline):
     assert all(len(g.action_history) == 6 for g in native[0])
 
 
+def test_three_slot_groups_play_what_the_python_loop_plays(backend):
+    """config.self_play_groups: more than two groups take turns (a natively played C2 shard runs as four); the order in which
+    games finish is (round, group, slot) in both loops."""
+    cfg = configs.tictactoe(num_simulations=8)
+    cfg.self_play_groups = 3
+    weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg, _backend=backend).state_dict(), 21)
+    calls = [(1.0, dict(min_games=5)), (0.5, dict(max_rounds=3, min_games=1 << 60)), (1.0, dict(min_games=30))]
+    native = _run(backend, games.TicTacToeNative, cfg, weights, 11, 7, calls, True, True)
+    python = _run(backend, games.TicTacToeBatched, cfg, weights, 11, 7, calls, False, True)
+    assert native[3] == python[3] == 3 and native[4]
+    _assert_equal_runs(native, python)
+
+
 def test_native_rounds_retry_searches_that_exhaust_their_tape(backend):
     """All-zero weights: equal priors and values everywhere, a tie at every level of every walk -- the 16-word tape of a
     search is exhausted at once and the library calls back for a longer one.  Same games as the Python loop's retries."""
