@@ -117,7 +117,7 @@ def parse():
                          "long ones); the line's value is the MEDIAN block, min / max are reported beside it")
     ap.add_argument("--trees", type=int, default=None, help="trees per GPU (default: the workload's)")
     ap.add_argument("--mode", default="auto", choices=["auto", "generic", "fused", "fused-v1"],
-                    help="fused-v1: first-generation fully connected whole-search kernel (A/B)")
+                    help="fused-v1: first-generation fully connected whole-search kernel (A/B; instrumented builds only)")
     ap.add_argument("--net-mode", default="fused", choices=["fused", "fused-4wave", "per-operator", "streamed"],
                     help="residual networks: fused MFMA engine (default) or one kernel per operator")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall budget of each CPU baseline leg (0 = skip)")

@@ -294,7 +294,7 @@ const char* mzx_search_kernel_name(const mzx_search* s);
 int mzx_search_set_mode(mzx_search* s, int32_t mode);
 /* What the NEXT mzx_search_run of this handle would launch (host-side, no GPU): out[0] = 0 the generic path, 1
  * mzx::rz_search_kernel or one of its small-board siblings, 2 per-simulation launches around the streamed engine, 3
- * mzx::rt_search_kernel (every simulation in one launch, csrc/mzx_tower_search.hip), 4 the fully connected whole-search
+ * mzx::rt_search_kernel (every simulation in one launch, csrc/mzx_tower_search.inc), 4 the fully connected whole-search
  * kernel; for 3: out[1..6] = {trees per workgroup, row tiles per wave, workgroups, workgroups per CU, LDS bytes, threads per
  * workgroup}; for 2: out[6..7] = trees of the two half-shards (second 0: undivided). */
 int mzx_search_route(const mzx_search* s, int32_t out[8]);

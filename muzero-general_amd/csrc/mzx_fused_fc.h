@@ -963,6 +963,11 @@ inline FusedPlan fused_plan(const mzx_search* s, bool allow_small = true) {
 
 inline int fused_fc_supported(const mzx_search* s) { return fused_plan(s).ok; }
 
+// The first-generation whole-search kernel itself (per-level UCB evaluation) is kept for A/B measurements only: it is
+// launched in instrumented builds (MZX_CXXFLAGS=-DMZX_EXPERIMENT); the product library does not carry its 16
+// instantiations (round 6).  What fc2_search_kernel shares with it -- the network engines, the row functions, the plan --
+// is above.
+#ifdef MZX_EXPERIMENT
 template <class Net, int AW, bool PROFILE>
 inline int fused_launch(const FusedPlan& P, unsigned grid, stream_t stream) {
   static std::atomic<uint64_t> lds_attr_done{0};   // per instantiation, one bit per device
@@ -985,8 +990,15 @@ inline int fused_launch_aw(const FusedPlan& P, unsigned grid, stream_t stream) {
   return fused_launch<Net, 16, PROFILE>(P, grid, stream);
 }
 
+#endif  // MZX_EXPERIMENT
+
 // mode bits: 1 = fused, 2 = export trees to the arena, 4 = force LdsNet, 8 = cycle-profile build
 inline int fused_fc_run(mzx_search* s, const mzx_search_io* io, void* d_arena, stream_t stream) {
+#ifndef MZX_EXPERIMENT
+  (void)io; (void)d_arena; (void)stream; (void)s;
+  set_error("the first-generation fully connected kernel (mode flag 16) is built into instrumented libraries only (-DMZX_EXPERIMENT)");
+  return MZX_ERR_INVALID;
+#else
   FusedPlan P = fused_plan(s, !(s->mode & 4));
   if (!P.ok) { set_error("fused search kernel does not support this configuration"); return MZX_ERR_INVALID; }
   int rc = ensure_tables(s, d_arena, stream);
@@ -1010,6 +1022,7 @@ inline int fused_fc_run(mzx_search* s, const mzx_search_io* io, void* d_arena, s
                    : fused_launch<SmallNetCartpole, 2, false>(P, grid, stream);
   }
   return profile ? fused_launch_aw<LdsNet, true>(P, grid, stream) : fused_launch_aw<LdsNet, false>(P, grid, stream);
+#endif
 }
 
 #endif  // !MZX_HOSTCHECK

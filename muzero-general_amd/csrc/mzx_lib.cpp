@@ -17,6 +17,9 @@
 #include "mzx_fused_fc2.h"
 #include "mzx_resnet_search.h"
 #include "mzx_row_search.h"
+// rt_search_kernel and its planner: part of THIS translation unit (round 6).  As a unit of its own it instantiated every
+// header-defined kernel a second time (648 kernels in both code objects: the library was 9.3 MB, half of it duplicates).
+#include "mzx_tower_search.inc"
 #endif
 
 namespace mzx {
@@ -487,8 +490,10 @@ int mzx_net_search_route(const mzx_net* net, int32_t num_trees, int32_t num_simu
 int mzx_search_set_mode(mzx_search* s, int32_t mode) {
   if (!s) { set_error("null search handle"); return MZX_ERR_INVALID; }
   if (mode < 0 || mode > 31) { set_error("mode is a 5-bit flag set"); return MZX_ERR_INVALID; }
-#ifndef MZX_HOSTCHECK
+#if !defined(MZX_HOSTCHECK) && defined(MZX_EXPERIMENT)
   if ((mode & 16) && !(s->fused_ok == 1 && fused_fc_supported(s))) { set_error("flag 16 selects the first-generation fully connected kernel"); return MZX_ERR_INVALID; }
+#else
+  if (mode & 16) { set_error("flag 16 (the first-generation fully connected kernel) needs an instrumented build (-DMZX_EXPERIMENT)"); return MZX_ERR_INVALID; }
 #endif
   if ((mode & 1) && !s->fused_ok) { set_error("fused search kernel does not support this configuration"); return MZX_ERR_INVALID; }
   s->mode = mode;

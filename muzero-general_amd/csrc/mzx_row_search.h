@@ -37,7 +37,7 @@ constexpr int ROWSEL_INTS = 64;
 
 inline bool row_search_supported(const SearchParams& p) { return p.num_actions <= WIDE_MAX_CHUNKS * FUSED_ROW; }
 
-// The tower whole-search kernel (mzx_tower_search.hip): every simulation of a search in ONE launch for wide residual
+// The tower whole-search kernel (mzx_tower_search.inc): every simulation of a search in ONE launch for wide residual
 // networks whose recurrent program is two towers + tails + head chains; bit-identical trees to the per-simulation
 // launches of search_run_rows on its tower route.  rt_search_shape: {trees per workgroup, row tiles per wave, workgroups,
 // workgroups per CU, LDS bytes, threads per workgroup}, zeros when the kernel does not take the search.
@@ -48,7 +48,7 @@ int rt_search_simulations(mzx_search* s, const mzx_search_io* io, void* d_arena,
 // One selection walk of tree `t` by its 16-lane row (self_play.py:325-334): the walk's result for the network
 // (parent node, action, leaf) and the row's share of the path -- 64 ints at `rs`: SelCtx (5), action, then (node, parent,
 // parent slot) of path depth d at 16 + 3 d -- for row_expand_backprop_body.  Shared by row_select_kernel (rs in the arena)
-// and rt_search_kernel (mzx_tower_search.hip: rs in LDS).
+// and rt_search_kernel (mzx_tower_search.inc: rs in LDS).
 template <int AW>
 __device__ __forceinline__ void row_select_body(const SearchParams& p, const TreeRef& t, const uint32_t* tape, int sim, int sub,
                                                 int row_in_wave, int32_t* rs, int32_t* out_parent, int32_t* out_action,
@@ -227,7 +227,7 @@ inline int search_run_rows(mzx_search* s, const mzx_search_io* io, void* d_arena
     mv.dense = ov ? const_cast<float*>(ov->hidden) : v.dense_out; mv.node = nullptr; mv.to_arena = 1;
     MZX_TRY_LAUNCH(launch<256>(mv, stream));
   }
-  // ---- the simulations, all of them in one launch (rt_search_kernel, mzx_tower_search.hip) ...
+  // ---- the simulations, all of them in one launch (rt_search_kernel, mzx_tower_search.inc) ...
   if (whole_search) {
     s->last_kernel = "mzx::rt_search_kernel";
     rc = rt_search_simulations(s, io, d_arena, stream);

@@ -34,7 +34,7 @@ struct mzx_search {
   void* ev_fork = nullptr;
   void* ev_join = nullptr;
   int32_t split_first = 0;     // trees of the first half-shard of the last run (rb_split_first), 0 = undivided
-  // launch plan of the tower whole-search kernel (mzx_tower_search.hip: RtPlan), computed once per (shard size, tuning)
+  // launch plan of the tower whole-search kernel (mzx_tower_search.inc: RtPlan), computed once per (shard size, tuning)
   // and reused by every move's search; owned by the handle
   mutable std::shared_ptr<void> rt_plan_cache;
   mutable int64_t rt_plan_key[4] = {-1, -1, -1, -1};

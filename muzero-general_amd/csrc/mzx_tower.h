@@ -1,5 +1,5 @@
 // mzx_tower.h -- what the two users of the TOWER body share: rb_tower_kernel (mzx_batched.hip: a whole trunk of
-// MuZeroResidualNetwork, models.py:300-433, as one launch over a batch) and rt_search_kernel (mzx_tower_search.hip: every
+// MuZeroResidualNetwork, models.py:300-433, as one launch over a batch) and rt_search_kernel (mzx_tower_search.inc: every
 // simulation of MCTS.run, self_play.py:319-355, in one launch with the same trunks inside).  The layer loop itself -- K loops,
 // barriers, in-place epilogues -- is mzx_tower_layers.inc, included textually by both kernels: the same instructions on
 // the same operands in the same order, hence the same bits on both routes.

@@ -76,7 +76,7 @@ def main():
                 continue
             seen.setdefault(name, (k, mix.get(name, collections.Counter()), []))[2].append(n)
     names = subprocess.run(["c++filt"], input="\n".join(seen), capture_output=True, text=True).stdout.splitlines()
-    print("ISA facts of %s (%d bytes): gfx950 code objects, one per translation unit (mzx_batched.hip, mzx_lib.cpp, mzx_tower_search.hip;\n"
+    print("ISA facts of %s (%d bytes): gfx950 code objects, one per translation unit (mzx_batched.hip, mzx_lib.cpp, mzx_tower_search.inc;\n"
           "kernels defined in headers that two units include are compiled into both).  vgpr = unified VGPR + AGPR budget of a lane (512 max;\n"
           "256 -> two waves per SIMD), scratch = bytes of private memory per lane, spill = spilled VGPRs; instruction counts are static\n"
           "(whole kernel body, loops counted once)." % (os.path.basename(lib), os.path.getsize(lib)))

@@ -122,7 +122,7 @@ def bench_streamed_workloads(lib, bench):
     return out
 
 
-# rt_search_kernel (csrc/mzx_tower_search.hip: every simulation in one launch) AT SIZE: (game, trees) -> the -m gpu test that
+# rt_search_kernel (csrc/mzx_tower_search.inc: every simulation in one launch) AT SIZE: (game, trees) -> the -m gpu test that
 # runs the planner's shape for that shard against the CPU oracle / the per-simulation launches
 RT_AT_SIZE = {
     ("connect4", 512): "test_gpu_tower_search.py::test_tower_search_other_shards_against_oracle[512-1-32]",

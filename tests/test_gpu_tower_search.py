@@ -1,5 +1,5 @@
 """
-GPU parity tests of rt_search_kernel (csrc/mzx_tower_search.hip): every simulation of MCTS.run
+GPU parity tests of rt_search_kernel (csrc/mzx_tower_search.inc): every simulation of MCTS.run
 (/root/reference/self_play.py:319-355) in ONE launch for wide residual networks, the trunks as towers inside.
 
 The kernel's claim is that it builds, bit for bit, the trees of the per-simulation launches of the streamed engine
