@@ -20,6 +20,8 @@ import ctypes
 import numpy
 
 from . import _lib
+from .history import ShardGameHistory, ShardGames, _ShardRecord, gc_paused
+from .search import TAPE_WORDS, BatchedMCTS
 
 
 def usable(actor):
@@ -32,8 +34,6 @@ def usable(actor):
 
 class _Group:
     def __init__(self, actor, game, first, n, engine, temperature):
-        from .self_play import TAPE_WORDS
-
         cfg, lib = actor.config, actor.model.backend.lib
         self.game, self.engine, self.first, self.n = game, engine, first, n
         A = len(cfg.action_space)
@@ -80,8 +80,6 @@ class NativeShard:
     """The state of ``play_rounds`` for a natively stepped shard: one ``mzx_actor`` per slot group."""
 
     def __init__(self, actor, temperature):
-        from .self_play import BatchedMCTS
-
         cfg, B = actor.config, actor.num_games
         spans = actor._batched_spans(B)
         self.groups = []
@@ -106,8 +104,6 @@ class NativeShard:
     def _retry_flagged(self, ctx, group, count, games):
         """Searches the flagged games of slot group ``group`` again on a longer tape -- same roots, same noise, the stream
         peeked further (BatchedMCTS._complete_run's loop) -- and writes the results into the group's output block."""
-        from .self_play import TAPE_WORDS
-
         try:
             actor, g = self._actor, self.groups[group]
             cfg, A, n = actor.config, len(actor.config.action_space), g.n
@@ -189,8 +185,6 @@ class NativeShard:
         they finished; their slots.  ``priorities_for`` (a configuration with PER on; ``continuous_self_play``'s hand-off):
         the initial PER priorities of every record are computed on the device right here and every view is created with its
         row -- the buffer's save_game reads them for every game."""
-        from .self_play import ShardGameHistory, ShardGames, _ShardRecord, gc_paused
-
         actor = self._actor
         lib, A = actor.model.backend.lib, len(actor.config.action_space)
         shape = tuple(actor.config.observation_shape)

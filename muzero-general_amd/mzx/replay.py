@@ -20,6 +20,7 @@ import numpy
 import torch
 
 from . import models, observations
+from .history import gc_paused
 
 
 def n_step_values(game_history, config):
@@ -127,8 +128,6 @@ def fill_initial_priorities_many(histories, config, backend=None):
     """
     if not getattr(config, "PER", False):
         return 0
-    from .self_play import gc_paused       # (self_play imports this module)
-
     filled, views, plain = 0, {}, {}
     jobs = []
     grouped = getattr(histories, "records", None)
