@@ -369,10 +369,10 @@ def _search_baseline_entry(res, cores, seconds, kind):
     sims = sum(r[0] for r in res)
     wall = max(r[2] for r in res)
     rates = [r[0] / r[2] for r in res]
-    what = ("unmodified reference MCTS.run + models.py (oracle/_ref)" if kind == "reference" else "oracle/mcts_oracle.py + net_oracle.py")
+    what = ("reference MCTS.run (oracle/_ref)" if kind == "reference" else "oracle/mcts_oracle.py + net_oracle.py")
     return {
         "value": sims / wall, "unit": "sims/s", "cores": cores, "kind": kind,
-        "sample": f"{sum(r[1] for r in res)} searches x {sims // max(1, sum(r[1] for r in res))} sims of the same workload, "
+        "sample": f"{sum(r[1] for r in res)} searches x {sims // max(1, sum(r[1] for r in res))} sims, "
                   f"{cores} processes x {seconds:.0f} s, 1 thread each; {what}",
         "per_core": res[0][0] / res[0][2],
         # spread over the worker processes (each one's own sims / wall): one aggregate number hides a slow socket / a
@@ -404,7 +404,7 @@ def cpu_baselines(workload, seconds, cores, kind, weights_kind="reference", c4=F
     k = 1
     if extra and c4:
         e = _search_baseline_entry(res[k], cores, seconds, kind)
-        e["workload"] = "C4 Connect4 ResNet (games/connect4.py), MCTS.run of one tree at a time, 200 sims"
+        e["workload"] = "C4 Connect4 ResNet, MCTS.run of one tree at a time, 200 sims"
         out["cpu_baseline_c4"] = e
         k += 1
     if extra and steps_moves > 0:
@@ -417,9 +417,8 @@ def cpu_baselines(workload, seconds, cores, kind, weights_kind="reference", c4=F
                           "games_finished": sum(x[1] for x in r), "moves_per_game": sum(x[0] for x in r) / max(1, sum(x[1] for x in r)),
                           "per_core_min_median_max": [float(numpy.min(rates)), float(numpy.median(rates)), float(numpy.max(rates))]}
         legs["kind"] = "reference"
-        legs["sample"] = (f"unmodified reference SelfPlay.play_game (oracle/_ref), {cores} processes, 1 thread each, whole games until "
-                          f"{seconds:.0f} s have passed (at least one per process); C2: the synthetic game of the GPU legs, "
-                          f"{steps_moves} moves per game; connect4: mzx.games.Connect4 (= games/connect4.py) on the C4 network")
+        legs["sample"] = (f"reference SelfPlay.play_game (oracle/_ref), {cores} processes x 1 thread, whole games for {seconds:.0f} s; "
+                          f"C2: synthetic game, {steps_moves} moves; connect4: real rules, C4 network")
         out["cpu_baseline_steps"] = legs
     return out
 
@@ -506,13 +505,13 @@ def selfplay_leg(cfg, net, B, moves, batched=False, game="synthetic", lockstep=F
         if hasattr(h, "materialize"):
             h.materialize()
     materialize = time.perf_counter() - t1
+    # (compact: the whole line must stay under 8 kB; sims/s = steps/s x num_simulations, the mode is play_rounds unless the key
+    # says lock-step)
     return {
-        "steps_per_sec": steps / wall, "sims_per_sec": steps * c.num_simulations / wall, "games": B,
-        "games_finished": len(histories), "moves_per_finished_game": (sum(len(h.action_history) - 1 for h in histories) /
-                                                                      max(1, len(histories))),
-        "game": game, "mode": "play_games (lock-step)" if lockstep else "play_rounds (slots refilled)",
-        "wall_s": wall, "search_share": sp.stats["search_seconds"] / wall,
-        "steps_per_sec_with_all_histories_as_lists": steps / (wall + (materialize if batched else 0.0)),
+        "steps_per_sec": round(steps / wall, 1), "games": B, "games_finished": len(histories),
+        "moves_per_finished_game": round(sum(len(h.action_history) - 1 for h in histories) / max(1, len(histories)), 2),
+        "game": game, "wall_s": round(wall, 5), "search_share": round(sp.stats["search_seconds"] / wall, 4),
+        **({"steps_per_sec_with_all_histories_as_lists": round(steps / (wall + materialize), 1)} if batched else {}),
         "game_protocol": "native rounds (mzx_selfplay_rounds)" if native else "batched" if batched else "B Game objects",
         "slot_groups": len((sp._live or {}).get("groups", ())) or 1,
         **({"native_phase_ms": [round(x * 1e3, 2) for x in sp.stats["native_phase_seconds"]]} if "native_phase_seconds" in sp.stats else {}),
@@ -567,7 +566,9 @@ def actor_loop_leg(cfg, net, B, moves, shards=3, native=True):
     wall = time.perf_counter() - t0
     return {"steps_per_sec": sp.stats["searches"] / wall, "games_saved": buffer.games, "with_priorities": buffer.with_priorities,
             "steps_saved": buffer.steps, "search_share": sp.stats["search_seconds"] / wall,
-            "game_protocol": "native rounds (mzx_selfplay_rounds) + device priorities" if native else "batched (Python game) + device priorities"}
+            "game_protocol": "native rounds (mzx_selfplay_rounds) + device priorities" if native else "batched (Python game) + device priorities",
+            **({"main_thread_ms": [round(x * 1e3, 1) for x in sp.stats["handoff_seconds"]],
+                "library_call_ms": round(sum(sp.stats.get("native_phase_seconds", [0.0])[:6]) * 1e3, 1)} if "handoff_seconds" in sp.stats else {})}
 
 
 # ----------------------------------------------------------------------------- weights
@@ -919,6 +920,12 @@ def main():
             others.append(r)
     if args.workload == "c4":
         c4_net = (cfg, net)
+    # the search workloads leave cyclic garbage that holds gigabytes of pinned host and device buffers (games/atari.py: 4.9 GB
+    # of observations per input set); collected HERE, not by a generation-2 pass in the middle of a timed self-play leg
+    # (round 6: the actor loop measured 4.1 M steps/s behind the default workloads and 9.4 M alone -- 73 ms of its hand-off
+    # were such a pass freeing those buffers)
+    import gc
+    gc.collect()
     if env.rank == 0:
         if others:
             line["workloads"] = others

@@ -312,11 +312,19 @@ class SelfPlay:
                                          self.config.temperature_threshold)
                 try:
                     if waiting is not None:          # the games the previous call finished (numbered below `waiting`)
+                        t0 = time.perf_counter()
                         histories, slots = self._live["native"].collect(waiting, priorities_for=self.config)
                         self.finished_slots = slots
+                        t1 = time.perf_counter()
                         hand_off(histories)
+                        t2 = time.perf_counter()
+                        spent = self.stats.setdefault("handoff_seconds", [0.0, 0.0, 0.0])     # collect (+ priorities), save_game, idle
+                        spent[0] += t1 - t0
+                        spent[1] += t2 - t1
                 finally:
+                    t3 = time.perf_counter()
                     waiting = future.result()
+                    self.stats.setdefault("handoff_seconds", [0.0, 0.0, 0.0])[2] += time.perf_counter() - t3
             elif not test_mode:
                 # every slot of the shard is one reference actor: its next game starts the moment one ends (:31-52), so
                 # every search runs at full width (``refill_finished_games = False``: whole shards in lock-step)

@@ -7,11 +7,17 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-sys.argv = ["bench.py"]
 import bench  # noqa: E402
 
 from mzx import configs, models  # noqa: E402
 
+if len(sys.argv) > 1:      # e.g. "atari gomoku": run these search workloads first, as the default bench line does
+    after = sys.argv[1:]
+    sys.argv = ["bench.py"]
+    args = bench.parse()
+    env = bench.Env(args)
+    for w in after:
+        bench.run_search_workload(env, args, w, 1, 1, compact=True)
 cfg = configs.cartpole()
 net = models.MuZeroNetwork(cfg)
 net.set_weights(bench.bench_weights(cfg, net, "c2", "reference")[0])
@@ -22,3 +28,5 @@ out = bench.actor_loop_leg(cfg, net, 4096, 32, shards=6)
 pr.disable()
 print(out)
 pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+import gc
+print("gc", gc.get_count(), gc.get_stats())
