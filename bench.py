@@ -891,6 +891,18 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
     return result, cfg, net
 
 
+def _compact_floats(obj, top=True):
+    """Floats below the top level to six significant digits (the line must fit the driver's 8 kB tail; `value`, `ms_per_step`
+    and the other top-level scalars keep every digit)."""
+    if isinstance(obj, dict):
+        return {k: (v if top and isinstance(v, float) else _compact_floats(v, False)) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_compact_floats(v, False) for v in obj]
+    if isinstance(obj, float) and obj == obj and abs(obj) != float("inf"):
+        return float(f"{obj:.6g}")
+    return obj
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -977,7 +989,7 @@ def main():
             line.update(cpu_baselines(args.workload, args.cpu_seconds, args.cpu_cores,
                                       "reference" if build_ref.available() else "port", args.weights,
                                       c4=c4_net is not None, steps_moves=args.selfplay_moves))
-        print(json.dumps(line), flush=True)
+        print(json.dumps(_compact_floats(line)), flush=True)
     env.barrier()
     env.close()
 
