@@ -814,7 +814,7 @@ def run_search_workload(env, args, workload, steps, warmup, trees=None, solo_ref
             traffic = entry["bytes_per_step"]
             # NOT an observation of this run: PMC counters need their own rocprofv3 --pmc passes, so the figure is the one
             # the builder collected for this workload and kernel on the commit named here
-            traffic_source = {"file": "profiles/pmc_traffic.json", "commit": table.get("_collected_at_commit", "755c514"),
+            traffic_source = {"file": "profiles/pmc_traffic.json", "commit": table.get("_collected_at_commit", "unknown"),
                               "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (gpu_job.sh pmc), not this run"}
     except (OSError, ValueError):
         pass
