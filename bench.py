@@ -979,6 +979,10 @@ def main():
                     c4_cfg, c4_model, WORKLOADS["c4"][2], 0, batched=True, game="connect4", lockstep=True)["steps_per_sec"]
                 line["selfplay_end_to_end_connect4_batched_game"]["native_rounds_steps_per_sec"] = selfplay_leg(
                     c4_cfg, c4_model, WORKLOADS["c4"][2], 0, batched=True, game="connect4", native=True)["steps_per_sec"]
+                # (the shard size is the actor's choice: 1536 games = six boards per workgroup of rt_search_kernel, whole rounds of
+                # 256 workgroups -- the shape the tower kernel runs best on)
+                line["selfplay_end_to_end_connect4_batched_game"]["native_rounds_1536_games_steps_per_sec"] = selfplay_leg(
+                    c4_cfg, c4_model, 1536, 0, batched=True, game="connect4", native=True)["steps_per_sec"]
             if not args.dry_run:
                 line["observation_stacker"] = observation_stacker_leg(net.backend)
         line["cpu_baseline"] = None
