@@ -159,7 +159,6 @@ inline void actor_harvest(mzx_actor* a, const std::vector<int32_t>& idx, int64_t
     o1 += n + 1; o0 += n;
   }
   mzx_actor::Batch* bp = &b;
-  bool* illegal = &any_illegal;
   std::vector<uint8_t> flag((size_t)k, 0);
   uint8_t* flagp = flag.data();
   const int64_t* p1 = off1.data();
@@ -190,7 +189,6 @@ inline void actor_harvest(mzx_actor* a, const std::vector<int32_t>& idx, int64_t
     }
   });
   for (int64_t j = 0; j < k; ++j) any_illegal = any_illegal || flag[(size_t)j];
-  (void)illegal;
   if (masks && !any_illegal) { b.mask.clear(); b.mask.shrink_to_fit(); }
   std::lock_guard<std::mutex> lk(a->finished_lock);
   a->finished.push_back(std::move(b));

@@ -1024,8 +1024,9 @@ def test_native_rounds_on_device_equal_the_python_loop(backend):
     weights = synthetic.fill_state_dict(models.MuZeroNetwork(cfg).state_dict(), 4)
     Native = games.make_native_synthetic_game(cfg.observation_shape, len(cfg.action_space), len(cfg.players))
     calls = [(1.0, {}), (0.5, dict(max_rounds=4, min_games=1 << 60)), (1.0, dict(min_games=1500))]
-    a = native._run(backend, Native, cfg, weights, 512, 1000, calls, True, True)
-    b = native._run(backend, Native, cfg, weights, 512, 1000, calls, False, True)
+    # BASELINE C2's shard as bench.py's self-play legs play it: 4096 games, two slot groups (the second on its own stream)
+    a = native._run(backend, Native, cfg, weights, 4096, 1000, calls[:2] + [(1.0, dict(min_games=9000))], True, None)
+    b = native._run(backend, Native, cfg, weights, 4096, 1000, calls[:2] + [(1.0, dict(min_games=9000))], False, None)
     assert a[4] and not b[4] and a[3] == b[3] == 2
     native._assert_equal_runs(a, b)
     cfg = configs.connect4(num_simulations=10)
@@ -1035,6 +1036,18 @@ def test_native_rounds_on_device_equal_the_python_loop(backend):
     b = native._run(backend, games.Connect4Batched, cfg, weights, 96, 3, calls, False, False)
     assert a[4] and not b[4]
     native._assert_equal_runs(a, b)
+
+
+def test_continuous_self_play_overlapped_hand_off_on_device(backend):
+    """continuous_self_play on a natively played shard ON THE DEVICE: rounds on a worker thread (the submitting thread's
+    stream), the hand-off -- mzx_actor_take by sequence, mzx_replay_priorities per record, save_game per game -- on the main
+    thread meanwhile; the same games with the same priorities in the same order as with the hand-off strictly in turn."""
+    import test_native_rounds as native
+
+    from mzx import games
+
+    games.NativeBatchedGame.backend = backend
+    native.test_continuous_self_play_hands_native_games_off_while_the_next_call_plays(backend, True)
 
 
 # ---- reference-compat facade (SURVEY.md 8f row 4): Node graph + override_root_with on the device
