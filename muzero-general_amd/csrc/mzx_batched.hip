@@ -225,10 +225,12 @@ rb_tower_kernel(const RbTowerArgs a) {
 #define RB_TOWER_HAS_TAIL (a.scale_y != nullptr || a.n_conv > 0)
 #define RB_TOWER_ACTION(b, t) a.action[b]
 #define RB_TOWER_LDS_BARRIER false
+#define RB_TOWER_SHORT_GROUP false
 #include "mzx_tower_layers.inc"
 #undef RB_TOWER_HAS_TAIL
 #undef RB_TOWER_ACTION
 #undef RB_TOWER_LDS_BARRIER
+#undef RB_TOWER_SHORT_GROUP
   if (!has_tail) return;
   __syncthreads();                                     // the last layer's output is in the tile's interior cells
   const int in0 = (a.PW + 1) * a.Cs;                   // cell (0, 0) of a board inside its halo

@@ -28,6 +28,7 @@ enum TuningKey {
   TUNE_RT_WAVES,              // 4 / 8: waves per workgroup of rt_search_kernel (0: the planner's cost model)
   TUNE_RT_MAX_TREES,          // automatic routing: shards above this many trees stay on the two-stream streamed path
   TUNE_RT_DBG,                // timing experiments of rt_search_kernel (results are wrong with any bit set; never set in production)
+  TUNE_RT_SHORT,              // 1: a last row group of MT - 1 row tiles runs the short K loop (0: every wave multiplies MT tiles, A/B)
   TUNE_ROUNDS_STREAMS,        // mzx_selfplay_rounds: 1 = every slot group behind the first searches on a stream of its own (0: one stream, A/B)
   TUNE_COUNT
 };
@@ -44,6 +45,7 @@ inline TuningEntry* tuning_table() {
       {"rt_waves", 0, 0, 0, 8, "waves per workgroup of the tower whole-search kernel: 4 or 8 (0 = cost model)"},
       {"rt_max_trees", 1 << 30, 1 << 30, 0, 1 << 30, "automatic routing: largest shard sent to the tower whole-search kernel"},
       {"rt_dbg", 0, 0, 0, 31, "timing experiments: 1 no K loops, 2 no epilogues, 4 no tree phases, 8 no staging / tails, 16 no head MLPs (wrong results)"},
+      {"rt_short", 1, 1, 0, 1, "tower whole-search kernel: waves of a row group one tile short skip that tile's products (0 = multiply it, A/B)"},
       {"rounds_streams", 1, 1, 0, 1, "mzx_selfplay_rounds: slot groups behind the first search on streams of their own (0 = the caller's stream for all)"},
   };
   return t;
