@@ -24,6 +24,14 @@ struct RbTensor {
   int32_t layout;        // RbLayout
 };
 
+// ReLU of a tower's epilogue: the maximum instruction fmaxf(x, 0.f) ends in, without the canonicalising v_max_f32 x, x
+// the compiler puts in front of it for signalling NaNs (there are none: same result for every other operand, -0 included).
+__device__ __forceinline__ float rb_relu(float x) {
+  float y;
+  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+  return y;
+}
+
 __device__ __forceinline__ int rb_div(int x, int d, uint32_t magic) {
   return d == 1 ? x : (int)__umulhi((unsigned)x, magic);
 }

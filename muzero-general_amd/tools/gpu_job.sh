@@ -95,6 +95,10 @@ print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['kind'], d['cpu_basel
     done
     one "rt 1024 K loops only" --workload c4 --tuning rt_dbg=30
     one "rt 1024 no epilogues" --workload c4 --tuning rt_dbg=2
+    one "rt 1024 no tree phases" --workload c4 --tuning rt_dbg=4
+    one "rt 1024 no staging / tails" --workload c4 --tuning rt_dbg=8
+    one "rt 1024 no heads" --workload c4 --tuning rt_dbg=16
+    one "rt 1024 every wave multiplies MT tiles" --workload c4 --tuning rt_short=0
     } > $OUT/rt_quick.txt 2>&1
     cat $OUT/rt_quick.txt
     ;;
