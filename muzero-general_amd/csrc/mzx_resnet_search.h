@@ -66,19 +66,23 @@ __device__ __forceinline__ RowSel row_select_wide(const TreeRef& t, const Search
   int node = 0, depth = 0, slot = 0;
   int vtp = st.root_to_play;
   int N = sim;  // every finished simulation visited the root once
+  double pbc = p.pbc_table[N], sq = p.sqrt_table[N];
   r.my_node = 0; r.my_parent = -1; r.my_pslot = -1;
   bool done = false;
   for (;;) {
     const int d1 = depth + 1;
     const int nc = (node == 0) ? st.root_n : p.num_actions;
-    const double pbc = p.pbc_table[N], sq = p.sqrt_table[N];
-    int nv[NCH];
+    // ONE round trip to the tree per level (round 6): the child of every slot comes with its statistics, and the winner's
+    // child / visit count are picked from the registers of the lane that scored it -- it was two dependent trips per
+    // level (statistics; then child and visit count of the winner), 6.8 us per level of a games/gomoku.py walk on the
+    // reference constructor's weights (107 levels on average).  Same values.
+    int nv[NCH], cv[NCH];
     double pv[NCH], qv[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {   // slots beyond the node's children re-read slot 0 (masked below)
       const int s = ch * FUSED_ROW + sub;
       const int ss = s < nc ? s : 0;
-      nv[ch] = t.slot_visit(node, ss); pv[ch] = t.prior(node, ss); qv[ch] = t.slot_q(node, ss);
+      nv[ch] = t.slot_visit(node, ss); pv[ch] = t.prior(node, ss); qv[ch] = t.slot_q(node, ss); cv[ch] = t.child(node, ss);
     }
     double sc[NCH];
     double mine = -MZX_INF;
@@ -115,8 +119,16 @@ __device__ __forceinline__ RowSel row_select_wide(const TreeRef& t, const Search
         }
       }
     }
-    const int cw = t.child(node, sl);
-    const int n_w = t.slot_visit(node, sl);
+    // the winner's child and visit count: chunk sl / 16 of lane sl % 16 of this row
+    int cw_mine = cv[0], nw_mine = nv[0];
+#pragma unroll
+    for (int ch = 1; ch < NCH; ++ch) {
+      const bool is = (sl >> 4) == ch;
+      cw_mine = is ? cv[ch] : cw_mine;
+      nw_mine = is ? nv[ch] : nw_mine;
+    }
+    const int cw = perm_i(cw_mine, sl & (FUSED_ROW - 1), row_in_wave);
+    const int n_w = perm_i(nw_mine, sl & (FUSED_ROW - 1), row_in_wave);
     const bool act = !done;
     const bool mine_lane = act && sub == d1;
     r.my_parent = mine_lane ? node : r.my_parent;
@@ -131,6 +143,7 @@ __device__ __forceinline__ RowSel row_select_wide(const TreeRef& t, const Search
     node = go ? cw : node;
     done = done || (cw < 0);
     if (__all(done)) break;
+    pbc = p.pbc_table[N]; sq = p.sqrt_table[N];     // (a hot 3 kB table: an L2 hit behind the level's last instruction)
   }
   int leaf = st.n_nodes;
   if (leaf >= p.num_nodes) { st.flags |= TF_NODE_OVERFLOW; leaf = p.num_nodes - 1; }
