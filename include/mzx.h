@@ -57,7 +57,8 @@ int mzx_is_device_build(void);
  *                  in); 0: mzx::rz_search_kernel (the A/B)
  *   rt_search      the tower whole-search kernel (every simulation in one launch): -1 automatic, 0 never, 1 whenever
  *                  the network fits;  rt_trees > 0: trees per workgroup;  rt_waves 4 | 8: waves per workgroup (0: cost
- *                  model);  rt_max_trees: largest shard routed to it;  rt_dbg: timing knock-outs (wrong results)
+ *                  model);  rt_max_trees: largest shard routed to it;  rt_dbg: timing knock-outs (wrong results);
+ *                  rt_short 1 | 0: waves of a row group one tile short skip that tile's products (0: A/B, same trees)
  *   rounds_streams mzx_selfplay_rounds: 1 = every slot group behind the first searches on a stream of its own (two half-shard
  *                  searches of a small network run side by side); 0 = all on the caller's stream (the A/B)
  * mzx_tuning_set / _get return MZX_ERR_INVALID for an unknown name or a value out of range; mzx_tuning_name /

@@ -126,6 +126,32 @@ def test_tower_search_kernel_bit_identical_to_per_simulation_launches(backend, n
     _assert_same(outs[1], outs[2], (name, "second run"))
 
 
+@pytest.mark.parametrize("name,B,S,trees_per_wg,waves", [("connect4", 133, 24, 4, 8), ("connect4", 50, 30, 1, 8), ("narrow4", 29, 20, 7, 8)])
+def test_short_row_group_same_trees(backend, name, B, S, trees_per_wg, waves):
+    """
+    A workgroup whose row tiles do not divide evenly among its row groups (four connect4 boards: eleven tiles dealt 6 + 5;
+    one board: three tiles dealt 2 + 1): the waves of the short group run a K loop over MT - 1 tiles (the <MT, 1, AW, true>
+    instantiations, tuning "rt_short" = 1, the default) instead of multiplying a tile that does not exist.  Same trees, bit
+    for bit, as with "rt_short" = 0.
+    """
+    cfg = CASES[name]()
+    cfg.num_simulations = S
+    net = models.MuZeroNetwork(cfg)
+    net.set_weights(synthetic.fill_state_dict(net.state_dict(), 13))
+    obs, legal, to_play = _inputs(cfg, net, B, 8)
+    outs = []
+    for short in (1, 0):
+        with backend.lib.tuning(rt_search=1, rt_trees=trees_per_wg, rt_waves=waves, rt_short=short):
+            engine = self_play.BatchedMCTS(cfg, net, B, mode=1)
+            route = _route(backend, engine, B)
+            assert route[0] == 3 and route[1] == trees_per_wg, route
+            res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(700 + i) for i in range(B)])
+            assert engine.kernel_name(B) == "mzx::rt_search_kernel"
+            outs.append((res, engine.export_trees(B)))
+    assert (outs[0][0].visit_counts.sum(1) == S).all()
+    _assert_same(outs[0], outs[1], (name, "short row group vs every wave multiplying MT tiles"))
+
+
 def test_tower_search_routing(backend):
     """Which searches the library sends to rt_search_kernel (mzx_search_route, host-side): connect4 at every shard size --
     the same arithmetic whatever the shard, csrc/mzx_row_search.h wide_search_route --, never a narrow network, a network
