@@ -16,6 +16,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int RB_THREADS = 512;
 
+// Row tiles per wave from which the tower kernels hide loop-invariant address arithmetic from the compiler (an empty asm
+// on the thread index / tree base / lane offsets, mzx_tower_search.inc, mzx_tower_layers.inc): the deep tilings keep
+// those values in scratch across the K loops otherwise; the shallow ones have the registers and only pay the recomputation.
+#ifndef MZX_OPAQUE_MIN_MT
+#define MZX_OPAQUE_MIN_MT 5
+#endif
+
 struct RbTensor {
   const float* p;
   const int32_t* node;   // node of sample b inside [batch][nodes][sstride] (null: node 0)

@@ -23,14 +23,16 @@ import torch
 import torch.distributed as dist
 
 
-def broadcast_weights(model, src=0, group=None):
+def broadcast_weights(model, src=0, group=None, with_one_rank=False):
     """
     Broadcast ``model``'s flat weight buffer from rank ``src`` to every rank of
     the process group (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests)
     and rebind derived terms.  A no-op group-wise when torch.distributed is not
-    initialised (single GPU).
+    initialised (single GPU).  ``with_one_rank``: a group of ONE rank issues the
+    collective too (the 1-GPU box's check that the flat buffer is something RCCL
+    takes, tests/test_gpu_rccl.py); by default a lone rank skips it.
     """
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or with_one_rank):
         dist.broadcast(model.flat_weights(), src=src, group=group)
     model.refresh_derived()
 
@@ -110,9 +112,14 @@ class ShardedStorage:
 
     CONTROL = ("training_step", "terminate", "num_played_games", "num_played_steps")
 
-    def __init__(self, storage=None, src=0, group=None, checkpoint_interval=None, training_steps=None):
+    def __init__(self, storage=None, src=0, group=None, checkpoint_interval=None, training_steps=None,
+                 collectives_with_one_rank=False):
         self.storage, self.src, self.group = storage, src, group
         on = dist.is_available() and dist.is_initialized()
+        # a world of ONE rank has nobody to exchange with and skips the collectives; with this flag it issues them
+        # all the same and waits for each on the spot (same flow otherwise): the 1-GPU box's check of the RCCL side
+        # of this class -- device control words, the staged broadcast (tests/test_gpu_rccl.py)
+        self._lone_collectives = bool(collectives_with_one_rank) and on
         self.rank = dist.get_rank(group) if on else 0
         self.world = dist.get_world_size(group) if on else 1
         if (self.rank == src) != (storage is not None):
@@ -159,9 +166,20 @@ class ShardedStorage:
     # ---- the collective sequence
     def _device(self, model):
         device = model.flat_weights().device if model is not None else torch.device("cpu")
-        if device.type == "cpu" and self.world > 1 and dist.get_backend(self.group) == "nccl":
+        if device.type == "cpu" and self._collective() and dist.get_backend(self.group) == "nccl":
             device = torch.device("cuda", torch.cuda.current_device())
         return device
+
+    def _collective(self):
+        return self.world > 1 or self._lone_collectives
+
+    def _lone_wait(self, work):
+        """A lone rank's collective (``collectives_with_one_rank``) is waited for where it is issued."""
+        if work is not None and self.world == 1:
+            work.wait()
+            self.lone_collectives_issued = getattr(self, "lone_collectives_issued", 0) + 1
+            return None
+        return work
 
     def _issue_control(self, model):
         word = torch.zeros(6, dtype=torch.float64)
@@ -174,8 +192,8 @@ class ShardedStorage:
         word[4] = float(self.local["num_played_steps"])
         word[5] = 1.0
         word = word.to(self._device(model))
-        work = dist.all_reduce(word, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self.world > 1 else None
-        self._pending = ("control", work, word)
+        work = dist.all_reduce(word, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self._collective() else None
+        self._pending = ("control", self._lone_wait(work), word)
 
     def _issue_weights(self, model, version):
         if self.rank == self.src:
@@ -183,8 +201,8 @@ class ShardedStorage:
             staging = model.flat_weights().clone()
         else:
             staging = torch.empty_like(model.flat_weights())
-        work = dist.broadcast(staging, src=self.src, group=self.group, async_op=True) if self.world > 1 else None
-        self._pending = ("weights", work, staging, version)
+        work = dist.broadcast(staging, src=self.src, group=self.group, async_op=True) if self._collective() else None
+        self._pending = ("weights", self._lone_wait(work), staging, version)
 
     def _complete(self, model):
         """Consumes the completed pending collective; returns True when another one was issued right away."""
