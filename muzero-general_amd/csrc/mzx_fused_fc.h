@@ -216,9 +216,10 @@ struct RowSel {
 // Lane-parallel selection walk (tree_select of mzx_tree.h; lane s = child slot s).
 template <int AW>
 __device__ __forceinline__ RowSel row_select(const TreeRef& t, const SearchParams& p, const uint32_t* tape, int sub,
-                                             int row_in_wave, int sim, RowState& st) {
+                                             int row_in_wave, int sim, RowState& st, int2* path = nullptr) {
   RowSel r;
   int node = 0, depth = 0, slot = 0;
+  if (path && sub == 0) path[0] = make_int2(0, -1);      // (the whole path for row_backprop: walks deeper than a row's lanes)
   int vtp = st.root_to_play;
   int N = sim;  // every finished simulation visited the root once
   double pbc = p.pbc_table[N], sq = p.sqrt_table[N];
@@ -263,6 +264,7 @@ __device__ __forceinline__ RowSel row_select(const TreeRef& t, const SearchParam
     r.my_parent = mine ? node : r.my_parent;
     r.my_pslot = mine ? sl : r.my_pslot;
     r.my_node = mine ? cw : r.my_node;
+    if (path && act && sub == 0) path[d1] = make_int2(cw, sl);
     const int nvtp = (vtp + 1 < p.num_players) ? vtp + 1 : 0;  // players turn by turn, :331-334
     depth = act ? d1 : depth;
     slot = act ? sl : slot;
@@ -278,6 +280,7 @@ __device__ __forceinline__ RowSel row_select(const TreeRef& t, const SearchParam
   int leaf = st.n_nodes;
   if (leaf >= p.num_nodes) { st.flags |= TF_NODE_OVERFLOW; leaf = p.num_nodes - 1; }
   if (sub == depth) r.my_node = leaf;
+  if (path && sub == 0) path[depth] = make_int2(leaf, slot);
   r.c.parent = node; r.c.slot = slot; r.c.leaf = leaf; r.c.depth = depth; r.c.to_play = vtp;
   r.action = (node == 0) ? t.root_action(slot) : slot;
   return r;
@@ -296,13 +299,75 @@ __device__ __forceinline__ void chain_step(double r_eff, double disc, int depth,
   if constexpr (J > 1) chain_step<J - 1>(r_eff, disc, depth, sub, val, my_in);
 }
 
+// One chunk of sixteen path nodes of a walk deeper than a row (lane j <-> depth 16 c + j), as row_backprop's single chunk.
+struct RowChunk { int n, par, ps, vc, tp; double rr, vs; bool active, is_leaf; };
+__device__ __forceinline__ RowChunk row_chunk_load(const TreeRef& t, const int2* path, const RowSel& r, int c, int top, int sub,
+                                                   int P, double reward) {
+  RowChunk k;
+  const int depth = r.c.depth, d = c * FUSED_ROW + sub, ld = (c == top) ? (depth & (FUSED_ROW - 1)) : FUSED_ROW - 1;
+  k.active = c >= 0 && sub <= ld; k.is_leaf = k.active && d == depth;
+  k.n = 0; k.par = -1; k.ps = -1; k.vc = 0; k.tp = r.c.to_play; k.rr = reward; k.vs = 0.0;
+  if (k.active) {
+    const int2 e = path[d];
+    k.n = e.x; k.ps = e.y;
+    if (d > 0) k.par = path[d - 1].x;
+    if (!k.is_leaf) {
+      k.rr = t.reward(k.n); k.vs = t.value_sum(k.n); k.vc = t.visit(k.n);
+      if (P == 2) k.tp = t.to_play(k.n);
+    }
+  }
+  return k;
+}
+
 __device__ __forceinline__ void row_backprop(const TreeRef& t, const SearchParams& p, const RowSel& r, int sub,
-                                             int row_in_wave, double value, double reward, RowState& st) {
+                                             int row_in_wave, double value, double reward, RowState& st,
+                                             const int2* path = nullptr) {
   const int depth = r.c.depth, P = p.num_players;
   st.n_nodes = r.c.leaf + 1;
   if (depth > st.max_depth) st.max_depth = depth;
   st.sum_depth += depth;
-  if (depth >= FUSED_ROW) {  // path longer than a row: serial walk on lane 0 (rare)
+  if (depth >= FUSED_ROW && path) {
+    // A path longer than a row, written down level by level by the selection walk (`path`: (node, slot taken) per depth):
+    // sixteen nodes at a time, the leaf's chunk first -- every node's statistics of a chunk requested together (and the
+    // chunk above already on its way), the value recurrence through the chunk in the reference's order, one more step through
+    // lane 0's node for the chunk above.  The reference constructor's gomoku weights dig 107-ply lines (400 plies at most):
+    // the serial walk below chased 107 parent links through the arena, a quarter of a millisecond per simulation (round 6).
+    const int top = depth / FUSED_ROW;
+    double val = value, hi = -MZX_INF, lo = MZX_INF;
+    RowChunk k = row_chunk_load(t, path, r, top, top, sub, P, reward);
+    for (int c = top; c >= 0; --c) {      // (row-uniform)
+      const RowChunk up = row_chunk_load(t, path, r, c - 1, top, sub, P, reward);
+      const int ld = (c == top) ? (depth & (FUSED_ROW - 1)) : FUSED_ROW - 1;
+      const bool same = (k.tp == r.c.to_play);
+      const double r_eff = (P == 1 || !same) ? k.rr : -k.rr;
+      double my_in = val;
+      chain_step<FUSED_ROW - 1>(r_eff, p.discount, ld, sub, val, my_in);
+      if (sub == 0) my_in = val;
+      if (c > 0) val = bcast_d<0>(r_eff) + p.discount * val;      // through lane 0's node, for the chunk above
+      double qv = 0.0;
+      if (k.active) {
+        const double vs2 = k.vs + ((P == 1 || same) ? my_in : -my_in);
+        const int vc2 = k.vc + 1;
+        const double mean = vs2 / (double)vc2;
+        qv = k.rr + p.discount * ((P == 1) ? mean : -mean);
+        t.value_sum(k.n) = vs2;
+        t.visit(k.n) = vc2;
+        if (k.par >= 0) { t.slot_visit(k.par, k.ps) = vc2; t.slot_q(k.par, k.ps) = qv; }
+        if (k.is_leaf) {
+          t.child(k.par, k.ps) = k.n;
+          t.parent(k.n) = k.par; t.parent_slot(k.n) = k.ps; t.to_play(k.n) = r.c.to_play; t.reward(k.n) = reward;
+        }
+      }
+      const double h2 = row_max_d<16>(k.active ? qv : -MZX_INF), l2 = row_min_d16(k.active ? qv : MZX_INF);
+      hi = h2 > hi ? h2 : hi;
+      lo = l2 < lo ? l2 : lo;
+      k = up;
+    }
+    if (hi > st.mx) st.mx = hi;      // MinMaxStats.update over the path (pure min / max: order-free)
+    if (lo < st.mn) st.mn = lo;
+    return;
+  }
+  if (depth >= FUSED_ROW) {  // path longer than a row and no path record: serial walk on lane 0 (rare)
     if (sub == 0) {
       store_state(t, st);
       t.child(r.c.parent, r.c.slot) = r.c.leaf;

@@ -61,9 +61,10 @@ constexpr int WIDE_MAX_CHUNKS = 16;   // up to 256 actions
 // where a level costs one memory round trip this way instead of one per chunk.
 template <int NCH = WIDE_MAX_CHUNKS>
 __device__ __forceinline__ RowSel row_select_wide(const TreeRef& t, const SearchParams& p, const uint32_t* tape, int sub,
-                                                  int row_in_wave, int sim, RowState& st) {
+                                                  int row_in_wave, int sim, RowState& st, int2* path = nullptr) {
   RowSel r;
   int node = 0, depth = 0, slot = 0;
+  if (path && sub == 0) path[0] = make_int2(0, -1);      // (the whole path for row_backprop: walks deeper than a row's lanes)
   int vtp = st.root_to_play;
   int N = sim;  // every finished simulation visited the root once
   double pbc = p.pbc_table[N], sq = p.sqrt_table[N];
@@ -134,6 +135,7 @@ __device__ __forceinline__ RowSel row_select_wide(const TreeRef& t, const Search
     r.my_parent = mine_lane ? node : r.my_parent;
     r.my_pslot = mine_lane ? sl : r.my_pslot;
     r.my_node = mine_lane ? cw : r.my_node;
+    if (path && act && sub == 0) path[d1] = make_int2(cw, sl);
     const int nvtp = (vtp + 1 < p.num_players) ? vtp + 1 : 0;  // players turn by turn, :331-334
     depth = act ? d1 : depth;
     slot = act ? sl : slot;
@@ -148,6 +150,7 @@ __device__ __forceinline__ RowSel row_select_wide(const TreeRef& t, const Search
   int leaf = st.n_nodes;
   if (leaf >= p.num_nodes) { st.flags |= TF_NODE_OVERFLOW; leaf = p.num_nodes - 1; }
   if (sub == depth) r.my_node = leaf;
+  if (path && sub == 0) path[depth] = make_int2(leaf, slot);
   r.c.parent = node; r.c.slot = slot; r.c.leaf = leaf; r.c.depth = depth; r.c.to_play = vtp;
   r.action = (node == 0) ? t.root_action(slot) : slot;
   return r;

@@ -27,6 +27,7 @@ struct RowSearchArgs {
   int32_t* sel_action;   // [B]
   int32_t* sel_leaf;     // [B]
   int32_t* rowsel;       // [B][64]: SelCtx (5), action, then (node, parent, parent slot) of path depth d at 16 + 3 d
+  int2* rowpath;         // [B][num_nodes + 1]: (node, slot taken from its parent) of EVERY depth of the walk (paths beyond 16 levels)
   const float* value;    // [B][F] logits of recurrent_inference
   const float* reward;   // [B][F]
   const float* policy;   // [B][A]
@@ -52,15 +53,15 @@ int rt_search_simulations(mzx_search* s, const mzx_search_io* io, void* d_arena,
 template <int AW>
 __device__ __forceinline__ void row_select_body(const SearchParams& p, const TreeRef& t, const uint32_t* tape, int sim, int sub,
                                                 int row_in_wave, int32_t* rs, int32_t* out_parent, int32_t* out_action,
-                                                int32_t* out_leaf) {
+                                                int32_t* out_leaf, int2* path = nullptr) {
   RowState st;
   load_state(t, st);
   RowSel sel;
   if constexpr (AW == 0) {
-    if (p.num_actions <= 8 * FUSED_ROW) sel = row_select_wide<8>(t, p, tape, sub, row_in_wave, sim, st);
-    else sel = row_select_wide<WIDE_MAX_CHUNKS>(t, p, tape, sub, row_in_wave, sim, st);
+    if (p.num_actions <= 8 * FUSED_ROW) sel = row_select_wide<8>(t, p, tape, sub, row_in_wave, sim, st, path);
+    else sel = row_select_wide<WIDE_MAX_CHUNKS>(t, p, tape, sub, row_in_wave, sim, st, path);
   }
-  else sel = row_select<AW>(t, p, tape, sub, row_in_wave, sim, st);
+  else sel = row_select<AW>(t, p, tape, sub, row_in_wave, sim, st, path);
   rs[16 + 3 * sub] = sel.my_node; rs[17 + 3 * sub] = sel.my_parent; rs[18 + 3 * sub] = sel.my_pslot;
   if (sub == 0) {
     *out_parent = sel.c.parent; *out_action = sel.action; *out_leaf = sel.c.leaf;
@@ -73,7 +74,8 @@ __device__ __forceinline__ void row_select_body(const SearchParams& p, const Tre
 // vl / rl = value / reward logits [2 support + 1], pl = policy logits [A] of the leaf's recurrent_inference.
 template <int AW>
 __device__ __forceinline__ void row_expand_backprop_body(const SearchParams& p, const TreeRef& t, int sub, int row_in_wave,
-                                                         const int32_t* rs, const float* vl, const float* rl, const float* pl) {
+                                                         const int32_t* rs, const float* vl, const float* rl, const float* pl,
+                                                         const int2* path = nullptr) {
   RowState st;
   load_state(t, st);
   RowSel sel;
@@ -102,7 +104,7 @@ __device__ __forceinline__ void row_expand_backprop_body(const SearchParams& p, 
     const float den = row_sum(e);
     if (in) tree_init_slot(t, sel.c.leaf, sub, (double)mzx_div(e, den));
   }
-  row_backprop(t, p, sel, sub, row_in_wave, (double)value, (double)reward, st);
+  row_backprop(t, p, sel, sub, row_in_wave, (double)value, (double)reward, st, path);
   if (sub == 0) store_state(t, st);
 }
 
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(64) row_select_kernel(const RowSearchArgs a) {
   t.base = a.trees + (size_t)tree * a.L.tree_bytes;
   t.L = a.L;
   row_select_body<AW>(a.p, t, a.tape + (size_t)tree * a.p.tape_words, a.sim, sub, row, a.rowsel + (size_t)tree * ROWSEL_INTS,
-                      a.sel_parent + tree, a.sel_action + tree, a.sel_leaf + tree);
+                      a.sel_parent + tree, a.sel_action + tree, a.sel_leaf + tree, a.rowpath + (size_t)tree * (a.p.num_nodes + 1));
 }
 
 template <int AW>
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(64) row_expand_backprop_kernel(const RowSearch
   t.L = a.L;
   const int F = 2 * a.p.support_size + 1, A = a.p.num_actions;
   row_expand_backprop_body<AW>(a.p, t, sub, row, a.rowsel + (size_t)tree * ROWSEL_INTS, a.value + (size_t)tree * F,
-                               a.reward + (size_t)tree * F, a.policy + (size_t)tree * A);
+                               a.reward + (size_t)tree * F, a.policy + (size_t)tree * A, a.rowpath + (size_t)tree * (a.p.num_nodes + 1));
 }
 
 template <int AW>
@@ -279,6 +281,7 @@ inline int search_run_rows(mzx_search* s, const mzx_search_io* io, void* d_arena
     a.trees = v.arena.trees + o * s->L.tree_bytes; a.tape = io->d_tape + o * s->p.tape_words;
     a.sel_parent = v.sel_parent + o; a.sel_action = v.sel_action + o; a.sel_leaf = v.sel_leaf + o;
     a.rowsel = (int32_t*)((char*)d_arena + s->off_rowsel) + o * ROWSEL_INTS;
+    a.rowpath = (int2*)((char*)d_arena + s->off_rowpath) + o * (s->p.num_nodes + 1);
     a.value = v.value + o * F; a.reward = v.reward + o * F; a.policy = v.policy + o * A;
     NetBuffers& n = nbs[h];
     n.in = v.arena.hidden + o * node_floats; n.hidden = v.arena.hidden + o * node_floats; n.action = a.sel_action;

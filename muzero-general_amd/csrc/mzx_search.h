@@ -19,7 +19,7 @@ struct mzx_search {
   std::vector<double> h_pbc, h_sqrt;
   // arena carve (byte offsets)
   int64_t off_tables = 0, off_trees = 0, off_hidden = 0, off_dense_in = 0, off_dense_out = 0;
-  int64_t off_value = 0, off_reward = 0, off_policy = 0, off_sel = 0, off_rowsel = 0, off_ws = 0, arena_bytes = 0;
+  int64_t off_value = 0, off_reward = 0, off_policy = 0, off_sel = 0, off_rowsel = 0, off_rowpath = 0, off_ws = 0, arena_bytes = 0;
   int64_t ws_floats = 0;
   // pbc[N+1] then sqrt[N+1] on the device: owned by the handle (uploaded once at create), NOT carved from the
   // caller's arena -- an arena may be cleared, freed or re-allocated at the same address between calls
@@ -66,6 +66,7 @@ inline void search_plan(mzx_search* s) {
   s->off_policy = o;    o += align256(int64_t(4) * B * A);
   s->off_sel = o;       o += align256(int64_t(4) * B * 3);
   s->off_rowsel = o;    o += align256(int64_t(4) * B * 64);   // path hand-off of the row kernels (mzx_row_search.h)
+  s->off_rowpath = o;   o += align256(int64_t(8) * B * (N + 1));   // ... and the whole path of a walk, (node, slot taken) per depth: paths beyond a row's 16 lanes
   s->ws_floats = s->net ? net_ws_per_sample(s->net) * (int64_t)B : 0;
   s->off_ws = o;        o += align256(int64_t(4) * s->ws_floats);
   s->arena_bytes = o;

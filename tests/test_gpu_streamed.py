@@ -408,6 +408,61 @@ def test_row_kernels_bit_identical_to_one_thread_per_tree(backend, name, B, S):
         assert numpy.array_equal(a, b), (name, key)
 
 
+DEEP_CASES = {
+    # 32 actions (several child slots per lane: row_select_wide), two players: walks of up to ~33 plies in 100 simulations
+    "wide32": (lambda: configs.connect4(observation_shape=(3, 4, 8), action_space=list(range(32)), channels=64, blocks=1), 100, 17),
+    # 16 actions (one slot per lane: row_select<16>), two players: up to ~48 plies in 160 simulations
+    "narrow16": (lambda: configs.connect4(observation_shape=(3, 4, 4), action_space=list(range(16)), channels=32, blocks=1), 160, 32),
+    # one player (the other back-propagation variant, self_play.py:412-419), 32 actions
+    "wide32_one_player": (lambda: configs.connect4(observation_shape=(3, 4, 8), action_space=list(range(32)), channels=64, blocks=1,
+                                                   players=[0]), 100, 16),
+}
+
+
+@pytest.mark.parametrize("name", sorted(DEEP_CASES))
+def test_row_kernels_deep_walks_bit_identical_to_one_thread_per_tree(backend, name):
+    """
+    Walks DEEPER than a row's sixteen lanes (the reference constructor's gomoku weights dig 107-ply lines): the selection
+    walk writes the whole path down, back-propagation takes it sixteen nodes at a time, the leaf's chunk first
+    (csrc/mzx_fused_fc.h row_backprop, round 6; before: a serial walk up the parent links on lane 0).  Against the generic
+    operators (one thread per tree, the serial tree_backprop of csrc/mzx_tree.h) around the same network engine: every
+    statistic of the finished trees bit for bit.  A flat policy head (last layer zeroed) makes the searches dig lines;
+    rows of one wavefront end at different depths (1 .. 4 chunks), full legal sets, a partial wavefront of rows.
+    """
+    make, S, want_depth = DEEP_CASES[name]
+    cfg = make()
+    cfg.num_simulations = S
+    net = models.MuZeroNetwork(cfg)
+    sd = synthetic.fill_state_dict(net.state_dict(), 3 if name == "wide32_one_player" else 12)
+    last = [k for k in sd if "fc_policy" in k and k.endswith(".weight")][-1]
+    sd[last] = sd[last] * 0
+    net.set_weights(sd)
+    net.set_mode(3)
+    B, A = 10, len(cfg.action_space)
+    obs = synthetic.observations(B, net.input_shape, seed=6)
+    legal = [list(range(A))] * B
+    to_play = [int(i % len(cfg.players)) for i in range(B)]
+    out = {}
+    for mode in (0, 1):
+        engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
+        res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(500 + i) for i in range(B)])
+        kernel = engine.kernel_name(B)
+        assert ("row_select_kernel" in kernel) == (mode == 1), kernel
+        out[mode] = (res, engine.export_trees(B))
+    (r0, t0), (r1, t1) = out[0], out[1]
+    depths = numpy.asarray(r0.max_tree_depth)
+    print(f"{name}: deepest walk per tree {depths.tolist()}")
+    assert depths.max() >= want_depth and (depths >= 16).sum() >= 1, depths       # (the case exercises what it is for)
+    assert numpy.array_equal(r0.visit_counts, r1.visit_counts)
+    assert numpy.array_equal(r0.root_values.view(numpy.int64), r1.root_values.view(numpy.int64))
+    assert numpy.array_equal(r0.max_tree_depth, r1.max_tree_depth) and numpy.array_equal(r0.tape_used, r1.tape_used)
+    for key in ("visit", "value_sum", "reward", "prior", "child", "parent", "to_play", "minmax", "n_nodes"):
+        a, b = t0[key], t1[key]
+        if a.dtype == numpy.float64:
+            a, b = a.view(numpy.int64), b.view(numpy.int64)
+        assert numpy.array_equal(a, b), (name, key)
+
+
 @pytest.mark.parametrize("name,B,S,split", [("gomoku", 77, 24, False), ("gomoku", 64, 16, True), ("connect4", 130, 30, True)])
 def test_two_half_shards_on_two_streams_build_the_same_trees(backend, name, B, S, split, monkeypatch):
     """
