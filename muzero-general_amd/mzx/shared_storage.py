@@ -120,6 +120,7 @@ class ShardedStorage:
         # all the same and waits for each on the spot (same flow otherwise): the 1-GPU box's check of the RCCL side
         # of this class -- device control words, the staged broadcast (tests/test_gpu_rccl.py)
         self._lone_collectives = bool(collectives_with_one_rank) and on
+        self.lone_collectives_issued = 0
         self.rank = dist.get_rank(group) if on else 0
         self.world = dist.get_world_size(group) if on else 1
         if (self.rank == src) != (storage is not None):
@@ -177,7 +178,7 @@ class ShardedStorage:
         """A lone rank's collective (``collectives_with_one_rank``) is waited for where it is issued."""
         if work is not None and self.world == 1:
             work.wait()
-            self.lone_collectives_issued = getattr(self, "lone_collectives_issued", 0) + 1
+            self.lone_collectives_issued += 1
             return None
         return work
 
