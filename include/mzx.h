@@ -61,6 +61,8 @@ int mzx_is_device_build(void);
  *                  rt_short 1 | 0: waves of a row group one tile short skip that tile's products (0: A/B, same trees)
  *   rounds_streams mzx_selfplay_rounds: 1 = every slot group behind the first searches on a stream of its own (two half-shard
  *                  searches of a small network run side by side); 0 = all on the caller's stream (the A/B)
+ *   wave_select    per-simulation launches, more than 16 actions: 1 = the selection walk by a wavefront per tree (lane l scores
+ *                  child slots l, l + 64, ...), 0 = by a 16-lane row per tree (the A/B); the same walks either way
  * mzx_tuning_set / _get return MZX_ERR_INVALID for an unknown name or a value out of range; mzx_tuning_name /
  * _help enumerate the table (NULL past its end).
  * ------------------------------------------------------------------------- */

@@ -133,8 +133,136 @@ __global__ void __launch_bounds__(64) row_expand_backprop_kernel(const RowSearch
                                a.reward + (size_t)tree * F, a.policy + (size_t)tree * A, a.rowpath + (size_t)tree * (a.p.num_nodes + 1));
 }
 
+// ---------------------------------------------------------------------------
+// Wide action spaces, a WAVEFRONT per tree (round 6): row_select_wide's walk (mzx_resnet_search.h: lane l scores slots l, l + 16,
+// ... of a 16-lane row, eight chunks per level for the 121 actions of games/gomoku.py) with lane l of the whole wave scoring slots
+// l, l + 64, ...: two chunks per level.  A level of such a walk is a trip to the tree in the arena + the binary64 UCB arithmetic of
+// the lane's chunks (two divisions per slot); with 107-ply walks (the reference constructor's gomoku weights) the arithmetic of
+// eight chunks was half of row_select_kernel<0> (341 us per launch alone against 169 us with two chunks' worth,
+// gpurun_out r06ag).  One tree per wave: the walk's state is wave-uniform, no frozen rows.  Same operations per slot, the same
+// maximum, maximisers counted in slot order, the same tape draws: the same walk (tests/test_gpu_streamed.py, row kernels against one
+// thread per tree).  Hands the path over exactly as row_select_body does: 64 ints (lanes 0 .. 15) + the whole path.
+__device__ __forceinline__ double wave_lane_d(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+template <int NCH>      // 64-slot chunks a lane holds: 2 = up to 128 actions, 4 = up to 256
+__device__ __forceinline__ RowSel wave_select_wide(const TreeRef& t, const SearchParams& p, const uint32_t* tape, int lane, int sim,
+                                                   RowState& st, int2* path) {
+  RowSel r;
+  int node = 0, depth = 0, slot = 0;
+  int vtp = st.root_to_play;
+  int N = sim;      // every finished simulation visited the root once
+  double pbc = p.pbc_table[N], sq = p.sqrt_table[N];
+  r.my_node = 0; r.my_parent = -1; r.my_pslot = -1;
+  if (lane == 0) path[0] = make_int2(0, -1);
+  for (;;) {
+    const int d1 = depth + 1;
+    const int nc = (node == 0) ? st.root_n : p.num_actions;
+    int nv[NCH], cv[NCH];
+    double pv[NCH], qv[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {   // slots beyond the node's children re-read slot 0 (masked below)
+      const int s = ch * 64 + lane;
+      const int ss = s < nc ? s : 0;
+      nv[ch] = t.slot_visit(node, ss); pv[ch] = t.prior(node, ss); qv[ch] = t.slot_q(node, ss); cv[ch] = t.child(node, ss);
+    }
+    double sc[NCH];
+    double mine = -MZX_INF;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const bool valid = ch * 64 + lane < nc;
+      const double u = ucb_from(pbc, sq, nv[ch], pv[ch], qv[ch], st.mn, st.mx);
+      sc[ch] = valid ? u : -MZX_INF;
+      mine = (sc[ch] > mine) ? sc[ch] : mine;
+    }
+    // the maximum of the wave: the row butterfly, then the four rows' maxima
+    const double rm = row_max_d<16>(mine);
+    const double m01 = fmax(wave_lane_d(rm, 0), wave_lane_d(rm, 16)), m23 = fmax(wave_lane_d(rm, 32), wave_lane_d(rm, 48));
+    const double best = fmax(m01, m23);
+    // maximisers, chunk by chunk in slot order
+    int nbest = 0, sl = 0;
+    unsigned long long bits[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      bits[ch] = __ballot(sc[ch] == best && ch * 64 + lane < nc);
+      if (nbest == 0 && bits[ch]) sl = ch * 64 + (__ffsll((long long)bits[ch]) - 1);
+      nbest += __popcll(bits[ch]);
+    }
+    if (nbest > 1) {  // numpy.random.choice(ties): k-th maximiser in slot order
+      ++st.ties;
+      int k = tape_draw(tape, p.tape_words, st.tape_pos, st.flags, nbest);
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int cnt = __popcll(bits[ch]);
+        if (k >= 0 && k < cnt) {
+          unsigned long long b = bits[ch];
+          for (int q = k; q > 0; --q) b &= b - 1;
+          sl = ch * 64 + (__ffsll((long long)b) - 1);
+          k = -1;
+        } else if (k >= cnt) {
+          k -= cnt;
+        }
+      }
+    }
+    sl = __builtin_amdgcn_readfirstlane(sl);
+    // the winner's child and visit count from the registers of the lane that scored it
+    int cw_mine = cv[0], nw_mine = nv[0];
+#pragma unroll
+    for (int ch = 1; ch < NCH; ++ch) {
+      const bool is = (sl >> 6) == ch;
+      cw_mine = is ? cv[ch] : cw_mine;
+      nw_mine = is ? nv[ch] : nw_mine;
+    }
+    const int cw = __builtin_amdgcn_readlane(cw_mine, sl & 63), n_w = __builtin_amdgcn_readlane(nw_mine, sl & 63);
+    const bool mine_lane = lane == d1;      // (lanes 0 .. 15 are handed over, as a row's)
+    r.my_parent = mine_lane ? node : r.my_parent;
+    r.my_pslot = mine_lane ? sl : r.my_pslot;
+    r.my_node = mine_lane ? cw : r.my_node;
+    if (lane == 0) path[d1] = make_int2(cw, sl);
+    vtp = (vtp + 1 < p.num_players) ? vtp + 1 : 0;      // players turn by turn, self_play.py:331-334
+    depth = d1;
+    slot = sl;
+    if (cw < 0) break;
+    N = n_w;
+    node = cw;
+    pbc = p.pbc_table[N]; sq = p.sqrt_table[N];
+  }
+  int leaf = st.n_nodes;
+  if (leaf >= p.num_nodes) { st.flags |= TF_NODE_OVERFLOW; leaf = p.num_nodes - 1; }
+  if (lane == depth) r.my_node = leaf;
+  if (lane == 0) path[depth] = make_int2(leaf, slot);
+  r.c.parent = node; r.c.slot = slot; r.c.leaf = leaf; r.c.depth = depth; r.c.to_play = vtp;
+  r.action = (node == 0) ? t.root_action(slot) : slot;
+  return r;
+}
+
+__global__ void __launch_bounds__(64) wave_select_kernel(const RowSearchArgs a) {
+  const int lane = threadIdx.x, tree = blockIdx.x;
+  TreeRef t;
+  t.base = a.trees + (size_t)tree * a.L.tree_bytes;
+  t.L = a.L;
+  RowState st;
+  load_state(t, st);
+  int2* path = a.rowpath + (size_t)tree * (a.p.num_nodes + 1);
+  const uint32_t* tape = a.tape + (size_t)tree * a.p.tape_words;
+  const RowSel sel = (a.p.num_actions <= 128) ? wave_select_wide<2>(t, a.p, tape, lane, a.sim, st, path)
+                                              : wave_select_wide<4>(t, a.p, tape, lane, a.sim, st, path);
+  int32_t* rs = a.rowsel + (size_t)tree * ROWSEL_INTS;
+  if (lane < FUSED_ROW) { rs[16 + 3 * lane] = sel.my_node; rs[17 + 3 * lane] = sel.my_parent; rs[18 + 3 * lane] = sel.my_pslot; }
+  if (lane == 0) {
+    a.sel_parent[tree] = sel.c.parent; a.sel_action[tree] = sel.action; a.sel_leaf[tree] = sel.c.leaf;
+    rs[0] = sel.c.parent; rs[1] = sel.c.slot; rs[2] = sel.c.leaf; rs[3] = sel.c.depth; rs[4] = sel.c.to_play; rs[5] = sel.action;
+    store_state(t, st);                  // tape position, tie draws, flags moved
+  }
+}
+
 template <int AW>
 inline int row_search_step(const RowSearchArgs& a, stream_t stream) {
+  if (AW == 0 && tune(TUNE_WAVE_SELECT) && a.p.num_actions <= 256) {      // wide records: a wavefront per tree
+    hipLaunchKernelGGL(wave_select_kernel, dim3((unsigned)a.p.num_trees), dim3(64), 0, stream, a);
+    return (int)hipGetLastError();
+  }
   const unsigned grid = (unsigned)((a.p.num_trees + 3) / 4);
   hipLaunchKernelGGL(row_select_kernel<AW>, dim3(grid), dim3(64), 0, stream, a);
   return (int)hipGetLastError();

@@ -30,6 +30,7 @@ enum TuningKey {
   TUNE_RT_DBG,                // timing experiments of rt_search_kernel (results are wrong with any bit set; never set in production)
   TUNE_RT_SHORT,              // 1: a last row group of MT - 1 row tiles runs the short K loop (0: every wave multiplies MT tiles, A/B)
   TUNE_ROUNDS_STREAMS,        // mzx_selfplay_rounds: 1 = every slot group behind the first searches on a stream of its own (0: one stream, A/B)
+  TUNE_WAVE_SELECT,           // per-simulation launches, wide child records: 1 = a wavefront per tree walks (wave_select_kernel), 0 = a 16-lane row (row_select_kernel<0>, A/B); same walks
   TUNE_COUNT
 };
 
@@ -47,6 +48,7 @@ inline TuningEntry* tuning_table() {
       {"rt_dbg", 0, 0, 0, 31, "timing experiments: 1 no K loops, 2 no epilogues, 4 no tree phases, 8 no staging / tails, 16 no head MLPs (wrong results)"},
       {"rt_short", 1, 1, 0, 1, "tower whole-search kernel: waves of a row group one tile short skip that tile's products (0 = multiply it, A/B)"},
       {"rounds_streams", 1, 1, 0, 1, "mzx_selfplay_rounds: slot groups behind the first search on streams of their own (0 = the caller's stream for all)"},
+      {"wave_select", 1, 1, 0, 1, "per-simulation launches, more than 16 actions: the selection walk by a wavefront per tree (0 = a 16-lane row per tree, A/B; same walks)"},
   };
   return t;
 }

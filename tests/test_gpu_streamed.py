@@ -408,6 +408,60 @@ def test_row_kernels_bit_identical_to_one_thread_per_tree(backend, name, B, S):
         assert numpy.array_equal(a, b), (name, key)
 
 
+WAVE_SELECT_CASES = {
+    "gomoku": (lambda: STREAMED_CASES["gomoku"][0](), 9, 30, False),      # 121 actions: two 64-slot chunks per lane
+    "wide200": (lambda: configs.connect4(observation_shape=(3, 4, 8), action_space=list(range(200)), channels=32, blocks=1), 11, 40, False),   # four chunks
+    "wide32_deep": (lambda: configs.connect4(observation_shape=(3, 4, 8), action_space=list(range(32)), channels=64, blocks=1), 10, 100, True),
+    "atari_narrow": (lambda: STREAMED_CASES["atari_narrow"][0](), 5, 12, False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(WAVE_SELECT_CASES))
+def test_wave_per_tree_selection_walks_the_same_trees(backend, name):
+    """
+    wave_select_kernel (csrc/mzx_row_search.h, round 6: a WAVEFRONT per tree scores the child slots of a wide action space, lane
+    l the slots l, l + 64, ...) against row_select_kernel<0> (a 16-lane row per tree, slots l, l + 16, ...; tuning "wave_select"
+    = 0) and against the generic operators (one thread per tree): every statistic of the finished trees bit for bit -- ragged
+    legal sets (root slots), forced ties at every first level (tape draws in slot order), both players, walks beyond sixteen
+    plies (the path record), a shard that is no multiple of four.
+    """
+    make, B, S, flat = WAVE_SELECT_CASES[name]
+    cfg = make()
+    cfg.num_simulations = S
+    net = models.MuZeroNetwork(cfg)
+    sd = synthetic.fill_state_dict(net.state_dict(), 12)
+    if flat:
+        last = [k for k in sd if "fc_policy" in k and k.endswith(".weight")][-1]
+        sd[last] = sd[last] * 0
+    net.set_weights(sd)
+    net.set_mode(3)
+    A = len(cfg.action_space)
+    obs = synthetic.observations(B, net.input_shape, seed=6)
+    rs = numpy.random.RandomState(4)
+    legal = [list(range(A))] * B if flat else [sorted(rs.choice(A, size=rs.randint(1, A + 1), replace=False).tolist()) for _ in range(B)]
+    to_play = [int(i % len(cfg.players)) for i in range(B)]
+    out = []
+    for mode, wave in ((0, 1), (1, 0), (1, 1)):
+        backend.lib.tuning_set("wave_select", wave)
+        engine = self_play.BatchedMCTS(cfg, net, B, mode=mode)
+        res = engine.run(list(obs), legal, to_play, True, [numpy.random.RandomState(500 + i) for i in range(B)])
+        kernel = engine.kernel_name(B)
+        assert ("row_select_kernel" in kernel) == (mode == 1), kernel
+        out.append((res, engine.export_trees(B)))
+    if flat:
+        assert numpy.asarray(out[0][0].max_tree_depth).max() >= 17
+    for k, label in ((1, "a row per tree"), (2, "a wavefront per tree")):
+        (r0, t0), (r1, t1) = out[0], out[k]
+        assert numpy.array_equal(r0.visit_counts, r1.visit_counts), (name, label)
+        assert numpy.array_equal(r0.root_values.view(numpy.int64), r1.root_values.view(numpy.int64)), (name, label)
+        assert numpy.array_equal(r0.max_tree_depth, r1.max_tree_depth) and numpy.array_equal(r0.tape_used, r1.tape_used), (name, label)
+        for key in ("visit", "value_sum", "reward", "prior", "child", "parent", "to_play", "minmax", "n_nodes"):
+            a, b = t0[key], t1[key]
+            if a.dtype == numpy.float64:
+                a, b = a.view(numpy.int64), b.view(numpy.int64)
+            assert numpy.array_equal(a, b), (name, label, key)
+
+
 DEEP_CASES = {
     # 32 actions (several child slots per lane: row_select_wide), two players: walks of up to ~33 plies in 100 simulations
     "wide32": (lambda: configs.connect4(observation_shape=(3, 4, 8), action_space=list(range(32)), channels=64, blocks=1), 100, 17),
