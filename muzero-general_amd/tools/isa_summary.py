@@ -15,7 +15,7 @@ import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin/"
 HERE = os.path.dirname(os.path.abspath(__file__))
-KEEP = ("search", "tower", "gemm", "network", "row_select", "row_expand", "ObsStack")
+KEEP = ("search", "tower", "gemm", "network", "row_select", "wave_select", "row_expand", "ObsStack")
 
 
 def code_objects(lib):
